@@ -1,0 +1,334 @@
+"""CPU oracle for the Rectified-SpaAttn hot path (numpy + oracle/librsa_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg,
+never by the product package.  Each function cites the reference lines (under /root/reference) it follows.
+The arithmetic contract for the mask statistics is written in oracle/rsa_oracle.c (C1..C8).
+
+Pinned against the reference itself: tests/golden/*.npz were produced by tests/golden/make_golden.py, which
+imports the reference's own Python on CPU in the build container; tests/test_oracle_golden.py checks this
+file against those vectors (masks bit-exact, floats <= 1e-5, O within the fp16 kernel tolerance).
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+import subprocess
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+BLOCK = 128
+
+
+def build_oracle_lib(force: bool = False) -> str:
+    so = os.path.join(_HERE, "librsa_oracle.so")
+    src = os.path.join(_HERE, "rsa_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "librsa_oracle.so"])
+    return so
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        L = ctypes.CDLL(build_oracle_lib())
+        f32p = ctypes.POINTER(ctypes.c_float)
+        u8p = ctypes.POINTER(ctypes.c_uint8)
+        L.orc_exp.restype = ctypes.c_float
+        L.orc_exp.argtypes = [ctypes.c_float]
+        L.orc_row_sum.restype = ctypes.c_float
+        L.orc_row_sum.argtypes = [f32p, ctypes.c_int]
+        L.orc_pool.restype = None
+        L.orc_pool.argtypes = [f32p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, f32p, f32p]
+        L.orc_dots.restype = None
+        L.orc_dots.argtypes = [f32p, f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, f32p]
+        L.orc_select_row.restype = None
+        L.orc_select_row.argtypes = [f32p, f32p, f32p, f32p, u8p] + [ctypes.c_int] * 7 + [
+            ctypes.c_float, ctypes.c_float, u8p, u8p, f32p, f32p, ctypes.POINTER(ctypes.c_int), f32p]
+        _LIB = L
+    return _LIB
+
+
+def _f32p(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def _u8p(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+
+
+# ------------------------------------------------------------------------------------------------------
+# rounding helpers (exact emulation of bf16 / fp16 storage)
+# ------------------------------------------------------------------------------------------------------
+def round_bf16(x: np.ndarray) -> np.ndarray:
+    """Round-to-nearest-even fp32 -> bf16 -> fp32."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return (r & 0xFFFFFFFF).astype(np.uint32).view(np.float32).reshape(np.shape(x))
+
+
+def round_fp16(x: np.ndarray) -> np.ndarray:
+    return np.asarray(x, dtype=np.float32).astype(np.float16).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------------------
+# layout: the four reference variants expressed as data
+# ------------------------------------------------------------------------------------------------------
+@dataclass
+class Layout:
+    """One self-attention call's geometry (all lengths in tokens / 128-token blocks).
+
+    S              true sequence length (q and kv)
+    NB_total       ceil(S / 128) -- the reference zero-pads to this (wan21 :299-302, cogvideo pad)
+    NBv            visual blocks = sparse query blocks
+    n_txt          valid text tokens scored individually ("attenable", hunyuan :315 / flux :139); 0 = no text tail
+    kv_valid       kv columns < kv_valid are attended by the sparse kernel ("seqlens", hunyuan :314)
+    pool_valid     rows >= pool_valid are zero when pooling K/V (hunyuan zeroes masked K/V in place :307-308)
+    text_end_block text blocks [NBv, text_end_block) are kept by every row (hunyuan :277,:331)
+    ffb            first_frame_blocks (wan21 :270-271)
+    q_text_valid   text query rows [NBv*128, NBv*128+q_text_valid) get dense attention over kv [0, kv_text_valid)
+                   (hunyuan :371-380); remaining rows up to S come out 0 (they only see zeroed K/V)
+    """
+    S: int
+    NB_total: int
+    NBv: int
+    n_txt: int
+    kv_valid: int
+    pool_valid: int
+    text_end_block: int
+    ffb: int
+    q_text_valid: int
+    kv_text_valid: int
+    name: str = ""
+
+    @property
+    def L(self) -> int:  # length of the sorted probability row
+        return self.NBv + (1 if self.n_txt > 0 else 0)
+
+
+def layout_hunyuan(S: int, num_true: int) -> Layout:
+    """rectified_hunyuan_attn.py:313-332 (text tail padded to 256; num_true = attention_mask.sum())."""
+    assert S % BLOCK == 0, "Hunyuan path has no padding branch (reference :326-327 with cu_seqlens given)"
+    NB = S // BLOCK
+    NBv = NB - 256 // BLOCK
+    n_txt = 256 - (S - num_true)
+    return Layout(S, NB, NBv, n_txt, num_true, num_true, (num_true + BLOCK - 1) // BLOCK, 0,
+                  num_true - NBv * BLOCK, num_true, "hunyuan")
+
+
+def layout_flux(S: int, text_length: int, s_k: Optional[int] = None) -> Layout:
+    """rectified_flux_attn.py:307-320 (no KV zeroing; seqlens = cu_seqlens_kv[1])."""
+    assert S % BLOCK == 0
+    s_k = S if s_k is None else s_k
+    NB = S // BLOCK
+    NBv = NB - text_length // BLOCK
+    return Layout(S, NB, NBv, text_length, s_k, S, (s_k + BLOCK - 1) // BLOCK, 0, S - NBv * BLOCK, s_k, "flux")
+
+
+def layout_cogvideo(S: int, text_length: int) -> Layout:
+    """rectified_cogvideo_attn.py:306-322 (pad to x128; all text blocks kept)."""
+    NB = (S + BLOCK - 1) // BLOCK
+    pad = NB * BLOCK - S
+    NBv = NB - (text_length + pad) // BLOCK
+    return Layout(S, NB, NBv, text_length, S, S, NB, 0, text_length, S, "cogvideo")
+
+
+def layout_wan(S: int, first_frame_blocks: int = 0) -> Layout:
+    """rectified_wan21_attn.py:297-313 (visual only, pad to x128, first-frame square)."""
+    NB = (S + BLOCK - 1) // BLOCK
+    return Layout(S, NB, NB, 0, S, S, NB, int(first_frame_blocks or 0), 0, S, "wan")
+
+
+# ------------------------------------------------------------------------------------------------------
+# statistics
+# ------------------------------------------------------------------------------------------------------
+def pool(x: np.ndarray, s_valid: int, nb: int, want_mad: bool):
+    """x [S?, D] fp32 -> (mean [nb, D], mad [nb, D] | None).  Contract C2/C3."""
+    x = np.ascontiguousarray(x[:s_valid], dtype=np.float32)
+    D = x.shape[1]
+    mean = np.empty((nb, D), np.float32)
+    mad = np.empty((nb, D), np.float32) if want_mad else None
+    _lib().orc_pool(_f32p(x), min(s_valid, x.shape[0]), nb, BLOCK, D, _f32p(mean),
+                    _f32p(mad) if want_mad else None)
+    return mean, mad
+
+
+def dots(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """out[i, j] = fmaf-chain dot(a[i], b[j]).  Contract C4."""
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    out = np.empty((a.shape[0], b.shape[0]), np.float32)
+    _lib().orc_dots(_f32p(a), _f32p(b), a.shape[0], b.shape[0], a.shape[1], _f32p(out))
+    return out
+
+
+def orc_exp(x: float) -> float:
+    return float(_lib().orc_exp(ctypes.c_float(x)))
+
+
+def softmax_scale(D: int) -> np.float32:
+    """head_dim ** -0.5 as the fp32 the reference multiplies with (hunyuan :208)."""
+    return np.float32(float(D) ** -0.5)
+
+
+@dataclass
+class HeadStats:
+    qbar: np.ndarray
+    kbar: np.ndarray
+    vbar: np.ndarray
+    aq: np.ndarray
+    ak: np.ndarray
+
+
+def head_stats(q, k, v, lay: Layout) -> HeadStats:
+    """Pooling of one (b, h) slice; q, k, v are [S, D] fp32 (hunyuan :189-194, :356; gapr_mask.py:19-23,:30)."""
+    nq = lay.NBv
+    qbar, aq = pool(q[: nq * BLOCK], min(lay.S, nq * BLOCK), nq, True)
+    kbar, ak = pool(k[: nq * BLOCK], min(lay.pool_valid, nq * BLOCK), nq, True)
+    vbar, _ = pool(v, lay.pool_valid, lay.NB_total, False)
+    return HeadStats(qbar, kbar, vbar, aq, ak)
+
+
+def select_head(q, k, v, lay: Layout, top_k: int, p: float, neighbor: Optional[np.ndarray],
+                rows: Optional[Sequence[int]] = None, stats: Optional[HeadStats] = None):
+    """Mask selection + rectification terms for one (b, h) slice.
+
+    Returns dict with kept [nrows, NB_total] u8, unrel [nrows, NBv] u8, probs [nrows, L], w [nrows, L],
+    n_needed [nrows], R [nrows], comp [nrows, D], rows.
+    Follows _build_block_index_with_importance_optimized (hunyuan :171-280 / wan21 :171-273) and the inline
+    rectification (hunyuan :348-357).
+    """
+    D = q.shape[1]
+    st = stats or head_stats(q, k, v, lay)
+    rows = list(range(lay.NBv)) if rows is None else list(rows)
+    nr = len(rows)
+    qb = st.qbar[rows]
+    s_vis = dots(qb, st.kbar)
+    eq = dots(st.aq[rows], st.kbar)
+    ek = dots(qb, st.ak)
+    if lay.n_txt > 0:
+        ktxt = np.ascontiguousarray(k[lay.NBv * BLOCK: lay.NBv * BLOCK + lay.n_txt], np.float32)
+        s_txt = dots(qb, ktxt)
+    else:
+        s_txt = np.zeros((nr, 1), np.float32)
+    L = lay.L
+    kept = np.zeros((nr, lay.NB_total), np.uint8)
+    unrel = np.zeros((nr, lay.NBv), np.uint8)
+    probs = np.zeros((nr, L), np.float32)
+    w = np.zeros((nr, L), np.float32)
+    n_needed = np.zeros(nr, np.int32)
+    R = np.zeros(nr, np.float32)
+    lib = _lib()
+    scale = softmax_scale(D)
+    thr = np.float32(p)
+    nbr_u8 = None
+    if neighbor is not None:
+        nbr_u8 = np.ascontiguousarray(np.asarray(neighbor)[: lay.NBv, : lay.NBv], np.uint8)
+    nn = ctypes.c_int(0)
+    rr = ctypes.c_float(0)
+    for a, i in enumerate(rows):
+        lib.orc_select_row(_f32p(s_vis[a]), _f32p(s_txt[a]), _f32p(eq[a]), _f32p(ek[a]),
+                           _u8p(nbr_u8[i]) if nbr_u8 is not None else None,
+                           lay.NBv, lay.n_txt, lay.NB_total, lay.text_end_block, int(i), lay.ffb, int(top_k),
+                           ctypes.c_float(thr), ctypes.c_float(scale), _u8p(kept[a]), _u8p(unrel[a]),
+                           _f32p(probs[a]), _f32p(w[a]), ctypes.byref(nn), ctypes.byref(rr))
+        n_needed[a] = nn.value
+        R[a] = rr.value
+    comp = (w.astype(np.float64) @ st.vbar[:L].astype(np.float64)).astype(np.float32)
+    return dict(kept=kept, unrel=unrel, probs=probs, w=w, n_needed=n_needed, R=R, comp=comp, rows=rows,
+                s_vis=s_vis, s_txt=s_txt, eq=eq, ek=ek, stats=st)
+
+
+# ------------------------------------------------------------------------------------------------------
+# attention proper
+# ------------------------------------------------------------------------------------------------------
+def _masked_attention_rows(qr, k, v, col_ok, sm_scale):
+    """softmax(qr k^T * sm_scale) v restricted to columns where col_ok; float64 math."""
+    s = (qr.astype(np.float64) @ k.astype(np.float64).T) * sm_scale
+    s = np.where(col_ok[None, :], s, -np.inf)
+    m = s.max(axis=1, keepdims=True)
+    e = np.exp(s - m)
+    return (e @ v.astype(np.float64)) / e.sum(axis=1, keepdims=True)
+
+
+def sparse_attention_head(q, k, v, lay: Layout, kept_rows: np.ndarray, rows: Sequence[int]):
+    """Block-sparse attention for q-blocks `rows` of one head (semantics of the reference Triton kernel,
+    hunyuan :15-105: kept blocks only, kv columns >= seqlen masked, q rows >= S not produced)."""
+    D = q.shape[1]
+    sm = float(D) ** -0.5
+    out = np.zeros((len(rows), BLOCK, D), np.float64)
+    Spad = lay.NB_total * BLOCK
+    kp = np.zeros((Spad, D), np.float32)
+    vp = np.zeros((Spad, D), np.float32)
+    kp[: k.shape[0]] = k
+    vp[: v.shape[0]] = v
+    col_tok = np.arange(Spad)
+    for a, i in enumerate(rows):
+        r0 = i * BLOCK
+        nrow = max(0, min(BLOCK, lay.S - r0))
+        if nrow == 0:
+            continue
+        col_ok = (np.repeat(kept_rows[a].astype(bool), BLOCK)) & (col_tok < lay.kv_valid)
+        out[a, :nrow] = _masked_attention_rows(q[r0: r0 + nrow], kp, vp, col_ok, sm)
+    return out
+
+
+def dense_attention(q, k, v, kv_valid: Optional[int] = None):
+    """Exact softmax attention for one head; fullattn(mode='torch'/'vanilla') semantics (attn.py:101-149)."""
+    D = q.shape[1]
+    n = k.shape[0] if kv_valid is None else kv_valid
+    ok = np.arange(k.shape[0]) < n
+    return _masked_attention_rows(q, k, v, ok, float(D) ** -0.5)
+
+
+def rectified_attention(q, k, v, lay: Layout, top_k: int, p: float, neighbor=None, want_parts: bool = False):
+    """Whole operator: q, k, v [B, H, S, D] fp32 (bf16/fp16-representable values) -> [B, S, H*D] fp32.
+
+    Follows block_sparse_attention_combined (hunyuan :283-389, flux :282-376, cogvideo :282-378,
+    wan21 :276-357), with all mask statistics in the fp32 contract.
+    """
+    B, H, S, D = q.shape
+    assert S == lay.S
+    out = np.zeros((B, S, H, D), np.float32)
+    parts = []
+    nvis_tok = lay.NBv * BLOCK
+    for b in range(B):
+        for h in range(H):
+            qq, kk, vv = q[b, h], k[b, h], v[b, h]
+            if lay.pool_valid < S:  # hunyuan zeroes masked K/V rows (:307-308)
+                kk = kk.copy()
+                vv = vv.copy()
+                kk[lay.pool_valid:] = 0
+                vv[lay.pool_valid:] = 0
+            sel = select_head(qq, kk, vv, lay, top_k, p, neighbor)
+            o = sparse_attention_head(qq, kk, vv, lay, sel["kept"], sel["rows"])
+            o = o * sel["R"][:, None, None].astype(np.float64) + sel["comp"][:, None, :].astype(np.float64)
+            o = o.reshape(-1, D)[: min(S, nvis_tok)]
+            out[b, : o.shape[0], h] = o
+            if lay.q_text_valid > 0:
+                r0 = nvis_tok
+                ot = dense_attention(qq[r0: r0 + lay.q_text_valid], kk, vv, lay.kv_text_valid)
+                out[b, r0: r0 + lay.q_text_valid, h] = ot
+            if want_parts:
+                parts.append(sel)
+    res = out.reshape(B, S, H * D)
+    return (res, parts) if want_parts else res
+
+
+def pack_bits(mask_u8: np.ndarray) -> np.ndarray:
+    """[..., N] 0/1 -> [..., ceil(N/32)] uint32, bit j%32 of word j//32 (the library's bitmask format)."""
+    n = mask_u8.shape[-1]
+    nw = (n + 31) // 32
+    padded = np.zeros(mask_u8.shape[:-1] + (nw * 32,), np.uint8)
+    padded[..., :n] = mask_u8 != 0
+    bits = padded.reshape(mask_u8.shape[:-1] + (nw, 32)).astype(np.uint32)
+    return (bits << np.arange(32, dtype=np.uint32)).sum(axis=-1).astype(np.uint32)
+
+
+def unpack_bits(words: np.ndarray, n: int) -> np.ndarray:
+    b = ((words[..., :, None] >> np.arange(32, dtype=np.uint32)) & 1).astype(np.uint8)
+    return b.reshape(words.shape[:-1] + (-1,))[..., :n]

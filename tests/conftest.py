@@ -1,0 +1,49 @@
+import ast
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_op_case(name):
+    """Load tests/golden/op_<name>.npz -> (meta dict, arrays dict with masks unpacked)."""
+    z = np.load(os.path.join(GOLDEN, f"op_{name}.npz"))
+    meta = ast.literal_eval(str(z["meta"]))
+    oh_shape = tuple(z["one_hot_shape"])
+    ng_shape = tuple(z["nogapr_shape"])
+    one_hot = np.unpackbits(z["one_hot"], axis=-1)[..., : oh_shape[-1]]
+    nogapr = np.unpackbits(z["nogapr"], axis=-1)[..., : ng_shape[-1]]
+    return meta, dict(one_hot=one_hot, nogapr=nogapr, probs=z["probs"], out=z["out"])
+
+
+OP_CASES = ["wan_640", "wan_pad_1450", "wan_d64_1100", "wan_nonbr_1024", "hunyuan_1280", "hunyuan_3328",
+            "hunyuan_full_1536", "flux_1536", "cogvideo_994", "wan_smooth_2048"]
+
+
+def case_inputs(meta):
+    """Regenerate the fixture's inputs (counter-based PRNG) and its oracle Layout + neighbour matrix."""
+    from oracle import oracle as orc
+    from rectified_spaattn_amd import synth
+    q, k, v = synth.structured_qkv(meta["seed"], meta["B"], meta["H"], meta["S"], meta["D"],
+                                   smooth=meta.get("smooth", 0.0))
+    var = meta["variant"]
+    if var == "hunyuan":
+        lay = orc.layout_hunyuan(meta["S"], meta["num_true"])
+    elif var == "flux":
+        lay = orc.layout_flux(meta["S"], meta["text_length"])
+    elif var == "cogvideo":
+        lay = orc.layout_cogvideo(meta["S"], meta["text_length"])
+    else:
+        lay = orc.layout_wan(meta["S"], meta.get("ffb", 0))
+    nbr = synth.banded_neighbors(lay.NBv, meta["nb_width"]) if meta["nb_width"] >= 0 else None
+    return q, k, v, lay, nbr

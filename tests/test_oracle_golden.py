@@ -1,0 +1,88 @@
+"""Pins the CPU oracle (oracle/) against vectors produced by the reference's own code
+(tests/golden/make_golden.py, run in the build container).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, OP_CASES, case_inputs, load_op_case
+from oracle import oracle as orc
+
+
+@pytest.mark.parametrize("name", OP_CASES)
+def test_operator_matches_reference(name):
+    meta, gold = load_op_case(name)
+    q, k, v, lay, nbr = case_inputs(meta)
+    out, parts = orc.rectified_attention(q, k, v, lay, meta["top_k"], meta["p"], nbr, want_parts=True)
+    for b in range(meta["B"]):
+        for h in range(meta["H"]):
+            sel = parts[b * meta["H"] + h]
+            # block mask and GAPR mask: bit-exact
+            assert np.array_equal(sel["kept"], gold["one_hot"][b, h]), f"{name}: block mask differs (b{b} h{h})"
+            assert np.array_equal(sel["unrel"], gold["nogapr"][b, h]), f"{name}: GAPR mask differs (b{b} h{h})"
+            # implicit full attention (IPAR probabilities): fp32 round-off only
+            np.testing.assert_allclose(sel["probs"], gold["probs"][b, h], rtol=2e-5, atol=1e-6)
+    # whole operator: the reference ran its Triton kernel in fp16 (interpreter), the oracle in fp64
+    err = np.abs(out - gold["out"])
+    assert err.max() < 2e-3, f"{name}: max|dO| = {err.max()}"
+    assert err.mean() < 2e-4
+
+
+def test_estimate_pr_gain_matches_reference():
+    from rectified_spaattn_amd import synth
+    z = np.load(os.path.join(GOLDEN, "gapr_1024.npz"))
+    shape = tuple(z["shape"])
+    gold = np.unpackbits(z["mask"], axis=-1)[..., : shape[-1]].astype(bool)
+    q, k, _ = synth.structured_qkv(int(z["seed"]), 1, 2, 1024, 128)
+    for h in range(2):
+        qbar, aq = orc.pool(q[0, h], 1024, 8, True)
+        kbar, ak = orc.pool(k[0, h], 1024, 8, True)
+        np.testing.assert_allclose(qbar, z["q_pools"][0, h], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(kbar, z["k_pools"][0, h], rtol=1e-5, atol=1e-6)
+        s = orc.dots(qbar, kbar)
+        np.testing.assert_allclose(s, z["scores"][0, h], rtol=1e-4, atol=1e-4)
+        unrel = ~(np.abs(s) > (np.abs(orc.dots(aq, kbar)) + np.abs(orc.dots(qbar, ak))))
+        assert np.array_equal(unrel, gold[0, h])
+
+
+def test_dense_matches_reference():
+    from rectified_spaattn_amd import synth
+    z = np.load(os.path.join(GOLDEN, "dense_1536.npz"))
+    q, k, v = synth.structured_qkv(int(z["seed"]), 1, 1, 1536, 128)
+    n = int(z["n_valid"])
+    o = orc.dense_attention(q[0, 0], k[0, 0], v[0, 0])
+    np.testing.assert_allclose(o, z["torch"][0, 0], atol=2e-5)
+    om = orc.dense_attention(q[0, 0], k[0, 0], v[0, 0], kv_valid=n)
+    np.testing.assert_allclose(om, z["vanilla_masked"][0, 0], atol=2e-5)
+    # flash mode also returns [b, a, s, d] (attn.py:153): rows < n attend kv < n ; rows >= n attend kv >= n
+    fl = z["flash_varlen"][0, 0]
+    np.testing.assert_allclose(om[:n], fl[:n], atol=2e-5)
+
+
+def test_exp_contract_accuracy():
+    xs = np.linspace(-80, 0, 4001, dtype=np.float32)
+    got = np.array([orc.orc_exp(float(x)) for x in xs])
+    ref = np.exp(xs.astype(np.float64))
+    rel = np.abs(got - ref) / ref
+    assert rel.max() < 2e-5
+    assert orc.orc_exp(0.0) == 1.0
+    assert orc.orc_exp(-1000.0) == 0.0
+
+
+def test_keep_all_equals_dense():
+    """top_k = NB  =>  R == 1, comp == 0, output == dense attention (SURVEY section 4 invariant)."""
+    from rectified_spaattn_amd import synth
+    q, k, v = synth.structured_qkv(3, 1, 1, 700, 64)
+    lay = orc.layout_wan(700, 0)
+    out, parts = orc.rectified_attention(q, k, v, lay, lay.NBv, 0.3, None, want_parts=True)
+    assert parts[0]["kept"].all()
+    np.testing.assert_allclose(parts[0]["R"], 1.0, atol=1e-5)
+    assert np.abs(parts[0]["comp"]).max() == 0
+    dense = orc.dense_attention(q[0, 0], k[0, 0], v[0, 0])
+    np.testing.assert_allclose(out[0], dense, atol=1e-5)
+
+
+def test_bit_packing_roundtrip():
+    rng = np.random.default_rng(0)
+    m = (rng.random((3, 5, 77)) < 0.3).astype(np.uint8)
+    assert np.array_equal(orc.unpack_bits(orc.pack_bits(m), 77), m)
