@@ -1,0 +1,149 @@
+/*
+ * rsa.h -- C-ABI of librsa_hip.so: the MI355X (gfx950) rectified block-sparse attention path.
+ *
+ * This is the drop-in boundary for the reference's hot path (BienLuky/Rectified-SpaAttn).  The reference has
+ * no FFI of its own (it is pure Python + one Triton kernel); each entry point below names the reference
+ * function (file:line under the reference root) whose work it replaces, and INTEGRATION.md shows the
+ * ctypes binding a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all tensor pointers are DEVICE pointers unless marked host
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), never allocates, never
+ *     synchronises, never throws; returns RSA_OK or a negative rsa_status
+ *   - q/k/v are [B, H, S, D] views described by element strides (stride_b, stride_h, stride_s); the head
+ *     dimension is contiguous.  dtype: RSA_BF16 or RSA_FP16 (2-byte elements)
+ *   - "bh" below means the flattened index b*H + h
+ *   - statistics follow the fp32 numeric contract written in oracle/rsa_oracle.c (C1..C8)
+ */
+#ifndef RSA_H_
+#define RSA_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSA_BLOCK 128 /* tokens per block (block_size_M = block_size_N = 128 in every reference script) */
+
+typedef enum rsa_status {
+    RSA_OK = 0,
+    RSA_ERR_BAD_ARG = -1,       /* null pointer, negative size, inconsistent layout */
+    RSA_ERR_UNSUPPORTED = -2,   /* head_dim not in {64,128}, dtype unknown, row too long for the select kernel */
+    RSA_ERR_WORKSPACE = -3,     /* workspace too small */
+    RSA_ERR_LAUNCH = -4         /* hipGetLastError() after a launch was not hipSuccess */
+} rsa_status;
+
+typedef enum rsa_dtype { RSA_BF16 = 0, RSA_FP16 = 1 } rsa_dtype;
+
+/* Geometry of one self-attention call.  The four reference variants differ only in these numbers
+ * (hunyuan :313-332, flux :307-320, cogvideo :306-322, wan21 :297-313). */
+typedef struct rsa_layout {
+    int32_t B, H, D;
+    int32_t S;               /* true sequence length (q and kv) */
+    int32_t NB_total;        /* ceil(S / 128): the reference zero-pads up to this */
+    int32_t NBv;             /* visual blocks == sparse query blocks */
+    int32_t n_txt;           /* valid text tokens scored individually ("attenable"); 0 = no text tail, no IPAR */
+    int32_t kv_valid;        /* kv columns >= kv_valid are masked in the sparse pass ("seqlens") */
+    int32_t pool_valid;      /* K/V rows >= pool_valid count as zero when pooling (hunyuan zeroes them :307-308) */
+    int32_t text_end_block;  /* text blocks [NBv, text_end_block) are kept by every query block */
+    int32_t first_frame_blocks; /* wan: rows < ffb keep cols < ffb (wan21 :270-271) */
+    int32_t q_text_valid;    /* text query rows [NBv*128, NBv*128+q_text_valid): dense attention */
+    int32_t kv_text_valid;   /*   ... over kv [0, kv_text_valid); later rows up to S are written as 0 */
+    int32_t dtype;           /* rsa_dtype */
+} rsa_layout;
+
+typedef struct rsa_tensor4 { /* a [B, H, S, D] view */
+    const void* ptr;
+    int64_t stride_b, stride_h, stride_s; /* in elements */
+} rsa_tensor4;
+
+typedef struct rsa_out4 {
+    void* ptr;
+    int64_t stride_b, stride_h, stride_s;
+} rsa_out4;
+
+/* Sizes (in elements) of the intermediate buffers for a layout; all are per call. */
+typedef struct rsa_buffers {
+    float* qbar;      /* [BH, NBv, D]       block means of visual Q            */
+    float* aq;        /* [BH, NBv, D]       mean |Q - qbar|                    */
+    float* kbar;      /* [BH, NBv, D]                                          */
+    float* ak;        /* [BH, NBv, D]                                          */
+    float* vbar;      /* [BH, NB_total, D]                                     */
+    float* scores;    /* [BH, NBv, NBv + n_txt]  unscaled pooled scores        */
+    uint8_t* unrel;   /* [BH, NBv, NBv]     GAPR: 1 = pooled compensation NOT trustworthy */
+    float* probs;     /* [BH, NBv, L]       L = NBv + (n_txt > 0): implicit full attention row */
+    float* w;         /* [BH, NBv, L]       compensation weights (probs where dropped & reliable, else 0) */
+    float* R;         /* [BH, NBv]          rectification factor               */
+    float* comp;      /* [BH, NBv, D]       sum_j w_ij * vbar_j                 */
+    uint32_t* bitmask;/* [BH, NBv, ceil(NB_total/32)]  kept blocks, bit j%32 of word j/32 */
+    int32_t* cols;    /* [BH, NBv, NB_total] kept block indices ascending (first counts[] entries valid) */
+    int32_t* counts;  /* [BH, NBv]                                              */
+} rsa_buffers;
+
+/* Library identification: returns 10000*major + 100*minor + patch. */
+int rsa_version(void);
+
+/* Bytes needed for each rsa_buffers member, written in member order into sizes[14], and their sum
+ * (each rounded up to 256 B) into *total.  Lets a caller carve one workspace.  Replaces the ~25 temporaries
+ * the reference allocates per call (hunyuan :189-262, :348-357). */
+int rsa_buffer_bytes(const rsa_layout* lay, size_t sizes[14], size_t* total);
+
+/* Carve `ws` (>= total bytes from rsa_buffer_bytes, 256-B aligned) into an rsa_buffers. */
+int rsa_carve_workspace(const rsa_layout* lay, void* ws, size_t ws_bytes, rsa_buffers* out);
+
+/* K1 -- one HBM pass over Q (visual rows), K, V: block means and mean-absolute-deviations.
+ * Replaces: Q/K pooling hunyuan :189-194 (wan21 :189-192), V pooling :356, and the |Q - qbar| / |K - kbar|
+ * statistics of estimate_pr_gain, gapr_mask.py:19-23,:30. */
+int rsa_pool_stats(const rsa_layout* lay, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v, const rsa_buffers* buf,
+                   void* stream);
+
+/* K2 -- pooled scores qbar.kbar^T (+ one column per valid text token), and the GAPR bit.
+ * Replaces: bmm hunyuan :198-205 and estimate_pr_gain gapr_mask.py:26-42. */
+int rsa_pooled_scores(const rsa_layout* lay, rsa_tensor4 k, const rsa_buffers* buf, void* stream);
+
+/* K3 -- per (b,h,q-block) row: softmax, IPAR, stable descending sort, cumulative threshold, top-k,
+ * neighbour / text / first-frame union, bitmask + ascending column list, R and compensation weights.
+ * neighbor: device uint8 [NBv, NBv] (row-major, nonzero = neighbour) or NULL.
+ * Replaces: hunyuan :208-277 (wan21 :206-271) and the rectification masks :348-355. */
+int rsa_select_mask(const rsa_layout* lay, const uint8_t* neighbor, int top_k, float p_remain,
+                    const rsa_buffers* buf, void* stream);
+
+/* K4 -- comp = w @ vbar.  Replaces torch.matmul(attn_pool_novalid, value_pool), hunyuan :357. */
+int rsa_compensation(const rsa_layout* lay, const rsa_buffers* buf, void* stream);
+
+/* K5 -- block-sparse flash attention over the kept lists with the fused rectification epilogue
+ *   O = (acc / l) * R + comp   for visual query blocks, exact dense attention for text query rows,
+ * written straight into `out` ([B, S, H, D] element strides: the reference's final permute+reshape,
+ * hunyuan :383-387, becomes a strided store).
+ * Replaces: _triton_block_sparse_attention_onehot + kernel hunyuan :15-168, the R/comp combine :365,
+ * the text-row flash call :371-380 and the concat :383. */
+int rsa_block_sparse_fwd(const rsa_layout* lay, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
+                         const rsa_buffers* buf, rsa_out4 out, void* stream);
+
+/* The whole operator = K1..K5 on one stream.  Replaces rectified_block_sparse_attention /
+ * block_sparse_attention_combined (hunyuan :283-417, flux :282-405, cogvideo :282-407, wan21 :276-386). */
+int rsa_rectified_attention(const rsa_layout* lay, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
+                            const uint8_t* neighbor, int top_k, float p_remain, void* workspace,
+                            size_t workspace_bytes, rsa_out4 out, void* stream);
+
+/* Dense attention with the reference's two-segment varlen semantics (attn.py:107-120 as called from
+ * hunyuan :503-524): query rows < q_split attend kv [0, kv_split); rows >= q_split attend kv [kv_split, Sk).
+ * q: [B,H,Sq,D], k/v: [B,H,Sk,D]; out: [B,Sq,H,D]-strided.  With q_split = Sq, kv_split = Sk it is plain
+ * softmax attention (fullattn mode "torch"/"vanilla", attn.py:101-106, :121-149, without bias). */
+int rsa_dense_fwd(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
+                  int q_split, int kv_split, rsa_out4 out, void* stream);
+
+/* Stand-alone GAPR for callers of estimate_pr_gain (gapr_mask.py:4): blocks are [BH, N, 128, D] contiguous
+ * 2-byte elements, pools [BH, N, D] fp32, scores [BH, NQ, NK] fp32 -> mask [BH, NQ, NK] uint8 (1 = ~gapr_mask). */
+int rsa_estimate_pr_gain(int BH, int NQ, int NK, int D, int dtype, const void* q_blocks, const void* k_blocks,
+                         const float* q_pools, const float* k_pools, const float* scores, float* scratch_aq,
+                         float* scratch_ak, uint8_t* mask_out, void* stream);
+
+const char* rsa_status_string(int status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSA_H_ */

@@ -1,0 +1,218 @@
+"""Host side of the rectified block-sparse attention path: layout bookkeeping + calls into librsa_hip.so.
+
+PyTorch is used only for device memory and the current HIP stream.  The four reference operator variants
+(rectified_{hunyuan,flux,cogvideo,wan21}_attn.py::block_sparse_attention_combined) differ only in the
+numbers of `LayoutSpec`; one code path serves them all.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+from ._lib import BLOCK, BUFFER_NAMES, RsaBuffers, RsaLayout, RsaOut4, RsaTensor4
+
+
+@dataclass
+class LayoutSpec:
+    """Geometry of one call; see include/rsa.h::rsa_layout for the field meanings."""
+    S: int
+    NB_total: int
+    NBv: int
+    n_txt: int
+    kv_valid: int
+    pool_valid: int
+    text_end_block: int
+    first_frame_blocks: int
+    q_text_valid: int
+    kv_text_valid: int
+
+    # -- the reference's variants (file:line under the reference root) ---------------------------------
+    @staticmethod
+    def hunyuan(S: int, num_true: int) -> "LayoutSpec":
+        """rectified_hunyuan_attn.py:313-332: text tail padded to 256, num_true = attention_mask.sum()."""
+        if S % BLOCK:
+            raise ValueError("HunyuanVideo layout needs S % 128 == 0 (the reference reshapes without padding)")
+        NB = S // BLOCK
+        NBv = NB - 256 // BLOCK
+        n_txt = 256 - (S - num_true)
+        if NBv < 0 or n_txt <= 0 or n_txt > 256:
+            # reference: attenable == 0 makes scores[..., :-0] empty and crashes
+            raise ValueError(f"HunyuanVideo layout needs 1..256 valid text tokens, got {n_txt}")
+        return LayoutSpec(S, NB, NBv, n_txt, num_true, num_true, (num_true + BLOCK - 1) // BLOCK, 0,
+                          num_true - NBv * BLOCK, num_true)
+
+    @staticmethod
+    def flux(S: int, text_length: int, s_k: Optional[int] = None) -> "LayoutSpec":
+        """rectified_flux_attn.py:307-320."""
+        if S % BLOCK:
+            raise ValueError("Flux layout needs S % 128 == 0")
+        s_k = S if s_k is None else int(s_k)
+        NB = S // BLOCK
+        NBv = NB - text_length // BLOCK
+        return LayoutSpec(S, NB, NBv, text_length, s_k, S, (s_k + BLOCK - 1) // BLOCK, 0, S - NBv * BLOCK, s_k)
+
+    @staticmethod
+    def cogvideo(S: int, text_length: int, s_k: Optional[int] = None) -> "LayoutSpec":
+        """rectified_cogvideo_attn.py:306-322 (zero-pad to x128, every text block kept)."""
+        NB = (S + BLOCK - 1) // BLOCK
+        pad = NB * BLOCK - S
+        NBv = NB - (text_length + pad) // BLOCK
+        s_k = S if s_k is None else int(s_k)
+        return LayoutSpec(S, NB, NBv, text_length, S, S, NB, 0, text_length, s_k)
+
+    @staticmethod
+    def wan(S: int, first_frame_blocks: Optional[int] = 0) -> "LayoutSpec":
+        """rectified_wan21_attn.py:297-313 (visual only)."""
+        NB = (S + BLOCK - 1) // BLOCK
+        return LayoutSpec(S, NB, NB, 0, S, S, NB, int(first_frame_blocks or 0), 0, S)
+
+    @property
+    def L(self) -> int:
+        return self.NBv + (1 if self.n_txt > 0 else 0)
+
+    def to_c(self, B: int, H: int, D: int, dtype: torch.dtype) -> RsaLayout:
+        return RsaLayout(B, H, D, self.S, self.NB_total, self.NBv, self.n_txt, self.kv_valid, self.pool_valid,
+                         self.text_end_block, self.first_frame_blocks, self.q_text_valid, self.kv_text_valid,
+                         dtype_code(dtype))
+
+
+def dtype_code(dtype: torch.dtype) -> int:
+    if dtype == torch.bfloat16:
+        return _lib.RSA_BF16
+    if dtype == torch.float16:
+        return _lib.RSA_FP16
+    raise AssertionError(f"rectified_spaattn_amd supports bfloat16 / float16 device tensors, got {dtype}")
+
+
+def _require_device(*ts):
+    for t in ts:
+        if not t.is_cuda:
+            raise _lib.RsaError("this operator runs only on the HIP extension (device tensors); "
+                                "CPU tensors are supported by fullattn(mode='torch'|'vanilla') alone")
+
+
+def _as_bhsd(t: torch.Tensor) -> torch.Tensor:
+    """Accept any [B,H,S,D] view whose head dim is contiguous and whose strides keep 16-byte row chunks."""
+    if t.stride(-1) != 1 or any(s % 8 for s in t.stride()[:-1]) or t.data_ptr() % 16:
+        t = t.contiguous()
+    return t
+
+
+def _t4(t: torch.Tensor) -> RsaTensor4:
+    return RsaTensor4(t.data_ptr(), t.stride(0), t.stride(1), t.stride(2))
+
+
+def _stream() -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_BUF_DTYPES = dict(qbar=torch.float32, aq=torch.float32, kbar=torch.float32, ak=torch.float32, vbar=torch.float32,
+                   scores=torch.float32, unrel=torch.uint8, probs=torch.float32, w=torch.float32, R=torch.float32,
+                   comp=torch.float32, bitmask=torch.int32, cols=torch.int32, counts=torch.int32)
+
+
+def buffer_shapes(spec: LayoutSpec, B: int, H: int, D: int) -> Dict[str, tuple]:
+    BH, NBv, NB = B * H, spec.NBv, spec.NB_total
+    NS, L, NW = NBv + spec.n_txt, spec.L, (NB + 31) // 32
+    return dict(qbar=(BH, NBv, D), aq=(BH, NBv, D), kbar=(BH, NBv, D), ak=(BH, NBv, D), vbar=(BH, NB, D),
+                scores=(BH, NBv, NS), unrel=(BH, NBv, NBv), probs=(BH, NBv, L), w=(BH, NBv, L), R=(BH, NBv),
+                comp=(BH, NBv, D), bitmask=(BH, NBv, NW), cols=(BH, NBv, NB), counts=(BH, NBv))
+
+
+def alloc_buffers(spec: LayoutSpec, B: int, H: int, D: int, device) -> Dict[str, torch.Tensor]:
+    return {n: torch.empty(s, dtype=_BUF_DTYPES[n], device=device) for n, s in buffer_shapes(spec, B, H, D).items()}
+
+
+def _c_buffers(bufs: Dict[str, torch.Tensor]) -> RsaBuffers:
+    return RsaBuffers(*[bufs[n].data_ptr() if bufs[n].numel() else None for n in BUFFER_NAMES])
+
+
+_NEIGHBOR_CACHE: Dict[tuple, torch.Tensor] = {}
+
+
+def neighbor_on_device(block_neighbor_list, NBv: int, device) -> Optional[torch.Tensor]:
+    """uint8 [NBv, NBv] device copy of block_neighbor_list[:NBv, :NBv], cached (the reference re-uploads
+    the CPU bool matrix on every call, rectified_hunyuan_attn.py:267-268)."""
+    if block_neighbor_list is None:
+        return None
+    t = block_neighbor_list
+    key = (t.data_ptr(), tuple(t.shape), str(t.device), t._version, NBv, str(device))
+    hit = _NEIGHBOR_CACHE.get(key)
+    if hit is None:
+        if len(_NEIGHBOR_CACHE) > 16:
+            _NEIGHBOR_CACHE.clear()
+        if t.shape[0] < NBv or t.shape[1] < NBv:
+            raise ValueError(f"block_neighbor_list {tuple(t.shape)} smaller than [{NBv},{NBv}]")
+        hit = t[:NBv, :NBv].to(device=device, dtype=torch.uint8).contiguous()
+        _NEIGHBOR_CACHE[key] = hit
+    return hit
+
+
+def rectified_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, spec: LayoutSpec, top_k: int,
+                        p_remain: float, block_neighbor_list=None, return_parts: bool = False,
+                        shape_xfuse: bool = False):
+    """q, k, v: [B, H, S, D] device tensors -> [B, S, H*D] (or [B, S, H, D] if shape_xfuse).
+
+    K1 pool_stats -> K2 pooled_scores -> K3 select_mask -> K4 compensation -> K5 block_sparse_fwd on the
+    current stream; no host synchronisation, no K/V mutation (the reference zeroes masked K/V rows in place,
+    hunyuan :307-308; here they are treated as zero by predication)."""
+    _require_device(q, k, v)
+    L = _lib.lib()
+    B, H, S, D = q.shape
+    assert k.shape == q.shape and v.shape == q.shape, "q, k, v must have equal shapes (self-attention)"
+    assert D in (16, 32, 64, 128), "head_dim must be in {16, 32, 64, 128}"  # reference :121
+    assert k.dtype == q.dtype and v.dtype == q.dtype
+    if S != spec.S:
+        raise ValueError(f"layout S={spec.S} does not match tensors S={S}")
+    q, k, v = _as_bhsd(q), _as_bhsd(k), _as_bhsd(v)
+    lay = spec.to_c(B, H, D, q.dtype)
+    bufs = alloc_buffers(spec, B, H, D, q.device)
+    cb = _c_buffers(bufs)
+    out = torch.empty((B, S, H, D), dtype=q.dtype, device=q.device)
+    o4 = RsaOut4(out.data_ptr(), out.stride(0), out.stride(2), out.stride(1))
+    nbr = neighbor_on_device(block_neighbor_list, spec.NBv, q.device)
+    st = _stream()
+    tq, tk, tv = _t4(q), _t4(k), _t4(v)
+    with torch.cuda.device(q.device):
+        _lib.check(L.rsa_pool_stats(ctypes.byref(lay), tq, tk, tv, ctypes.byref(cb), st), "rsa_pool_stats")
+        _lib.check(L.rsa_pooled_scores(ctypes.byref(lay), tk, ctypes.byref(cb), st), "rsa_pooled_scores")
+        _lib.check(L.rsa_select_mask(ctypes.byref(lay), nbr.data_ptr() if nbr is not None else None, int(top_k),
+                                     float(p_remain), ctypes.byref(cb), st), "rsa_select_mask")
+        _lib.check(L.rsa_compensation(ctypes.byref(lay), ctypes.byref(cb), st), "rsa_compensation")
+        _lib.check(L.rsa_block_sparse_fwd(ctypes.byref(lay), tq, tk, tv, ctypes.byref(cb), o4, st),
+                   "rsa_block_sparse_fwd")
+    res = out if shape_xfuse else out.view(B, S, H * D)
+    return (res, bufs) if return_parts else res
+
+
+def dense_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, q_split: Optional[int] = None,
+                    kv_split: Optional[int] = None) -> torch.Tensor:
+    """Exact attention on the HIP kernel.  q [B,H,Sq,D], k/v [B,H,Sk,D] -> [B,Sq,H,D].
+    Rows < q_split attend kv [0, kv_split); rows >= q_split attend kv [kv_split, Sk) (attn.py:107-120)."""
+    _require_device(q, k, v)
+    L = _lib.lib()
+    B, H, Sq, D = q.shape
+    Sk = k.shape[2]
+    assert k.shape == v.shape and k.shape[0] == B and k.shape[1] == H and k.shape[3] == D
+    assert D in (16, 32, 64, 128), "head_dim must be in {16, 32, 64, 128}"
+    q, k, v = _as_bhsd(q), _as_bhsd(k), _as_bhsd(v)
+    q_split = Sq if q_split is None else int(q_split)
+    kv_split = Sk if kv_split is None else int(kv_split)
+    out = torch.empty((B, Sq, H, D), dtype=q.dtype, device=q.device)
+    o4 = RsaOut4(out.data_ptr(), out.stride(0), out.stride(2), out.stride(1))
+    with torch.cuda.device(q.device):
+        _lib.check(L.rsa_dense_fwd(B, H, Sq, Sk, D, dtype_code(q.dtype), _t4(q), _t4(k), _t4(v), q_split, kv_split,
+                                   o4, _stream()), "rsa_dense_fwd")
+    return out
+
+
+def unpack_bitmask(bitmask: torch.Tensor, n: int) -> torch.Tensor:
+    """[..., NW] int32 words -> [..., n] bool (bit j%32 of word j//32)."""
+    w = bitmask.to(torch.int64) & 0xFFFFFFFF
+    bits = (w.unsqueeze(-1) >> torch.arange(32, device=bitmask.device)) & 1
+    return bits.flatten(-2)[..., :n].bool()

@@ -1,0 +1,94 @@
+"""ctypes binding of librsa_hip.so (C-ABI declared in include/rsa.h).
+
+The HIP library is the product: there is no CPU or PyTorch fallback for device tensors.  If the shared
+object is missing or cannot be loaded this module raises, and every operator that needs it fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librsa_hip.so")
+
+RSA_BF16, RSA_FP16 = 0, 1
+BLOCK = 128
+
+
+class RsaError(RuntimeError):
+    pass
+
+
+class RsaLayout(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "B", "H", "D", "S", "NB_total", "NBv", "n_txt", "kv_valid", "pool_valid", "text_end_block",
+        "first_frame_blocks", "q_text_valid", "kv_text_valid", "dtype")]
+
+
+class RsaTensor4(ctypes.Structure):
+    _fields_ = [("ptr", ctypes.c_void_p), ("stride_b", ctypes.c_int64), ("stride_h", ctypes.c_int64),
+                ("stride_s", ctypes.c_int64)]
+
+
+class RsaOut4(ctypes.Structure):
+    _fields_ = RsaTensor4._fields_
+
+
+BUFFER_NAMES = ("qbar", "aq", "kbar", "ak", "vbar", "scores", "unrel", "probs", "w", "R", "comp", "bitmask",
+                "cols", "counts")
+
+
+class RsaBuffers(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in BUFFER_NAMES]
+
+
+_lib = None
+
+
+def lib():
+    """Load librsa_hip.so once; raise RsaError if it is not there (run __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RsaError(f"{LIB_PATH} not found: the HIP extension is not built "
+                       f"(python -c 'import __graft_entry__ as g; g.build()'); there is no fallback path")
+    L = ctypes.CDLL(LIB_PATH)
+    P = ctypes.POINTER
+    vp, i32, f32, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+    L.rsa_version.restype = i32
+    L.rsa_status_string.restype = ctypes.c_char_p
+    L.rsa_status_string.argtypes = [i32]
+    L.rsa_buffer_bytes.argtypes = [P(RsaLayout), P(sz * 14), P(sz)]
+    L.rsa_carve_workspace.argtypes = [P(RsaLayout), vp, sz, P(RsaBuffers)]
+    L.rsa_pool_stats.argtypes = [P(RsaLayout), RsaTensor4, RsaTensor4, RsaTensor4, P(RsaBuffers), vp]
+    L.rsa_pooled_scores.argtypes = [P(RsaLayout), RsaTensor4, P(RsaBuffers), vp]
+    L.rsa_select_mask.argtypes = [P(RsaLayout), vp, i32, f32, P(RsaBuffers), vp]
+    L.rsa_compensation.argtypes = [P(RsaLayout), P(RsaBuffers), vp]
+    L.rsa_block_sparse_fwd.argtypes = [P(RsaLayout), RsaTensor4, RsaTensor4, RsaTensor4, P(RsaBuffers), RsaOut4, vp]
+    L.rsa_rectified_attention.argtypes = [P(RsaLayout), RsaTensor4, RsaTensor4, RsaTensor4, vp, i32, f32, vp, sz,
+                                          RsaOut4, vp]
+    L.rsa_dense_fwd.argtypes = [i32] * 6 + [RsaTensor4, RsaTensor4, RsaTensor4, i32, i32, RsaOut4, vp]
+    L.rsa_estimate_pr_gain.argtypes = [i32] * 5 + [vp] * 9
+    for name in ("rsa_buffer_bytes", "rsa_carve_workspace", "rsa_pool_stats", "rsa_pooled_scores",
+                 "rsa_select_mask", "rsa_compensation", "rsa_block_sparse_fwd", "rsa_rectified_attention",
+                 "rsa_dense_fwd", "rsa_estimate_pr_gain"):
+        getattr(L, name).restype = i32
+    _lib = L
+    return L
+
+
+EXPORTED = ("rsa_version", "rsa_buffer_bytes", "rsa_carve_workspace", "rsa_pool_stats", "rsa_pooled_scores",
+            "rsa_select_mask", "rsa_compensation", "rsa_block_sparse_fwd", "rsa_rectified_attention",
+            "rsa_dense_fwd", "rsa_estimate_pr_gain", "rsa_status_string")
+
+
+def check(status: int, what: str):
+    """Status code -> the exception types the reference raises: bad head_dim / dtype are
+    AssertionError there (hunyuan :119-121); everything else is a RuntimeError subclass."""
+    if status == 0:
+        return
+    msg = f"{what}: {lib().rsa_status_string(status).decode()} (rsa_status {status})"
+    if status == -2:
+        raise AssertionError(msg)
+    raise RsaError(msg)

@@ -1,0 +1,451 @@
+// K5: block-sparse flash attention forward for gfx950 (MI355X), with the rectification epilogue fused.
+//
+// One workgroup (4 waves, 256 threads) owns one 128-row query block; wave w owns rows 32w..32w+31.
+// Keys/values stream through LDS in 64-key tiles (two per kept 128-key block), double-buffered, staged
+// through registers (global loads for tile t+1 are issued before tile t's MFMAs and written to LDS after
+// the next barrier).  Both GEMMs run on v_mfma_f32_32x32x16_{bf16,f16} in the "key on the register, query
+// row on the lane" orientation:
+//      S^T[key][q]  = K . Q^T      A = K rows (ds_read_b128 from an XOR-swizzled row-major tile), B = Q (registers)
+//      O^T[d][q]   += V^T . P^T    A = V^T (ds_read_b64_tr_b16 transposing reads), B = P^T = the S^T accumulator
+//                                      converted in place (no LDS round trip, no cross-lane traffic)
+// so the online-softmax state (m, l, rescale factor) of a query row lives on one lane (pair), and the only
+// cross-lane operation per tile is one v_permlane32_swap for the row max.
+//
+// Semantics kept from the reference kernel (rectified_hunyuan_attn.py:15-105): Q is pre-multiplied by
+// sm_scale*log2(e) and rounded to the input dtype (:61-62), P is rounded to the input dtype before PV (:97),
+// fp32 softmax statistics and accumulators, kv columns outside the row's range are -inf (:86-87), rows
+// beyond the sequence are not stored (:105).  Added: per-row kv ranges (the two-segment varlen semantics of
+// the flash call, attn.py:107-120), a NaN-free fully-masked-tile path, the fused O*R+comp epilogue
+// (hunyuan :365) and a strided [B,S,H,D] store (hunyuan :383-387).
+#include "rsa_common.h"
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <typename Tag>
+struct Elem;
+template <>
+struct Elem<bf16_tag> {
+    static __device__ __forceinline__ f32x16 mfma(s16x8 a, s16x8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
+                                                       c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ unsigned short from_f32(float f) {
+        return __builtin_bit_cast(unsigned short, (__bf16)f);
+    }
+    static __device__ __forceinline__ s16x8 cvt8(const float* f) {
+        bf16x8 r;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r[i] = (__bf16)f[i];
+        return __builtin_bit_cast(s16x8, r);
+    }
+};
+template <>
+struct Elem<fp16_tag> {
+    static __device__ __forceinline__ f32x16 mfma(s16x8 a, s16x8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c,
+                                                      0, 0, 0);
+    }
+    static __device__ __forceinline__ unsigned short from_f32(float f) {
+        return __builtin_bit_cast(unsigned short, (_Float16)f);
+    }
+    static __device__ __forceinline__ s16x8 cvt8(const float* f) {
+        f16x8 r;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r[i] = (_Float16)f[i];
+        return __builtin_bit_cast(s16x8, r);
+    }
+};
+
+enum { MODE_SPARSE = 0, MODE_DENSE = 1 };
+
+struct AttnArgs {
+    const unsigned short *q, *k, *v;
+    long qsb, qsh, qss, ksb, ksh, kss, vsb, vsh, vss;
+    unsigned short* out;
+    long osb, osh, oss;
+    const int32_t* cols;    // [BH, NBv, NB_total]
+    const int32_t* counts;  // [BH, NBv]
+    const float* R;         // [BH, NBv] or null
+    const float* comp;      // [BH, NBv, D] or null
+    int mode, H, Sq, Sk;
+    int NBv, NQB, NB_total;  // sparse: q blocks < NBv use lists; NQB = total q blocks
+    int kv_valid, kv_text_valid, q_text_end;  // sparse mode (q_text_end = NBv*128 + q_text_valid)
+    int q_split, kv_split;                    // dense mode
+    int n_heavy_pad, NBp, BH;                 // work mapping
+    float qk_scale;
+};
+
+// byte offset of 16-byte chunk `ch` of row `row` inside a [64][D] 2-byte tile.  The XOR keeps both the
+// ds_read_b128 row reads (K as MFMA A operand) and the ds_read_b64_tr_b16 transposing reads (V^T as A
+// operand) bank-conflict free for D = 128 (256-byte rows).
+template <int D>
+__device__ __forceinline__ int tile_off(int row, int ch) {
+    if constexpr (D == 128) {
+        return row * 256 + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
+    } else {
+        return row * 128 + ((ch ^ ((row >> 1) & 7)) << 4);
+    }
+}
+
+template <int D, typename Tag>
+__global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
+    constexpr int KS = D / 16;             // k-steps of QK^T
+    constexpr int DT = D / 32;             // 32-wide d tiles of O^T
+    constexpr int CHR = D / 8;             // 16-byte chunks per row
+    constexpr int NST = 64 * CHR / 256;    // staging chunks per thread per tile (4 or 2)
+    constexpr int TILE_BYTES = 64 * D * 2;
+    using E = Elem<Tag>;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * TILE_BYTES];  // K0 V0 K1 V1
+
+    // ---------------- work mapping (heavy dense rows first; visual rows XCD-contiguous) ----------------
+    int bh, qblk;
+    {
+        const int bid = blockIdx.x;
+        if (bid < a.n_heavy_pad) {
+            const int ntq = a.NQB - a.NBv;
+            if (ntq <= 0 || bid >= a.BH * ntq) return;
+            bh = bid / ntq;
+            qblk = a.NBv + bid % ntq;
+        } else {
+            const int v = bid - a.n_heavy_pad;
+            bh = v / a.NBp;
+            const int j = v % a.NBp;
+            const int chunk = a.NBp >> 3;
+            qblk = (j & 7) * chunk + (j >> 3);
+            if (qblk >= a.NBv) return;
+        }
+    }
+    const int b = bh / a.H, h = bh % a.H;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int grow = qblk * RSA_BLOCK + 32 * wv + r;  // this lane's global query row
+
+    // ---------------- per-row plan ----------------
+    int lo_r = 0, hi_r = 0;
+    bool store_r = false, zero_r = false;
+    int n_items, first_blk = 0, lo_max, hi_min, hi_max;
+    const int32_t* list = nullptr;
+    bool rectify = false;
+    if (a.mode == MODE_SPARSE) {
+        if (qblk < a.NBv) {
+            hi_r = a.kv_valid;
+            store_r = grow < a.Sq;
+            const long rowi = (long)bh * a.NBv + qblk;
+            list = a.cols + rowi * a.NB_total;
+            n_items = a.counts[rowi];
+            lo_max = 0; hi_min = hi_max = a.kv_valid;
+            rectify = a.R != nullptr;
+        } else {
+            hi_r = a.kv_text_valid;
+            store_r = grow < a.q_text_end;
+            zero_r = !store_r && grow < a.Sq;
+            n_items = (a.kv_text_valid + RSA_BLOCK - 1) / RSA_BLOCK;
+            lo_max = 0; hi_min = hi_max = a.kv_text_valid;
+        }
+    } else {
+        const int row0 = qblk * RSA_BLOCK, row1 = row0 + RSA_BLOCK;
+        if (grow < a.q_split) { lo_r = 0; hi_r = a.kv_split; } else { lo_r = a.kv_split; hi_r = a.Sk; }
+        store_r = grow < a.Sq;
+        int lo_min;
+        if (row1 <= a.q_split) { lo_min = 0; lo_max = 0; hi_min = hi_max = a.kv_split; }
+        else if (row0 >= a.q_split) { lo_min = lo_max = a.kv_split; hi_min = hi_max = a.Sk; }
+        else { lo_min = 0; lo_max = a.kv_split; hi_min = a.kv_split; hi_max = a.Sk; }
+        first_blk = lo_min / RSA_BLOCK;
+        n_items = (hi_max + RSA_BLOCK - 1) / RSA_BLOCK - first_blk;
+        if (hi_max <= lo_min) n_items = 0;
+    }
+    int n_tiles = 2 * n_items;
+    if (n_items > 0) {
+        const int last_blk = list ? list[n_items - 1] : first_blk + n_items - 1;
+        if (last_blk * RSA_BLOCK + 64 >= hi_max) n_tiles -= 1;
+    }
+    const int kv_limit = hi_max < a.Sk ? hi_max : a.Sk;  // rows >= this are staged as zeros
+
+    // ---------------- Q fragments: B operand, lane (r,hh) holds Q'[row][16ks + 8hh + 0..7] ----------------
+    s16x8 qf[KS];
+    {
+        const unsigned short* qp = a.q + (long)b * a.qsb + (long)h * a.qsh + (long)grow * a.qss + 8 * hh;
+        const bool qok = grow < a.Sq;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            uint4 raw = make_uint4(0, 0, 0, 0);
+            if (qok) raw = *reinterpret_cast<const uint4*>(qp + 16 * ks);
+            const unsigned w4[4] = {raw.x, raw.y, raw.z, raw.w};
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f[2 * e] = rsa_to_f32<Tag>((unsigned short)(w4[e] & 0xFFFF)) * a.qk_scale;
+                f[2 * e + 1] = rsa_to_f32<Tag>((unsigned short)(w4[e] >> 16)) * a.qk_scale;
+            }
+            qf[ks] = E::cvt8(f);
+        }
+    }
+
+    // ---------------- staging ----------------
+    const unsigned short* kbase = a.k + (long)b * a.ksb + (long)h * a.ksh;
+    const unsigned short* vbase = a.v + (long)b * a.vsb + (long)h * a.vsh;
+    const int st_row = t / CHR, st_ch = t % CHR;                  // + (256/CHR) rows per step
+    constexpr int ST_ROWS = 256 / CHR;
+    const int st_off = tile_off<D>(st_row, st_ch);                 // + ST_ROWS*D*2 bytes per step (swizzle-invariant)
+    uint4 kreg[NST], vreg[NST];
+    auto load_tile = [&](int tile) {
+        const int item = tile >> 1;
+        const int blk = list ? list[item] : first_blk + item;
+        const int key0 = blk * RSA_BLOCK + (tile & 1) * 64;
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int krow = key0 + st_row + ST_ROWS * i;
+            uint4 kk = make_uint4(0, 0, 0, 0), vv = kk;
+            if (krow < kv_limit) {
+                kk = *reinterpret_cast<const uint4*>(kbase + (long)krow * a.kss + st_ch * 8);
+                vv = *reinterpret_cast<const uint4*>(vbase + (long)krow * a.vss + st_ch * 8);
+            }
+            kreg[i] = kk;
+            vreg[i] = vv;
+        }
+        return key0;
+    };
+    auto write_tile = [&](int buf) {
+        unsigned char* kd = lds + buf * 2 * TILE_BYTES;
+        unsigned char* vd = kd + TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            *reinterpret_cast<uint4*>(kd + st_off + i * ST_ROWS * D * 2) = kreg[i];
+            *reinterpret_cast<uint4*>(vd + st_off + i * ST_ROWS * D * 2) = vreg[i];
+        }
+    };
+
+    // ---------------- state ----------------
+    f32x16 o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[dt][i] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;
+
+    // per-lane read addressing
+    const int kswz = ((r & 3) << 2) | ((r >> 2) & 3);   // K row reads (D = 128); D = 64 recomputed below
+    const int g4 = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+
+    int key0_next = 0;
+    if (n_tiles > 0) key0_next = load_tile(0);
+    for (int tile = 0; tile < n_tiles; ++tile) {
+        const int buf = tile & 1;
+        const int key0 = key0_next;
+        write_tile(buf);
+        __syncthreads();
+        if (tile + 1 < n_tiles) key0_next = load_tile(tile + 1);
+        const unsigned char* kt_ = lds + buf * 2 * TILE_BYTES;
+        const unsigned char* vt_ = kt_ + TILE_BYTES;
+
+        // ---- S^T = K . Q^T  (two 32-key sub-tiles) ----
+        f32x16 s0, s1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s0[i] = 0.0f; s1[i] = 0.0f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            int off0, off1;
+            if constexpr (D == 128) {
+                off0 = r * 256 + (((2 * ks + hh) ^ kswz) << 4);
+                off1 = off0 + 32 * 256;
+            } else {
+                off0 = tile_off<D>(r, 2 * ks + hh);
+                off1 = tile_off<D>(32 + r, 2 * ks + hh);
+            }
+            const s16x8 a0 = *reinterpret_cast<const s16x8*>(kt_ + off0);
+            const s16x8 a1 = *reinterpret_cast<const s16x8*>(kt_ + off1);
+            s0 = E::mfma(a0, qf[ks], s0);
+            s1 = E::mfma(a1, qf[ks], s1);
+        }
+        // ---- range mask (wave-uniform decision) ----
+        if (key0 < lo_max || key0 + 64 > hi_min) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int kk = key0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                if (kk < lo_r || kk >= hi_r) s0[i] = -INFINITY;
+                if (kk + 32 < lo_r || kk + 32 >= hi_r) s1[i] = -INFINITY;
+            }
+        }
+        // ---- online softmax (row = lane pair r, r+32) ----
+        float mx = fmaxf(s0[0], s1[0]);
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, fmaxf(s0[i], s1[i]));
+        {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = (m_new == -INFINITY) ? 0.0f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+        m_run = m_new;
+        float psum = 0.0f;
+        float p0[16], p1[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            p0[i] = __builtin_amdgcn_exp2f(s0[i] - m_use);
+            p1[i] = __builtin_amdgcn_exp2f(s1[i] - m_use);
+            psum += p0[i] + p1[i];
+        }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+        // P^T fragments: registers 8s..8s+7 of a 32-key sub-tile are k-step s of the B operand
+        s16x8 pb[4];
+        pb[0] = E::cvt8(p0);
+        pb[1] = E::cvt8(p0 + 8);
+        pb[2] = E::cvt8(p1);
+        pb[3] = E::cvt8(p1 + 8);
+
+        // ---- O^T += V^T . P^T ----
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {        // kk = 2*kt + s : 16 keys each
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                // element j of lane half hh is key 16kk + 8(j>>2) + 4hh + (j&3); lane column d = 32dt + r
+                const int row_a = 16 * kk + 4 * hh + tq;
+                const int ch = 4 * dt + 2 * (g4 & 1) + (tp >> 1);
+                const int offa = tile_off<D>(row_a, ch) + 8 * (tp & 1);
+                const int offb = tile_off<D>(row_a + 8, ch) + 8 * (tp & 1);
+                const s16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (s16x4 __attribute__((address_space(3)))*)(vt_ + offa));
+                const s16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (s16x4 __attribute__((address_space(3)))*)(vt_ + offb));
+                const s16x8 av = __builtin_shufflevector(va, vb, 0, 1, 2, 3, 4, 5, 6, 7);
+                o[dt] = E::mfma(av, pb[kk], o[dt]);
+            }
+        }
+    }
+
+    // ---------------- epilogue ----------------
+    {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+        l_run = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+    if (!(store_r || zero_r)) return;
+    float inv = l_run > 0.0f ? 1.0f / l_run : 0.0f;
+    float Rv = 1.0f;
+    const float* cp = nullptr;
+    if (rectify) {
+        const long rowi = (long)bh * a.NBv + qblk;
+        Rv = a.R[rowi];
+        cp = a.comp + rowi * D;
+    }
+    if (zero_r) { inv = 0.0f; }
+    const float sc = inv * Rv;
+    unsigned short* op = a.out + (long)b * a.osb + (long)h * a.osh + (long)grow * a.oss;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d0 = 32 * dt + 8 * g + 4 * hh;
+            float4 c4 = make_float4(0, 0, 0, 0);
+            if (cp && !zero_r) c4 = *reinterpret_cast<const float4*>(cp + d0);
+            const float v0 = o[dt][4 * g + 0] * sc + c4.x;
+            const float v1 = o[dt][4 * g + 1] * sc + c4.y;
+            const float v2 = o[dt][4 * g + 2] * sc + c4.z;
+            const float v3 = o[dt][4 * g + 3] * sc + c4.w;
+            uint2 pk;
+            pk.x = (unsigned)E::from_f32(v0) | ((unsigned)E::from_f32(v1) << 16);
+            pk.y = (unsigned)E::from_f32(v2) | ((unsigned)E::from_f32(v3) << 16);
+            *reinterpret_cast<uint2*>(op + d0) = pk;
+        }
+    }
+}
+
+// =====================================================================================================
+// host side
+// =====================================================================================================
+static int launch_attn(AttnArgs& a, int BH, int D, int dtype, hipStream_t s) {
+    const int ntq = a.NQB - a.NBv;
+    const int n_heavy = ntq > 0 ? BH * ntq : 0;
+    a.BH = BH;
+    a.n_heavy_pad = (n_heavy + 7) & ~7;
+    a.NBp = (a.NBv + 7) & ~7;
+    const long nblocks = (long)a.n_heavy_pad + (long)BH * a.NBp;
+    if (nblocks <= 0) return RSA_OK;
+    if (nblocks > 0x7FFFFFFF) return RSA_ERR_UNSUPPORTED;
+    dim3 grid((unsigned)nblocks);
+    if (D == 128) {
+        if (dtype == RSA_BF16) bsfwd_kernel<128, bf16_tag><<<grid, 256, 0, s>>>(a);
+        else bsfwd_kernel<128, fp16_tag><<<grid, 256, 0, s>>>(a);
+    } else {
+        if (dtype == RSA_BF16) bsfwd_kernel<64, bf16_tag><<<grid, 256, 0, s>>>(a);
+        else bsfwd_kernel<64, fp16_tag><<<grid, 256, 0, s>>>(a);
+    }
+    return rsa_launch_status();
+}
+
+static void fill_qkv(AttnArgs& a, const rsa_tensor4& q, const rsa_tensor4& k, const rsa_tensor4& v,
+                     const rsa_out4& out) {
+    a.q = static_cast<const unsigned short*>(q.ptr); a.qsb = q.stride_b; a.qsh = q.stride_h; a.qss = q.stride_s;
+    a.k = static_cast<const unsigned short*>(k.ptr); a.ksb = k.stride_b; a.ksh = k.stride_h; a.kss = k.stride_s;
+    a.v = static_cast<const unsigned short*>(v.ptr); a.vsb = v.stride_b; a.vsh = v.stride_h; a.vss = v.stride_s;
+    a.out = static_cast<unsigned short*>(out.ptr); a.osb = out.stride_b; a.osh = out.stride_h; a.oss = out.stride_s;
+}
+
+static int check_out(const rsa_out4& o) {
+    if (!o.ptr || (reinterpret_cast<uintptr_t>(o.ptr) & 7)) return RSA_ERR_BAD_ARG;
+    if ((o.stride_b % 4) || (o.stride_h % 4) || (o.stride_s % 4)) return RSA_ERR_BAD_ARG;  // 8-byte stores
+    return RSA_OK;
+}
+
+extern "C" int rsa_block_sparse_fwd(const rsa_layout* l, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
+                                    const rsa_buffers* buf, rsa_out4 out, void* stream) {
+    int st = rsa_check_layout(l);
+    if (st != RSA_OK) return st;
+    if ((st = rsa_check_tensor(q)) || (st = rsa_check_tensor(k)) || (st = rsa_check_tensor(v)) ||
+        (st = check_out(out)))
+        return st;
+    if (!buf || (l->NBv > 0 && (!buf->cols || !buf->counts))) return RSA_ERR_BAD_ARG;
+    if ((buf->R == nullptr) != (buf->comp == nullptr)) return RSA_ERR_BAD_ARG;
+    AttnArgs a;
+    fill_qkv(a, q, k, v, out);
+    a.cols = buf->cols; a.counts = buf->counts; a.R = buf->R; a.comp = buf->comp;
+    a.mode = MODE_SPARSE; a.H = l->H; a.Sq = l->S; a.Sk = l->S;
+    a.NBv = l->NBv; a.NQB = l->NB_total; a.NB_total = l->NB_total;
+    a.kv_valid = l->kv_valid; a.kv_text_valid = l->kv_text_valid;
+    a.q_text_end = l->NBv * RSA_BLOCK + l->q_text_valid;
+    a.q_split = 0; a.kv_split = 0;
+    a.qk_scale = (float)((1.0 / sqrt((double)l->D)) * 1.44269504);  // sm_scale * 1.44269504 (hunyuan :145)
+    return launch_attn(a, l->B * l->H, l->D, l->dtype, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int rsa_dense_fwd(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k,
+                             rsa_tensor4 v, int q_split, int kv_split, rsa_out4 out, void* stream) {
+    if (B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0) return RSA_ERR_BAD_ARG;
+    if (D != 64 && D != 128) return RSA_ERR_UNSUPPORTED;
+    if (dtype != RSA_BF16 && dtype != RSA_FP16) return RSA_ERR_UNSUPPORTED;
+    if (q_split < 0 || q_split > Sq || kv_split < 0 || kv_split > Sk) return RSA_ERR_BAD_ARG;
+    int st;
+    if ((st = rsa_check_tensor(q)) || (st = rsa_check_tensor(k)) || (st = rsa_check_tensor(v)) ||
+        (st = check_out(out)))
+        return st;
+    AttnArgs a;
+    fill_qkv(a, q, k, v, out);
+    a.cols = nullptr; a.counts = nullptr; a.R = nullptr; a.comp = nullptr;
+    a.mode = MODE_DENSE; a.H = H; a.Sq = Sq; a.Sk = Sk;
+    a.NQB = (Sq + RSA_BLOCK - 1) / RSA_BLOCK; a.NBv = a.NQB; a.NB_total = (Sk + RSA_BLOCK - 1) / RSA_BLOCK;
+    a.kv_valid = Sk; a.kv_text_valid = Sk; a.q_text_end = 0;
+    a.q_split = q_split; a.kv_split = kv_split;
+    a.qk_scale = (float)((1.0 / sqrt((double)D)) * 1.44269504);
+    return launch_attn(a, B * H, D, dtype, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int rsa_rectified_attention(const rsa_layout* l, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
+                                       const uint8_t* neighbor, int top_k, float p_remain, void* workspace,
+                                       size_t workspace_bytes, rsa_out4 out, void* stream) {
+    rsa_buffers buf;
+    int st = rsa_carve_workspace(l, workspace, workspace_bytes, &buf);
+    if (st != RSA_OK) return st;
+    if ((st = rsa_pool_stats(l, q, k, v, &buf, stream))) return st;
+    if ((st = rsa_pooled_scores(l, k, &buf, stream))) return st;
+    if ((st = rsa_select_mask(l, neighbor, top_k, p_remain, &buf, stream))) return st;
+    if ((st = rsa_compensation(l, &buf, stream))) return st;
+    return rsa_block_sparse_fwd(l, q, k, v, &buf, out, stream);
+}

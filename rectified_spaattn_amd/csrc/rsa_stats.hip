@@ -1,0 +1,629 @@
+// Mask-selection pass of the rectified block-sparse attention path: K1 pool_stats, K2 pooled_scores,
+// K3 select_mask, K4 compensation.  gfx950 only.  Compiled with -ffp-contract=off: every fused multiply-add
+// is an explicit __builtin_fmaf so the arithmetic equals the fp32 statistics contract (oracle/rsa_oracle.c)
+// bit for bit.  All of this is HBM/LDS-bound integer-and-fp32 work; no MFMA on purpose.
+#include "rsa_common.h"
+
+// =====================================================================================================
+// K1: pool_stats -- block means (and mean |x - mean|) of Q, K, V in one launch.
+//   grid (NB_total, BH, 3); D*2 threads: thread t owns 8 consecutive head-dim elements (16 B) of the rows
+//   16*i + g (g = t / (D/8), i = 0..7): a wave reads 1 KiB contiguous per load instruction.
+//   Reduction order = contract C2/C3.
+// =====================================================================================================
+struct PoolArgs {
+    const unsigned short* src[3];
+    long sb[3], sh[3], ss[3];
+    float* mean[3];
+    float* mad[3];   // mad[2] == nullptr
+    int nblk[3];     // blocks to produce per tensor
+    int valid[3];    // rows >= valid are zero
+    int H;
+};
+
+template <int D, typename Tag>
+__global__ __launch_bounds__(D * 2) void pool_stats_kernel(PoolArgs a) {
+    constexpr int CH = D / 8;        // 16-byte chunks per row
+    constexpr int NTH = 16 * CH;     // threads
+    constexpr int NW = NTH / 64;     // waves
+    const int which = blockIdx.z;
+    const int blk = blockIdx.x;
+    if (blk >= a.nblk[which]) return;
+    const int bh = blockIdx.y;
+    const int b = bh / a.H, h = bh % a.H;
+    const int t = threadIdx.x;
+    const int c = t % CH, g = t / CH;
+    const unsigned short* base = a.src[which] + (long)b * a.sb[which] + (long)h * a.sh[which] + c * 8;
+    const long ss = a.ss[which];
+    const int valid = a.valid[which];
+
+    float x[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = blk * RSA_BLOCK + 16 * i + g;
+        uint4 raw = make_uint4(0, 0, 0, 0);
+        if (row < valid) raw = *reinterpret_cast<const uint4*>(base + (long)row * ss);
+        const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            x[i][2 * e] = rsa_to_f32<Tag>((unsigned short)(w[e] & 0xFFFF));
+            x[i][2 * e + 1] = rsa_to_f32<Tag>((unsigned short)(w[e] >> 16));
+        }
+    }
+    __shared__ float red[NW][D];
+    float mean[8];
+    // ---- sum -> mean
+    {
+        float s[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            s[e] = x[0][e];
+#pragma unroll
+            for (int i = 1; i < 8; ++i) s[e] = s[e] + x[i][e];
+        }
+        // tree over g: in-wave lanes differ in g by multiples of CH
+#pragma unroll
+        for (int m = CH; m < 64; m <<= 1)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] = s[e] + __shfl_xor(s[e], m, 64);
+        if ((t & 63) < CH)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[t >> 6][c * 8 + e] = s[e];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float tot;
+            if (NW == 4)
+                tot = (red[0][c * 8 + e] + red[1][c * 8 + e]) + (red[2 % NW][c * 8 + e] + red[3 % NW][c * 8 + e]);
+            else
+                tot = red[0][c * 8 + e] + red[1][c * 8 + e];
+            mean[e] = tot * (1.0f / RSA_BLOCK);
+        }
+    }
+    const long orow = ((long)bh * a.nblk[which] + blk) * D + c * 8;
+    if (g == 0) {
+        float4* o = reinterpret_cast<float4*>(a.mean[which] + orow);
+        o[0] = make_float4(mean[0], mean[1], mean[2], mean[3]);
+        o[1] = make_float4(mean[4], mean[5], mean[6], mean[7]);
+    }
+    if (a.mad[which] == nullptr) return;
+    // ---- mean absolute deviation
+    {
+        float s[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            s[e] = fabsf(x[0][e] - mean[e]);
+#pragma unroll
+            for (int i = 1; i < 8; ++i) s[e] = s[e] + fabsf(x[i][e] - mean[e]);
+        }
+#pragma unroll
+        for (int m = CH; m < 64; m <<= 1)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] = s[e] + __shfl_xor(s[e], m, 64);
+        __syncthreads();
+        if ((t & 63) < CH)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[t >> 6][c * 8 + e] = s[e];
+        __syncthreads();
+        if (g == 0) {
+            float r[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float tot;
+                if (NW == 4)
+                    tot = (red[0][c * 8 + e] + red[1][c * 8 + e]) +
+                          (red[2 % NW][c * 8 + e] + red[3 % NW][c * 8 + e]);
+                else
+                    tot = red[0][c * 8 + e] + red[1][c * 8 + e];
+                r[e] = tot * (1.0f / RSA_BLOCK);
+            }
+            float4* o = reinterpret_cast<float4*>(a.mad[which] + orow);
+            o[0] = make_float4(r[0], r[1], r[2], r[3]);
+            o[1] = make_float4(r[4], r[5], r[6], r[7]);
+        }
+    }
+}
+
+// =====================================================================================================
+// K2: pooled scores.  out tile 64(i) x 64(j) per workgroup, 4x4 per thread, d staged through LDS in
+// chunks of 32; accumulation is one k-ordered fmaf chain per output (contract C4).
+//   MODE 0: visual columns: s = qbar.kbar, eq = aq.kbar, ek = qbar.ak -> scores + GAPR byte
+//   MODE 1: text columns:   s = qbar.K_u for every valid text token u
+// =====================================================================================================
+struct ScoreArgs {
+    const float *qbar, *aq, *kbar, *ak;
+    const unsigned short* ktxt;  // K base pointer (MODE 1)
+    long ksb, ksh, kss;
+    float* scores;
+    uint8_t* unrel;
+    int NBv, n_txt, NS, D, H;
+};
+
+template <int MODE, typename Tag>
+__global__ __launch_bounds__(256) void pooled_scores_kernel(ScoreArgs a) {
+    constexpr int TI = 64, TJ = 64, DK = 32, LD = 68;
+    __shared__ __attribute__((aligned(16))) float Aq[DK][LD];
+    __shared__ __attribute__((aligned(16))) float Aa[MODE == 0 ? DK : 1][LD];
+    __shared__ __attribute__((aligned(16))) float Bk[DK][LD];
+    __shared__ __attribute__((aligned(16))) float Ba[MODE == 0 ? DK : 1][LD];
+    const int bh = blockIdx.z;
+    const int i0 = blockIdx.y * TI, j0 = blockIdx.x * TJ;
+    const int t = threadIdx.x;
+    const int ti = t >> 4, tj = t & 15;
+    const int ncols = MODE == 0 ? a.NBv : a.n_txt;
+    const int D = a.D;
+    const float* qb = a.qbar + (long)bh * a.NBv * D;
+    const float* aqp = a.aq + (long)bh * a.NBv * D;
+    const float* kb = a.kbar + (long)bh * a.NBv * D;
+    const float* akp = a.ak + (long)bh * a.NBv * D;
+    const unsigned short* kt = nullptr;
+    if (MODE == 1) {
+        const int b = bh / a.H, h = bh % a.H;
+        kt = a.ktxt + (long)b * a.ksb + (long)h * a.ksh + (long)a.NBv * RSA_BLOCK * a.kss;
+    }
+    float s[4][4], eq[4][4], ek[4][4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) s[x][y] = eq[x][y] = ek[x][y] = 0.0f;
+
+    for (int d0 = 0; d0 < D; d0 += DK) {
+        __syncthreads();
+        // stage: 64 rows x 32 d = 512 float4 per operand, 2 per thread; stored transposed [d][row]
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int idx = t + r * 256;
+            const int row = idx >> 3, dc = (idx & 7) * 4;
+            float4 vq = make_float4(0, 0, 0, 0), va = vq, vk = vq, vb = vq;
+            if (i0 + row < a.NBv) {
+                vq = *reinterpret_cast<const float4*>(qb + (long)(i0 + row) * D + d0 + dc);
+                if (MODE == 0) va = *reinterpret_cast<const float4*>(aqp + (long)(i0 + row) * D + d0 + dc);
+            }
+            if (j0 + row < ncols) {
+                if (MODE == 0) {
+                    vk = *reinterpret_cast<const float4*>(kb + (long)(j0 + row) * D + d0 + dc);
+                    vb = *reinterpret_cast<const float4*>(akp + (long)(j0 + row) * D + d0 + dc);
+                } else {
+                    const uint2 raw = *reinterpret_cast<const uint2*>(kt + (long)(j0 + row) * a.kss + d0 + dc);
+                    vk.x = rsa_to_f32<Tag>((unsigned short)(raw.x & 0xFFFF));
+                    vk.y = rsa_to_f32<Tag>((unsigned short)(raw.x >> 16));
+                    vk.z = rsa_to_f32<Tag>((unsigned short)(raw.y & 0xFFFF));
+                    vk.w = rsa_to_f32<Tag>((unsigned short)(raw.y >> 16));
+                }
+            }
+            Aq[dc + 0][row] = vq.x; Aq[dc + 1][row] = vq.y; Aq[dc + 2][row] = vq.z; Aq[dc + 3][row] = vq.w;
+            Bk[dc + 0][row] = vk.x; Bk[dc + 1][row] = vk.y; Bk[dc + 2][row] = vk.z; Bk[dc + 3][row] = vk.w;
+            if (MODE == 0) {
+                Aa[dc + 0][row] = va.x; Aa[dc + 1][row] = va.y; Aa[dc + 2][row] = va.z; Aa[dc + 3][row] = va.w;
+                Ba[dc + 0][row] = vb.x; Ba[dc + 1][row] = vb.y; Ba[dc + 2][row] = vb.z; Ba[dc + 3][row] = vb.w;
+            }
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int dd = 0; dd < DK; ++dd) {
+            const float4 q4 = *reinterpret_cast<const float4*>(&Aq[dd][4 * ti]);
+            const float4 k4 = *reinterpret_cast<const float4*>(&Bk[dd][4 * tj]);
+            const float qa[4] = {q4.x, q4.y, q4.z, q4.w};
+            const float ka[4] = {k4.x, k4.y, k4.z, k4.w};
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 4; ++y) s[x][y] = __builtin_fmaf(qa[x], ka[y], s[x][y]);
+            if (MODE == 0) {
+                const float4 a4 = *reinterpret_cast<const float4*>(&Aa[dd][4 * ti]);
+                const float4 b4 = *reinterpret_cast<const float4*>(&Ba[dd][4 * tj]);
+                const float aa[4] = {a4.x, a4.y, a4.z, a4.w};
+                const float ba[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int y = 0; y < 4; ++y) {
+                        eq[x][y] = __builtin_fmaf(aa[x], ka[y], eq[x][y]);
+                        ek[x][y] = __builtin_fmaf(qa[x], ba[y], ek[x][y]);
+                    }
+            }
+        }
+    }
+    const int colbase = MODE == 0 ? 0 : a.NBv;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        const int i = i0 + 4 * ti + x;
+        if (i >= a.NBv) continue;
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            const int j = j0 + 4 * tj + y;
+            if (j >= ncols) continue;
+            a.scores[((long)bh * a.NBv + i) * a.NS + colbase + j] = s[x][y];
+            if (MODE == 0)
+                a.unrel[((long)bh * a.NBv + i) * a.NBv + j] =
+                    !(fabsf(s[x][y]) > (fabsf(eq[x][y]) + fabsf(ek[x][y])));
+        }
+    }
+}
+
+// =====================================================================================================
+// K3: select_mask -- one workgroup (256 threads) per (bh, q-block) row.  Contract C5..C8.
+// dynamic LDS: float e[NS] | float pr[L] | u64 keys[N2] | u8 kept[NB_total(pad 4)]
+// =====================================================================================================
+struct SelectArgs {
+    const float* scores;
+    const uint8_t* unrel;
+    const uint8_t* neighbor;
+    float *probs, *w, *R;
+    uint32_t* bitmask;
+    int32_t *cols, *counts;
+    int NBv, n_txt, NS, L, N2, NB_total, NW, text_end_block, ffb, top_k;
+    float thr, scale;
+};
+
+__global__ __launch_bounds__(RSA_NT) void select_mask_kernel(SelectArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
+    float* e = reinterpret_cast<float*>(smem + (size_t)a.N2 * 8);
+    float* pr = e + ((a.NS + 3) & ~3);
+    uint8_t* kept = reinterpret_cast<uint8_t*>(pr + ((a.L + 3) & ~3));
+    __shared__ float red[4];
+    __shared__ int s_n;
+
+    const int t = threadIdx.x;
+    const int qblk = blockIdx.x;
+    const long row = (long)blockIdx.y * a.NBv + qblk;
+    const float* sc = a.scores + row * a.NS;
+    const bool has_txt = a.n_txt > 0;
+
+    // scaled scores, max
+    float mx = -INFINITY;
+    for (int j = t; j < a.NS; j += RSA_NT) {
+        const float x = sc[j] * a.scale;
+        e[j] = x;
+        mx = fmaxf(mx, x);
+    }
+    mx = block_max(mx, red);
+    float part = 0.0f;
+    for (int j = t; j < a.NS; j += RSA_NT) {
+        const float v = rsa_exp(e[j] - mx);
+        e[j] = v;
+        part = part + v;
+    }
+    const float Z = block_tree_sum(part, red);
+    for (int j = t; j < a.NS; j += RSA_NT) e[j] = e[j] / Z;
+    __syncthreads();
+    if (has_txt) {  // IPAR
+        float pn = 0.0f, pt = 0.0f;
+        for (int j = t; j < a.NBv; j += RSA_NT) pn = pn + e[j];
+        for (int u = t; u < a.n_txt; u += RSA_NT) pt = pt + e[a.NBv + u];
+        const float normal_sum = block_tree_sum(pn, red);
+        const float text_sum = block_tree_sum(pt, red);
+        const float denom = normal_sum * 128.0f + text_sum;
+        for (int j = t; j < a.NBv; j += RSA_NT) pr[j] = (e[j] * 128.0f) / denom;
+        if (t == 0) pr[a.NBv] = text_sum / denom;
+    } else {
+        for (int j = t; j < a.NBv; j += RSA_NT) pr[j] = e[j];
+    }
+    __syncthreads();
+    // keys: (prob bits << 32) | (0xFFFFFFFF - idx); descending sort == prob desc, lower index first
+    for (int j = t; j < a.N2; j += RSA_NT) {
+        unsigned long long kk = 0ull;
+        if (j < a.L) {
+            const float pj = pr[j];
+            a.probs[row * a.L + j] = pj;
+            kk = ((unsigned long long)__float_as_uint(pj) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)j);
+        }
+        keys[j] = kk;
+    }
+    __syncthreads();
+    for (int k = 2; k <= a.N2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int idx = t; idx < (a.N2 >> 1); idx += RSA_NT) {
+                const int lo = ((idx & ~(j - 1)) << 1) | (idx & (j - 1));
+                const int hi = lo | j;
+                const bool desc = (lo & k) == 0;
+                const unsigned long long ka = keys[lo], kb = keys[hi];
+                if ((ka < kb) == desc) {
+                    keys[lo] = kb;
+                    keys[hi] = ka;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // sequential cumulative sum (C8); monotone, so stop at the first c > thr
+    if (t == 0) {
+        float c = 0.0f;
+        int count = 0;
+        for (int k = 0; k < a.L; ++k) {
+            c = c + __uint_as_float((unsigned)(keys[k] >> 32));
+            if (c <= a.thr) ++count; else break;
+        }
+        int n = count + 1;
+        if (n < a.top_k) n = a.top_k;
+        if (n > a.L) n = a.L;
+        s_n = n;
+    }
+    for (int j = t; j < a.NB_total; j += RSA_NT) kept[j] = 0;
+    __syncthreads();
+    const int n = s_n;
+    for (int k = t; k < n; k += RSA_NT) kept[0xFFFFFFFFu - (unsigned)(keys[k] & 0xFFFFFFFFull)] = 1;
+    __syncthreads();
+    for (int j = t; j < a.NB_total; j += RSA_NT) {
+        uint8_t kj = kept[j];
+        if (j < a.NBv && a.neighbor) kj |= (a.neighbor[(long)qblk * a.NBv + j] != 0);
+        if (has_txt && j >= a.NBv && j < a.text_end_block) kj = 1;
+        if (qblk < a.ffb && j < a.ffb) kj = 1;
+        kept[j] = kj;
+    }
+    __syncthreads();
+    // rectification factor and compensation weights
+    float pR = 0.0f;
+    for (int j = t; j < a.L; j += RSA_NT) {
+        bool m = kept[j] != 0;
+        if (j < a.NBv) m = m || (a.unrel[row * a.NBv + j] != 0);
+        const float pj = pr[j];
+        pR = pR + (m ? pj : 0.0f);
+        a.w[row * a.L + j] = m ? 0.0f : pj;
+    }
+    const float Rv = block_tree_sum(pR, red);
+    if (t == 0) a.R[row] = Rv;
+    // bitmask + ascending column list (wave 0)
+    if (t < 64) {
+        int off = 0;
+        for (int base = 0; base < a.NB_total; base += 64) {
+            const int j = base + t;
+            const bool f = j < a.NB_total && kept[j] != 0;
+            const unsigned long long m = __ballot(f);
+            if (f) a.cols[row * a.NB_total + off + __popcll(m & ((1ull << t) - 1ull))] = j;
+            off += __popcll(m);
+            const int wi = (base >> 5) + (t >> 5);
+            if ((t & 31) == 0 && wi < a.NW) a.bitmask[row * a.NW + wi] = (unsigned)(m >> (t & 32));
+        }
+        if (t == 0) a.counts[row] = off;
+    }
+}
+
+// =====================================================================================================
+// K4: comp[i, :] = sum_j w[i, j] * vbar[j, :]   (tolerance-only quantity; fp32 FMA, j ascending)
+// =====================================================================================================
+template <int D>
+__global__ __launch_bounds__(256) void compensation_kernel(const float* w, const float* vbar, float* comp, int NBv,
+                                                           int L, int NB_total) {
+    constexpr int TI = 32, TJ = 64, RG = 256 / D, RPT = TI / RG;
+    __shared__ float Ws[TI][TJ + 1];
+    const int bh = blockIdx.y, i0 = blockIdx.x * TI, t = threadIdx.x;
+    const int d = t % D, rg = t / D;
+    const float* wp = w + (long)bh * NBv * L;
+    const float* vp = vbar + (long)bh * NB_total * D;
+    float acc[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) acc[r] = 0.0f;
+    for (int j0 = 0; j0 < L; j0 += TJ) {
+        __syncthreads();
+        for (int idx = t; idx < TI * TJ; idx += 256) {
+            const int r = idx / TJ, jj = idx % TJ;
+            Ws[r][jj] = (i0 + r < NBv && j0 + jj < L) ? wp[(long)(i0 + r) * L + j0 + jj] : 0.0f;
+        }
+        __syncthreads();
+        const int jn = min(TJ, L - j0);
+        for (int jj = 0; jj < jn; ++jj) {
+            const float vv = vp[(long)(j0 + jj) * D + d];
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) acc[r] = __builtin_fmaf(Ws[rg * RPT + r][jj], vv, acc[r]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int i = i0 + rg * RPT + r;
+        if (i < NBv) comp[((long)bh * NBv + i) * D + d] = acc[r];
+    }
+}
+
+// =====================================================================================================
+// stand-alone GAPR mask for estimate_pr_gain callers: mask = !(|s| > |aq.kbar| + |qbar.ak|)
+// =====================================================================================================
+__global__ void gapr_compare_kernel(const float* qbar, const float* aq, const float* kbar, const float* ak,
+                                    const float* scores, uint8_t* mask, int NQ, int NK, int D) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y, bh = blockIdx.z;
+    if (j >= NK) return;
+    const float* q = qbar + ((long)bh * NQ + i) * D;
+    const float* a = aq + ((long)bh * NQ + i) * D;
+    const float* k = kbar + ((long)bh * NK + j) * D;
+    const float* b = ak + ((long)bh * NK + j) * D;
+    float eq = 0.0f, ek = 0.0f;
+    for (int d = 0; d < D; ++d) {
+        eq = __builtin_fmaf(a[d], k[d], eq);
+        ek = __builtin_fmaf(q[d], b[d], ek);
+    }
+    const float s = scores[((long)bh * NQ + i) * NK + j];
+    mask[((long)bh * NQ + i) * NK + j] = !(fabsf(s) > (fabsf(eq) + fabsf(ek)));
+}
+
+// =====================================================================================================
+// host entry points
+// =====================================================================================================
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" int rsa_buffer_bytes(const rsa_layout* l, size_t sizes[14], size_t* total) {
+    int st = rsa_check_layout(l);
+    if (st != RSA_OK) return st;
+    if (!sizes || !total) return RSA_ERR_BAD_ARG;
+    const size_t BH = (size_t)l->B * l->H, NBv = l->NBv, NB = l->NB_total, D = l->D;
+    const size_t NS = NBv + l->n_txt, L = NBv + (l->n_txt > 0 ? 1 : 0), NW = (NB + 31) / 32;
+    const size_t s[14] = {BH * NBv * D * 4, BH * NBv * D * 4, BH * NBv * D * 4, BH * NBv * D * 4, BH * NB * D * 4,
+                          BH * NBv * NS * 4, BH * NBv * NBv,  BH * NBv * L * 4, BH * NBv * L * 4, BH * NBv * 4,
+                          BH * NBv * D * 4,  BH * NBv * NW * 4, BH * NBv * NB * 4, BH * NBv * 4};
+    size_t tot = 0;
+    for (int i = 0; i < 14; ++i) {
+        sizes[i] = s[i];
+        tot += align256(s[i] ? s[i] : 1);
+    }
+    *total = tot;
+    return RSA_OK;
+}
+
+extern "C" int rsa_carve_workspace(const rsa_layout* l, void* ws, size_t ws_bytes, rsa_buffers* out) {
+    size_t sizes[14], total;
+    int st = rsa_buffer_bytes(l, sizes, &total);
+    if (st != RSA_OK) return st;
+    if (!ws || !out || (reinterpret_cast<uintptr_t>(ws) & 255)) return RSA_ERR_BAD_ARG;
+    if (ws_bytes < total) return RSA_ERR_WORKSPACE;
+    unsigned char* p = static_cast<unsigned char*>(ws);
+    void* ptrs[14];
+    for (int i = 0; i < 14; ++i) {
+        ptrs[i] = p;
+        p += align256(sizes[i] ? sizes[i] : 1);
+    }
+    out->qbar = (float*)ptrs[0]; out->aq = (float*)ptrs[1]; out->kbar = (float*)ptrs[2]; out->ak = (float*)ptrs[3];
+    out->vbar = (float*)ptrs[4]; out->scores = (float*)ptrs[5]; out->unrel = (uint8_t*)ptrs[6];
+    out->probs = (float*)ptrs[7]; out->w = (float*)ptrs[8]; out->R = (float*)ptrs[9]; out->comp = (float*)ptrs[10];
+    out->bitmask = (uint32_t*)ptrs[11]; out->cols = (int32_t*)ptrs[12]; out->counts = (int32_t*)ptrs[13];
+    return RSA_OK;
+}
+
+extern "C" int rsa_pool_stats(const rsa_layout* l, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
+                              const rsa_buffers* buf, void* stream) {
+    int st = rsa_check_layout(l);
+    if (st != RSA_OK) return st;
+    if (!buf || !buf->qbar || !buf->aq || !buf->kbar || !buf->ak || !buf->vbar) return RSA_ERR_BAD_ARG;
+    if ((st = rsa_check_tensor(q)) || (st = rsa_check_tensor(k)) || (st = rsa_check_tensor(v))) return st;
+    PoolArgs a;
+    const rsa_tensor4* ts[3] = {&q, &k, &v};
+    for (int i = 0; i < 3; ++i) {
+        a.src[i] = static_cast<const unsigned short*>(ts[i]->ptr);
+        a.sb[i] = ts[i]->stride_b; a.sh[i] = ts[i]->stride_h; a.ss[i] = ts[i]->stride_s;
+    }
+    const int vis_tok = l->NBv * RSA_BLOCK;
+    a.mean[0] = buf->qbar; a.mad[0] = buf->aq; a.nblk[0] = l->NBv; a.valid[0] = l->S < vis_tok ? l->S : vis_tok;
+    a.mean[1] = buf->kbar; a.mad[1] = buf->ak; a.nblk[1] = l->NBv;
+    a.valid[1] = l->pool_valid < vis_tok ? l->pool_valid : vis_tok;
+    a.mean[2] = buf->vbar; a.mad[2] = nullptr; a.nblk[2] = l->NB_total; a.valid[2] = l->pool_valid;
+    a.H = l->H;
+    dim3 grid(l->NB_total, l->B * l->H, 3);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (l->D == 128) {
+        if (l->dtype == RSA_BF16) pool_stats_kernel<128, bf16_tag><<<grid, 256, 0, s>>>(a);
+        else pool_stats_kernel<128, fp16_tag><<<grid, 256, 0, s>>>(a);
+    } else {
+        if (l->dtype == RSA_BF16) pool_stats_kernel<64, bf16_tag><<<grid, 128, 0, s>>>(a);
+        else pool_stats_kernel<64, fp16_tag><<<grid, 128, 0, s>>>(a);
+    }
+    return rsa_launch_status();
+}
+
+extern "C" int rsa_pooled_scores(const rsa_layout* l, rsa_tensor4 k, const rsa_buffers* buf, void* stream) {
+    int st = rsa_check_layout(l);
+    if (st != RSA_OK) return st;
+    if (!buf || !buf->qbar || !buf->aq || !buf->kbar || !buf->ak || !buf->scores || !buf->unrel)
+        return RSA_ERR_BAD_ARG;
+    if ((st = rsa_check_tensor(k))) return st;
+    if (l->NBv == 0) return RSA_OK;
+    ScoreArgs a;
+    a.qbar = buf->qbar; a.aq = buf->aq; a.kbar = buf->kbar; a.ak = buf->ak;
+    a.ktxt = static_cast<const unsigned short*>(k.ptr);
+    a.ksb = k.stride_b; a.ksh = k.stride_h; a.kss = k.stride_s;
+    a.scores = buf->scores; a.unrel = buf->unrel;
+    a.NBv = l->NBv; a.n_txt = l->n_txt; a.NS = l->NBv + l->n_txt; a.D = l->D; a.H = l->H;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int BH = l->B * l->H;
+    dim3 g0((l->NBv + 63) / 64, (l->NBv + 63) / 64, BH);
+    if (l->dtype == RSA_BF16) pooled_scores_kernel<0, bf16_tag><<<g0, 256, 0, s>>>(a);
+    else pooled_scores_kernel<0, fp16_tag><<<g0, 256, 0, s>>>(a);
+    if (l->n_txt > 0) {
+        dim3 g1((l->n_txt + 63) / 64, (l->NBv + 63) / 64, BH);
+        if (l->dtype == RSA_BF16) pooled_scores_kernel<1, bf16_tag><<<g1, 256, 0, s>>>(a);
+        else pooled_scores_kernel<1, fp16_tag><<<g1, 256, 0, s>>>(a);
+    }
+    return rsa_launch_status();
+}
+
+extern "C" int rsa_select_mask(const rsa_layout* l, const uint8_t* neighbor, int top_k, float p_remain,
+                               const rsa_buffers* buf, void* stream) {
+    int st = rsa_check_layout(l);
+    if (st != RSA_OK) return st;
+    if (!buf || !buf->scores || !buf->unrel || !buf->probs || !buf->w || !buf->R || !buf->bitmask || !buf->cols ||
+        !buf->counts || top_k < 0)
+        return RSA_ERR_BAD_ARG;
+    if (l->NBv == 0) return RSA_OK;
+    SelectArgs a;
+    a.scores = buf->scores; a.unrel = buf->unrel; a.neighbor = neighbor;
+    a.probs = buf->probs; a.w = buf->w; a.R = buf->R; a.bitmask = buf->bitmask; a.cols = buf->cols;
+    a.counts = buf->counts;
+    a.NBv = l->NBv; a.n_txt = l->n_txt; a.NS = l->NBv + l->n_txt; a.L = l->NBv + (l->n_txt > 0 ? 1 : 0);
+    int n2 = 2;
+    while (n2 < a.L) n2 <<= 1;
+    a.N2 = n2; a.NB_total = l->NB_total; a.NW = (l->NB_total + 31) / 32;
+    a.text_end_block = l->text_end_block; a.ffb = l->first_frame_blocks; a.top_k = top_k;
+    a.thr = p_remain;
+    a.scale = (float)(1.0 / sqrt((double)l->D));  // head_dim ** -0.5 rounded to fp32 (hunyuan :208)
+    const size_t lds = (size_t)a.N2 * 8 + (size_t)((a.NS + 3) & ~3) * 4 + (size_t)((a.L + 3) & ~3) * 4 +
+                       (size_t)((a.NB_total + 15) & ~15);
+    if (lds > 60 * 1024) return RSA_ERR_UNSUPPORTED;
+    dim3 grid(l->NBv, l->B * l->H);
+    select_mask_kernel<<<grid, RSA_NT, lds, static_cast<hipStream_t>(stream)>>>(a);
+    return rsa_launch_status();
+}
+
+extern "C" int rsa_compensation(const rsa_layout* l, const rsa_buffers* buf, void* stream) {
+    int st = rsa_check_layout(l);
+    if (st != RSA_OK) return st;
+    if (!buf || !buf->w || !buf->vbar || !buf->comp) return RSA_ERR_BAD_ARG;
+    if (l->NBv == 0) return RSA_OK;
+    const int L = l->NBv + (l->n_txt > 0 ? 1 : 0);
+    dim3 grid((l->NBv + 31) / 32, l->B * l->H);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (l->D == 128) compensation_kernel<128><<<grid, 256, 0, s>>>(buf->w, buf->vbar, buf->comp, l->NBv, L, l->NB_total);
+    else compensation_kernel<64><<<grid, 256, 0, s>>>(buf->w, buf->vbar, buf->comp, l->NBv, L, l->NB_total);
+    return rsa_launch_status();
+}
+
+extern "C" int rsa_estimate_pr_gain(int BH, int NQ, int NK, int D, int dtype, const void* q_blocks,
+                                    const void* k_blocks, const float* q_pools, const float* k_pools,
+                                    const float* scores, float* scratch_aq, float* scratch_ak, uint8_t* mask_out,
+                                    void* stream) {
+    if (BH <= 0 || NQ <= 0 || NK <= 0 || !q_blocks || !k_blocks || !q_pools || !k_pools || !scores || !scratch_aq ||
+        !scratch_ak || !mask_out)
+        return RSA_ERR_BAD_ARG;
+    if (D != 64 && D != 128) return RSA_ERR_UNSUPPORTED;
+    if (dtype != RSA_BF16 && dtype != RSA_FP16) return RSA_ERR_UNSUPPORTED;
+    // a_q / a_k with the library's own block means (the caller's pools are used for the dots, as in the reference)
+    rsa_layout lq = {1, BH, D, NQ * RSA_BLOCK, NQ, NQ, 0, NQ * RSA_BLOCK, NQ * RSA_BLOCK, NQ, 0, 0, NQ * RSA_BLOCK, dtype};
+    (void)lq;
+    // Pool kernel writes mean+mad; means go to scratch that we then ignore (aq/ak double as [mean|mad] halves).
+    // scratch_aq / scratch_ak must each hold 2 * BH * N * D floats.
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    for (int which = 0; which < 2; ++which) {
+        PoolArgs a;
+        const int N = which == 0 ? NQ : NK;
+        float* scratch = which == 0 ? scratch_aq : scratch_ak;
+        for (int i = 0; i < 3; ++i) {
+            a.src[i] = static_cast<const unsigned short*>(which == 0 ? q_blocks : k_blocks);
+            a.sb[i] = 0; a.sh[i] = (long)N * RSA_BLOCK * D; a.ss[i] = D;
+            a.mean[i] = scratch; a.mad[i] = scratch + (size_t)BH * N * D;
+            a.nblk[i] = i == 0 ? N : 0; a.valid[i] = N * RSA_BLOCK;
+        }
+        a.H = BH;
+        dim3 grid(N, BH, 1);
+        if (D == 128) {
+            if (dtype == RSA_BF16) pool_stats_kernel<128, bf16_tag><<<grid, 256, 0, s>>>(a);
+            else pool_stats_kernel<128, fp16_tag><<<grid, 256, 0, s>>>(a);
+        } else {
+            if (dtype == RSA_BF16) pool_stats_kernel<64, bf16_tag><<<grid, 128, 0, s>>>(a);
+            else pool_stats_kernel<64, fp16_tag><<<grid, 128, 0, s>>>(a);
+        }
+    }
+    dim3 g((NK + 127) / 128, NQ, BH);
+    gapr_compare_kernel<<<g, 128, 0, s>>>(q_pools, scratch_aq + (size_t)BH * NQ * D, k_pools,
+                                          scratch_ak + (size_t)BH * NK * D, scores, mask_out, NQ, NK, D);
+    return rsa_launch_status();
+}
+
+extern "C" const char* rsa_status_string(int status) {
+    switch (status) {
+        case RSA_OK: return "ok";
+        case RSA_ERR_BAD_ARG: return "bad argument";
+        case RSA_ERR_UNSUPPORTED: return "unsupported head_dim / dtype / row length";
+        case RSA_ERR_WORKSPACE: return "workspace too small";
+        case RSA_ERR_LAUNCH: return "kernel launch failed";
+        default: return "unknown status";
+    }
+}
+
+extern "C" int rsa_version(void) { return 100; }
