@@ -142,6 +142,8 @@ int rsa_estimate_pr_gain(int BH, int NQ, int NK, int D, int dtype, const void* q
                          float* scratch_ak, uint8_t* mask_out, void* stream);
 
 const char* rsa_status_string(int status);
+/* hipGetErrorString of the HIP error behind the most recent RSA_ERR_LAUNCH (diagnostics only). */
+const char* rsa_last_hip_error(void);
 
 #ifdef __cplusplus
 }

@@ -8,6 +8,11 @@ from __future__ import annotations
 import ctypes
 import os
 
+# PyTorch-ROCm bundles its own HIP runtime (soname libamdhip64.so.7).  It must be loaded BEFORE librsa_hip.so so
+# that the library binds to the same runtime instance that owns torch's device context and streams; loading
+# the system copy first leaves torch without a device on the GPU box.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librsa_hip.so")
 
@@ -59,6 +64,7 @@ def lib():
     L.rsa_version.restype = i32
     L.rsa_status_string.restype = ctypes.c_char_p
     L.rsa_status_string.argtypes = [i32]
+    L.rsa_last_hip_error.restype = ctypes.c_char_p
     L.rsa_buffer_bytes.argtypes = [P(RsaLayout), P(sz * 14), P(sz)]
     L.rsa_carve_workspace.argtypes = [P(RsaLayout), vp, sz, P(RsaBuffers)]
     L.rsa_pool_stats.argtypes = [P(RsaLayout), RsaTensor4, RsaTensor4, RsaTensor4, P(RsaBuffers), vp]
@@ -80,7 +86,7 @@ def lib():
 
 EXPORTED = ("rsa_version", "rsa_buffer_bytes", "rsa_carve_workspace", "rsa_pool_stats", "rsa_pooled_scores",
             "rsa_select_mask", "rsa_compensation", "rsa_block_sparse_fwd", "rsa_rectified_attention",
-            "rsa_dense_fwd", "rsa_estimate_pr_gain", "rsa_status_string")
+            "rsa_dense_fwd", "rsa_estimate_pr_gain", "rsa_status_string", "rsa_last_hip_error")
 
 
 def check(status: int, what: str):
@@ -89,6 +95,8 @@ def check(status: int, what: str):
     if status == 0:
         return
     msg = f"{what}: {lib().rsa_status_string(status).decode()} (rsa_status {status})"
+    if status == -4:
+        msg += f": {lib().rsa_last_hip_error().decode()}"
     if status == -2:
         raise AssertionError(msg)
     raise RsaError(msg)

@@ -89,4 +89,11 @@ static inline int rsa_check_tensor(const rsa_tensor4& t) {
     return RSA_OK;
 }
 
-static inline int rsa_launch_status() { return hipGetLastError() == hipSuccess ? RSA_OK : RSA_ERR_LAUNCH; }
+// last HIP error seen by a launch of this library (for rsa_last_hip_error); defined in rsa_stats.hip
+extern int g_rsa_last_hip_error;
+static inline int rsa_launch_status() {
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return RSA_OK;
+    g_rsa_last_hip_error = (int)e;
+    return RSA_ERR_LAUNCH;
+}

@@ -626,4 +626,7 @@ extern "C" const char* rsa_status_string(int status) {
     }
 }
 
+int g_rsa_last_hip_error = 0;
+extern "C" const char* rsa_last_hip_error(void) { return hipGetErrorString((hipError_t)g_rsa_last_hip_error); }
+
 extern "C" int rsa_version(void) { return 100; }
