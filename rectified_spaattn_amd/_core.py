@@ -153,6 +153,47 @@ def neighbor_on_device(block_neighbor_list, NBv: int, device) -> Optional[torch.
     return hit
 
 
+class StagedCall:
+    """One rectified-attention call with its buffers: select() runs K1..K4 (mask-selection pass), attend() runs
+    K5.  Both are asynchronous on the current stream.  q, k, v: [B, H, S, D] device tensors."""
+
+    def __init__(self, q, k, v, spec: LayoutSpec, top_k: int, p_remain: float, block_neighbor_list=None):
+        _require_device(q, k, v)
+        self.L = _lib.lib()
+        B, H, S, D = q.shape
+        assert k.shape == q.shape and v.shape == q.shape, "q, k, v must have equal shapes (self-attention)"
+        assert D in (16, 32, 64, 128), "head_dim must be in {16, 32, 64, 128}"  # reference :121
+        assert k.dtype == q.dtype and v.dtype == q.dtype
+        if S != spec.S:
+            raise ValueError(f"layout S={spec.S} does not match tensors S={S}")
+        self.q, self.k, self.v = _as_bhsd(q), _as_bhsd(k), _as_bhsd(v)
+        self.spec, self.top_k, self.p = spec, int(top_k), float(p_remain)
+        self.lay = spec.to_c(B, H, D, q.dtype)
+        self.bufs = alloc_buffers(spec, B, H, D, q.device)
+        self.cb = _c_buffers(self.bufs)
+        self.out = torch.empty((B, S, H, D), dtype=q.dtype, device=q.device)
+        self.o4 = RsaOut4(self.out.data_ptr(), self.out.stride(0), self.out.stride(2), self.out.stride(1))
+        self.nbr = neighbor_on_device(block_neighbor_list, spec.NBv, q.device)
+        self.t = (_t4(self.q), _t4(self.k), _t4(self.v))
+
+    def select(self):
+        L, lay, cb, st = self.L, ctypes.byref(self.lay), ctypes.byref(self.cb), _stream()
+        tq, tk, tv = self.t
+        with torch.cuda.device(self.q.device):
+            _lib.check(L.rsa_pool_stats(lay, tq, tk, tv, cb, st), "rsa_pool_stats")
+            _lib.check(L.rsa_pooled_scores(lay, tk, cb, st), "rsa_pooled_scores")
+            _lib.check(L.rsa_select_mask(lay, self.nbr.data_ptr() if self.nbr is not None else None, self.top_k,
+                                         self.p, cb, st), "rsa_select_mask")
+            _lib.check(L.rsa_compensation(lay, cb, st), "rsa_compensation")
+
+    def attend(self):
+        tq, tk, tv = self.t
+        with torch.cuda.device(self.q.device):
+            _lib.check(self.L.rsa_block_sparse_fwd(ctypes.byref(self.lay), tq, tk, tv, ctypes.byref(self.cb),
+                                                   self.o4, _stream()), "rsa_block_sparse_fwd")
+        return self.out
+
+
 def rectified_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, spec: LayoutSpec, top_k: int,
                         p_remain: float, block_neighbor_list=None, return_parts: bool = False,
                         shape_xfuse: bool = False):
@@ -161,33 +202,12 @@ def rectified_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, spec:
     K1 pool_stats -> K2 pooled_scores -> K3 select_mask -> K4 compensation -> K5 block_sparse_fwd on the
     current stream; no host synchronisation, no K/V mutation (the reference zeroes masked K/V rows in place,
     hunyuan :307-308; here they are treated as zero by predication)."""
-    _require_device(q, k, v)
-    L = _lib.lib()
+    call = StagedCall(q, k, v, spec, top_k, p_remain, block_neighbor_list)
+    call.select()
+    out = call.attend()
     B, H, S, D = q.shape
-    assert k.shape == q.shape and v.shape == q.shape, "q, k, v must have equal shapes (self-attention)"
-    assert D in (16, 32, 64, 128), "head_dim must be in {16, 32, 64, 128}"  # reference :121
-    assert k.dtype == q.dtype and v.dtype == q.dtype
-    if S != spec.S:
-        raise ValueError(f"layout S={spec.S} does not match tensors S={S}")
-    q, k, v = _as_bhsd(q), _as_bhsd(k), _as_bhsd(v)
-    lay = spec.to_c(B, H, D, q.dtype)
-    bufs = alloc_buffers(spec, B, H, D, q.device)
-    cb = _c_buffers(bufs)
-    out = torch.empty((B, S, H, D), dtype=q.dtype, device=q.device)
-    o4 = RsaOut4(out.data_ptr(), out.stride(0), out.stride(2), out.stride(1))
-    nbr = neighbor_on_device(block_neighbor_list, spec.NBv, q.device)
-    st = _stream()
-    tq, tk, tv = _t4(q), _t4(k), _t4(v)
-    with torch.cuda.device(q.device):
-        _lib.check(L.rsa_pool_stats(ctypes.byref(lay), tq, tk, tv, ctypes.byref(cb), st), "rsa_pool_stats")
-        _lib.check(L.rsa_pooled_scores(ctypes.byref(lay), tk, ctypes.byref(cb), st), "rsa_pooled_scores")
-        _lib.check(L.rsa_select_mask(ctypes.byref(lay), nbr.data_ptr() if nbr is not None else None, int(top_k),
-                                     float(p_remain), ctypes.byref(cb), st), "rsa_select_mask")
-        _lib.check(L.rsa_compensation(ctypes.byref(lay), ctypes.byref(cb), st), "rsa_compensation")
-        _lib.check(L.rsa_block_sparse_fwd(ctypes.byref(lay), tq, tk, tv, ctypes.byref(cb), o4, st),
-                   "rsa_block_sparse_fwd")
     res = out if shape_xfuse else out.view(B, S, H * D)
-    return (res, bufs) if return_parts else res
+    return (res, call.bufs) if return_parts else res
 
 
 def dense_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, q_split: Optional[int] = None,
