@@ -1,0 +1,14 @@
+"""rectified_spaattn_amd -- MI355X-native Rectified SpaAttn attention path.
+
+Module names mirror the reference package `rectified_spaattn`:
+    attn                      fullattn, get_cu_seqlens, get_attn_mask, get_flash_attn_params, MEMORY_LAYOUT
+    gapr_mask                 estimate_pr_gain
+    rectified_hunyuan_attn    rectified_block_sparse_attention, RectifiedHunyuanVideoSpaAttnProcessor2_0
+    rectified_flux_attn       rectified_block_sparse_attention, RectifiedFluxSpaAttnProcessor2_0
+    rectified_wan21_attn      rectified_block_sparse_attention, RectifiedWan{T2V,I2V}SpaAttnProcessor2_0
+    rectified_wan22_attn      RectifiedWan{TI2V,T2V,I2V}SpaAttnProcessor2_0
+    rectified_cogvideo_attn   rectified_block_sparse_attention, RectifiedCogVideoXVideoSpaAttnProcessor2_0
+    attn_processor            get_attn_processors, set_attn_processor
+Device work goes through librsa_hip.so (C-ABI in include/rsa.h); nothing here falls back to PyTorch kernels.
+"""
+__version__ = "0.1.0"

@@ -1,0 +1,71 @@
+"""Shared implementation behind the four `rectified_block_sparse_attention` variants.
+
+The reference keeps four near-identical copies of block_sparse_attention_combined (hunyuan :283-389,
+flux :282-376, cogvideo :282-378, wan21 :276-357); here each variant only builds a LayoutSpec and calls the
+one HIP pipeline (_core.rectified_attention)."""
+from typing import Optional
+
+import torch
+
+from . import _core
+from ._lib import BLOCK
+
+
+def _int_at(x, idx: int, default: Optional[int] = None) -> int:
+    """cu_seqlens may be a python sequence (no sync) or a tensor (one .item(), as in the reference)."""
+    if x is None:
+        if default is None:
+            raise ValueError("cu_seqlens is required for this layout (reference appendix B-2)")
+        return default
+    v = x[idx]
+    return int(v.item()) if isinstance(v, torch.Tensor) else int(v)
+
+
+def _check_blocks(bm: int, bn: int):
+    if bm != BLOCK or bn != BLOCK:
+        raise NotImplementedError("the HIP path is built for block_size_M = block_size_N = 128 "
+                                  "(the only value the reference scripts use)")
+
+
+def run(variant: str, query, key, value, top_k, prob_threshold, block_neighbor_list, shape_xfuse,
+        cu_seqlens_q=None, cu_seqlens_kv=None, text_length: int = 256, first_frame_blocks=None,
+        block_size_M: int = 128, block_size_N: int = 128):
+    _check_blocks(block_size_M, block_size_N)
+    B, H, S, D = query.shape
+    if variant == "hunyuan":
+        spec = _core.LayoutSpec.hunyuan(S, _int_at(cu_seqlens_q, 1))
+    elif variant == "flux":
+        spec = _core.LayoutSpec.flux(S, int(text_length), _int_at(cu_seqlens_kv, 1, S))
+    elif variant == "cogvideo":
+        spec = _core.LayoutSpec.cogvideo(S, int(text_length), _int_at(cu_seqlens_kv, 1, S))
+    elif variant == "wan":
+        spec = _core.LayoutSpec.wan(S, first_frame_blocks)
+    else:
+        raise ValueError(variant)
+    return _core.rectified_attention(query, key, value, spec, int(top_k), float(prob_threshold),
+                                     block_neighbor_list, shape_xfuse=shape_xfuse)
+
+
+# ---- small helpers shared by the processors ---------------------------------------------------------
+def split_heads(x: torch.Tensor, heads: int) -> torch.Tensor:
+    """[B, S, H*D] -> [B, H, S, D] view (no copy; the kernels take the strides as they are)."""
+    return x.unflatten(2, (heads, -1)).transpose(1, 2)
+
+
+def rotary(x: torch.Tensor, freqs):
+    """diffusers.models.embeddings.apply_rotary_emb when diffusers is installed, else the same maths for the
+    (cos, sin) / use_real=True / unbind_dim=-1 convention the Hunyuan, Flux and CogVideoX pipelines use."""
+    try:
+        from diffusers.models.embeddings import apply_rotary_emb
+        return apply_rotary_emb(x, freqs)
+    except ImportError:
+        cos, sin = freqs
+        cos, sin = cos[None, None].to(x.device), sin[None, None].to(x.device)
+        re, im = x.reshape(*x.shape[:-1], -1, 2).unbind(-1)
+        rot = torch.stack([-im, re], dim=-1).flatten(3)
+        return (x.float() * cos + rot.float() * sin).to(x.dtype)
+
+
+def valid_keys(attention_mask, default: int) -> int:
+    """attention_mask.sum().item() -- the one host sync per call the reference also has (hunyuan :502)."""
+    return default if attention_mask is None else int(attention_mask.sum().item())

@@ -15,6 +15,7 @@ struct PoolArgs {
     long sb[3], sh[3], ss[3];
     float* mean[3];
     float* mad[3];   // mad[2] == nullptr
+    const float* ext_mean[3];  // if set, deviations are taken from these means (estimate_pr_gain's q_pools)
     int nblk[3];     // blocks to produce per tensor
     int valid[3];    // rows >= valid are zero
     int H;
@@ -86,6 +87,12 @@ __global__ __launch_bounds__(D * 2) void pool_stats_kernel(PoolArgs a) {
         o[1] = make_float4(mean[4], mean[5], mean[6], mean[7]);
     }
     if (a.mad[which] == nullptr) return;
+    if (a.ext_mean[which] != nullptr) {
+        const float4* em = reinterpret_cast<const float4*>(a.ext_mean[which] + orow);
+        const float4 m0 = em[0], m1 = em[1];
+        mean[0] = m0.x; mean[1] = m0.y; mean[2] = m0.z; mean[3] = m0.w;
+        mean[4] = m1.x; mean[5] = m1.y; mean[6] = m1.z; mean[7] = m1.w;
+    }
     // ---- mean absolute deviation
     {
         float s[8];
@@ -489,6 +496,7 @@ extern "C" int rsa_pool_stats(const rsa_layout* l, rsa_tensor4 q, rsa_tensor4 k,
     for (int i = 0; i < 3; ++i) {
         a.src[i] = static_cast<const unsigned short*>(ts[i]->ptr);
         a.sb[i] = ts[i]->stride_b; a.sh[i] = ts[i]->stride_h; a.ss[i] = ts[i]->stride_s;
+        a.ext_mean[i] = nullptr;
     }
     const int vis_tok = l->NBv * RSA_BLOCK;
     a.mean[0] = buf->qbar; a.mad[0] = buf->aq; a.nblk[0] = l->NBv; a.valid[0] = l->S < vis_tok ? l->S : vis_tok;
@@ -583,11 +591,8 @@ extern "C" int rsa_estimate_pr_gain(int BH, int NQ, int NK, int D, int dtype, co
         return RSA_ERR_BAD_ARG;
     if (D != 64 && D != 128) return RSA_ERR_UNSUPPORTED;
     if (dtype != RSA_BF16 && dtype != RSA_FP16) return RSA_ERR_UNSUPPORTED;
-    // a_q / a_k with the library's own block means (the caller's pools are used for the dots, as in the reference)
-    rsa_layout lq = {1, BH, D, NQ * RSA_BLOCK, NQ, NQ, 0, NQ * RSA_BLOCK, NQ * RSA_BLOCK, NQ, 0, 0, NQ * RSA_BLOCK, dtype};
-    (void)lq;
-    // Pool kernel writes mean+mad; means go to scratch that we then ignore (aq/ak double as [mean|mad] halves).
-    // scratch_aq / scratch_ak must each hold 2 * BH * N * D floats.
+    // mean |X - pool| with the CALLER's pools (gapr_mask.py:19-23,:30); the pool kernel also writes its own block
+    // means into the first half of each scratch (unused).  scratch_aq / scratch_ak hold 2 * BH * N * D floats.
     hipStream_t s = static_cast<hipStream_t>(stream);
     for (int which = 0; which < 2; ++which) {
         PoolArgs a;
@@ -598,6 +603,7 @@ extern "C" int rsa_estimate_pr_gain(int BH, int NQ, int NK, int D, int dtype, co
             a.sb[i] = 0; a.sh[i] = (long)N * RSA_BLOCK * D; a.ss[i] = D;
             a.mean[i] = scratch; a.mad[i] = scratch + (size_t)BH * N * D;
             a.nblk[i] = i == 0 ? N : 0; a.valid[i] = N * RSA_BLOCK;
+            a.ext_mean[i] = which == 0 ? q_pools : k_pools;
         }
         a.H = BH;
         dim3 grid(N, BH, 1);

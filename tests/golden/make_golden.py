@@ -241,5 +241,70 @@ def main():
     print("dense_1536 done; |torch-vanilla| =", float((o_t - o_v).abs().max()))
 
 
+def processors():
+    """Processor-level vectors: the reference processors' __call__ on CPU (dense modes) through fake
+    `Attention` modules (tests/helpers.py) -- pins projection / norm / RoPE / concat order / split logic."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers
+    import rectified_spaattn.attn as ref_attn
+    import rectified_spaattn.rectified_hunyuan_attn as ref_hy
+    import rectified_spaattn.rectified_flux_attn as ref_fx
+    import rectified_spaattn.rectified_wan21_attn as ref_wan
+    import rectified_spaattn.rectified_cogvideo_attn as ref_cog
+    ref_attn.flash_attn_varlen_func = _varlen_sdpa
+    outdir = os.path.dirname(os.path.abspath(__file__))
+    heads, hd = 2, 128
+    dim = heads * hd
+    res = {}
+    with torch.no_grad():
+        # HunyuanVideo dual-stream block, mode "torch", padded text (200 of 256 valid)
+        a = helpers.fake_attn(101, heads, hd, added=True)
+        hs, enc = helpers.hidden(101, 20, 1, 1024, dim), helpers.hidden(101, 21, 1, 256, dim)
+        mask = torch.zeros(1, 1, 1, 1280, dtype=torch.bool)
+        mask[..., :1224] = True
+        rope = helpers.rope_tables(1024, hd)
+        p = ref_hy.RectifiedHunyuanVideoSpaAttnProcessor2_0("torch", 2, None, 0.3, 0)
+        o, e = p(a, hs, enc, mask, rope)
+        res["hy_dual_out"], res["hy_dual_enc"] = o.numpy(), e.numpy()
+        # HunyuanVideo single-stream block (add_q_proj None), mode "vanilla"
+        a = helpers.fake_attn(102, heads, hd, added=False)
+        p = ref_hy.RectifiedHunyuanVideoSpaAttnProcessor2_0("vanilla", 2, None, 0.3, 25)
+        o, e = p(a, hs, enc, mask, rope)
+        res["hy_single_out"], res["hy_single_enc"] = o.numpy(), e.numpy()
+        # Flux double-stream block at the config-1 shape (1024 image + 512 text), dense
+        a = helpers.fake_attn(103, heads, hd, added=True)
+        hs_f, enc_f = helpers.hidden(103, 20, 1, 1024, dim), helpers.hidden(103, 21, 1, 512, dim)
+        rope_f = helpers.rope_tables(1536, hd)
+        p = ref_fx.RectifiedFluxSpaAttnProcessor2_0("torch", 2, None, 0.3, 0, 512)
+        o, e = p(a, hs_f, enc_f, None, rope_f)
+        res["fx_dual_out"], res["fx_dual_enc"] = o.numpy(), e.numpy()
+        # Flux single-stream block (no encoder states): [image | text] already concatenated
+        a = helpers.fake_attn(104, heads, hd, added=False)
+        p = ref_fx.RectifiedFluxSpaAttnProcessor2_0("torch", 2, None, 0.3, 40, 512)
+        res["fx_single_out"] = p(a, helpers.hidden(104, 22, 1, 1536, dim), None, None, rope_f).numpy()
+        # Wan2.1 T2V self-attention, mode "torch", complex RoPE, S not a multiple of 128
+        a = helpers.fake_attn(105, heads, hd, wan=True)
+        p = ref_wan.RectifiedWanT2VSpaAttnProcessor2_0("torch", 2, None, 0.3, 5, 1)
+        res["wan_self_out"] = p(a, helpers.hidden(105, 20, 1, 900, dim), None, None,
+                                helpers.wan_freqs(900, hd)).numpy()
+        # Wan2.1 cross-attention (attn2 processors run mode "flash"): S_q != S_k
+        p = ref_wan.RectifiedWanT2VSpaAttnProcessor2_0("flash", 2, None, 0.3, 5, 1)
+        res["wan_cross_out"] = p(a, helpers.hidden(105, 20, 1, 900, dim), helpers.hidden(105, 23, 1, 512, dim),
+                                 None, None).numpy()
+        # CogVideoX, head_dim 64, dense (step counter < 5)
+        a = helpers.fake_attn(106, 4, 64, added=False)
+        p = ref_cog.RectifiedCogVideoXVideoSpaAttnProcessor2_0("sparse", 2, None, 0.3, 0)
+        o, e = p(a, helpers.hidden(106, 20, 1, 768, 256), helpers.hidden(106, 21, 1, 226, 256), None,
+                 helpers.rope_tables(768, 64))
+        res["cog_out"], res["cog_enc"] = o.numpy(), e.numpy()
+    np.savez_compressed(os.path.join(outdir, "processors.npz"), **{k: v.astype(np.float16) for k, v in res.items()})
+    print("processors.npz:", {k: v.shape for k, v in res.items()})
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "processors":
+        _install_stubs()
+        processors()
+    else:
+        main()
+        processors()

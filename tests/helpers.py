@@ -1,0 +1,75 @@
+"""Fake diffusers `Attention` modules and deterministic inputs for the processor tests (shared by
+tests/golden/make_golden.py and the tests, so fixtures and tests build identical modules)."""
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from rectified_spaattn_amd import synth
+
+
+def _linear(seed, stream, din, dout, scale=0.06):
+    lin = nn.Linear(din, dout, bias=True)
+    with torch.no_grad():
+        lin.weight.copy_(torch.from_numpy((synth.normal(seed, stream, (dout, din)) * scale).astype(np.float32)))
+        lin.bias.copy_(torch.from_numpy((synth.normal(seed, stream + 50, (dout,)) * 0.02).astype(np.float32)))
+    return lin
+
+
+class RMS(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.w = nn.Parameter(torch.linspace(0.8, 1.2, d))
+
+    def forward(self, x):
+        return (x.float() * torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + 1e-6) * self.w).to(x.dtype)
+
+
+def fake_attn(seed, heads, head_dim, added=True, norms=True, wan=False):
+    dim = heads * head_dim
+    a = types.SimpleNamespace()
+    a.heads = heads
+    a.to_q, a.to_k, a.to_v = (_linear(seed, i, dim, dim) for i in (1, 2, 3))
+    a.to_out = nn.ModuleList([_linear(seed, 4, dim, dim), nn.Identity()])
+    if wan:  # Wan norms act on the full hidden dim before the head split
+        a.norm_q, a.norm_k = (RMS(dim), RMS(dim)) if norms else (None, None)
+        a.add_k_proj = None
+        a.add_q_proj = None
+    else:
+        a.norm_q, a.norm_k = (RMS(head_dim), RMS(head_dim)) if norms else (None, None)
+        if added:
+            a.add_q_proj, a.add_k_proj, a.add_v_proj = (_linear(seed, i, dim, dim) for i in (5, 6, 7))
+            a.norm_added_q, a.norm_added_k = (RMS(head_dim), RMS(head_dim)) if norms else (None, None)
+            a.to_add_out = _linear(seed, 8, dim, dim)
+        else:
+            a.add_q_proj = a.add_k_proj = a.add_v_proj = None
+            a.norm_added_q = a.norm_added_k = None
+            a.to_add_out = None
+    a.is_cross_attention = False
+    a.modules_ = [m for m in vars(a).values() if isinstance(m, nn.Module)]
+    return a
+
+
+def attn_to(a, device=None, dtype=None):
+    for m in a.modules_:
+        m.to(device=device, dtype=dtype)
+    return a
+
+
+def hidden(seed, stream, B, S, dim):
+    return torch.from_numpy(synth.normal(seed, stream, (B, S, dim)).astype(np.float32))
+
+
+def rope_tables(S, head_dim):
+    """(cos, sin) [S, head_dim] in the interleaved-pair convention of diffusers' apply_rotary_emb."""
+    pos = torch.arange(S, dtype=torch.float32)[:, None]
+    inv = 1.0 / (10000 ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+    ang = pos * inv[None, :]
+    return ang.cos().repeat_interleave(2, dim=1), ang.sin().repeat_interleave(2, dim=1)
+
+
+def wan_freqs(S, head_dim):
+    pos = torch.arange(S, dtype=torch.float64)[:, None]
+    inv = 1.0 / (10000 ** (torch.arange(0, head_dim, 2, dtype=torch.float64) / head_dim))
+    return torch.polar(torch.ones(S, head_dim // 2, dtype=torch.float64), pos * inv[None, :])[None, None]

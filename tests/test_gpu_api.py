@@ -1,0 +1,170 @@
+"""GPU tests of the public, reference-shaped API (module functions and processors) -- all through librsa_hip.so."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from conftest import GOLDEN, OP_CASES, case_inputs, load_op_case
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("name", OP_CASES)
+def test_public_operator_matches_reference_vectors(name):
+    """rectified_block_sparse_attention(...) of each variant module, called like the reference's processors call
+    it, against the output of the reference's own operator (fixture)."""
+    from rectified_spaattn_amd import (rectified_cogvideo_attn, rectified_flux_attn, rectified_hunyuan_attn,
+                                       rectified_wan21_attn)
+    meta, gold = load_op_case(name)
+    q, k, v, lay, nbr = case_inputs(meta)
+    tq, tk, tv = (torch.from_numpy(x).to(DEV, torch.bfloat16) for x in (q, k, v))
+    tn = torch.from_numpy(nbr) if nbr is not None else None
+    S = meta["S"]
+    var = meta["variant"]
+    if var == "hunyuan":
+        mask = torch.zeros(1, 1, 1, S, dtype=torch.bool, device=DEV)
+        mask[..., : meta["num_true"]] = True
+        cu = torch.tensor([0, meta["num_true"], S], dtype=torch.int32, device=DEV)  # tensor form, like the reference
+        k0 = tk.clone()
+        out = rectified_hunyuan_attn.rectified_block_sparse_attention(
+            tq, tk, tv, attn_mask=mask, top_k=meta["top_k"], cu_seqlens_q=cu, cu_seqlens_kv=cu, max_seqlen_q=S,
+            max_seqlen_kv=S, block_neighbor_list=tn, p_remain_rates=meta["p"])
+        assert torch.equal(tk, k0), "key must not be modified (documented deviation from the reference)"
+    elif var == "flux":
+        out = rectified_flux_attn.rectified_block_sparse_attention(
+            tq, tk, tv, attn_mask=None, top_k=meta["top_k"], cu_seqlens_q=[0, S, S], cu_seqlens_kv=[0, S, S],
+            max_seqlen_q=S, max_seqlen_kv=S, block_neighbor_list=tn, p_remain_rates=meta["p"],
+            text_length=meta["text_length"])
+    elif var == "cogvideo":
+        out = rectified_cogvideo_attn.rectified_block_sparse_attention(
+            tq, tk, tv, attn_mask=None, top_k=meta["top_k"], cu_seqlens_q=[0, S, S], cu_seqlens_kv=[0, S, S],
+            max_seqlen_q=S, max_seqlen_kv=S, block_neighbor_list=tn, p_remain_rates=meta["p"],
+            text_length=meta["text_length"])
+    else:
+        out = rectified_wan21_attn.rectified_block_sparse_attention(
+            tq, tk, tv, attn_mask=None, top_k=meta["top_k"], cu_seqlens_q=[0, S, S], cu_seqlens_kv=[0, S, S],
+            max_seqlen_q=S, max_seqlen_kv=S, block_neighbor_list=tn, p_remain_rates=meta["p"],
+            first_frame_blocks=meta.get("ffb", 0))
+    assert out.shape == (meta["B"], S, meta["H"] * meta["D"]) and out.dtype == torch.bfloat16
+    err = np.abs(out.float().cpu().numpy() - gold["out"])
+    assert err.max() <= 2e-2 and err.mean() <= 2e-3, (err.max(), err.mean())
+
+
+def test_shape_xfuse_returns_bshd():
+    from rectified_spaattn_amd import rectified_wan21_attn, synth
+    q, k, v = (torch.from_numpy(x).to(DEV, torch.bfloat16) for x in synth.structured_qkv(2, 1, 2, 512, 128))
+    a = rectified_wan21_attn.rectified_block_sparse_attention(q, k, v, None, 2, shape_xfuse=True)
+    b = rectified_wan21_attn.rectified_block_sparse_attention(q, k, v, None, 2)
+    assert a.shape == (1, 512, 2, 128) and torch.equal(a.reshape(1, 512, 256), b)
+    with pytest.raises(NotImplementedError):
+        rectified_wan21_attn.rectified_block_sparse_attention(q, k, v, None, 2, block_size_M=64)
+
+
+@pytest.mark.parametrize("mode", ["flash", "torch", "vanilla"])
+def test_fullattn_device_modes(mode):
+    from rectified_spaattn_amd import attn, synth
+    z = np.load(os.path.join(GOLDEN, "dense_1536.npz"))
+    q, k, v = (torch.from_numpy(x).to(DEV, torch.bfloat16) for x in synth.structured_qkv(int(z["seed"]), 1, 1, 1536, 128))
+    n = int(z["n_valid"])
+    out = attn.fullattn(q, k, v, mode=mode, cu_seqlens_q=None, cu_seqlens_kv=None)
+    assert out.shape == (1, 1, 1536, 128)
+    assert np.abs(out.float().cpu().numpy() - z["torch"]).max() <= 2e-2
+    if mode == "flash":
+        cu = torch.tensor([0, n, 1536], dtype=torch.int32, device=DEV)
+        o2 = attn.fullattn(q, k, v, mode="flash", cu_seqlens_q=cu, cu_seqlens_kv=cu, max_seqlen_q=1536,
+                           max_seqlen_kv=1536, batch_size=1)
+        assert np.abs(o2.float().cpu().numpy() - z["flash_varlen"]).max() <= 2e-2
+    else:
+        am = torch.zeros(1, 1, 1, 1536, dtype=torch.bool, device=DEV)
+        am[..., :n] = True
+        o2 = attn.fullattn(q, k, v, mode=mode, attn_mask=am)
+        assert np.abs(o2.float().cpu().numpy() - z["vanilla_masked"]).max() <= 2e-2
+        bad = am.clone()
+        bad[..., 3] = False
+        with pytest.raises(NotImplementedError):
+            attn.fullattn(q, k, v, mode=mode, attn_mask=bad)
+    with pytest.raises(NotImplementedError):
+        attn.fullattn(q, k, v, mode=mode, causal=True)
+
+
+def test_estimate_pr_gain_device():
+    from rectified_spaattn_amd import synth
+    from rectified_spaattn_amd.gapr_mask import estimate_pr_gain
+    z = np.load(os.path.join(GOLDEN, "gapr_1024.npz"))
+    shape = tuple(z["shape"])
+    gold = np.unpackbits(z["mask"], axis=-1)[..., : shape[-1]].astype(bool)
+    q, k, _ = synth.structured_qkv(int(z["seed"]), 1, 2, 1024, 128)
+    Qb = torch.from_numpy(q).to(DEV, torch.bfloat16).reshape(1, 2, 8, 128, 128)
+    Kb = torch.from_numpy(k).to(DEV, torch.bfloat16).reshape(1, 2, 8, 128, 128)
+    qp, kp, sc = (torch.from_numpy(z[n]).to(DEV) for n in ("q_pools", "k_pools", "scores"))
+    got = estimate_pr_gain(Qb, Kb, qp, kp, sc)
+    assert got.shape == shape and got.dtype == torch.bool
+    assert np.array_equal(got.cpu().numpy(), gold)
+
+
+@torch.no_grad()
+def test_hunyuan_processor_sparse_on_device():
+    """Processor in "sparse" mode on the GPU: its output must equal to_out(oracle(q, k, v)) for the q/k/v the
+    processor itself built (captured), and the dense mode must agree with the reference's CPU vector."""
+    from rectified_spaattn_amd import rectified_hunyuan_attn as hy
+    from rectified_spaattn_amd import synth
+    heads, hd = 2, 128
+    dim = heads * hd
+    a = helpers.attn_to(helpers.fake_attn(101, heads, hd, added=True), DEV, torch.bfloat16)
+    hs = helpers.hidden(101, 20, 1, 1024, dim).to(DEV, torch.bfloat16)
+    enc = helpers.hidden(101, 21, 1, 256, dim).to(DEV, torch.bfloat16)
+    mask = torch.zeros(1, 1, 1, 1280, dtype=torch.bool, device=DEV)
+    mask[..., :1224] = True
+    rope = tuple(t.to(DEV) for t in helpers.rope_tables(1024, hd))
+    nbr = torch.from_numpy(synth.banded_neighbors(8, 1))
+    captured = {}
+    orig = hy.rectified_block_sparse_attention
+
+    def spy(q, k, v, **kw):
+        captured["qkv"] = tuple(x.float().cpu().numpy() for x in (q, k, v))
+        captured["out"] = orig(q, k, v, **kw)
+        return captured["out"]
+
+    hy.rectified_block_sparse_attention = spy
+    try:
+        p = hy.RectifiedHunyuanVideoSpaAttnProcessor2_0("sparse", 2, nbr, 0.3, 3)
+        o, e = p(a, hs, enc, mask, rope)
+    finally:
+        hy.rectified_block_sparse_attention = orig
+    q, k, v = captured["qkv"]
+    ref = orc.rectified_attention(q, k, v, orc.layout_hunyuan(1280, 1224), 2, 0.3, nbr.numpy())
+    err = np.abs(captured["out"].float().cpu().numpy() - ref)
+    assert err.max() <= 2e-2 and err.mean() <= 2e-3
+    assert o.shape == (1, 1024, dim) and e.shape == (1, 256, dim)
+    want_o = a.to_out[0](captured["out"][:, :1024])
+    assert torch.allclose(o.float(), want_o.float(), atol=1e-2)
+    # dense mode on device vs the reference processor's CPU output (bf16 linear layers: loose tolerance)
+    G = np.load(os.path.join(GOLDEN, "processors.npz"))
+    p = hy.RectifiedHunyuanVideoSpaAttnProcessor2_0("torch", 2, None, 0.3, 0)
+    o, e = p(a, hs, enc, mask, rope)
+    assert np.abs(o.float().cpu().numpy() - G["hy_dual_out"].astype(np.float32)).max() <= 6e-2
+    assert np.abs(e.float().cpu().numpy() - G["hy_dual_enc"].astype(np.float32)).max() <= 6e-2
+
+
+@torch.no_grad()
+def test_wan_processor_sparse_gate_and_cross_attention_on_device():
+    from rectified_spaattn_amd import rectified_wan21_attn as wan
+    heads, hd = 2, 128
+    dim = heads * hd
+    a = helpers.attn_to(helpers.fake_attn(105, heads, hd, wan=True), DEV, torch.bfloat16)
+    hs = helpers.hidden(105, 20, 1, 900, dim).to(DEV, torch.bfloat16)
+    fr = helpers.wan_freqs(900, hd).to(DEV)
+    G = np.load(os.path.join(GOLDEN, "processors.npz"))
+    p = wan.RectifiedWanT2VSpaAttnProcessor2_0("sparse", 8, None, 0.3, 5, 1)  # step < 10: dense warm-up
+    o = p(a, hs, None, None, fr)
+    assert np.abs(o.float().cpu().numpy() - G["wan_self_out"].astype(np.float32)).max() <= 6e-2
+    p.current_step = 10  # sparse now; top_k = all 8 blocks  =>  equals dense
+    o2 = p(a, hs, None, None, fr)
+    assert float((o2.float() - o.float()).abs().max()) <= 3e-2
+    pc = wan.RectifiedWanT2VSpaAttnProcessor2_0("flash", 2, None, 0.3, 5, 1)
+    oc = pc(a, hs, helpers.hidden(105, 23, 1, 512, dim).to(DEV, torch.bfloat16), None, None)
+    assert np.abs(oc.float().cpu().numpy() - G["wan_cross_out"].astype(np.float32)).max() <= 6e-2
