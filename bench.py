@@ -109,14 +109,12 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    from rectified_spaattn_amd import _core, synth
+    from rectified_spaattn_amd import _core, parallel, synth
 
     wl = WORKLOADS[args.workload]
     D = 128
     H = wl["H"]
-    assert H % world == 0, "heads must divide evenly over the ranks"
-    H_local = H // world
-    head0 = rank * H_local
+    head0, H_local = parallel.head_shard(H, world, rank)
     S = wl["S_vis"] + wl["text"]
     if wl["variant"] == "hunyuan":
         num_true = wl["S_vis"] + wl["text_valid"]
@@ -139,8 +137,7 @@ def main():
         if ev is not None:
             ev[1].record()
         if args.gather_output and world > 1:
-            outs = [torch.empty_like(stages.out) for _ in range(world)]
-            dist.all_gather(outs, stages.out)
+            parallel.gather_heads(stages.out)
 
     for _ in range(args.warmup):
         step()
@@ -164,16 +161,9 @@ def main():
     pair_flops = 4.0 * D * 128 * 128
     text_flops = 4.0 * D * spec.q_text_valid * spec.kv_text_valid * H_local
     local_flops = pair_flops * counts + text_flops
-    t = torch.tensor([elapsed, local_flops, float(counts), k5_ms], dtype=torch.float64, device=dev)
-    if world > 1:
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = t.clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        elapsed, k5_ms = tmax[0].item(), tmax[3].item()
-        total_flops, total_pairs = tsum[1].item(), tsum[2].item()
-    else:
-        total_flops, total_pairs = local_flops, float(counts)
+    k5_ms_local = k5_ms
+    elapsed, total_flops, total_pairs, k5_ms, per_rank_s = parallel.reduce_step_stats(
+        elapsed, local_flops, float(counts), k5_ms, dev)
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -183,7 +173,7 @@ def main():
     value = total_flops / (elapsed / args.steps) / 1e12
     kept_frac = total_pairs / (H * spec.NBv * spec.NB_total)
     k5_flops_local = local_flops  # rank-0 launch
-    achieved = k5_flops_local / (k5_ms * 1e-3) / 1e12
+    achieved = k5_flops_local / (k5_ms_local * 1e-3) / 1e12
     res = {
         "metric": "attention-layer TFLOPs/sec (rectified block-sparse attention, HunyuanVideo seq~120k d=128 bf16)",
         "value": round(value, 3), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -194,11 +184,12 @@ def main():
                                f"neighbors={'none' if nbr is None else 'band%d' % args.neighbors}",
                    "kept_block_fraction": round(kept_frac, 4), "heads_per_gpu": H_local,
                    "dense_equivalent_tflops": round(4.0 * S * S * D * H / (elapsed / args.steps) / 1e12, 1),
-                   "gather_output": bool(args.gather_output), "parallelism": f"head-shard x{world}"},
+                   "gather_output": bool(args.gather_output), "parallelism": f"head-shard x{world}",
+                   "per_rank_ms": [round(x / args.steps * 1e3, 3) for x in per_rank_s]},
         "roofline": {"kernel": "bsfwd_kernel<128,bf16> (K5 block_sparse_fwd)", "bound": "mfma",
                      "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-                     "k5_ms": round(k5_ms, 4), "select_pass_ms": round(ms_per_step - k5_ms, 4)},
+                     "k5_ms": round(k5_ms_local, 4), "select_pass_ms": round(ms_per_step - k5_ms, 4)},
     }
     if not args.no_cpu_baseline and world == 1:
         res["cpu_baseline"] = cpu_baseline(S, D)

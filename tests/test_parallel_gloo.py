@@ -1,0 +1,52 @@
+"""world_size-2 gloo test (CPU) of the multi-GPU host logic: head sharding, output all-gather order, and the
+max-over-ranks / sum-of-work reduction bench.py reports."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from rectified_spaattn_amd import parallel
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        H, B, S, D = 6, 1, 5, 4
+        full = torch.arange(B * S * H * D, dtype=torch.float32).view(B, S, H, D)
+        h0, hl = parallel.head_shard(H, world, rank)
+        local = full[:, :, h0:h0 + hl].contiguous()
+        got = parallel.gather_heads(local)
+        ok_gather = torch.equal(got, full.reshape(B, S, H * D))
+        el, fl, pr, k5, per = parallel.reduce_step_stats(1.0 + rank, 10.0 * (rank + 1), 3.0, 0.5 + rank, "cpu")
+        q.put((rank, ok_gather, el, fl, pr, k5, per))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_head_shard_gather_and_reduce_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, el, fl, pr, k5, per in res:
+        assert ok, "all-gather must reproduce the unsharded [B,S,H*D] layout"
+        assert el == 2.0 and fl == 30.0 and pr == 6.0 and k5 == 1.5 and per == [1.0, 2.0]
+
+
+def test_head_shard_rules():
+    assert parallel.head_shard(24, 8, 3) == (9, 3)
+    assert parallel.head_shard(40, 8, 7) == (35, 5)
+    with pytest.raises(ValueError):
+        parallel.head_shard(24, 5, 0)
+    x = torch.zeros(1, 3, 2, 4)
+    assert parallel.gather_heads(x).shape == (1, 3, 8)  # world of one: reshape only
