@@ -141,6 +141,9 @@ int rsa_estimate_pr_gain(int BH, int NQ, int NK, int D, int dtype, const void* q
                          const float* q_pools, const float* k_pools, const float* scores, float* scratch_aq,
                          float* scratch_ak, uint8_t* mask_out, void* stream);
 
+/* Tuning / diagnostics hook, not part of the data path.  Keys: "k5_opt" (bit set of K5 kernel variants). */
+int rsa_set_tuning(const char* key, int value);
+
 const char* rsa_status_string(int status);
 /* hipGetErrorString of the HIP error behind the most recent RSA_ERR_LAUNCH (diagnostics only). */
 const char* rsa_last_hip_error(void);

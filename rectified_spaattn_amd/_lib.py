@@ -65,6 +65,8 @@ def lib():
     L.rsa_status_string.restype = ctypes.c_char_p
     L.rsa_status_string.argtypes = [i32]
     L.rsa_last_hip_error.restype = ctypes.c_char_p
+    L.rsa_set_tuning.argtypes = [ctypes.c_char_p, i32]
+    L.rsa_set_tuning.restype = i32
     L.rsa_buffer_bytes.argtypes = [P(RsaLayout), P(sz * 14), P(sz)]
     L.rsa_carve_workspace.argtypes = [P(RsaLayout), vp, sz, P(RsaBuffers)]
     L.rsa_pool_stats.argtypes = [P(RsaLayout), RsaTensor4, RsaTensor4, RsaTensor4, P(RsaBuffers), vp]
@@ -86,7 +88,7 @@ def lib():
 
 EXPORTED = ("rsa_version", "rsa_buffer_bytes", "rsa_carve_workspace", "rsa_pool_stats", "rsa_pooled_scores",
             "rsa_select_mask", "rsa_compensation", "rsa_block_sparse_fwd", "rsa_rectified_attention",
-            "rsa_dense_fwd", "rsa_estimate_pr_gain", "rsa_status_string", "rsa_last_hip_error")
+            "rsa_dense_fwd", "rsa_estimate_pr_gain", "rsa_status_string", "rsa_last_hip_error", "rsa_set_tuning")
 
 
 def check(status: int, what: str):

@@ -17,6 +17,8 @@
 // beyond the sequence are not stored (:105).  Added: per-row kv ranges (the two-segment varlen semantics of
 // the flash call, attn.py:107-120), a NaN-free fully-masked-tile path, the fused O*R+comp epilogue
 // (hunyuan :365) and a strided [B,S,H,D] store (hunyuan :383-387).
+#include <string.h>
+
 #include "rsa_common.h"
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -91,15 +93,27 @@ __device__ __forceinline__ int tile_off(int row, int ch) {
     }
 }
 
-template <int D, typename Tag>
+// OPT bits (tuning experiments, selected at launch by rsa_set_tuning("k5_opt", bits)):
+//   2 deferred max (skip the O rescale while no row max of the wave grows by more than 2^8)
+//   8 K fragment reads software-pipelined four k-steps ahead of the QK^T MFMAs
+//
+// Staging: K/V tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction) issued from
+// inline asm so that hipcc neither counts them nor drains them (vmcnt(0)) in front of the current tile's LDS
+// reads; the only wait is the hand-placed vmcnt(0) + barrier at the top of the next iteration.  The LDS image
+// is lane-linear, so the XOR swizzle is applied to the per-lane SOURCE chunk (same involution as tile_off on the
+// read side).  Per-lane source offsets are tile-invariant 32-bit values; the tile only moves a scalar base.
+template <int D, typename Tag, int OPT>
 __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
     constexpr int KS = D / 16;             // k-steps of QK^T
     constexpr int DT = D / 32;             // 32-wide d tiles of O^T
     constexpr int CHR = D / 8;             // 16-byte chunks per row
-    constexpr int NST = 64 * CHR / 256;    // staging chunks per thread per tile (4 or 2)
+    constexpr int NST = 64 * CHR / 256;    // 1-KiB pieces per wave per tile operand (4 or 2)
+    constexpr int RPI = 1024 / (D * 2);    // rows per piece (4 or 8)
     constexpr int TILE_BYTES = 64 * D * 2;
     using E = Elem<Tag>;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * TILE_BYTES];  // K0 V0 K1 V1
+    // one LDS object: [K0 V0 K1 V1 | kept-block list (u16)]
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned short* lds_list = reinterpret_cast<unsigned short*>(lds + 4 * TILE_BYTES);
 
     // ---------------- work mapping (heavy dense rows first; visual rows XCD-contiguous) ----------------
     int bh, qblk;
@@ -120,7 +134,8 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
         }
     }
     const int b = bh / a.H, h = bh % a.H;
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int r = lane & 31, hh = lane >> 5;
     const int grow = qblk * RSA_BLOCK + 32 * wv + r;  // this lane's global query row
 
@@ -158,12 +173,22 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
         n_items = (hi_max + RSA_BLOCK - 1) / RSA_BLOCK - first_blk;
         if (hi_max <= lo_min) n_items = 0;
     }
+    n_items = __builtin_amdgcn_readfirstlane(n_items);
+    // kept-block list -> LDS (u16), so the per-tile block index is an LDS broadcast read, not a dependent
+    // global load at the head of every iteration
+    const bool use_list = list != nullptr;
+    if (use_list) {
+        for (int i = t; i < n_items; i += 256) lds_list[i] = (unsigned short)list[i];
+        __syncthreads();
+    }
+    auto blk_of = [&](int item) -> int { return use_list ? (int)lds_list[item] : first_blk + item; };
     int n_tiles = 2 * n_items;
     if (n_items > 0) {
-        const int last_blk = list ? list[n_items - 1] : first_blk + n_items - 1;
+        const int last_blk = blk_of(n_items - 1);
         if (last_blk * RSA_BLOCK + 64 >= hi_max) n_tiles -= 1;
     }
-    const int kv_limit = hi_max < a.Sk ? hi_max : a.Sk;  // rows >= this are staged as zeros
+    n_tiles = __builtin_amdgcn_readfirstlane(n_tiles);
+    const int kv_limit = hi_max < a.Sk ? hi_max : a.Sk;  // rows >= this are never read (clamped to the last one)
 
     // ---------------- Q fragments: B operand, lane (r,hh) holds Q'[row][16ks + 8hh + 0..7] ----------------
     s16x8 qf[KS];
@@ -185,38 +210,47 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
         }
     }
 
-    // ---------------- staging ----------------
-    const unsigned short* kbase = a.k + (long)b * a.ksb + (long)h * a.ksh;
-    const unsigned short* vbase = a.v + (long)b * a.vsb + (long)h * a.vsh;
-    const int st_row = t / CHR, st_ch = t % CHR;                  // + (256/CHR) rows per step
-    constexpr int ST_ROWS = 256 / CHR;
-    const int st_off = tile_off<D>(st_row, st_ch);                 // + ST_ROWS*D*2 bytes per step (swizzle-invariant)
-    uint4 kreg[NST], vreg[NST];
-    auto load_tile = [&](int tile) {
-        const int item = tile >> 1;
-        const int blk = list ? list[item] : first_blk + item;
+    // ---------------- LDS-DMA staging ----------------
+    const unsigned char* kbase = reinterpret_cast<const unsigned char*>(a.k + (long)b * a.ksb + (long)h * a.ksh);
+    const unsigned char* vbase = reinterpret_cast<const unsigned char*>(a.v + (long)b * a.vsb + (long)h * a.vsh);
+    // piece pc = 4j + wv covers tile rows pc*RPI .. pc*RPI+RPI-1; this lane: row (wv*RPI + lane/CHR) of the
+    // j-th group of 4*RPI rows, LDS chunk c = lane%CHR, source chunk g = c ^ f(row) (f does not depend on j)
+    const int rowl = wv * RPI + lane / CHR;
+    int gch;
+    if constexpr (D == 128) gch = (lane % CHR) ^ (((rowl & 3) << 2) | ((rowl >> 2) & 3));
+    else gch = (lane % CHR) ^ ((rowl >> 1) & 7);
+    const unsigned voffk = (unsigned)(((long)rowl * a.kss + gch * 8) * 2);
+    const unsigned voffv = (unsigned)(((long)rowl * a.vss + gch * 8) * 2);
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const long kstep = (long)(4 * RPI) * a.kss * 2, vstep = (long)(4 * RPI) * a.vss * 2;  // bytes per j
+    auto dma_tile = [&](int tile, int buf, int blk_v) -> int {
+        const int blk = __builtin_amdgcn_readfirstlane(blk_v);
         const int key0 = blk * RSA_BLOCK + (tile & 1) * 64;
+        const unsigned ldk = lds_base + buf * 2 * TILE_BYTES + wv * 1024;
+        if (key0 + 64 <= kv_limit) {
+            const unsigned char* kb = kbase + (long)key0 * a.kss * 2;
+            const unsigned char* vb = vbase + (long)key0 * a.vss * 2;
 #pragma unroll
-        for (int i = 0; i < NST; ++i) {
-            const int krow = key0 + st_row + ST_ROWS * i;
-            uint4 kk = make_uint4(0, 0, 0, 0), vv = kk;
-            if (krow < kv_limit) {
-                kk = *reinterpret_cast<const uint4*>(kbase + (long)krow * a.kss + st_ch * 8);
-                vv = *reinterpret_cast<const uint4*>(vbase + (long)krow * a.vss + st_ch * 8);
+            for (int j = 0; j < NST; ++j) {
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                             :: "v"(voffk), "s"(kb + j * kstep), "s"(ldk + j * 4096) : "memory");
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                             :: "v"(voffv), "s"(vb + j * vstep), "s"(ldk + TILE_BYTES + j * 4096) : "memory");
             }
-            kreg[i] = kk;
-            vreg[i] = vv;
+        } else {  // last, partial tile: clamp the row (masked scores make P = 0 for the duplicates)
+#pragma unroll
+            for (int j = 0; j < NST; ++j) {
+                int krow = key0 + j * 4 * RPI + rowl;
+                krow = krow < kv_limit ? krow : kv_limit - 1;
+                const unsigned ok = (unsigned)(((long)krow * a.kss + gch * 8) * 2);
+                const unsigned ov = (unsigned)(((long)krow * a.vss + gch * 8) * 2);
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                             :: "v"(ok), "s"(kbase), "s"(ldk + j * 4096) : "memory");
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                             :: "v"(ov), "s"(vbase), "s"(ldk + TILE_BYTES + j * 4096) : "memory");
+            }
         }
         return key0;
-    };
-    auto write_tile = [&](int buf) {
-        unsigned char* kd = lds + buf * 2 * TILE_BYTES;
-        unsigned char* vd = kd + TILE_BYTES;
-#pragma unroll
-        for (int i = 0; i < NST; ++i) {
-            *reinterpret_cast<uint4*>(kd + st_off + i * ST_ROWS * D * 2) = kreg[i];
-            *reinterpret_cast<uint4*>(vd + st_off + i * ST_ROWS * D * 2) = vreg[i];
-        }
     };
 
     // ---------------- state ----------------
@@ -228,17 +262,25 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
     float m_run = -INFINITY, l_run = 0.0f;
 
     // per-lane read addressing
-    const int kswz = ((r & 3) << 2) | ((r >> 2) & 3);   // K row reads (D = 128); D = 64 recomputed below
+    const int kswz = ((r & 3) << 2) | ((r >> 2) & 3);   // K row reads (D = 128)
     const int g4 = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
 
     int key0_next = 0;
-    if (n_tiles > 0) key0_next = load_tile(0);
+    int blk_pf = 0;  // block index of tile+1, read from LDS one iteration early
+    if (n_tiles > 0) {
+        key0_next = dma_tile(0, 0, blk_of(0));
+        blk_pf = blk_of(n_tiles > 1 ? 0 : 0);  // tile 1 is the second half of item 0
+    }
     for (int tile = 0; tile < n_tiles; ++tile) {
         const int buf = tile & 1;
         const int key0 = key0_next;
-        write_tile(buf);
-        __syncthreads();
-        if (tile + 1 < n_tiles) key0_next = load_tile(tile + 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile `tile` have landed
+        __syncthreads();                                  // ... and everybody else's; buffer buf^1 is free again
+        if (tile + 1 < n_tiles) key0_next = dma_tile(tile + 1, buf ^ 1, blk_pf);
+        {
+            const int it2 = (tile + 2) >> 1;
+            blk_pf = blk_of(it2 < n_items ? it2 : n_items - 1);
+        }
         const unsigned char* kt_ = lds + buf * 2 * TILE_BYTES;
         const unsigned char* vt_ = kt_ + TILE_BYTES;
 
@@ -246,20 +288,43 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
         f32x16 s0, s1;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { s0[i] = 0.0f; s1[i] = 0.0f; }
+        auto k_off = [&](int ks, int sub) {
+            if constexpr (D == 128) return (32 * sub + r) * 256 + (((2 * ks + hh) ^ kswz) << 4);
+            else return tile_off<D>(32 * sub + r, 2 * ks + hh);
+        };
+        if constexpr (OPT & 8) {
+            constexpr int PD = KS < 4 ? KS : 4;  // prefetch depth in k-steps
+            s16x8 fa[PD], fb[PD];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            int off0, off1;
-            if constexpr (D == 128) {
-                off0 = r * 256 + (((2 * ks + hh) ^ kswz) << 4);
-                off1 = off0 + 32 * 256;
-            } else {
-                off0 = tile_off<D>(r, 2 * ks + hh);
-                off1 = tile_off<D>(32 + r, 2 * ks + hh);
+            for (int ks = 0; ks < PD; ++ks) {
+                fa[ks] = *reinterpret_cast<const s16x8*>(kt_ + k_off(ks, 0));
+                fb[ks] = *reinterpret_cast<const s16x8*>(kt_ + k_off(ks, 1));
             }
-            const s16x8 a0 = *reinterpret_cast<const s16x8*>(kt_ + off0);
-            const s16x8 a1 = *reinterpret_cast<const s16x8*>(kt_ + off1);
-            s0 = E::mfma(a0, qf[ks], s0);
-            s1 = E::mfma(a1, qf[ks], s1);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                s0 = E::mfma(fa[ks % PD], qf[ks], s0);
+                s1 = E::mfma(fb[ks % PD], qf[ks], s1);
+                if (ks + PD < KS) {
+                    fa[ks % PD] = *reinterpret_cast<const s16x8*>(kt_ + k_off(ks + PD, 0));
+                    fb[ks % PD] = *reinterpret_cast<const s16x8*>(kt_ + k_off(ks + PD, 1));
+                }
+            }
+            // pin the interleave: 2*PD reads up front, then {2 MFMA, 2 reads} per k-step (hipcc otherwise sinks
+            // every read pair right in front of its MFMAs and exposes the LDS latency eight times per tile)
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * PD, 0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                if (ks + PD < KS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const s16x8 a0 = *reinterpret_cast<const s16x8*>(kt_ + k_off(ks, 0));
+                const s16x8 a1 = *reinterpret_cast<const s16x8*>(kt_ + k_off(ks, 1));
+                s0 = E::mfma(a0, qf[ks], s0);
+                s1 = E::mfma(a1, qf[ks], s1);
+            }
         }
         // ---- range mask (wave-uniform decision) ----
         if (key0 < lo_max || key0 + 64 > hi_min) {
@@ -278,10 +343,27 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
             mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
         }
-        const float m_new = fmaxf(m_run, mx);
-        const float m_use = (m_new == -INFINITY) ? 0.0f : m_new;
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
-        m_run = m_new;
+        float m_use;
+        bool rescale = true;
+        if constexpr (OPT & 2) {
+            // deferred max: keep the old reference max while no row of this wave grew by more than 2^8; P is then
+            // bounded by 2^8 instead of 1 (fp32 l / O accumulators; bf16/fp16 P keeps its relative precision)
+            const bool grow_r = mx > m_run + 8.0f;  // also true for the first tile (m_run = -inf, mx finite)
+            rescale = __builtin_amdgcn_ballot_w64(grow_r) != 0ull;
+        }
+        if (rescale) {
+            const float m_new = fmaxf(m_run, mx);
+            m_use = (m_new == -INFINITY) ? 0.0f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+        } else {
+            m_use = (m_run == -INFINITY) ? 0.0f : m_run;
+        }
         float psum = 0.0f;
         float p0[16], p1[16];
 #pragma unroll
@@ -290,11 +372,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
             p1[i] = __builtin_amdgcn_exp2f(s1[i] - m_use);
             psum += p0[i] + p1[i];
         }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+        l_run += psum;
         // P^T fragments: registers 8s..8s+7 of a 32-key sub-tile are k-step s of the B operand
         s16x8 pb[4];
         pb[0] = E::cvt8(p0);
@@ -361,6 +439,15 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
 // =====================================================================================================
 // host side
 // =====================================================================================================
+static int g_k5_opt = 10;
+
+// Tuning / diagnostics hook (not part of the data path): "k5_opt" selects the K5 variant bits.
+extern "C" int rsa_set_tuning(const char* key, int value) {
+    if (!key) return RSA_ERR_BAD_ARG;
+    if (strcmp(key, "k5_opt") == 0) { g_k5_opt = value; return RSA_OK; }
+    return RSA_ERR_BAD_ARG;
+}
+
 static int launch_attn(AttnArgs& a, int BH, int D, int dtype, hipStream_t s) {
     const int ntq = a.NQB - a.NBv;
     const int n_heavy = ntq > 0 ? BH * ntq : 0;
@@ -371,13 +458,25 @@ static int launch_attn(AttnArgs& a, int BH, int D, int dtype, hipStream_t s) {
     if (nblocks <= 0) return RSA_OK;
     if (nblocks > 0x7FFFFFFF) return RSA_ERR_UNSUPPORTED;
     dim3 grid((unsigned)nblocks);
-    if (D == 128) {
-        if (dtype == RSA_BF16) bsfwd_kernel<128, bf16_tag><<<grid, 256, 0, s>>>(a);
-        else bsfwd_kernel<128, fp16_tag><<<grid, 256, 0, s>>>(a);
+    if (a.NB_total > 8192) return RSA_ERR_UNSUPPORTED;  // kept list lives in LDS as u16, 16 KiB max
+    const int opt = g_k5_opt;
+    const size_t lds_bytes = (size_t)4 * 64 * D * 2 + (((size_t)a.NB_total * 2 + 15) & ~(size_t)15);
+#define RSA_LAUNCH(DD, TT, OO) bsfwd_kernel<DD, TT, OO><<<grid, 256, lds_bytes, s>>>(a)
+    if (D == 128 && dtype == RSA_BF16) {
+        switch (opt) {
+            case 0: RSA_LAUNCH(128, bf16_tag, 0); break;
+            case 2: RSA_LAUNCH(128, bf16_tag, 2); break;
+            case 8: RSA_LAUNCH(128, bf16_tag, 8); break;
+            default: RSA_LAUNCH(128, bf16_tag, 10); break;
+        }
+    } else if (D == 128) {
+        RSA_LAUNCH(128, fp16_tag, 10);
+    } else if (dtype == RSA_BF16) {
+        RSA_LAUNCH(64, bf16_tag, 10);
     } else {
-        if (dtype == RSA_BF16) bsfwd_kernel<64, bf16_tag><<<grid, 256, 0, s>>>(a);
-        else bsfwd_kernel<64, fp16_tag><<<grid, 256, 0, s>>>(a);
+        RSA_LAUNCH(64, fp16_tag, 10);
     }
+#undef RSA_LAUNCH
     return rsa_launch_status();
 }
 

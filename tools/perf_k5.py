@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""K5 micro-benchmarks on the GPU box: (a) block-sparse pass at the bench shape (mask from the selection
+kernels), (b) the same kernel in dense mode at a few sequence lengths.  Prints TFLOP/s; used for A/B of kernel
+variants in one process (env RSA_PERF_* select cases)."""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import WORKLOADS, gen_qkv  # noqa: E402
+from rectified_spaattn_amd import _core  # noqa: E402
+
+
+def timeit(fn, n=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    evs = []
+    for _ in range(n):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record()
+        evs.append((a, b))
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    return ts[len(ts) // 2], ts[0]
+
+
+def main():
+    dev = torch.device("cuda:0")
+    what = sys.argv[1:] or ["sparse", "dense"]
+    D = 128
+    if "sparse" in what:
+        H = int(os.environ.get("RSA_PERF_H", "24"))
+        wl = WORKLOADS["hunyuan_720p_128f"]
+        S = wl["S_vis"] + wl["text"]
+        spec = _core.LayoutSpec.hunyuan(S, wl["S_vis"] + wl["text_valid"])
+        q, k, v = gen_qkv(H, 0, S, wl["S_vis"], D, dev)
+        call = _core.StagedCall(q, k, v, spec, wl["top_k"], 0.0, None)
+        call.select()
+        torch.cuda.synchronize()
+        pairs = call.bufs["counts"].sum().item()
+        flops = 4.0 * D * 128 * 128 * pairs + 4.0 * D * spec.q_text_valid * spec.kv_text_valid * H
+        med, mn = timeit(call.attend)
+        print(f"sparse hunyuan H={H}: K5 median {med:.3f} ms (min {mn:.3f})  {flops/med/1e9:.1f} TFLOP/s  pairs={pairs}")
+        msel, _ = timeit(call.select)
+        print(f"select pass: {msel:.3f} ms")
+        del q, k, v, call
+    if "pmc" in what:  # few launches, for rocprofv3 --pmc passes
+        H = 24
+        wl = WORKLOADS["hunyuan_720p_128f"]
+        S = wl["S_vis"] + wl["text"]
+        spec = _core.LayoutSpec.hunyuan(S, wl["S_vis"] + wl["text_valid"])
+        q, k, v = gen_qkv(H, 0, S, wl["S_vis"], D, dev)
+        call = _core.StagedCall(q, k, v, spec, wl["top_k"], 0.0, None)
+        for _ in range(2):
+            call.select()
+            call.attend()
+        Sd = 16384
+        qd = torch.randn(1, H, Sd, D, device=dev).to(torch.bfloat16)
+        for _ in range(2):
+            _core.dense_attention(qd, qd, qd)
+        torch.cuda.synchronize()
+        return
+    if "variants" in what:
+        from rectified_spaattn_amd import _lib
+        L = _lib.lib()
+        H = 24
+        wl = WORKLOADS["hunyuan_720p_128f"]
+        S = wl["S_vis"] + wl["text"]
+        spec = _core.LayoutSpec.hunyuan(S, wl["S_vis"] + wl["text_valid"])
+        q, k, v = gen_qkv(H, 0, S, wl["S_vis"], D, dev)
+        call = _core.StagedCall(q, k, v, spec, wl["top_k"], 0.0, None)
+        call.select()
+        pairs = call.bufs["counts"].sum().item()
+        flops = 4.0 * D * 128 * 128 * pairs + 4.0 * D * spec.q_text_valid * spec.kv_text_valid * H
+        Sd = 16384
+        qd = torch.randn(1, H, Sd, D, device=dev).to(torch.bfloat16)
+        kd = torch.randn(1, H, Sd, D, device=dev).to(torch.bfloat16)
+        vd = torch.randn(1, H, Sd, D, device=dev).to(torch.bfloat16)
+        fld = 4.0 * Sd * Sd * D * H
+        ref = None
+        opts = [int(x) for x in os.environ.get("RSA_PERF_OPTS", "0,2,8,10").split(",")]
+        for rnd in range(2):
+            for opt in opts:
+                assert L.rsa_set_tuning(b"k5_opt", opt) == 0
+                med, mn = timeit(call.attend, n=4, warm=1)
+                o = call.out.float()
+                if ref is None:
+                    ref = o.clone()
+                err = (o - ref).abs().max().item()
+                medd, _ = timeit(lambda: _core.dense_attention(qd, kd, vd), n=3, warm=1)
+                print(f"round {rnd} opt {opt:2d}: sparse {med:7.3f} ms {flops/med/1e9:7.1f} TF/s | dense16k {medd:6.3f} ms "
+                      f"{fld/medd/1e9:7.1f} TF/s | max|d vs opt0| {err:.2e}", flush=True)
+        return
+    if "dense" in what:
+        for S in (8192, 16384, 32768):
+            H = 24
+            q = torch.randn(1, H, S, D, device=dev).to(torch.bfloat16)
+            k = torch.randn(1, H, S, D, device=dev).to(torch.bfloat16)
+            v = torch.randn(1, H, S, D, device=dev).to(torch.bfloat16)
+            med, mn = timeit(lambda: _core.dense_attention(q, k, v), n=3, warm=1)
+            fl = 4.0 * S * S * D * H
+            print(f"dense S={S} H={H}: median {med:.3f} ms  {fl/med/1e9:.1f} TFLOP/s")
+
+
+if __name__ == "__main__":
+    main()
