@@ -19,6 +19,8 @@
 // (hunyuan :365) and a strided [B,S,H,D] store (hunyuan :383-387).
 #include <string.h>
 
+#include <type_traits>
+
 #include "rsa_common.h"
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -95,7 +97,7 @@ __device__ __forceinline__ int tile_off(int row, int ch) {
 
 // OPT bits (tuning experiments, selected at launch by rsa_set_tuning("k5_opt", bits)):
 //   2 deferred max (skip the O rescale while no row max of the wave grows by more than 2^8)
-//   8 K fragment reads software-pipelined four k-steps ahead of the QK^T MFMAs
+//   8 / 4 / 12: K fragment reads software-pipelined 4 / 2 / 3 k-steps ahead of the QK^T MFMAs
 //
 // Staging: K/V tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction) issued from
 // inline asm so that hipcc neither counts them nor drains them (vmcnt(0)) in front of the current tile's LDS
@@ -264,15 +266,26 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
     // per-lane read addressing
     const int kswz = ((r & 3) << 2) | ((r >> 2) & 3);   // K row reads (D = 128)
     const int g4 = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+    // V^T transposing reads: per-lane byte offsets for (d tile, first/second 4-key group); the key group index
+    // kk and the buffer only add immediates (tile_off is linear in multiples of 16 rows)
+    int vrd[DT][2];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        const int ch = 4 * dt + 2 * (g4 & 1) + (tp >> 1);
+        vrd[dt][0] = tile_off<D>(4 * hh + tq, ch) + 8 * (tp & 1);
+        vrd[dt][1] = tile_off<D>(4 * hh + tq + 8, ch) + 8 * (tp & 1);
+    }
 
     int key0_next = 0;
     int blk_pf = 0;  // block index of tile+1, read from LDS one iteration early
     if (n_tiles > 0) {
         key0_next = dma_tile(0, 0, blk_of(0));
-        blk_pf = blk_of(n_tiles > 1 ? 0 : 0);  // tile 1 is the second half of item 0
+        blk_pf = blk_of(0);  // tile 1 is the second half of item 0
     }
-    for (int tile = 0; tile < n_tiles; ++tile) {
-        const int buf = tile & 1;
+    // One tile of work; BUF is a compile-time constant (the tile loop is unrolled by two) so that every LDS
+    // address is a loop-invariant VGPR plus an immediate offset -- no per-tile address arithmetic.
+    auto tile_body = [&](auto BUFC, int tile) {
+        constexpr int buf = decltype(BUFC)::value;
         const int key0 = key0_next;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile `tile` have landed
         __syncthreads();                                  // ... and everybody else's; buffer buf^1 is free again
@@ -292,8 +305,8 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
             if constexpr (D == 128) return (32 * sub + r) * 256 + (((2 * ks + hh) ^ kswz) << 4);
             else return tile_off<D>(32 * sub + r, 2 * ks + hh);
         };
-        if constexpr (OPT & 8) {
-            constexpr int PD = KS < 4 ? KS : 4;  // prefetch depth in k-steps
+        if constexpr (OPT & 12) {
+            constexpr int PD = (OPT & 8) ? (KS < 4 ? KS : 4) : ((OPT & 4) ? 2 : 3);  // prefetch depth in k-steps
             s16x8 fa[PD], fb[PD];
 #pragma unroll
             for (int ks = 0; ks < PD; ++ks) {
@@ -386,10 +399,8 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 // element j of lane half hh is key 16kk + 8(j>>2) + 4hh + (j&3); lane column d = 32dt + r
-                const int row_a = 16 * kk + 4 * hh + tq;
-                const int ch = 4 * dt + 2 * (g4 & 1) + (tp >> 1);
-                const int offa = tile_off<D>(row_a, ch) + 8 * (tp & 1);
-                const int offb = tile_off<D>(row_a + 8, ch) + 8 * (tp & 1);
+                const int offa = vrd[dt][0] + kk * 16 * D * 2;
+                const int offb = vrd[dt][1] + kk * 16 * D * 2;
                 const s16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                     (s16x4 __attribute__((address_space(3)))*)(vt_ + offa));
                 const s16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -398,6 +409,14 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
                 o[dt] = E::mfma(av, pb[kk], o[dt]);
             }
         }
+    };
+    {
+        int tile = 0;
+        for (; tile + 1 < n_tiles; tile += 2) {
+            tile_body(std::integral_constant<int, 0>{}, tile);
+            tile_body(std::integral_constant<int, 1>{}, tile + 1);
+        }
+        if (tile < n_tiles) tile_body(std::integral_constant<int, 0>{}, tile);
     }
 
     // ---------------- epilogue ----------------
@@ -439,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
 // =====================================================================================================
 // host side
 // =====================================================================================================
-static int g_k5_opt = 10;
+static int g_k5_opt = 4;
 
 // Tuning / diagnostics hook (not part of the data path): "k5_opt" selects the K5 variant bits.
 extern "C" int rsa_set_tuning(const char* key, int value) {
@@ -466,15 +485,17 @@ static int launch_attn(AttnArgs& a, int BH, int D, int dtype, hipStream_t s) {
         switch (opt) {
             case 0: RSA_LAUNCH(128, bf16_tag, 0); break;
             case 2: RSA_LAUNCH(128, bf16_tag, 2); break;
+            case 12: RSA_LAUNCH(128, bf16_tag, 12); break;
             case 8: RSA_LAUNCH(128, bf16_tag, 8); break;
-            default: RSA_LAUNCH(128, bf16_tag, 10); break;
+            case 10: RSA_LAUNCH(128, bf16_tag, 10); break;
+            default: RSA_LAUNCH(128, bf16_tag, 4); break;
         }
     } else if (D == 128) {
-        RSA_LAUNCH(128, fp16_tag, 10);
+        RSA_LAUNCH(128, fp16_tag, 4);
     } else if (dtype == RSA_BF16) {
-        RSA_LAUNCH(64, bf16_tag, 10);
+        RSA_LAUNCH(64, bf16_tag, 4);
     } else {
-        RSA_LAUNCH(64, fp16_tag, 10);
+        RSA_LAUNCH(64, fp16_tag, 4);
     }
 #undef RSA_LAUNCH
     return rsa_launch_status();
