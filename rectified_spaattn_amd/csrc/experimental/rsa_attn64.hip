@@ -1,0 +1,428 @@
+// K5, second structure: 2 waves x 64 query rows per workgroup, ONE wave per SIMD with the whole 512-entry
+// register file, software-pipelined across tiles inside the wave.
+//
+// Why: the 4x32 structure (rsa_attn.hip) needs two co-resident waves per SIMD to overlap one wave's softmax VALU
+// with the other's MFMAs, and measured only ~50 % MFMA-pipe occupancy (VALU and MFMA barely co-execute), with
+// every wave re-reading the full K and V tile from LDS for only 32 rows.  Here a wave owns 64 rows (two 32-row
+// sub-tiles share every K / V^T fragment: half the LDS bytes per FLOP) and overlaps, inside one basic block,
+//        MFMA stream:  S(t+1)^T = K(t+1) . Q^T   then   O^T += V(t)^T . P(t)^T
+//        VALU stream:  P(t) = exp2(S(t) - m)  (+ row sums, bf16 packing)   then   row max of S(t+1)
+// S is double-buffered in registers (the tile loop is unrolled by two).  The running max is "deferred": the
+// reference max m only moves when some row's max grew by more than 2^8 since it was set (P <= 2^8: no
+// precision loss in bf16/fp16 P, fp32 accumulators), and that rare rescale sits in a branch at the head of the
+// iteration, outside the pipelined block.
+//
+// LDS: [K0 K1 V0 V1 | kept list]; K(t+2) is DMA'd into K(t)'s slot and V(t+1) into V(t-1)'s slot at the top of
+// iteration t (after the barrier that retires their last readers); data has one full iteration to land.
+// Semantics identical to rsa_attn.hip (see its header for the reference citations).
+//
+// STATUS (round 1): NOT BUILT, not part of librsa_hip.so.  Numerically correct on the GPU (max |d| 7.8e-3 vs the
+// 4x32 kernel, i.e. the deferred-max rounding), but 32.3 ms vs 18.3 ms at the bench shape: hipcc (ROCm 7.2)
+// allocates 256 VGPR + 256 AGPR and still spills 46 VGPRs / 25 SGPRs, and the scratch reloads sit next to the
+// hand-issued LDS-DMA, so their compiler-inserted `s_waitcnt vmcnt(0)` drains the DMA at the head of every
+// sub-step.  The register plan that fits (O and Q in AGPRs = 192, everything the VALU touches in < 180 VGPRs)
+// needs the MFMA operands pinned by register class (inline-asm MFMAs with "a"/"v" constraints + hand-placed
+// hazard nops), which is next round's work.  Kept here so that work starts from a correct pipeline.
+#include "../rsa_attn.h"
+
+template <int D, typename Tag>
+__global__ __launch_bounds__(128, 1) void bsfwd64_kernel(AttnArgs a) {
+    constexpr int KS = D / 16;
+    constexpr int DT = D / 32;
+    constexpr int CHR = D / 8;
+    constexpr int RPI = 1024 / (D * 2);     // rows per 1-KiB piece
+    constexpr int TILE_BYTES = 64 * D * 2;
+    constexpr int NPC = TILE_BYTES / 1024 / 2;  // pieces per wave per tile operand (8 or 4)
+    using E = Elem<Tag>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned short* lds_list = reinterpret_cast<unsigned short*>(lds + 4 * TILE_BYTES);
+
+    // ---------------- work mapping (same as the 4x32 kernel) ----------------
+    int bh, qblk;
+    {
+        const int bid = blockIdx.x;
+        if (bid < a.n_heavy_pad) {
+            const int ntq = a.NQB - a.NBv;
+            if (ntq <= 0 || bid >= a.BH * ntq) return;
+            bh = bid / ntq;
+            qblk = a.NBv + bid % ntq;
+        } else {
+            const int v = bid - a.n_heavy_pad;
+            bh = v / a.NBp;
+            const int j = v % a.NBp;
+            const int chunk = a.NBp >> 3;
+            qblk = (j & 7) * chunk + (j >> 3);
+            if (qblk >= a.NBv) return;
+        }
+    }
+    const int b = bh / a.H, h = bh % a.H;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    int grow[2];
+    grow[0] = qblk * RSA_BLOCK + 64 * wv + r;
+    grow[1] = grow[0] + 32;
+
+    // ---------------- per-row plan ----------------
+    int lo_r[2] = {0, 0}, hi_r[2] = {0, 0};
+    bool store_r[2] = {false, false}, zero_r[2] = {false, false};
+    int n_items, first_blk = 0, lo_max, hi_min, hi_max;
+    const int32_t* list = nullptr;
+    bool rectify = false;
+    if (a.mode == MODE_SPARSE) {
+        if (qblk < a.NBv) {
+            const long rowi = (long)bh * a.NBv + qblk;
+            list = a.cols + rowi * a.NB_total;
+            n_items = a.counts[rowi];
+            lo_max = 0; hi_min = hi_max = a.kv_valid;
+            rectify = a.R != nullptr;
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) { hi_r[qt] = a.kv_valid; store_r[qt] = grow[qt] < a.Sq; }
+        } else {
+            n_items = (a.kv_text_valid + RSA_BLOCK - 1) / RSA_BLOCK;
+            lo_max = 0; hi_min = hi_max = a.kv_text_valid;
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                hi_r[qt] = a.kv_text_valid;
+                store_r[qt] = grow[qt] < a.q_text_end;
+                zero_r[qt] = !store_r[qt] && grow[qt] < a.Sq;
+            }
+        }
+    } else {
+        const int row0 = qblk * RSA_BLOCK, row1 = row0 + RSA_BLOCK;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            if (grow[qt] < a.q_split) { lo_r[qt] = 0; hi_r[qt] = a.kv_split; }
+            else { lo_r[qt] = a.kv_split; hi_r[qt] = a.Sk; }
+            store_r[qt] = grow[qt] < a.Sq;
+        }
+        int lo_min;
+        if (row1 <= a.q_split) { lo_min = 0; lo_max = 0; hi_min = hi_max = a.kv_split; }
+        else if (row0 >= a.q_split) { lo_min = lo_max = a.kv_split; hi_min = hi_max = a.Sk; }
+        else { lo_min = 0; lo_max = a.kv_split; hi_min = a.kv_split; hi_max = a.Sk; }
+        first_blk = lo_min / RSA_BLOCK;
+        n_items = (hi_max + RSA_BLOCK - 1) / RSA_BLOCK - first_blk;
+        if (hi_max <= lo_min) n_items = 0;
+    }
+    n_items = __builtin_amdgcn_readfirstlane(n_items);
+    const bool use_list = list != nullptr;
+    if (use_list) {
+        for (int i = t; i < n_items; i += 128) lds_list[i] = (unsigned short)list[i];
+        __syncthreads();
+    }
+    auto blk_of = [&](int item) -> int { return use_list ? (int)lds_list[item] : first_blk + item; };
+    int n_tiles = 2 * n_items;
+    if (n_items > 0) {
+        const int last_blk = blk_of(n_items - 1);
+        if (last_blk * RSA_BLOCK + 64 >= hi_max) n_tiles -= 1;
+    }
+    n_tiles = __builtin_amdgcn_readfirstlane(n_tiles);
+    const int kv_limit = hi_max < a.Sk ? hi_max : a.Sk;
+    auto key0_of = [&](int tile) -> int {  // first key of tile `tile` (clamped index: callers guard tile < n_tiles)
+        const int it = tile >> 1;
+        const int blk = __builtin_amdgcn_readfirstlane(blk_of(it < n_items ? it : (n_items > 0 ? n_items - 1 : 0)));
+        return blk * RSA_BLOCK + (tile & 1) * 64;
+    };
+
+    // ---------------- Q fragments (B operand), two 32-row sub-tiles ----------------
+    s16x8 qf[2][KS];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const unsigned short* qp = a.q + (long)b * a.qsb + (long)h * a.qsh + (long)grow[qt] * a.qss + 8 * hh;
+        const bool qok = grow[qt] < a.Sq;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            uint4 raw = make_uint4(0, 0, 0, 0);
+            if (qok) raw = *reinterpret_cast<const uint4*>(qp + 16 * ks);
+            const unsigned w4[4] = {raw.x, raw.y, raw.z, raw.w};
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f[2 * e] = rsa_to_f32<Tag>((unsigned short)(w4[e] & 0xFFFF)) * a.qk_scale;
+                f[2 * e + 1] = rsa_to_f32<Tag>((unsigned short)(w4[e] >> 16)) * a.qk_scale;
+            }
+            qf[qt][ks] = E::cvt8(f);
+        }
+    }
+
+    // ---------------- LDS-DMA staging ----------------
+    const unsigned char* kbase = reinterpret_cast<const unsigned char*>(a.k + (long)b * a.ksb + (long)h * a.ksh);
+    const unsigned char* vbase = reinterpret_cast<const unsigned char*>(a.v + (long)b * a.vsb + (long)h * a.vsh);
+    // piece pc = 4*(j>>1) + 2*wv + (j&1), j = 0..NPC-1: tile rows pc*RPI .. +RPI-1.  The source-chunk swizzle
+    // depends on pc & 3 = 2*wv + (j&1): two per-lane offsets per operand (j even / odd).
+    const int rsub = lane / CHR, cl = lane % CHR;
+    unsigned voffk[2], voffv[2];
+    int gsw[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+        const int rowl = (2 * wv + par) * RPI + rsub;  // row inside the first group of 4 pieces
+        if constexpr (D == 128) gsw[par] = cl ^ (((rowl & 3) << 2) | ((rowl >> 2) & 3));
+        else gsw[par] = cl ^ ((rowl >> 1) & 7);
+        voffk[par] = (unsigned)(((long)rowl * a.kss + gsw[par] * 8) * 2);
+        voffv[par] = (unsigned)(((long)rowl * a.vss + gsw[par] * 8) * 2);
+    }
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const long kstep = (long)(4 * RPI) * a.kss * 2, vstep = (long)(4 * RPI) * a.vss * 2;  // bytes per 4 pieces
+    // is_v: 0 = K tile into K slot `slot`, 1 = V tile into V slot `slot`
+    auto dma = [&](int is_v, int key0, int slot) {
+        const unsigned ld0 = lds_base + (is_v ? 2 : 0) * TILE_BYTES + slot * TILE_BYTES + (2 * wv) * 1024;
+        const unsigned char* base = is_v ? vbase : kbase;
+        const long ss = is_v ? a.vss : a.kss;
+        if (key0 + 64 <= kv_limit) {
+            const unsigned char* tb = base + (long)key0 * ss * 2;
+            const long step = is_v ? vstep : kstep;
+#pragma unroll
+            for (int j = 0; j < NPC; ++j) {
+                const unsigned vo = is_v ? voffv[j & 1] : voffk[j & 1];
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                             :: "v"(vo), "s"(tb + (j >> 1) * step), "s"(ld0 + (j >> 1) * 4096 + (j & 1) * 1024)
+                             : "memory");
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NPC; ++j) {
+                const int rowl = (2 * wv + (j & 1)) * RPI + rsub;
+                int krow = key0 + (j >> 1) * 4 * RPI + rowl;
+                krow = krow < kv_limit ? krow : kv_limit - 1;
+                const unsigned vo = (unsigned)(((long)krow * ss + gsw[j & 1] * 8) * 2);
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                             :: "v"(vo), "s"(base), "s"(ld0 + (j >> 1) * 4096 + (j & 1) * 1024) : "memory");
+            }
+        }
+    };
+
+    // ---------------- state ----------------
+    f32x16 o[DT][2];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[dt][qt][i] = 0.0f;
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.0f, 0.0f};
+
+    // per-lane read addressing
+    const int kswz = ((r & 3) << 2) | ((r >> 2) & 3);
+    const int g4 = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+    int vrd[DT][2];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        const int ch = 4 * dt + 2 * (g4 & 1) + (tp >> 1);
+        vrd[dt][0] = tile_off<D>(4 * hh + tq, ch) + 8 * (tp & 1);
+        vrd[dt][1] = tile_off<D>(4 * hh + tq + 8, ch) + 8 * (tp & 1);
+    }
+    auto k_off = [&](int ks, int sub) {
+        if constexpr (D == 128) return (32 * sub + r) * 256 + (((2 * ks + hh) ^ kswz) << 4);
+        else return tile_off<D>(32 * sub + r, 2 * ks + hh);
+    };
+
+    // S^T[qt] (32 keys x 32 rows per qt) = K[sub-tile SUB of K slot] . Q^T ; one K fragment feeds both query sub-tiles
+    auto qk_sub = [&](auto KSLOT, auto SUB, f32x16 (&S)[2]) {
+        constexpr int slot = decltype(KSLOT)::value, sub = decltype(SUB)::value;
+        const unsigned char* kt_ = lds + slot * TILE_BYTES;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) S[qt][i] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const s16x8 a0 = *reinterpret_cast<const s16x8*>(kt_ + k_off(ks, sub));
+            S[0] = E::mfma(a0, qf[0][ks], S[0]);
+            S[1] = E::mfma(a0, qf[1][ks], S[1]);
+        }
+    };
+    auto rowmax_sub = [&](const f32x16 (&S)[2], float (&mx)[2]) {
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float m = S[qt][0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) m = fmaxf(m, S[qt][i]);
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+            mx[qt] = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+    };
+    auto apply_mask_sub = [&](f32x16 (&S)[2], int key_first) {
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int kk = key_first + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                if (kk < lo_r[qt] || kk >= hi_r[qt]) S[qt][i] = -INFINITY;
+            }
+    };
+
+    int kq1 = 0, kq2 = 0;  // first keys of tile+1 / tile+2 (fetched from LDS ahead of use)
+
+    // One pipelined sub-step u = 2*tile + SUB: consumes S_cur (scores of 32 keys, row max in mx_cur), produces
+    // S_nxt / mx_nxt for sub-step u+1.  VS = slot parity of `tile` (its K and V slots).
+    //   SUB = 0: head issues V(tile+1);  next scores = K(tile) sub-tile 1
+    //   SUB = 1: head issues K(tile+2);  next scores = K(tile+1) sub-tile 0
+    auto step = [&](auto VS, auto SUB, int tile, int key0, f32x16 (&S_cur)[2], float (&mx_cur)[2],
+                    f32x16 (&S_nxt)[2], float (&mx_nxt)[2]) {
+        constexpr int vs = decltype(VS)::value, sub = decltype(SUB)::value;
+        // the newest DMA group (issued half a tile ago) may stay in flight; the one issued a tile ago must land
+        if (tile + 1 < n_tiles) {
+            if constexpr (NPC == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if constexpr (sub == 0) {
+            if (tile + 1 < n_tiles) dma(1, kq1, vs ^ 1);   // V(tile+1) -> slot of V(tile-1)
+        } else {
+            if (tile + 2 < n_tiles) dma(0, kq2, vs);       // K(tile+2) -> slot of K(tile)
+        }
+        // ---- head (rare branches): boundary mask, deferred rescale ----
+        const int kfirst = key0 + 32 * sub;
+        if (kfirst < lo_max || kfirst + 32 > hi_min) {
+            apply_mask_sub(S_cur, kfirst);
+            rowmax_sub(S_cur, mx_cur);
+        }
+        bool grow_any = false;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) grow_any |= mx_cur[qt] > m_run[qt] + 8.0f;
+        if (__builtin_amdgcn_ballot_w64(grow_any) != 0ull) {
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                const float m_new = fmaxf(m_run[qt], mx_cur[qt]);
+                const float mu = (m_new == -INFINITY) ? 0.0f : m_new;
+                const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - mu);
+                m_run[qt] = m_new;
+                l_run[qt] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) o[dt][qt][i] *= alpha;
+            }
+        }
+        float m_use[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) m_use[qt] = (m_run[qt] == -INFINITY) ? 0.0f : m_run[qt];
+
+        // ---- pipelined block (branch-free on purpose: the scheduler interleaves the MFMA and VALU streams) ----
+        if constexpr (sub == 0) qk_sub(std::integral_constant<int, vs>{}, std::integral_constant<int, 1>{}, S_nxt);
+        else qk_sub(std::integral_constant<int, vs ^ 1>{}, std::integral_constant<int, 0>{}, S_nxt);
+        s16x8 pb[2][2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float ps = 0.0f;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                float pv8[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    pv8[i] = __builtin_amdgcn_exp2f(S_cur[qt][8 * half + i] - m_use[qt]);
+                    ps += pv8[i];
+                }
+                pb[qt][half] = E::cvt8(pv8);
+            }
+            l_run[qt] += ps;
+        }
+        const unsigned char* vt_ = lds + (2 + vs) * TILE_BYTES;
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int offa = vrd[dt][0] + (2 * sub + k2) * 16 * D * 2;
+                const int offb = vrd[dt][1] + (2 * sub + k2) * 16 * D * 2;
+                const s16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (s16x4 __attribute__((address_space(3)))*)(vt_ + offa));
+                const s16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (s16x4 __attribute__((address_space(3)))*)(vt_ + offb));
+                const s16x8 av = __builtin_shufflevector(va, vb, 0, 1, 2, 3, 4, 5, 6, 7);
+                o[dt][0] = E::mfma(av, pb[0][k2], o[dt][0]);
+                o[dt][1] = E::mfma(av, pb[1][k2], o[dt][1]);
+            }
+        }
+        rowmax_sub(S_nxt, mx_nxt);
+    };
+
+    // ---------------- prologue + main loop ----------------
+    f32x16 SA[2], SB[2];
+    float mxA[2] = {-INFINITY, -INFINITY}, mxB[2] = {-INFINITY, -INFINITY};
+    int key0 = 0;
+    if (n_tiles > 0) {
+        key0 = key0_of(0);
+        kq1 = key0_of(1);
+        kq2 = key0_of(2);
+        dma(0, key0, 0);
+        dma(1, key0, 0);
+        if (n_tiles > 1) dma(0, kq1, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        qk_sub(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, SA);
+        rowmax_sub(SA, mxA);
+    }
+    auto advance = [&](int tile) {  // after finishing `tile`: shift the key queue, fetch tile+3's first key
+        key0 = kq1;
+        kq1 = kq2;
+        kq2 = key0_of(tile + 3);
+    };
+    {
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        int tile = 0;
+        for (; tile + 1 < n_tiles; tile += 2) {
+            step(I0{}, I0{}, tile, key0, SA, mxA, SB, mxB);
+            step(I0{}, I1{}, tile, key0, SB, mxB, SA, mxA);
+            advance(tile);
+            step(I1{}, I0{}, tile + 1, key0, SA, mxA, SB, mxB);
+            step(I1{}, I1{}, tile + 1, key0, SB, mxB, SA, mxA);
+            advance(tile + 1);
+        }
+        if (tile < n_tiles) {
+            step(I0{}, I0{}, tile, key0, SA, mxA, SB, mxB);
+            step(I0{}, I1{}, tile, key0, SB, mxB, SA, mxA);
+        }
+    }
+
+    // ---------------- epilogue ----------------
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run[qt]), __float_as_uint(l_run[qt]),
+                                                         false, false);
+        const float l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        if (!(store_r[qt] || zero_r[qt])) continue;
+        float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
+        float Rv = 1.0f;
+        const float* cp = nullptr;
+        if (rectify) {
+            const long rowi = (long)bh * a.NBv + qblk;
+            Rv = a.R[rowi];
+            cp = a.comp + rowi * D;
+        }
+        if (zero_r[qt]) inv = 0.0f;
+        const float sc = inv * Rv;
+        unsigned short* op = a.out + (long)b * a.osb + (long)h * a.osh + (long)grow[qt] * a.oss;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = 32 * dt + 8 * g + 4 * hh;
+                float4 c4 = make_float4(0, 0, 0, 0);
+                if (cp && !zero_r[qt]) c4 = *reinterpret_cast<const float4*>(cp + d0);
+                const float v0 = o[dt][qt][4 * g + 0] * sc + c4.x;
+                const float v1 = o[dt][qt][4 * g + 1] * sc + c4.y;
+                const float v2 = o[dt][qt][4 * g + 2] * sc + c4.z;
+                const float v3 = o[dt][qt][4 * g + 3] * sc + c4.w;
+                uint2 pk;
+                pk.x = (unsigned)E::from_f32(v0) | ((unsigned)E::from_f32(v1) << 16);
+                pk.y = (unsigned)E::from_f32(v2) | ((unsigned)E::from_f32(v3) << 16);
+                *reinterpret_cast<uint2*>(op + d0) = pk;
+            }
+        }
+    }
+}
+
+// launch hook used by rsa_attn.hip::launch_attn
+int rsa_launch_bsfwd64(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int dtype, hipStream_t s) {
+    if (D == 128) {
+        if (dtype == RSA_BF16) bsfwd64_kernel<128, bf16_tag><<<grid, 128, lds_bytes, s>>>(a);
+        else bsfwd64_kernel<128, fp16_tag><<<grid, 128, lds_bytes, s>>>(a);
+    } else {
+        if (dtype == RSA_BF16) bsfwd64_kernel<64, bf16_tag><<<grid, 128, lds_bytes, s>>>(a);
+        else bsfwd64_kernel<64, fp16_tag><<<grid, 128, lds_bytes, s>>>(a);
+    }
+    return rsa_launch_status();
+}

@@ -17,83 +17,7 @@
 // beyond the sequence are not stored (:105).  Added: per-row kv ranges (the two-segment varlen semantics of
 // the flash call, attn.py:107-120), a NaN-free fully-masked-tile path, the fused O*R+comp epilogue
 // (hunyuan :365) and a strided [B,S,H,D] store (hunyuan :383-387).
-#include <string.h>
-
-#include <type_traits>
-
-#include "rsa_common.h"
-
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-template <typename Tag>
-struct Elem;
-template <>
-struct Elem<bf16_tag> {
-    static __device__ __forceinline__ f32x16 mfma(s16x8 a, s16x8 b, f32x16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
-                                                       c, 0, 0, 0);
-    }
-    static __device__ __forceinline__ unsigned short from_f32(float f) {
-        return __builtin_bit_cast(unsigned short, (__bf16)f);
-    }
-    static __device__ __forceinline__ s16x8 cvt8(const float* f) {
-        bf16x8 r;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) r[i] = (__bf16)f[i];
-        return __builtin_bit_cast(s16x8, r);
-    }
-};
-template <>
-struct Elem<fp16_tag> {
-    static __device__ __forceinline__ f32x16 mfma(s16x8 a, s16x8 b, f32x16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c,
-                                                      0, 0, 0);
-    }
-    static __device__ __forceinline__ unsigned short from_f32(float f) {
-        return __builtin_bit_cast(unsigned short, (_Float16)f);
-    }
-    static __device__ __forceinline__ s16x8 cvt8(const float* f) {
-        f16x8 r;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) r[i] = (_Float16)f[i];
-        return __builtin_bit_cast(s16x8, r);
-    }
-};
-
-enum { MODE_SPARSE = 0, MODE_DENSE = 1 };
-
-struct AttnArgs {
-    const unsigned short *q, *k, *v;
-    long qsb, qsh, qss, ksb, ksh, kss, vsb, vsh, vss;
-    unsigned short* out;
-    long osb, osh, oss;
-    const int32_t* cols;    // [BH, NBv, NB_total]
-    const int32_t* counts;  // [BH, NBv]
-    const float* R;         // [BH, NBv] or null
-    const float* comp;      // [BH, NBv, D] or null
-    int mode, H, Sq, Sk;
-    int NBv, NQB, NB_total;  // sparse: q blocks < NBv use lists; NQB = total q blocks
-    int kv_valid, kv_text_valid, q_text_end;  // sparse mode (q_text_end = NBv*128 + q_text_valid)
-    int q_split, kv_split;                    // dense mode
-    int n_heavy_pad, NBp, BH;                 // work mapping
-    float qk_scale;
-};
-
-// byte offset of 16-byte chunk `ch` of row `row` inside a [64][D] 2-byte tile.  The XOR keeps both the
-// ds_read_b128 row reads (K as MFMA A operand) and the ds_read_b64_tr_b16 transposing reads (V^T as A
-// operand) bank-conflict free for D = 128 (256-byte rows).
-template <int D>
-__device__ __forceinline__ int tile_off(int row, int ch) {
-    if constexpr (D == 128) {
-        return row * 256 + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
-    } else {
-        return row * 128 + ((ch ^ ((row >> 1) & 7)) << 4);
-    }
-}
+#include "rsa_attn.h"
 
 // OPT bits (tuning experiments, selected at launch by rsa_set_tuning("k5_opt", bits)):
 //   2 deferred max (skip the O rescale while no row max of the wave grows by more than 2^8)
