@@ -25,10 +25,12 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 (MI355X_MICROARCH.md, chip-l
 
 WORKLOADS = {
     # name: (H, S_visual, text_pad, text_valid, top_k, variant)
-    "hunyuan_720p_128f": dict(H=24, S_vis=115200, text=256, text_valid=200, top_k=90, variant="hunyuan"),
-    "flux_4096": dict(H=24, S_vis=65536, text=512, text_valid=512, top_k=51, variant="flux"),
-    "wan21_720p_81f": dict(H=40, S_vis=75600, text=0, text_valid=0, top_k=147, variant="wan", ffb=28),
-    "tiny": dict(H=4, S_vis=4096, text=256, text_valid=200, top_k=6, variant="hunyuan"),
+    "hunyuan_720p_128f": dict(H=24, S_vis=115200, text=256, text_valid=200, top_k=90, variant="hunyuan",
+                              latent=(32, 45, 80)),
+    "flux_4096": dict(H=24, S_vis=65536, text=512, text_valid=512, top_k=51, variant="flux", latent=(1, 256, 256)),
+    "wan21_720p_81f": dict(H=40, S_vis=75600, text=0, text_valid=0, top_k=147, variant="wan", ffb=28,
+                           latent=(21, 45, 80)),
+    "tiny": dict(H=4, S_vis=4096, text=256, text_valid=200, top_k=6, variant="hunyuan", latent=(4, 32, 32)),
 }
 
 
@@ -88,7 +90,9 @@ def main():
     ap.add_argument("--workload", default="hunyuan_720p_128f", choices=list(WORKLOADS))
     ap.add_argument("--p-remain", type=float, default=0.0,
                     help="cumulative-probability threshold; 0 keeps exactly top_k visual blocks per row")
-    ap.add_argument("--neighbors", type=int, default=-1, help="banded stand-in neighbour half-width (-1: none)")
+    ap.add_argument("--neighbors", default="none",
+                    help="block-neighbour matrix: 'none' (exactly top_k kept: the 10 %% regime), 'gilbert' (true "
+                         "26-neighbourhood along the Gilbert curve of the workload's latent), or an int band width")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather-output", action="store_true", help="all-gather O along heads inside the timed region")
     args = ap.parse_args()
@@ -124,7 +128,13 @@ def main():
     else:
         spec = _core.LayoutSpec.wan(S, wl.get("ffb", 0))
     q, k, v = gen_qkv(H_local, head0, S, wl["S_vis"], D, dev)
-    nbr = torch.from_numpy(synth.banded_neighbors(spec.NBv, args.neighbors)) if args.neighbors >= 0 else None
+    if args.neighbors == "none":
+        nbr = None
+    elif args.neighbors == "gilbert":
+        from rectified_spaattn_amd.utils import jenga_gilbert
+        nbr = jenga_gilbert.gilbert_block_neighbor_mapping(*wl["latent"], axis_order=("w", "h", "t"))
+    else:
+        nbr = torch.from_numpy(synth.banded_neighbors(spec.NBv, int(args.neighbors)))
     top_k = wl["top_k"]
 
     stages = _core.StagedCall(q, k, v, spec, top_k, args.p_remain, nbr)
@@ -181,7 +191,7 @@ def main():
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"{args.workload}: B=1 H={H} S={S} ({wl['S_vis']} visual + {wl['text']} text, "
                                f"{wl['text_valid']} valid) D={D}, top_k={top_k}, p_remain={args.p_remain}, "
-                               f"neighbors={'none' if nbr is None else 'band%d' % args.neighbors}",
+                               f"neighbors={args.neighbors}",
                    "kept_block_fraction": round(kept_frac, 4), "heads_per_gpu": H_local,
                    "dense_equivalent_tflops": round(4.0 * S * S * D * H / (elapsed / args.steps) / 1e12, 1),
                    "gather_output": bool(args.gather_output), "parallelism": f"head-shard x{world}",

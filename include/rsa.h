@@ -141,6 +141,20 @@ int rsa_estimate_pr_gain(int BH, int NQ, int NK, int D, int dtype, const void* q
                          const float* q_pools, const float* k_pools, const float* scores, float* scratch_aq,
                          float* scratch_ak, uint8_t* mask_out, void* stream);
 
+/* ---- host-side geometry: produces the hot path's `neighbor` input and the token permutation ---- */
+
+/* Generalized Hilbert ("Gilbert") curve over a t x h x w cuboid (x spans w, y spans h, z spans t; linear index =
+ * z*h*w + y*w + x).  axis_order: 3 chars out of "w","h","t" = major, middle, minor axis (the scripts pass "wht",
+ * main_hunyuan.py:245) or NULL for the size-ordered default.  HOST pointers; linear_to_hilbert may be NULL.
+ * Replaces gilbert_mapping / gilbert_xyz2d (utils/jenga_gilbert.py:12-288, :458-504). */
+int rsa_gilbert_mapping(int t, int h, int w, const char* axis_order, int32_t* linear_to_hilbert,
+                        int32_t* hilbert_to_linear);
+
+/* 26-neighbourhood relation between `block_size`-token blocks along the curve: neighbor[i*NB + j] = 1 iff some
+ * point of block i touches (Chebyshev distance <= 1) a point of block j; NB = ceil(t*h*w / block_size).  HOST
+ * pointer, NB*NB bytes.  Replaces gilbert_block_neighbor_mapping (utils/jenga_gilbert.py:613-693). */
+int rsa_gilbert_block_neighbors(int t, int h, int w, int block_size, const char* axis_order, uint8_t* neighbor);
+
 /* Tuning / diagnostics hook, not part of the data path.  Keys: "k5_opt" (bit set of K5 kernel variants). */
 int rsa_set_tuning(const char* key, int value);
 

@@ -65,6 +65,10 @@ def lib():
     L.rsa_status_string.restype = ctypes.c_char_p
     L.rsa_status_string.argtypes = [i32]
     L.rsa_last_hip_error.restype = ctypes.c_char_p
+    L.rsa_gilbert_mapping.argtypes = [i32, i32, i32, ctypes.c_char_p, vp, vp]
+    L.rsa_gilbert_mapping.restype = i32
+    L.rsa_gilbert_block_neighbors.argtypes = [i32, i32, i32, i32, ctypes.c_char_p, vp]
+    L.rsa_gilbert_block_neighbors.restype = i32
     L.rsa_set_tuning.argtypes = [ctypes.c_char_p, i32]
     L.rsa_set_tuning.restype = i32
     L.rsa_buffer_bytes.argtypes = [P(RsaLayout), P(sz * 14), P(sz)]
@@ -88,7 +92,8 @@ def lib():
 
 EXPORTED = ("rsa_version", "rsa_buffer_bytes", "rsa_carve_workspace", "rsa_pool_stats", "rsa_pooled_scores",
             "rsa_select_mask", "rsa_compensation", "rsa_block_sparse_fwd", "rsa_rectified_attention",
-            "rsa_dense_fwd", "rsa_estimate_pr_gain", "rsa_status_string", "rsa_last_hip_error", "rsa_set_tuning")
+            "rsa_dense_fwd", "rsa_estimate_pr_gain", "rsa_status_string", "rsa_last_hip_error", "rsa_set_tuning", "rsa_gilbert_mapping",
+            "rsa_gilbert_block_neighbors")
 
 
 def check(status: int, what: str):

@@ -392,33 +392,58 @@ __global__ __launch_bounds__(RSA_NT) void select_mask_kernel(SelectArgs a) {
 template <int D>
 __global__ __launch_bounds__(256) void compensation_kernel(const float* w, const float* vbar, float* comp, int NBv,
                                                            int L, int NB_total) {
-    constexpr int TI = 32, TJ = 64, RG = 256 / D, RPT = TI / RG;
-    __shared__ float Ws[TI][TJ + 1];
+    // out tile 32 (i) x D (d); thread = RI rows x 4 d; j staged through LDS in chunks of 32 (W transposed so a
+    // thread's rows are one vector read)
+    constexpr int TI = 32, TJ = 32, TD = D / 4, TG = 256 / TD, RI = TI / TG;
+    __shared__ __attribute__((aligned(16))) float Ws[TJ][TI + 4];
+    __shared__ __attribute__((aligned(16))) float Vs[TJ][D];
     const int bh = blockIdx.y, i0 = blockIdx.x * TI, t = threadIdx.x;
-    const int d = t % D, rg = t / D;
+    const int td = t % TD, tg = t / TD;
     const float* wp = w + (long)bh * NBv * L;
     const float* vp = vbar + (long)bh * NB_total * D;
-    float acc[RPT];
+    float acc[RI][4];
 #pragma unroll
-    for (int r = 0; r < RPT; ++r) acc[r] = 0.0f;
+    for (int r = 0; r < RI; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[r][e] = 0.0f;
     for (int j0 = 0; j0 < L; j0 += TJ) {
         __syncthreads();
-        for (int idx = t; idx < TI * TJ; idx += 256) {
-            const int r = idx / TJ, jj = idx % TJ;
-            Ws[r][jj] = (i0 + r < NBv && j0 + jj < L) ? wp[(long)(i0 + r) * L + j0 + jj] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < TI * TJ / 256; ++k) {
+            const int idx = t + k * 256;
+            const int ii = idx / TJ, jj = idx % TJ;
+            Ws[jj][ii] = (i0 + ii < NBv && j0 + jj < L) ? wp[(long)(i0 + ii) * L + j0 + jj] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < TJ * D / 4 / 256; ++k) {
+            const int idx = t + k * 256;
+            const int jj = idx / TD, dd = (idx % TD) * 4;
+            float4 v4 = make_float4(0, 0, 0, 0);
+            if (j0 + jj < L) v4 = *reinterpret_cast<const float4*>(vp + (long)(j0 + jj) * D + dd);
+            *reinterpret_cast<float4*>(&Vs[jj][dd]) = v4;
         }
         __syncthreads();
-        const int jn = min(TJ, L - j0);
-        for (int jj = 0; jj < jn; ++jj) {
-            const float vv = vp[(long)(j0 + jj) * D + d];
+#pragma unroll 8
+        for (int jj = 0; jj < TJ; ++jj) {
+            const float4 v4 = *reinterpret_cast<const float4*>(&Vs[jj][4 * td]);
+            float wr[RI];
 #pragma unroll
-            for (int r = 0; r < RPT; ++r) acc[r] = __builtin_fmaf(Ws[rg * RPT + r][jj], vv, acc[r]);
+            for (int r = 0; r < RI; ++r) wr[r] = Ws[jj][tg * RI + r];
+#pragma unroll
+            for (int r = 0; r < RI; ++r) {
+                acc[r][0] = __builtin_fmaf(wr[r], v4.x, acc[r][0]);
+                acc[r][1] = __builtin_fmaf(wr[r], v4.y, acc[r][1]);
+                acc[r][2] = __builtin_fmaf(wr[r], v4.z, acc[r][2]);
+                acc[r][3] = __builtin_fmaf(wr[r], v4.w, acc[r][3]);
+            }
         }
     }
 #pragma unroll
-    for (int r = 0; r < RPT; ++r) {
-        const int i = i0 + rg * RPT + r;
-        if (i < NBv) comp[((long)bh * NBv + i) * D + d] = acc[r];
+    for (int r = 0; r < RI; ++r) {
+        const int i = i0 + tg * RI + r;
+        if (i < NBv)
+            *reinterpret_cast<float4*>(comp + ((long)bh * NBv + i) * D + 4 * td) =
+                make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
     }
 }
 

@@ -301,10 +301,48 @@ def processors():
     print("processors.npz:", {k: v.shape for k, v in res.items()})
 
 
+def gilbert():
+    """utils/jenga_gilbert.py vectors: permutations and block-neighbour matrices for small cuboids (full
+    arrays) and the HunyuanVideo 32x45x80 latent (sha256 digests only)."""
+    import contextlib
+    import hashlib
+    import io
+    import matplotlib
+    matplotlib.use("Agg")
+    with contextlib.redirect_stdout(io.StringIO()):
+        import utils.jenga_gilbert as ref
+    outdir = os.path.dirname(os.path.abspath(__file__))
+    res = {}
+    shapes = [(4, 12, 16), (1, 32, 32), (2, 6, 10), (3, 5, 7), (5, 4, 3)]
+    orders = [("w", "h", "t"), None, ("t", "h", "w")]
+    for (t, h, w) in shapes:
+        for ao in orders:
+            tag = f"{t}x{h}x{w}_{''.join(ao) if ao else 'auto'}"
+            with contextlib.redirect_stdout(io.StringIO()):
+                l2h, h2l = ref.gilbert_mapping(t, h, w, axis_order=ao) if ao else ref.gilbert_mapping(t, h, w, axis_order=None)
+                nb = ref.gilbert_block_neighbor_mapping(t, h, w, block_size=16, axis_order=ao)
+            res[f"l2h_{tag}"] = np.asarray(l2h, np.int32)
+            res[f"h2l_{tag}"] = np.asarray(h2l, np.int32)
+            res[f"nbr16_{tag}"] = np.packbits(nb.numpy(), axis=-1)
+            res[f"nbr16n_{tag}"] = np.array(nb.shape[0])
+    with contextlib.redirect_stdout(io.StringIO()):
+        l2h, h2l = ref.gilbert_mapping(32, 45, 80, axis_order=("w", "h", "t"))
+        nb = ref.gilbert_block_neighbor_mapping(32, 45, 80, axis_order=("w", "h", "t"))
+    res["hunyuan_l2h_sha256"] = np.array(hashlib.sha256(np.asarray(l2h, np.int32).tobytes()).hexdigest())
+    res["hunyuan_nbr_sha256"] = np.array(hashlib.sha256(nb.numpy().astype(np.uint8).tobytes()).hexdigest())
+    res["hunyuan_nbr_rowsum"] = nb.sum(1).numpy().astype(np.int32)
+    np.savez_compressed(os.path.join(outdir, "gilbert.npz"), **res)
+    print("gilbert.npz:", len(res), "arrays; hunyuan neighbour density", float(nb.float().mean()))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "processors":
+    if len(sys.argv) > 1 and sys.argv[1] == "gilbert":
+        _install_stubs()
+        gilbert()
+    elif len(sys.argv) > 1 and sys.argv[1] == "processors":
         _install_stubs()
         processors()
     else:
         main()
         processors()
+        gilbert()
