@@ -184,6 +184,15 @@ def main():
     kept_frac = total_pairs / (H * spec.NBv * spec.NB_total)
     k5_flops_local = local_flops  # rank-0 launch
     achieved = k5_flops_local / (k5_ms_local * 1e-3) / 1e12
+    # HBM-side traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE with
+    # the gfx950 x2 correction; tools/pmc_to_json.py) of this same command; it cannot be collected inside this process.
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "r01_k5_traffic.json")
+    if args.workload == "hunyuan_720p_128f" and args.neighbors == "none" and world == 1 and os.path.exists(tfile):
+        try:
+            traffic = json.load(open(tfile)).get("traffic_bytes_per_launch")
+        except (OSError, ValueError):
+            traffic = None
     res = {
         "metric": "attention-layer TFLOPs/sec (rectified block-sparse attention, HunyuanVideo seq~120k d=128 bf16)",
         "value": round(value, 3), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -198,7 +207,9 @@ def main():
                    "per_rank_ms": [round(x / args.steps * 1e3, 3) for x in per_rank_s]},
         "roofline": {"kernel": "bsfwd_kernel<128,bf16> (K5 block_sparse_fwd)", "bound": "mfma",
                      "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                     "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
+                     "traffic_note": "L2 memory-side bytes/launch from rocprofv3 PMC (profiles/r01_k5_traffic.json); "
+                                     "includes Infinity-Cache hits; compulsory Q+K+V+O = 2.84e9",
                      "k5_ms": round(k5_ms_local, 4), "select_pass_ms": round(ms_per_step - k5_ms, 4)},
     }
     if not args.no_cpu_baseline and world == 1:
