@@ -155,7 +155,7 @@ int rsa_gilbert_mapping(int t, int h, int w, const char* axis_order, int32_t* li
  * pointer, NB*NB bytes.  Replaces gilbert_block_neighbor_mapping (utils/jenga_gilbert.py:613-693). */
 int rsa_gilbert_block_neighbors(int t, int h, int w, int block_size, const char* axis_order, uint8_t* neighbor);
 
-/* Tuning / diagnostics hook, not part of the data path.  Keys: "k5_opt" (bit set of K5 kernel variants). */
+/* Tuning / diagnostics hook, not part of the data path.  Keys: "k5_prio" (0/1: issue-priority raise inside K5's pipelined block). */
 int rsa_set_tuning(const char* key, int value);
 
 const char* rsa_status_string(int status);

@@ -1,38 +1,59 @@
-// K5, second structure: 2 waves x 64 query rows per workgroup, ONE wave per SIMD with the whole 512-entry
-// register file, software-pipelined across tiles inside the wave.
+// K5: block-sparse flash attention forward for gfx950 (MI355X) with the rectification epilogue fused.
 //
-// Why: the 4x32 structure (rsa_attn.hip) needs two co-resident waves per SIMD to overlap one wave's softmax VALU
-// with the other's MFMAs, and measured only ~50 % MFMA-pipe occupancy (VALU and MFMA barely co-execute), with
-// every wave re-reading the full K and V tile from LDS for only 32 rows.  Here a wave owns 64 rows (two 32-row
-// sub-tiles share every K / V^T fragment: half the LDS bytes per FLOP) and overlaps, inside one basic block,
-//        MFMA stream:  S(t+1)^T = K(t+1) . Q^T   then   O^T += V(t)^T . P(t)^T
-//        VALU stream:  P(t) = exp2(S(t) - m)  (+ row sums, bf16 packing)   then   row max of S(t+1)
-// S is double-buffered in registers (the tile loop is unrolled by two).  The running max is "deferred": the
-// reference max m only moves when some row's max grew by more than 2^8 since it was set (P <= 2^8: no
-// precision loss in bf16/fp16 P, fp32 accumulators), and that rare rescale sits in a branch at the head of the
-// iteration, outside the pipelined block.
+// One workgroup (4 waves, 256 threads, two workgroups per CU) owns one 128-row query block; wave w owns rows
+// 32w..32w+31.  Both GEMMs run on v_mfma_f32_32x32x16_{bf16,f16} in the "key on the register, query row on
+// the lane" orientation:
+//      S^T[key][q]  = K . Q^T      A = K rows (ds_read_b128 from an XOR-swizzled row-major tile), B = Q (registers)
+//      O^T[d][q]   += V^T . P^T    A = V^T (ds_read_b64_tr_b16 transposing reads), B = P^T = the S^T accumulator
+//                                      converted in place (no LDS round trip, no cross-lane traffic)
+// so the softmax state (m, l) of a query row lives on one lane pair and the only cross-lane operation per
+// 32 keys is one v_permlane32_swap for the row max.
 //
-// LDS: [K0 K1 V0 V1 | kept list]; K(t+2) is DMA'd into K(t)'s slot and V(t+1) into V(t-1)'s slot at the top of
-// iteration t (after the barrier that retires their last readers); data has one full iteration to land.
-// Semantics identical to rsa_attn.hip (see its header for the reference citations).
+// Software pipeline (per wave, at 32-key granularity, S double-buffered in registers, loop unrolled by two
+// 64-key tiles so every LDS address is a loop-invariant VGPR plus an immediate):
+//      MFMA stream:  S(u+1)^T = K(u+1) . Q^T      then   O^T += V(u)^T . P(u)^T
+//      VALU stream:  P(u) = exp2(S(u) - m) (+ row sums, 2-byte packing)   then   row max of S(u+1)
+// The block is branch-free; hipcc emits the VALU part first and the MFMA cluster after it, and the two
+// co-resident waves of a SIMD (one per workgroup) alternate between the two (measured: pinning a fine
+// per-MFMA interleave with sched_group_barrier is 3.5 % slower).  The running max is deferred: the reference
+// max only moves when some row's max grew by more than 2^8 since it was set (P <= 2^8: same relative precision
+// in bf16/fp16 P, fp32 accumulators); that rare rescale and the boundary-tile mask sit in branches at the head
+// of the sub-step, outside the pipelined block.
 //
-// STATUS (round 1): NOT BUILT, not part of librsa_hip.so.  Numerically correct on the GPU (max |d| 7.8e-3 vs the
-// 4x32 kernel, i.e. the deferred-max rounding), but 32.3 ms vs 18.3 ms at the bench shape: hipcc (ROCm 7.2)
-// allocates 256 VGPR + 256 AGPR and still spills 46 VGPRs / 25 SGPRs, and the scratch reloads sit next to the
-// hand-issued LDS-DMA, so their compiler-inserted `s_waitcnt vmcnt(0)` drains the DMA at the head of every
-// sub-step.  The register plan that fits (O and Q in AGPRs = 192, everything the VALU touches in < 180 VGPRs)
-// needs the MFMA operands pinned by register class (inline-asm MFMAs with "a"/"v" constraints + hand-placed
-// hazard nops), which is next round's work.  Kept here so that work starts from a correct pipeline.
-#include "../rsa_attn.h"
+// Staging: K/V tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction) issued
+// from inline asm so that hipcc neither counts nor drains them; LDS = [K0 K1 V0 V1 | kept list (u16)].  At the
+// head of sub-step (t,0) V(t+1) is issued into V(t-1)'s slot, at the head of (t,1) K(t+2) into K(t)'s slot,
+// each behind a counted vmcnt (the group issued half a tile ago stays in flight) + barrier; every tile has a
+// full tile time to land.  The LDS image is lane-linear, so the XOR swizzle is applied to the per-lane SOURCE
+// chunk (same involution as tile_off on the read side); per-lane source offsets are tile-invariant 32-bit
+// values and the tile only moves a scalar base.
+//
+// Semantics kept from the reference kernel (rectified_hunyuan_attn.py:15-105): Q is pre-multiplied by
+// sm_scale*log2(e) and rounded to the input dtype (:61-62), P is rounded to the input dtype before PV (:97),
+// fp32 softmax statistics and accumulators, kv columns outside the row's range are -inf (:86-87), rows
+// beyond the sequence are not stored (:105).  Added: per-row kv ranges (the two-segment varlen semantics of
+// the flash call, attn.py:107-120), a NaN-free fully-masked path, the fused O*R+comp epilogue (hunyuan :365)
+// and a strided [B,S,H,D] store (hunyuan :383-387).
+//
+// The template also instantiates as NW = 2 waves x QT = 2 sub-tiles (64 rows per wave, one wave per SIMD).
+// That form is correct but not built: hipcc (ROCm 7.2) then needs 256 VGPR + 256 AGPR, spills 46 VGPRs, and
+// the scratch reloads' vmcnt(0) drains the hand-issued DMA (32 ms vs 17 ms); it needs MFMA operands pinned by
+// register class, i.e. an asm-level body.
+#include "rsa_attn.h"
 
-template <int D, typename Tag>
-__global__ __launch_bounds__(128, 1) void bsfwd64_kernel(AttnArgs a) {
+// PIPE_OPT bits (tuning experiments): 2 = issue priority 2 for this wave while it is inside the pipelined block.
+// (Pinning a per-MFMA interleave {2 LDS reads, 1 MFMA, 1 exp, 4 VALU} with sched_group_barrier measured -3.5 %: the
+// compiler's own order -- softmax VALU first, then the MFMA cluster -- lets the two co-resident waves alternate.)
+template <int D, typename Tag, int NW, int QT, int PIPE_OPT>
+__global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bsfwd_kernel(AttnArgs a) {
+    static_assert(NW * QT == 4, "a workgroup owns one 128-row query block");
     constexpr int KS = D / 16;
     constexpr int DT = D / 32;
     constexpr int CHR = D / 8;
     constexpr int RPI = 1024 / (D * 2);     // rows per 1-KiB piece
     constexpr int TILE_BYTES = 64 * D * 2;
-    constexpr int NPC = TILE_BYTES / 1024 / 2;  // pieces per wave per tile operand (8 or 4)
+    constexpr int NPC = TILE_BYTES / 1024 / NW;  // 1-KiB pieces per wave per tile operand
+    constexpr int PG = 4 / NW;                  // pieces of each group of 4 that this wave moves (1 or 2)
     using E = Elem<Tag>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned short* lds_list = reinterpret_cast<unsigned short*>(lds + 4 * TILE_BYTES);
@@ -59,13 +80,15 @@ __global__ __launch_bounds__(128, 1) void bsfwd64_kernel(AttnArgs a) {
     const int t = threadIdx.x, lane = t & 63;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int r = lane & 31, hh = lane >> 5;
-    int grow[2];
-    grow[0] = qblk * RSA_BLOCK + 64 * wv + r;
-    grow[1] = grow[0] + 32;
+    int grow[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) grow[qt] = qblk * RSA_BLOCK + 32 * QT * wv + 32 * qt + r;
 
     // ---------------- per-row plan ----------------
-    int lo_r[2] = {0, 0}, hi_r[2] = {0, 0};
-    bool store_r[2] = {false, false}, zero_r[2] = {false, false};
+    int lo_r[QT], hi_r[QT];
+    bool store_r[QT], zero_r[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) { lo_r[qt] = 0; hi_r[qt] = 0; store_r[qt] = false; zero_r[qt] = false; }
     int n_items, first_blk = 0, lo_max, hi_min, hi_max;
     const int32_t* list = nullptr;
     bool rectify = false;
@@ -77,12 +100,12 @@ __global__ __launch_bounds__(128, 1) void bsfwd64_kernel(AttnArgs a) {
             lo_max = 0; hi_min = hi_max = a.kv_valid;
             rectify = a.R != nullptr;
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) { hi_r[qt] = a.kv_valid; store_r[qt] = grow[qt] < a.Sq; }
+            for (int qt = 0; qt < QT; ++qt) { hi_r[qt] = a.kv_valid; store_r[qt] = grow[qt] < a.Sq; }
         } else {
             n_items = (a.kv_text_valid + RSA_BLOCK - 1) / RSA_BLOCK;
             lo_max = 0; hi_min = hi_max = a.kv_text_valid;
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
+            for (int qt = 0; qt < QT; ++qt) {
                 hi_r[qt] = a.kv_text_valid;
                 store_r[qt] = grow[qt] < a.q_text_end;
                 zero_r[qt] = !store_r[qt] && grow[qt] < a.Sq;
@@ -91,7 +114,7 @@ __global__ __launch_bounds__(128, 1) void bsfwd64_kernel(AttnArgs a) {
     } else {
         const int row0 = qblk * RSA_BLOCK, row1 = row0 + RSA_BLOCK;
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
+        for (int qt = 0; qt < QT; ++qt) {
             if (grow[qt] < a.q_split) { lo_r[qt] = 0; hi_r[qt] = a.kv_split; }
             else { lo_r[qt] = a.kv_split; hi_r[qt] = a.Sk; }
             store_r[qt] = grow[qt] < a.Sq;
@@ -107,7 +130,7 @@ __global__ __launch_bounds__(128, 1) void bsfwd64_kernel(AttnArgs a) {
     n_items = __builtin_amdgcn_readfirstlane(n_items);
     const bool use_list = list != nullptr;
     if (use_list) {
-        for (int i = t; i < n_items; i += 128) lds_list[i] = (unsigned short)list[i];
+        for (int i = t; i < n_items; i += 64 * NW) lds_list[i] = (unsigned short)list[i];
         __syncthreads();
     }
     auto blk_of = [&](int item) -> int { return use_list ? (int)lds_list[item] : first_blk + item; };
@@ -125,9 +148,9 @@ __global__ __launch_bounds__(128, 1) void bsfwd64_kernel(AttnArgs a) {
     };
 
     // ---------------- Q fragments (B operand), two 32-row sub-tiles ----------------
-    s16x8 qf[2][KS];
+    s16x8 qf[QT][KS];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
         const unsigned short* qp = a.q + (long)b * a.qsb + (long)h * a.qsh + (long)grow[qt] * a.qss + 8 * hh;
         const bool qok = grow[qt] < a.Sq;
 #pragma unroll
@@ -148,14 +171,14 @@ __global__ __launch_bounds__(128, 1) void bsfwd64_kernel(AttnArgs a) {
     // ---------------- LDS-DMA staging ----------------
     const unsigned char* kbase = reinterpret_cast<const unsigned char*>(a.k + (long)b * a.ksb + (long)h * a.ksh);
     const unsigned char* vbase = reinterpret_cast<const unsigned char*>(a.v + (long)b * a.vsb + (long)h * a.vsh);
-    // piece pc = 4*(j>>1) + 2*wv + (j&1), j = 0..NPC-1: tile rows pc*RPI .. +RPI-1.  The source-chunk swizzle
-    // depends on pc & 3 = 2*wv + (j&1): two per-lane offsets per operand (j even / odd).
+    // piece pc = 4*(j/PG) + PG*wv + (j%PG), j = 0..NPC-1: tile rows pc*RPI .. +RPI-1.  The source-chunk swizzle
+    // depends on pc & 3 = PG*wv + (j%PG): PG per-lane offsets per operand.
     const int rsub = lane / CHR, cl = lane % CHR;
-    unsigned voffk[2], voffv[2];
-    int gsw[2];
+    unsigned voffk[PG], voffv[PG];
+    int gsw[PG];
 #pragma unroll
-    for (int par = 0; par < 2; ++par) {
-        const int rowl = (2 * wv + par) * RPI + rsub;  // row inside the first group of 4 pieces
+    for (int par = 0; par < PG; ++par) {
+        const int rowl = (PG * wv + par) * RPI + rsub;  // row inside the first group of 4 pieces
         if constexpr (D == 128) gsw[par] = cl ^ (((rowl & 3) << 2) | ((rowl >> 2) & 3));
         else gsw[par] = cl ^ ((rowl >> 1) & 7);
         voffk[par] = (unsigned)(((long)rowl * a.kss + gsw[par] * 8) * 2);
@@ -165,7 +188,7 @@ __global__ __launch_bounds__(128, 1) void bsfwd64_kernel(AttnArgs a) {
     const long kstep = (long)(4 * RPI) * a.kss * 2, vstep = (long)(4 * RPI) * a.vss * 2;  // bytes per 4 pieces
     // is_v: 0 = K tile into K slot `slot`, 1 = V tile into V slot `slot`
     auto dma = [&](int is_v, int key0, int slot) {
-        const unsigned ld0 = lds_base + (is_v ? 2 : 0) * TILE_BYTES + slot * TILE_BYTES + (2 * wv) * 1024;
+        const unsigned ld0 = lds_base + (is_v ? 2 : 0) * TILE_BYTES + slot * TILE_BYTES + (PG * wv) * 1024;
         const unsigned char* base = is_v ? vbase : kbase;
         const long ss = is_v ? a.vss : a.kss;
         if (key0 + 64 <= kv_limit) {
@@ -173,33 +196,35 @@ __global__ __launch_bounds__(128, 1) void bsfwd64_kernel(AttnArgs a) {
             const long step = is_v ? vstep : kstep;
 #pragma unroll
             for (int j = 0; j < NPC; ++j) {
-                const unsigned vo = is_v ? voffv[j & 1] : voffk[j & 1];
+                const unsigned vo = is_v ? voffv[j % PG] : voffk[j % PG];
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                             :: "v"(vo), "s"(tb + (j >> 1) * step), "s"(ld0 + (j >> 1) * 4096 + (j & 1) * 1024)
+                             :: "v"(vo), "s"(tb + (j / PG) * step), "s"(ld0 + (j / PG) * 4096 + (j % PG) * 1024)
                              : "memory");
             }
         } else {
 #pragma unroll
             for (int j = 0; j < NPC; ++j) {
-                const int rowl = (2 * wv + (j & 1)) * RPI + rsub;
-                int krow = key0 + (j >> 1) * 4 * RPI + rowl;
+                const int rowl = (PG * wv + (j % PG)) * RPI + rsub;
+                int krow = key0 + (j / PG) * 4 * RPI + rowl;
                 krow = krow < kv_limit ? krow : kv_limit - 1;
-                const unsigned vo = (unsigned)(((long)krow * ss + gsw[j & 1] * 8) * 2);
+                const unsigned vo = (unsigned)(((long)krow * ss + gsw[j % PG] * 8) * 2);
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                             :: "v"(vo), "s"(base), "s"(ld0 + (j >> 1) * 4096 + (j & 1) * 1024) : "memory");
+                             :: "v"(vo), "s"(base), "s"(ld0 + (j / PG) * 4096 + (j % PG) * 1024) : "memory");
             }
         }
     };
 
     // ---------------- state ----------------
-    f32x16 o[DT][2];
+    f32x16 o[DT][QT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
+        for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) o[dt][qt][i] = 0.0f;
-    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.0f, 0.0f};
+    float m_run[QT], l_run[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) { m_run[qt] = -INFINITY; l_run[qt] = 0.0f; }
 
     // per-lane read addressing
     const int kswz = ((r & 3) << 2) | ((r >> 2) & 3);
@@ -217,23 +242,23 @@ __global__ __launch_bounds__(128, 1) void bsfwd64_kernel(AttnArgs a) {
     };
 
     // S^T[qt] (32 keys x 32 rows per qt) = K[sub-tile SUB of K slot] . Q^T ; one K fragment feeds both query sub-tiles
-    auto qk_sub = [&](auto KSLOT, auto SUB, f32x16 (&S)[2]) {
+    auto qk_sub = [&](auto KSLOT, auto SUB, f32x16 (&S)[QT]) {
         constexpr int slot = decltype(KSLOT)::value, sub = decltype(SUB)::value;
         const unsigned char* kt_ = lds + slot * TILE_BYTES;
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
+        for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) S[qt][i] = 0.0f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const s16x8 a0 = *reinterpret_cast<const s16x8*>(kt_ + k_off(ks, sub));
-            S[0] = E::mfma(a0, qf[0][ks], S[0]);
-            S[1] = E::mfma(a0, qf[1][ks], S[1]);
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) S[qt] = E::mfma(a0, qf[qt][ks], S[qt]);
         }
     };
-    auto rowmax_sub = [&](const f32x16 (&S)[2], float (&mx)[2]) {
+    auto rowmax_sub = [&](const f32x16 (&S)[QT], float (&mx)[QT]) {
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
+        for (int qt = 0; qt < QT; ++qt) {
             float m = S[qt][0];
 #pragma unroll
             for (int i = 1; i < 16; ++i) m = fmaxf(m, S[qt][i]);
@@ -241,9 +266,9 @@ __global__ __launch_bounds__(128, 1) void bsfwd64_kernel(AttnArgs a) {
             mx[qt] = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
         }
     };
-    auto apply_mask_sub = [&](f32x16 (&S)[2], int key_first) {
+    auto apply_mask_sub = [&](f32x16 (&S)[QT], int key_first) {
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
+        for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int kk = key_first + (i & 3) + 8 * (i >> 2) + 4 * hh;
@@ -257,13 +282,14 @@ __global__ __launch_bounds__(128, 1) void bsfwd64_kernel(AttnArgs a) {
     // S_nxt / mx_nxt for sub-step u+1.  VS = slot parity of `tile` (its K and V slots).
     //   SUB = 0: head issues V(tile+1);  next scores = K(tile) sub-tile 1
     //   SUB = 1: head issues K(tile+2);  next scores = K(tile+1) sub-tile 0
-    auto step = [&](auto VS, auto SUB, int tile, int key0, f32x16 (&S_cur)[2], float (&mx_cur)[2],
-                    f32x16 (&S_nxt)[2], float (&mx_nxt)[2]) {
+    auto step = [&](auto VS, auto SUB, int tile, int key0, f32x16 (&S_cur)[QT], float (&mx_cur)[QT],
+                    f32x16 (&S_nxt)[QT], float (&mx_nxt)[QT]) {
         constexpr int vs = decltype(VS)::value, sub = decltype(SUB)::value;
         // the newest DMA group (issued half a tile ago) may stay in flight; the one issued a tile ago must land
         if (tile + 1 < n_tiles) {
             if constexpr (NPC == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if constexpr (NPC == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -281,10 +307,10 @@ __global__ __launch_bounds__(128, 1) void bsfwd64_kernel(AttnArgs a) {
         }
         bool grow_any = false;
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) grow_any |= mx_cur[qt] > m_run[qt] + 8.0f;
+        for (int qt = 0; qt < QT; ++qt) grow_any |= mx_cur[qt] > m_run[qt] + 8.0f;
         if (__builtin_amdgcn_ballot_w64(grow_any) != 0ull) {
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
+            for (int qt = 0; qt < QT; ++qt) {
                 const float m_new = fmaxf(m_run[qt], mx_cur[qt]);
                 const float mu = (m_new == -INFINITY) ? 0.0f : m_new;
                 const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - mu);
@@ -296,16 +322,17 @@ __global__ __launch_bounds__(128, 1) void bsfwd64_kernel(AttnArgs a) {
                     for (int i = 0; i < 16; ++i) o[dt][qt][i] *= alpha;
             }
         }
-        float m_use[2];
+        float m_use[QT];
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) m_use[qt] = (m_run[qt] == -INFINITY) ? 0.0f : m_run[qt];
+        for (int qt = 0; qt < QT; ++qt) m_use[qt] = (m_run[qt] == -INFINITY) ? 0.0f : m_run[qt];
 
         // ---- pipelined block (branch-free on purpose: the scheduler interleaves the MFMA and VALU streams) ----
+        if constexpr (PIPE_OPT & 2) __builtin_amdgcn_s_setprio(2);
         if constexpr (sub == 0) qk_sub(std::integral_constant<int, vs>{}, std::integral_constant<int, 1>{}, S_nxt);
         else qk_sub(std::integral_constant<int, vs ^ 1>{}, std::integral_constant<int, 0>{}, S_nxt);
-        s16x8 pb[2][2];
+        s16x8 pb[QT][2];
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
+        for (int qt = 0; qt < QT; ++qt) {
             float ps = 0.0f;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
@@ -331,16 +358,19 @@ __global__ __launch_bounds__(128, 1) void bsfwd64_kernel(AttnArgs a) {
                 const s16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                     (s16x4 __attribute__((address_space(3)))*)(vt_ + offb));
                 const s16x8 av = __builtin_shufflevector(va, vb, 0, 1, 2, 3, 4, 5, 6, 7);
-                o[dt][0] = E::mfma(av, pb[0][k2], o[dt][0]);
-                o[dt][1] = E::mfma(av, pb[1][k2], o[dt][1]);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) o[dt][qt] = E::mfma(av, pb[qt][k2], o[dt][qt]);
             }
         }
         rowmax_sub(S_nxt, mx_nxt);
+        if constexpr (PIPE_OPT & 2) __builtin_amdgcn_s_setprio(0);
     };
 
     // ---------------- prologue + main loop ----------------
-    f32x16 SA[2], SB[2];
-    float mxA[2] = {-INFINITY, -INFINITY}, mxB[2] = {-INFINITY, -INFINITY};
+    f32x16 SA[QT], SB[QT];
+    float mxA[QT], mxB[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) { mxA[qt] = -INFINITY; mxB[qt] = -INFINITY; }
     int key0 = 0;
     if (n_tiles > 0) {
         key0 = key0_of(0);
@@ -379,7 +409,7 @@ __global__ __launch_bounds__(128, 1) void bsfwd64_kernel(AttnArgs a) {
 
     // ---------------- epilogue ----------------
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run[qt]), __float_as_uint(l_run[qt]),
                                                          false, false);
         const float l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
@@ -416,13 +446,17 @@ __global__ __launch_bounds__(128, 1) void bsfwd64_kernel(AttnArgs a) {
 }
 
 // launch hook used by rsa_attn.hip::launch_attn
-int rsa_launch_bsfwd64(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int dtype, hipStream_t s) {
+int rsa_launch_bsfwd(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int dtype, int prio, hipStream_t s) {
+#define RSA_K5(DD, TT) \
+    do { \
+        if (prio) bsfwd_kernel<DD, TT, 4, 1, 2><<<grid, 256, lds_bytes, s>>>(a); \
+        else bsfwd_kernel<DD, TT, 4, 1, 0><<<grid, 256, lds_bytes, s>>>(a); \
+    } while (0)
     if (D == 128) {
-        if (dtype == RSA_BF16) bsfwd64_kernel<128, bf16_tag><<<grid, 128, lds_bytes, s>>>(a);
-        else bsfwd64_kernel<128, fp16_tag><<<grid, 128, lds_bytes, s>>>(a);
+        if (dtype == RSA_BF16) RSA_K5(128, bf16_tag); else RSA_K5(128, fp16_tag);
     } else {
-        if (dtype == RSA_BF16) bsfwd64_kernel<64, bf16_tag><<<grid, 128, lds_bytes, s>>>(a);
-        else bsfwd64_kernel<64, fp16_tag><<<grid, 128, lds_bytes, s>>>(a);
+        if (dtype == RSA_BF16) RSA_K5(64, bf16_tag); else RSA_K5(64, fp16_tag);
     }
+#undef RSA_K5
     return rsa_launch_status();
 }
