@@ -205,7 +205,7 @@ def main():
                    "dense_equivalent_tflops": round(4.0 * S * S * D * H / (elapsed / args.steps) / 1e12, 1),
                    "gather_output": bool(args.gather_output), "parallelism": f"head-shard x{world}",
                    "per_rank_ms": [round(x / args.steps * 1e3, 3) for x in per_rank_s]},
-        "roofline": {"kernel": "bsfwd_kernel<128,bf16> (K5 block_sparse_fwd)", "bound": "mfma",
+        "roofline": {"kernel": "bsfwd_kernel<128,bf16_tag,4,1,2> (K5 block_sparse_fwd)", "bound": "mfma",
                      "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
                      "traffic_note": "L2 memory-side bytes/launch from rocprofv3 PMC (profiles/r01_k5_traffic.json); "
