@@ -132,24 +132,28 @@ def _c_buffers(bufs: Dict[str, torch.Tensor]) -> RsaBuffers:
     return RsaBuffers(*[bufs[n].data_ptr() if bufs[n].numel() else None for n in BUFFER_NAMES])
 
 
-_NEIGHBOR_CACHE: Dict[tuple, torch.Tensor] = {}
-
-
 def neighbor_on_device(block_neighbor_list, NBv: int, device) -> Optional[torch.Tensor]:
-    """uint8 [NBv, NBv] device copy of block_neighbor_list[:NBv, :NBv], cached (the reference re-uploads
-    the CPU bool matrix on every call, rectified_hunyuan_attn.py:267-268)."""
+    """uint8 [NBv, NBv] device copy of block_neighbor_list[:NBv, :NBv] (the reference re-uploads the CPU bool
+    matrix on every call, rectified_hunyuan_attn.py:267-268).  The copy is cached ON the source tensor object
+    (so it lives and dies with it) and is refreshed when the tensor was modified in place."""
     if block_neighbor_list is None:
         return None
     t = block_neighbor_list
-    key = (t.data_ptr(), tuple(t.shape), str(t.device), t._version, NBv, str(device))
-    hit = _NEIGHBOR_CACHE.get(key)
+    if t.shape[0] < NBv or t.shape[1] < NBv:
+        raise ValueError(f"block_neighbor_list {tuple(t.shape)} smaller than [{NBv},{NBv}]")
+    key = (t._version, NBv, str(device))
+    cache = getattr(t, "_rsa_device_copies", None)
+    if cache is None:
+        cache = {}
+        try:
+            t._rsa_device_copies = cache
+        except AttributeError:  # exotic tensor subclass without a __dict__: no caching
+            pass
+    hit = cache.get(key)
     if hit is None:
-        if len(_NEIGHBOR_CACHE) > 16:
-            _NEIGHBOR_CACHE.clear()
-        if t.shape[0] < NBv or t.shape[1] < NBv:
-            raise ValueError(f"block_neighbor_list {tuple(t.shape)} smaller than [{NBv},{NBv}]")
+        cache.clear()
         hit = t[:NBv, :NBv].to(device=device, dtype=torch.uint8).contiguous()
-        _NEIGHBOR_CACHE[key] = hit
+        cache[key] = hit
     return hit
 
 

@@ -168,3 +168,28 @@ def test_wan_processor_sparse_gate_and_cross_attention_on_device():
     pc = wan.RectifiedWanT2VSpaAttnProcessor2_0("flash", 2, None, 0.3, 5, 1)
     oc = pc(a, hs, helpers.hidden(105, 23, 1, 512, dim).to(DEV, torch.bfloat16), None, None)
     assert np.abs(oc.float().cpu().numpy() - G["wan_cross_out"].astype(np.float32)).max() <= 6e-2
+
+
+def test_neighbor_cache_is_not_fooled_by_recycled_memory():
+    """Regression: the device copy of block_neighbor_list used to be keyed by data_ptr; a new matrix allocated at
+    a freed matrix's address then silently reused the stale copy."""
+    from rectified_spaattn_amd import _core, synth
+    q, k, v = (torch.from_numpy(x).to(DEV, torch.bfloat16) for x in synth.structured_qkv(4, 1, 1, 1152, 128))
+    spec = _core.LayoutSpec.wan(1152, 0)
+    masks = []
+    for width in (1, 2, 1, 3):
+        nbr = torch.from_numpy(synth.banded_neighbors(9, width))  # temporaries of identical shape
+        _, bufs = _core.rectified_attention(q, k, v, spec, 1, 0.0, nbr, return_parts=True)
+        kept = _core.unpack_bitmask(bufs["bitmask"], 9)[0].cpu()
+        assert bool(kept[nbr].all()), f"band {width} not applied"
+        masks.append(kept)
+        del nbr
+    assert not torch.equal(masks[0], masks[1]) and torch.equal(masks[0], masks[2])
+    same = torch.from_numpy(synth.banded_neighbors(9, 1))
+    _core.rectified_attention(q, k, v, spec, 1, 0.0, same)
+    a = same._rsa_device_copies
+    _core.rectified_attention(q, k, v, spec, 1, 0.0, same)
+    assert same._rsa_device_copies is a and len(a) == 1  # second call reuses the upload
+    same[0, 8] = True  # in-place edit bumps the version -> refreshed
+    _, bufs = _core.rectified_attention(q, k, v, spec, 1, 0.0, same, return_parts=True)
+    assert bool(_core.unpack_bitmask(bufs["bitmask"], 9)[0, 0, 8])

@@ -1,0 +1,102 @@
+"""Parity at BASELINE.json's full sizes (GPU).  The oracle cannot run a whole 115k-token layer in seconds, so the
+full-size checks are (i) bit-exact masks / statistics and output tolerance on SAMPLED query blocks (the oracle
+pools the whole head, then evaluates only those rows), and (ii) size-independent properties over the whole
+result: list/bitmask consistency, top-k lower bound, text blocks always kept, R in [0, 1+eps], finite output."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _gen(H, S, D, seed):
+    from bench import gen_qkv
+    return gen_qkv(H, 0, S, S, D, torch.device(DEV), seed=seed)
+
+
+def _check_config(name, spec, lay, H, top_k, p, nbr, sample_rows, seed=77):
+    from rectified_spaattn_amd import _core
+    D = 128
+    q, k, v = _gen(H, lay.S, D, seed)
+    tn = torch.from_numpy(nbr) if nbr is not None else None
+    out, bufs = _core.rectified_attention(q, k, v, spec, top_k, p, tn, return_parts=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all(), f"{name}: non-finite output"
+    counts = bufs["counts"].cpu().numpy()
+    kept = _core.unpack_bitmask(bufs["bitmask"], lay.NB_total).cpu().numpy()
+    cols = bufs["cols"].cpu().numpy()
+    R = bufs["R"].cpu().numpy()
+    # ---- properties over the whole result ----
+    assert np.array_equal(kept.sum(-1), counts)
+    assert (counts >= min(top_k, lay.L)).all()
+    if lay.n_txt > 0:
+        assert kept[:, :, lay.NBv: lay.text_end_block].all(), "text blocks must be kept by every row"
+    if lay.ffb > 0:
+        assert kept[:, : lay.ffb, : lay.ffb].all()
+    if nbr is not None:
+        assert kept[:, :, : lay.NBv][:, nbr[: lay.NBv, : lay.NBv]].all(), "neighbour blocks must be kept"
+    assert (R >= 0).all() and (R <= 1 + 1e-5).all()
+    for bh in (0, H - 1):
+        for i in (0, lay.NBv // 2, lay.NBv - 1):
+            assert np.array_equal(cols[bh, i, : counts[bh, i]], np.nonzero(kept[bh, i])[0])
+    # ---- sampled rows against the oracle (bit-exact statistics, tolerance on O) ----
+    o = out.view(1, lay.S, H, D)
+    for bh in (0, H - 1):
+        qh, kh, vh = (x[0, bh].float().cpu().numpy() for x in (q, k, v))
+        if lay.pool_valid < lay.S:
+            kh[lay.pool_valid:] = 0
+            vh[lay.pool_valid:] = 0
+        sel = orc.select_head(qh, kh, vh, lay, top_k, p, nbr, rows=sample_rows)
+        for a, i in enumerate(sample_rows):
+            assert np.array_equal(kept[bh, i], sel["kept"][a].astype(bool)), f"{name}: mask row {i} head {bh}"
+            assert np.array_equal(bufs["probs"][bh, i].cpu().numpy(), sel["probs"][a])
+            assert bufs["R"][bh, i].item() == sel["R"][a]
+        ref = orc.sparse_attention_head(qh, kh, vh, lay, sel["kept"], sample_rows)
+        ref = ref * sel["R"][:, None, None] + sel["comp"][:, None, :]
+        for a, i in enumerate(sample_rows):
+            n = min(128, lay.S - i * 128)
+            got = o[0, i * 128: i * 128 + n, bh].float().cpu().numpy()
+            err = np.abs(got - ref[a, :n])
+            assert err.max() <= 2e-2 and err.mean() <= 2e-3, f"{name}: O row-block {i}: {err.max():.3e}"
+        if lay.q_text_valid > 0:  # a few text rows: exact attention over the valid keys
+            r0 = lay.NBv * 128
+            rows = [r0, r0 + lay.q_text_valid - 1]
+            reft = orc.dense_attention(qh[rows], kh, vh, lay.kv_text_valid)
+            got = o[0, rows, bh].float().cpu().numpy()
+            assert np.abs(got - reft).max() <= 2e-2
+            if r0 + lay.q_text_valid < lay.S:
+                assert float(o[0, r0 + lay.q_text_valid:, bh].abs().max()) == 0.0, "padded text rows must be 0"
+
+
+def test_hunyuan_720p_full_size():
+    """BASELINE configs[3]: HunyuanVideo 128f 720p, S = 115 200 + 256 (200 valid), top_k = 90; 4 of 24 heads."""
+    from rectified_spaattn_amd import _core
+    from rectified_spaattn_amd.utils import jenga_gilbert
+    S, nt = 115456, 115400
+    nbr = jenga_gilbert.gilbert_block_neighbor_mapping(32, 45, 80).numpy()
+    _check_config("hunyuan", _core.LayoutSpec.hunyuan(S, nt), orc.layout_hunyuan(S, nt), 4, 90, 0.05, nbr,
+                  [0, 437, 899])
+
+
+def test_flux_4096_full_size():
+    """BASELINE configs[1]: Flux.1-dev 4096x4096, S = 65 536 + 512, top_k = 51, p = 0.3; 4 of 24 heads."""
+    from rectified_spaattn_amd import _core
+    S = 66048
+    _check_config("flux", _core.LayoutSpec.flux(S, 512), orc.layout_flux(S, 512), 4, 51, 0.3, None, [3, 511])
+
+
+def test_wan21_720p_full_size():
+    """BASELINE configs[2]: Wan2.1-T2V 81f 720p, S = 75 600 (padded to 591 blocks), top_k = 147, ffb = 28."""
+    from rectified_spaattn_amd import _core
+    S = 75600
+    _check_config("wan", _core.LayoutSpec.wan(S, 28), orc.layout_wan(S, 28), 3, 147, 0.3, None, [5, 590])
+
+
+def test_wan22_ti2v_full_size():
+    """BASELINE configs[4] shape (bf16 here; the reference has no fp8 path): S = 27 280, top_k = 53, ffb = 6."""
+    from rectified_spaattn_amd import _core
+    S = 27280
+    _check_config("wan22", _core.LayoutSpec.wan(S, 6), orc.layout_wan(S, 6), 4, 53, 0.3, None, [0, 100, 213])
