@@ -240,3 +240,28 @@ def unpack_bitmask(bitmask: torch.Tensor, n: int) -> torch.Tensor:
     w = bitmask.to(torch.int64) & 0xFFFFFFFF
     bits = (w.unsqueeze(-1) >> torch.arange(32, device=bitmask.device)) & 1
     return bits.flatten(-2)[..., :n].bool()
+
+
+def rectified_attention_onecall(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, spec: LayoutSpec, top_k: int,
+                                p_remain: float, block_neighbor_list=None, workspace: Optional[torch.Tensor] = None):
+    """Same operator through the single C entry point rsa_rectified_attention with one caller-provided workspace
+    (what a non-Python host would call).  Returns ([B, S, H*D], workspace)."""
+    _require_device(q, k, v)
+    L = _lib.lib()
+    B, H, S, D = q.shape
+    q, k, v = _as_bhsd(q), _as_bhsd(k), _as_bhsd(v)
+    lay = spec.to_c(B, H, D, q.dtype)
+    sizes = (ctypes.c_size_t * 14)()
+    total = ctypes.c_size_t()
+    _lib.check(L.rsa_buffer_bytes(ctypes.byref(lay), ctypes.byref(sizes), ctypes.byref(total)), "rsa_buffer_bytes")
+    if workspace is None or workspace.numel() < total.value:
+        workspace = torch.empty(total.value, dtype=torch.uint8, device=q.device)
+    out = torch.empty((B, S, H, D), dtype=q.dtype, device=q.device)
+    o4 = RsaOut4(out.data_ptr(), out.stride(0), out.stride(2), out.stride(1))
+    nbr = neighbor_on_device(block_neighbor_list, spec.NBv, q.device)
+    with torch.cuda.device(q.device):
+        _lib.check(L.rsa_rectified_attention(ctypes.byref(lay), _t4(q), _t4(k), _t4(v),
+                                             nbr.data_ptr() if nbr is not None else None, int(top_k),
+                                             float(p_remain), workspace.data_ptr(), workspace.numel(), o4, _stream()),
+                   "rsa_rectified_attention")
+    return out.view(B, S, H * D), workspace

@@ -193,3 +193,51 @@ def test_neighbor_cache_is_not_fooled_by_recycled_memory():
     same[0, 8] = True  # in-place edit bumps the version -> refreshed
     _, bufs = _core.rectified_attention(q, k, v, spec, 1, 0.0, same, return_parts=True)
     assert bool(_core.unpack_bitmask(bufs["bitmask"], 9)[0, 0, 8])
+
+
+def test_one_call_entry_point_and_workspace_checks():
+    """rsa_rectified_attention (single C entry, caller-provided workspace) == the staged calls, bit for bit."""
+    import ctypes
+    from rectified_spaattn_amd import _core, _lib, synth
+    q, k, v = (torch.from_numpy(x).to(DEV, torch.bfloat16) for x in synth.structured_qkv(6, 1, 2, 1280, 128))
+    spec = _core.LayoutSpec.hunyuan(1280, 1224)
+    nbr = torch.from_numpy(synth.banded_neighbors(8, 1))
+    ref = _core.rectified_attention(q, k, v, spec, 2, 0.3, nbr)
+    got, ws = _core.rectified_attention_onecall(q, k, v, spec, 2, 0.3, nbr)
+    assert torch.equal(ref, got)
+    got2, ws2 = _core.rectified_attention_onecall(q, k, v, spec, 2, 0.3, nbr, workspace=ws)  # reuse
+    assert ws2 is ws and torch.equal(ref, got2)
+    # too-small workspace -> RSA_ERR_WORKSPACE before any launch
+    L = _lib.lib()
+    lay = spec.to_c(1, 2, 128, torch.bfloat16)
+    out = torch.empty(1, 1280, 2, 128, dtype=torch.bfloat16, device=DEV)
+    o4 = _lib.RsaOut4(out.data_ptr(), out.stride(0), out.stride(2), out.stride(1))
+    small = torch.empty(1024, dtype=torch.uint8, device=DEV)
+    rc = L.rsa_rectified_attention(ctypes.byref(lay), _core._t4(q), _core._t4(k), _core._t4(v), None, 2,
+                                   ctypes.c_float(0.3), small.data_ptr(), small.numel(), o4, _core._stream())
+    assert rc == -3
+
+
+def test_hip_graph_capture_and_replay():
+    """The library never allocates or synchronises: a whole call (K1..K5) can be captured into a HIP graph and
+    replayed; the replay on new input values matches an eager call."""
+    from rectified_spaattn_amd import _core, synth
+    qa, ka, va = (torch.from_numpy(x).to(DEV, torch.bfloat16) for x in synth.structured_qkv(31, 1, 2, 1024, 128))
+    qb, kb, vb = (torch.from_numpy(x).to(DEV, torch.bfloat16) for x in synth.structured_qkv(32, 1, 2, 1024, 128))
+    spec = _core.LayoutSpec.wan(1024, 1)
+    q, k, v = qa.clone(), ka.clone(), va.clone()
+    call = _core.StagedCall(q, k, v, spec, 3, 0.3, None)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        call.select(); call.attend()   # warm-up outside capture
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        call.select()
+        call.attend()
+    q.copy_(qb); k.copy_(kb); v.copy_(vb)
+    g.replay()
+    torch.cuda.synchronize()
+    eager = _core.rectified_attention(qb, kb, vb, spec, 3, 0.3, None)
+    assert torch.equal(call.out.view(1, 1024, 256), eager)
