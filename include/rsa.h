@@ -155,6 +155,22 @@ int rsa_gilbert_mapping(int t, int h, int w, const char* axis_order, int32_t* li
  * pointer, NB*NB bytes.  Replaces gilbert_block_neighbor_mapping (utils/jenga_gilbert.py:613-693). */
 int rsa_gilbert_block_neighbors(int t, int h, int w, int block_size, const char* axis_order, uint8_t* neighbor);
 
+/* ---- producers / consumers either side of the path; DEVICE pointers ---- */
+
+/* Row gather out[b, i, :] = x[b, order[i], :] for i < S; rows are C 2-byte elements (C % 8 == 0), strides in
+ * elements.  Replaces hidden_states[:, hilbert_order] and hidden_states[:, linear_to_hilbert]
+ * (scripts/main_hunyuan.py:88, :183; main_wan21t2v.py:92-93, :167). */
+int rsa_permute_tokens(int B, int S, int C, const void* x, int64_t x_stride_b, int64_t x_stride_s,
+                       const int32_t* order, void* out, int64_t o_stride_b, int64_t o_stride_s, void* stream);
+
+/* Fused per-head RMSNorm (if apply_norm; weight fp32 [D] or NULL) + rotary embedding (if cos/sin non-NULL: fp32
+ * [S_rope, D] tables in the interleaved-pair convention of diffusers' apply_rotary_emb, applied to tokens < S_rope)
+ * over a [B,H,S,D] view, written to a strided [B,H,S,D] destination (e.g. a slice of the [visual | text] concat).
+ * Replaces attn.norm_q / attn.norm_k + apply_rotary_emb + torch.cat in the processors
+ * (rectified_hunyuan_attn.py:452-498, rectified_flux_attn.py:443-484). */
+int rsa_qk_norm_rope(int B, int H, int S, int D, int dtype, rsa_tensor4 x, const float* weight, float eps,
+                     int apply_norm, const float* cos, const float* sin, int S_rope, rsa_out4 y, void* stream);
+
 /* Tuning / diagnostics hook, not part of the data path.  Keys: "k5_prio" (0/1: issue-priority raise inside K5's pipelined block). */
 int rsa_set_tuning(const char* key, int value);
 

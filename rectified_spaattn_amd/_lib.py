@@ -69,6 +69,11 @@ def lib():
     L.rsa_gilbert_mapping.restype = i32
     L.rsa_gilbert_block_neighbors.argtypes = [i32, i32, i32, i32, ctypes.c_char_p, vp]
     L.rsa_gilbert_block_neighbors.restype = i32
+    i64 = ctypes.c_int64
+    L.rsa_permute_tokens.argtypes = [i32, i32, i32, vp, i64, i64, vp, vp, i64, i64, vp]
+    L.rsa_permute_tokens.restype = i32
+    L.rsa_qk_norm_rope.argtypes = [i32, i32, i32, i32, i32, RsaTensor4, vp, f32, i32, vp, vp, i32, RsaOut4, vp]
+    L.rsa_qk_norm_rope.restype = i32
     L.rsa_set_tuning.argtypes = [ctypes.c_char_p, i32]
     L.rsa_set_tuning.restype = i32
     L.rsa_buffer_bytes.argtypes = [P(RsaLayout), P(sz * 14), P(sz)]
@@ -93,7 +98,7 @@ def lib():
 EXPORTED = ("rsa_version", "rsa_buffer_bytes", "rsa_carve_workspace", "rsa_pool_stats", "rsa_pooled_scores",
             "rsa_select_mask", "rsa_compensation", "rsa_block_sparse_fwd", "rsa_rectified_attention",
             "rsa_dense_fwd", "rsa_estimate_pr_gain", "rsa_status_string", "rsa_last_hip_error", "rsa_set_tuning", "rsa_gilbert_mapping",
-            "rsa_gilbert_block_neighbors")
+            "rsa_gilbert_block_neighbors", "rsa_permute_tokens", "rsa_qk_norm_rope")
 
 
 def check(status: int, what: str):

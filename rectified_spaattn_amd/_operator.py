@@ -69,3 +69,26 @@ def rotary(x: torch.Tensor, freqs):
 def valid_keys(attention_mask, default: int) -> int:
     """attention_mask.sum().item() -- the one host sync per call the reference also has (hunyuan :502)."""
     return default if attention_mask is None else int(attention_mask.sum().item())
+
+
+# ---- fused producer path (SURVEY 8(f-3)) --------------------------------------------------------------
+FUSED_PRODUCER = True  # processors use the fused RMSNorm + RoPE + concat kernel when its preconditions hold
+
+
+def fused_qk_ok(x: torch.Tensor, heads: int, norms, rotary) -> bool:
+    """Preconditions of glue.qk_norm_rope for a processor: device bf16/fp16 projections, head_dim 64/128, every
+    norm either absent or RMSNorm-like, rotary absent or a (cos, sin) pair of real tables."""
+    from . import glue
+    if not (FUSED_PRODUCER and x.is_cuda and x.dtype in (torch.bfloat16, torch.float16)):
+        return False
+    if x.shape[-1] % heads or (x.shape[-1] // heads) not in (64, 128):
+        return False
+    for n in norms:
+        if n is not None and glue.norm_params(n) is None:
+            return False
+    if rotary is not None:
+        if not (isinstance(rotary, (tuple, list)) and len(rotary) == 2 and all(torch.is_tensor(t) for t in rotary)):
+            return False
+        if rotary[0].dim() != 2 or rotary[0].is_complex():
+            return False
+    return True

@@ -1,0 +1,162 @@
+// Producers / consumers either side of the attention path; all HBM-bound, 16 B per lane.
+//   rsa_permute_tokens : row gather  out[b, i, :] = x[b, order[i], :]   (Hilbert permute in / out)
+//   rsa_qk_norm_rope   : per-head RMSNorm (optional) + rotary embedding (optional) in one pass, writing into a
+//                        strided [B,S,H,D] destination (so the visual/text concat needs no extra copy)
+// Compiled with -ffp-contract=off: the arithmetic follows diffusers' RMSNorm / apply_rotary_emb operation by
+// operation (fp32 statistics, the same intermediate roundings), so results match the PyTorch ops to the last bit
+// except where rsqrt or the mean's summation order differ by an fp32 ulp.
+#include "rsa_common.h"
+
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void permute_tokens_kernel(const uint4* x, long xsb, long xss, const int32_t* order,
+                                                            uint4* out, long osb, long oss, int S, int C16) {
+    // one wave per output row chunk: grid.x covers rows, lanes stride over the row's 16-byte chunks
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= S) return;
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int src = order[row];
+    const uint4* xp = x + ((long)b * xsb + (long)src * xss);
+    uint4* op = out + ((long)b * osb + (long)row * oss);
+    for (int c = lane; c < C16; c += 64) op[c] = xp[c];
+}
+
+extern "C" int rsa_permute_tokens(int B, int S, int C, const void* x, int64_t x_stride_b, int64_t x_stride_s,
+                                  const int32_t* order, void* out, int64_t o_stride_b, int64_t o_stride_s,
+                                  void* stream) {
+    if (B <= 0 || S <= 0 || C <= 0 || !x || !order || !out) return RSA_ERR_BAD_ARG;
+    if ((C % 8) || (x_stride_b % 8) || (x_stride_s % 8) || (o_stride_b % 8) || (o_stride_s % 8)) return RSA_ERR_BAD_ARG;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return RSA_ERR_BAD_ARG;
+    dim3 grid((S + 3) / 4, B);
+    permute_tokens_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(
+        static_cast<const uint4*>(x), x_stride_b / 8, x_stride_s / 8, order, static_cast<uint4*>(out), o_stride_b / 8,
+        o_stride_s / 8, S, C / 8);
+    return rsa_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+template <typename Tag>
+__device__ __forceinline__ unsigned short rsa_from_f32(float f);
+template <>
+__device__ __forceinline__ unsigned short rsa_from_f32<bf16_tag>(float f) {
+    return __builtin_bit_cast(unsigned short, (__bf16)f);
+}
+template <>
+__device__ __forceinline__ unsigned short rsa_from_f32<fp16_tag>(float f) {
+    return __builtin_bit_cast(unsigned short, (_Float16)f);
+}
+
+struct NormRopeArgs {
+    const unsigned short* x;
+    long xsb, xsh, xss;
+    unsigned short* y;
+    long ysb, ysh, yss;
+    const float *weight, *cos, *sin;
+    float eps;
+    int H, S, S_rope, apply_norm;
+};
+
+// D/8 lanes per token row, 8 elements (16 B) per lane; a 256-thread block covers 256/(D/8) tokens and one group of
+// heads: every thread loads its 8 cos / 8 sin values ONCE per token and reuses them for all heads of the group (the
+// fp32 tables are 4x the bytes of a 2-byte row; re-reading them per head made the kernel table-bound).
+template <int D, typename Tag>
+__global__ __launch_bounds__(256) void qk_norm_rope_kernel(NormRopeArgs a, int heads_per_group) {
+    constexpr int LPR = D / 8;            // lanes per row (16 or 8)
+    constexpr int TPB = 256 / LPR;        // tokens per block
+    const int t = threadIdx.x, c = t % LPR;
+    const int s = blockIdx.x * TPB + t / LPR;
+    const int b = blockIdx.z;
+    const int h0 = blockIdx.y * heads_per_group;
+    if (s >= a.S) return;
+    const bool rope = a.cos != nullptr && s < a.S_rope;
+    float cs[8], sn[8];
+    if (rope) {
+        const float4* cp = reinterpret_cast<const float4*>(a.cos + (long)s * D + c * 8);
+        const float4* sp = reinterpret_cast<const float4*>(a.sin + (long)s * D + c * 8);
+        const float4 c0 = cp[0], c1 = cp[1], s0 = sp[0], s1 = sp[1];
+        cs[0] = c0.x; cs[1] = c0.y; cs[2] = c0.z; cs[3] = c0.w; cs[4] = c1.x; cs[5] = c1.y; cs[6] = c1.z; cs[7] = c1.w;
+        sn[0] = s0.x; sn[1] = s0.y; sn[2] = s0.z; sn[3] = s0.w; sn[4] = s1.x; sn[5] = s1.y; sn[6] = s1.z; sn[7] = s1.w;
+    }
+    float wt[8];
+    if (a.apply_norm && a.weight) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wt[e] = a.weight[c * 8 + e];
+    }
+    const unsigned short* xp = a.x + (long)b * a.xsb + (long)s * a.xss + c * 8;
+    unsigned short* yp = a.y + (long)b * a.ysb + (long)s * a.yss + c * 8;
+    const int h1 = min(h0 + heads_per_group, a.H);
+    for (int h = h0; h < h1; ++h) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(xp + (long)h * a.xsh);
+        const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[2 * e] = rsa_to_f32<Tag>((unsigned short)(w[e] & 0xFFFF));
+            v[2 * e + 1] = rsa_to_f32<Tag>((unsigned short)(w[e] >> 16));
+        }
+        if (a.apply_norm) {
+            // variance = mean(x^2) in fp32; x * rsqrt(var + eps); round to the storage type; * weight; round
+            float ss = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss = ss + v[e] * v[e];
+#pragma unroll
+            for (int m = 1; m < LPR; m <<= 1) ss = ss + __shfl_xor(ss, m, 64);
+            const float r = rsqrtf(ss * (1.0f / D) + a.eps);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float n = v[e] * r;
+                if (a.weight) {
+                    n = rsa_to_f32<Tag>(rsa_from_f32<Tag>(n));
+                    n = n * wt[e];
+                }
+                v[e] = rsa_to_f32<Tag>(rsa_from_f32<Tag>(n));
+            }
+        }
+        if (rope) {
+            // out = x * cos + rotate_half_pairs(x) * sin, pairs (2i, 2i+1): rot[2i] = -x[2i+1], rot[2i+1] = x[2i]
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                o[e] = v[e] * cs[e] + (-v[e + 1]) * sn[e];
+                o[e + 1] = v[e + 1] * cs[e + 1] + v[e] * sn[e + 1];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = o[e];
+        }
+        uint4 pk;
+        pk.x = (unsigned)rsa_from_f32<Tag>(v[0]) | ((unsigned)rsa_from_f32<Tag>(v[1]) << 16);
+        pk.y = (unsigned)rsa_from_f32<Tag>(v[2]) | ((unsigned)rsa_from_f32<Tag>(v[3]) << 16);
+        pk.z = (unsigned)rsa_from_f32<Tag>(v[4]) | ((unsigned)rsa_from_f32<Tag>(v[5]) << 16);
+        pk.w = (unsigned)rsa_from_f32<Tag>(v[6]) | ((unsigned)rsa_from_f32<Tag>(v[7]) << 16);
+        *reinterpret_cast<uint4*>(yp + (long)h * a.ysh) = pk;
+    }
+}
+
+extern "C" int rsa_qk_norm_rope(int B, int H, int S, int D, int dtype, rsa_tensor4 x, const float* weight, float eps,
+                                int apply_norm, const float* cos, const float* sin, int S_rope, rsa_out4 y,
+                                void* stream) {
+    if (B <= 0 || H <= 0 || S <= 0 || !y.ptr) return RSA_ERR_BAD_ARG;
+    if (D != 64 && D != 128) return RSA_ERR_UNSUPPORTED;
+    if (dtype != RSA_BF16 && dtype != RSA_FP16) return RSA_ERR_UNSUPPORTED;
+    int st = rsa_check_tensor(x);
+    if (st != RSA_OK) return st;
+    if ((reinterpret_cast<uintptr_t>(y.ptr) & 15) || (y.stride_b % 8) || (y.stride_h % 8) || (y.stride_s % 8))
+        return RSA_ERR_BAD_ARG;
+    if ((cos == nullptr) != (sin == nullptr) || S_rope < 0 || S_rope > S) return RSA_ERR_BAD_ARG;
+    NormRopeArgs a;
+    a.x = static_cast<const unsigned short*>(x.ptr); a.xsb = x.stride_b; a.xsh = x.stride_h; a.xss = x.stride_s;
+    a.y = static_cast<unsigned short*>(y.ptr); a.ysb = y.stride_b; a.ysh = y.stride_h; a.yss = y.stride_s;
+    a.weight = weight; a.cos = cos; a.sin = sin; a.eps = eps; a.H = H; a.S = S; a.S_rope = S_rope;
+    a.apply_norm = apply_norm;
+    const int tpb = 256 / (D / 8);
+    const int hpg = H >= 8 ? 8 : H;  // heads sharing one cos/sin load
+    dim3 grid((unsigned)((S + tpb - 1) / tpb), (unsigned)((H + hpg - 1) / hpg), B);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (D == 128) {
+        if (dtype == RSA_BF16) qk_norm_rope_kernel<128, bf16_tag><<<grid, 256, 0, s>>>(a, hpg);
+        else qk_norm_rope_kernel<128, fp16_tag><<<grid, 256, 0, s>>>(a, hpg);
+    } else {
+        if (dtype == RSA_BF16) qk_norm_rope_kernel<64, bf16_tag><<<grid, 256, 0, s>>>(a, hpg);
+        else qk_norm_rope_kernel<64, fp16_tag><<<grid, 256, 0, s>>>(a, hpg);
+    }
+    return rsa_launch_status();
+}

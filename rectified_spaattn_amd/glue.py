@@ -1,0 +1,107 @@
+"""Producers / consumers either side of the attention path on the HIP library:
+
+  permute_tokens     hidden_states[:, order]  (Hilbert permute in / out; scripts/main_hunyuan.py:88, :183)
+  build_attention_mask   the [B,1,1,N] key-padding mask + valid lengths (scripts/main_hunyuan.py:91-103)
+  qk_norm_rope       per-head RMSNorm + rotary embedding (+ placement into the [visual | text] concat) in one pass
+                     (rectified_hunyuan_attn.py:452-498, rectified_flux_attn.py:443-484)
+"""
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+
+from . import _core, _lib
+from ._lib import RsaOut4
+
+
+def _order_i32(order: torch.Tensor, device) -> torch.Tensor:
+    """int32 device copy of an index vector, cached on the source tensor (scripts keep it as a long CUDA tensor)."""
+    key = (order._version, str(device))
+    cache = getattr(order, "_rsa_i32", None)
+    if cache is None or cache[0] != key:
+        cache = (key, order.to(device=device, dtype=torch.int32).contiguous())
+        try:
+            order._rsa_i32 = cache
+        except AttributeError:
+            pass
+    return cache[1]
+
+
+def permute_tokens(x: torch.Tensor, order: torch.Tensor) -> torch.Tensor:
+    """x [B, S, C] -> x[:, order]  ([B, len(order), C]) with one HBM pass on the HIP gather kernel."""
+    _core._require_device(x)
+    _core.dtype_code(x.dtype)
+    B, S, C = x.shape
+    if x.stride(-1) != 1 or C % 8 or x.stride(0) % 8 or x.stride(1) % 8 or x.data_ptr() % 16:
+        x = x.contiguous()
+    if C % 8:
+        raise AssertionError("permute_tokens needs a row length that is a multiple of 8 elements")
+    idx = _order_i32(order, x.device)
+    n = idx.numel()
+    out = torch.empty((B, n, C), dtype=x.dtype, device=x.device)
+    vp = ctypes.c_void_p
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().rsa_permute_tokens(B, n, C, vp(x.data_ptr()), x.stride(0), x.stride(1),
+                                                 vp(idx.data_ptr()), vp(out.data_ptr()), out.stride(0), out.stride(1),
+                                                 _core._stream()), "rsa_permute_tokens")
+    return out
+
+
+def build_attention_mask(latent_len: int, encoder_attention_mask: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """([B,1,1,N] bool mask, [B] valid lengths): latent tokens always valid, text tokens up to each sample's count."""
+    B, n_txt = encoder_attention_mask.shape
+    eff = latent_len + encoder_attention_mask.sum(dim=1, dtype=torch.int)
+    idx = torch.arange(latent_len + n_txt, device=encoder_attention_mask.device)[None, :]
+    return (idx < eff[:, None])[:, None, None, :], eff
+
+
+def norm_params(norm) -> Optional[Tuple[Optional[torch.Tensor], float]]:
+    """(weight | None, eps) of an RMSNorm-like module, or None if the module is something else (then the caller
+    keeps the module call)."""
+    if norm is None:
+        return None
+    if type(norm).__name__ not in ("RMSNorm", "RMS") or not hasattr(norm, "eps"):
+        return None
+    if getattr(norm, "bias", None) is not None:
+        return None
+    return getattr(norm, "weight", None), float(norm.eps)
+
+
+def qk_norm_rope(x: torch.Tensor, heads: int, norm=None, rotary=None, rope_tokens: Optional[int] = None,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [B, S, H*D] projection -> [B, H, S, D] view of a [B, S, H, D] buffer holding RMSNorm(x) rotated.
+
+    norm: (weight [D] | None, eps) or None (no normalisation); rotary: (cos, sin) fp32 [>= rope_tokens, D] or None;
+    rope_tokens: tokens [0, rope_tokens) are rotated (default all); out: optional [B, S, H, D] destination (e.g. a
+    slice of the concat buffer), else a new one."""
+    _core._require_device(x)
+    B, S, HD = x.shape
+    D = HD // heads
+    xv = x.view(B, S, heads, D).transpose(1, 2)  # [B,H,S,D] view
+    if xv.stride(-1) != 1 or any(s % 8 for s in xv.stride()[:-1]) or xv.data_ptr() % 16:
+        xv = xv.contiguous()
+    if out is None:
+        out = torch.empty((B, S, heads, D), dtype=x.dtype, device=x.device)
+    assert out.shape == (B, S, heads, D) and out.dtype == x.dtype and out.stride(-1) == 1
+    w = eps = None
+    if norm is not None:
+        w, eps = norm
+        if w is not None:
+            w = w.detach().to(device=x.device, dtype=torch.float32).contiguous()
+    cos = sin = None
+    if rotary is not None:
+        cos, sin = rotary
+        cos = cos.to(device=x.device, dtype=torch.float32).contiguous()
+        sin = sin.to(device=x.device, dtype=torch.float32).contiguous()
+        if rope_tokens is None:
+            rope_tokens = S
+        assert cos.shape[-1] == D and cos.shape[0] >= rope_tokens
+    vp = ctypes.c_void_p
+    o4 = RsaOut4(out.data_ptr(), out.stride(0), out.stride(2), out.stride(1))
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().rsa_qk_norm_rope(
+            B, heads, S, D, _core.dtype_code(x.dtype), _core._t4(xv), vp(w.data_ptr()) if w is not None else None,
+            ctypes.c_float(eps if eps is not None else 0.0), 1 if norm is not None else 0,
+            vp(cos.data_ptr()) if cos is not None else None, vp(sin.data_ptr()) if sin is not None else None,
+            int(rope_tokens or 0), o4, _core._stream()), "rsa_qk_norm_rope")
+    return out.transpose(1, 2)

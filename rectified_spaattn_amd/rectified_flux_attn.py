@@ -47,24 +47,51 @@ class RectifiedFluxSpaAttnProcessor2_0:
         self.text_length = text_length
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, image_rotary_emb=None):
-        q = op.split_heads(attn.to_q(hidden_states), attn.heads)
-        k = op.split_heads(attn.to_k(hidden_states), attn.heads)
-        v = op.split_heads(attn.to_v(hidden_states), attn.heads)
-        if attn.norm_q is not None:
-            q = attn.norm_q(q)
-        if attn.norm_k is not None:
-            k = attn.norm_k(k)
-        if encoder_hidden_states is not None:  # double-stream block: text goes LAST ("Jenga" order, :476-478)
-            eq = op.split_heads(attn.add_q_proj(encoder_hidden_states), attn.heads)
-            ek = op.split_heads(attn.add_k_proj(encoder_hidden_states), attn.heads)
-            ev = op.split_heads(attn.add_v_proj(encoder_hidden_states), attn.heads)
-            if attn.norm_added_q is not None:
-                eq = attn.norm_added_q(eq)
-            if attn.norm_added_k is not None:
-                ek = attn.norm_added_k(ek)
-            q, k, v = torch.cat([q, eq], 2), torch.cat([k, ek], 2), torch.cat([v, ev], 2)
-        if image_rotary_emb is not None:
-            q, k = op.rotary(q, image_rotary_emb), op.rotary(k, image_rotary_emb)
+        dual = encoder_hidden_states is not None
+        norms = [attn.norm_q, attn.norm_k] + ([attn.norm_added_q, attn.norm_added_k] if dual else [])
+        if op.fused_qk_ok(hidden_states, attn.heads, norms, image_rotary_emb):
+            # RMSNorm + RoPE (over the whole [image | text] sequence) fused, written into the concat buffers
+            from . import glue
+            Bq, S_v, _ = hidden_states.shape
+            n_enc = encoder_hidden_states.shape[1] if dual else 0
+            hd = hidden_states.shape[-1] // attn.heads
+            qbuf = torch.empty((Bq, S_v + n_enc, attn.heads, hd), dtype=hidden_states.dtype, device=hidden_states.device)
+            kbuf = torch.empty_like(qbuf)
+            rot_v = rot_t = None
+            if image_rotary_emb is not None:  # rows [0, S_v) for the image part, [S_v, S_v + n_enc) for the text part
+                rot_v = (image_rotary_emb[0][:S_v], image_rotary_emb[1][:S_v])
+                rot_t = (image_rotary_emb[0][S_v:], image_rotary_emb[1][S_v:])
+            glue.qk_norm_rope(attn.to_q(hidden_states), attn.heads, glue.norm_params(attn.norm_q), rot_v, S_v,
+                              out=qbuf[:, :S_v])
+            glue.qk_norm_rope(attn.to_k(hidden_states), attn.heads, glue.norm_params(attn.norm_k), rot_v, S_v,
+                              out=kbuf[:, :S_v])
+            v_all = attn.to_v(hidden_states)
+            if dual:
+                glue.qk_norm_rope(attn.add_q_proj(encoder_hidden_states), attn.heads,
+                                  glue.norm_params(attn.norm_added_q), rot_t, n_enc, out=qbuf[:, S_v:])
+                glue.qk_norm_rope(attn.add_k_proj(encoder_hidden_states), attn.heads,
+                                  glue.norm_params(attn.norm_added_k), rot_t, n_enc, out=kbuf[:, S_v:])
+                v_all = torch.cat([v_all, attn.add_v_proj(encoder_hidden_states)], dim=1)
+            q, k, v = qbuf.transpose(1, 2), kbuf.transpose(1, 2), op.split_heads(v_all, attn.heads)
+        else:
+            q = op.split_heads(attn.to_q(hidden_states), attn.heads)
+            k = op.split_heads(attn.to_k(hidden_states), attn.heads)
+            v = op.split_heads(attn.to_v(hidden_states), attn.heads)
+            if attn.norm_q is not None:
+                q = attn.norm_q(q)
+            if attn.norm_k is not None:
+                k = attn.norm_k(k)
+            if dual:  # double-stream block: text goes LAST ("Jenga" order, :476-478)
+                eq = op.split_heads(attn.add_q_proj(encoder_hidden_states), attn.heads)
+                ek = op.split_heads(attn.add_k_proj(encoder_hidden_states), attn.heads)
+                ev = op.split_heads(attn.add_v_proj(encoder_hidden_states), attn.heads)
+                if attn.norm_added_q is not None:
+                    eq = attn.norm_added_q(eq)
+                if attn.norm_added_k is not None:
+                    ek = attn.norm_added_k(ek)
+                q, k, v = torch.cat([q, eq], 2), torch.cat([k, ek], 2), torch.cat([v, ev], 2)
+            if image_rotary_emb is not None:
+                q, k = op.rotary(q, image_rotary_emb), op.rotary(k, image_rotary_emb)
 
         B, H, S_q, D = q.shape
         S_k = k.shape[2]

@@ -53,28 +53,52 @@ class RectifiedHunyuanVideoSpaAttnProcessor2_0:
         n_txt = encoder_hidden_states.shape[1] if encoder_hidden_states is not None else 0
         if single_stream:  # single-stream blocks project the concatenated sequence
             hidden_states = torch.cat([hidden_states, encoder_hidden_states], dim=1)
-        q = op.split_heads(attn.to_q(hidden_states), attn.heads)
-        k = op.split_heads(attn.to_k(hidden_states), attn.heads)
-        v = op.split_heads(attn.to_v(hidden_states), attn.heads)
-        if attn.norm_q is not None:
-            q = attn.norm_q(q)
-        if attn.norm_k is not None:
-            k = attn.norm_k(k)
-        if image_rotary_emb is not None:  # RoPE on the visual part only
-            if single_stream:
-                q = torch.cat([op.rotary(q[:, :, :-n_txt], image_rotary_emb), q[:, :, -n_txt:]], dim=2)
-                k = torch.cat([op.rotary(k[:, :, :-n_txt], image_rotary_emb), k[:, :, -n_txt:]], dim=2)
-            else:
-                q, k = op.rotary(q, image_rotary_emb), op.rotary(k, image_rotary_emb)
-        if attn.add_q_proj is not None and encoder_hidden_states is not None:  # dual-stream: text appended last
-            eq = op.split_heads(attn.add_q_proj(encoder_hidden_states), attn.heads)
-            ek = op.split_heads(attn.add_k_proj(encoder_hidden_states), attn.heads)
-            ev = op.split_heads(attn.add_v_proj(encoder_hidden_states), attn.heads)
-            if attn.norm_added_q is not None:
-                eq = attn.norm_added_q(eq)
-            if attn.norm_added_k is not None:
-                ek = attn.norm_added_k(ek)
-            q, k, v = torch.cat([q, eq], 2), torch.cat([k, ek], 2), torch.cat([v, ev], 2)
+        dual = attn.add_q_proj is not None and encoder_hidden_states is not None
+        norms = [attn.norm_q, attn.norm_k] + ([attn.norm_added_q, attn.norm_added_k] if dual else [])
+        if op.fused_qk_ok(hidden_states, attn.heads, norms, image_rotary_emb):
+            # one pass per tensor: RMSNorm + RoPE, written straight into the [visual | text] buffers
+            from . import glue
+            Bq, S_v, _ = hidden_states.shape
+            S_all = S_v + (n_txt if dual else 0)
+            hd = hidden_states.shape[-1] // attn.heads
+            qbuf = torch.empty((Bq, S_all, attn.heads, hd), dtype=hidden_states.dtype, device=hidden_states.device)
+            kbuf = torch.empty_like(qbuf)
+            rope_tokens = S_v - n_txt if single_stream else S_v
+            glue.qk_norm_rope(attn.to_q(hidden_states), attn.heads, glue.norm_params(attn.norm_q), image_rotary_emb,
+                              rope_tokens, out=qbuf[:, :S_v])
+            glue.qk_norm_rope(attn.to_k(hidden_states), attn.heads, glue.norm_params(attn.norm_k), image_rotary_emb,
+                              rope_tokens, out=kbuf[:, :S_v])
+            v_all = attn.to_v(hidden_states)
+            if dual:
+                glue.qk_norm_rope(attn.add_q_proj(encoder_hidden_states), attn.heads,
+                                  glue.norm_params(attn.norm_added_q), None, 0, out=qbuf[:, S_v:])
+                glue.qk_norm_rope(attn.add_k_proj(encoder_hidden_states), attn.heads,
+                                  glue.norm_params(attn.norm_added_k), None, 0, out=kbuf[:, S_v:])
+                v_all = torch.cat([v_all, attn.add_v_proj(encoder_hidden_states)], dim=1)
+            q, k, v = qbuf.transpose(1, 2), kbuf.transpose(1, 2), op.split_heads(v_all, attn.heads)
+        else:
+            q = op.split_heads(attn.to_q(hidden_states), attn.heads)
+            k = op.split_heads(attn.to_k(hidden_states), attn.heads)
+            v = op.split_heads(attn.to_v(hidden_states), attn.heads)
+            if attn.norm_q is not None:
+                q = attn.norm_q(q)
+            if attn.norm_k is not None:
+                k = attn.norm_k(k)
+            if image_rotary_emb is not None:  # RoPE on the visual part only
+                if single_stream:
+                    q = torch.cat([op.rotary(q[:, :, :-n_txt], image_rotary_emb), q[:, :, -n_txt:]], dim=2)
+                    k = torch.cat([op.rotary(k[:, :, :-n_txt], image_rotary_emb), k[:, :, -n_txt:]], dim=2)
+                else:
+                    q, k = op.rotary(q, image_rotary_emb), op.rotary(k, image_rotary_emb)
+            if dual:  # dual-stream: text appended last
+                eq = op.split_heads(attn.add_q_proj(encoder_hidden_states), attn.heads)
+                ek = op.split_heads(attn.add_k_proj(encoder_hidden_states), attn.heads)
+                ev = op.split_heads(attn.add_v_proj(encoder_hidden_states), attn.heads)
+                if attn.norm_added_q is not None:
+                    eq = attn.norm_added_q(eq)
+                if attn.norm_added_k is not None:
+                    ek = attn.norm_added_k(ek)
+                q, k, v = torch.cat([q, eq], 2), torch.cat([k, ek], 2), torch.cat([v, ev], 2)
 
         B, H, S, D = q.shape
         num_true = op.valid_keys(attention_mask, S)

@@ -18,12 +18,21 @@ def _linear(seed, stream, din, dout, scale=0.06):
 
 
 class RMS(nn.Module):
-    def __init__(self, d):
+    """diffusers.models.normalization.RMSNorm, operation by operation (weight / eps attributes included)."""
+
+    def __init__(self, d, eps=1e-6):
         super().__init__()
-        self.w = nn.Parameter(torch.linspace(0.8, 1.2, d))
+        self.weight = nn.Parameter(torch.linspace(0.8, 1.2, d))
+        self.eps = eps
+        self.bias = None
 
     def forward(self, x):
-        return (x.float() * torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + 1e-6) * self.w).to(x.dtype)
+        input_dtype = x.dtype
+        variance = x.to(torch.float32).pow(2).mean(-1, keepdim=True)
+        x = x * torch.rsqrt(variance + self.eps)
+        if self.weight.dtype in (torch.float16, torch.bfloat16):
+            x = x.to(self.weight.dtype)
+        return (x * self.weight).to(input_dtype)
 
 
 def fake_attn(seed, heads, head_dim, added=True, norms=True, wan=False):

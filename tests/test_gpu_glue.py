@@ -1,0 +1,119 @@
+"""GPU tests of the producers either side of the path: token permutation and the fused
+RMSNorm + RoPE (+ concat placement) kernel, against the PyTorch ops they replace."""
+import numpy as np
+import pytest
+import torch
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_permute_tokens_is_exact_and_invertible(dt):
+    from rectified_spaattn_amd import glue
+    from rectified_spaattn_amd.utils import jenga_gilbert
+    l2h, h2l = jenga_gilbert.gilbert_mapping(4, 12, 16)
+    S, C = len(l2h), 256
+    x = torch.randn(2, S, C, device=DEV).to(dt)
+    order = torch.tensor(h2l, dtype=torch.long, device=DEV)   # scripts keep long CUDA tensors (main_hunyuan.py:42)
+    inv = torch.tensor(l2h, dtype=torch.long, device=DEV)
+    y = glue.permute_tokens(x, order)
+    assert torch.equal(y, x[:, order])
+    assert torch.equal(glue.permute_tokens(y, inv), x)
+    # strided source (a slice of a wider buffer) and a partial gather
+    wide = torch.randn(2, S, 2 * C, device=DEV).to(dt)
+    assert torch.equal(glue.permute_tokens(wide[:, :, C:], order[:100]), wide[:, order[:100], C:])
+    with pytest.raises(AssertionError):
+        glue.permute_tokens(x.float(), order)
+
+
+def test_build_attention_mask_matches_reference_recipe():
+    from rectified_spaattn_amd import glue
+    enc = torch.zeros(2, 256, dtype=torch.bool, device=DEV)
+    enc[0, :200] = True
+    enc[1, :17] = True
+    mask, eff = glue.build_attention_mask(1024, enc)
+    assert mask.shape == (2, 1, 1, 1280) and eff.tolist() == [1224, 1041]
+    assert int(mask[0].sum()) == 1224 and bool(mask[1, 0, 0, 1040]) and not bool(mask[1, 0, 0, 1041])
+
+
+def _unfused(x, heads, norm, rope, rope_tokens):
+    from rectified_spaattn_amd import _operator as op
+    q = op.split_heads(x, heads)
+    if norm is not None:
+        q = norm(q)
+    if rope is not None:
+        q = torch.cat([op.rotary(q[:, :, :rope_tokens], rope), q[:, :, rope_tokens:]], dim=2)
+    return q
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("hd", [128, 64])
+@torch.no_grad()
+def test_fused_norm_rope_matches_torch_ops(dt, hd):
+    from rectified_spaattn_amd import glue
+    heads, S, n_txt = 3, 515, 77
+    x = (torch.randn(2, S, heads * hd, device=DEV) * 1.7).to(dt)
+    norm = helpers.RMS(hd).to(DEV, dt)
+    cos, sin = (t.to(DEV) for t in helpers.rope_tables(S - n_txt, hd))
+    ref = _unfused(x, heads, norm, (cos, sin), S - n_txt).float()
+    got = glue.qk_norm_rope(x, heads, glue.norm_params(norm), (cos, sin), S - n_txt).float()
+    assert got.shape == ref.shape
+    d = (got - ref).abs()
+    ulp = 2.0 ** (-7 if dt == torch.bfloat16 else -10)
+    assert float(d.max()) <= 2 * ulp * float(ref.abs().max())         # at most a last-bit flip
+    assert float((d > 0).float().mean()) < 0.02                        # and only on a small fraction
+    # norm only, rope only, neither-weight variants
+    got_n = glue.qk_norm_rope(x, heads, glue.norm_params(norm), None, 0).float()
+    assert float((got_n - _unfused(x, heads, norm, None, 0).float()).abs().max()) <= 2 * ulp * float(ref.abs().max())
+    got_r = glue.qk_norm_rope(x, heads, None, (cos, sin), S - n_txt)
+    assert torch.equal(got_r, _unfused(x, heads, None, (cos, sin), S - n_txt))   # pure fp32 mul/add: exact
+    # destination slice of a concat buffer
+    buf = torch.zeros(2, S + 10, heads, hd, dtype=dt, device=DEV)
+    glue.qk_norm_rope(x, heads, glue.norm_params(norm), (cos, sin), S - n_txt, out=buf[:, 10:])
+    assert torch.equal(buf[:, 10:].transpose(1, 2).float(), got) and float(buf[:, :10].abs().max()) == 0.0
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("which", ["hunyuan_dual", "hunyuan_single", "flux_dual", "flux_single"])
+def test_processors_fused_producer_equals_unfused(which):
+    from rectified_spaattn_amd import _operator as op
+    from rectified_spaattn_amd.rectified_flux_attn import RectifiedFluxSpaAttnProcessor2_0
+    from rectified_spaattn_amd.rectified_hunyuan_attn import RectifiedHunyuanVideoSpaAttnProcessor2_0
+    heads, hd = 2, 128
+    dim = heads * hd
+    dt = torch.bfloat16
+    hy = which.startswith("hunyuan")
+    dual = which.endswith("dual")
+    a = helpers.attn_to(helpers.fake_attn(200, heads, hd, added=dual), DEV, dt)
+    n_txt = 256 if hy else 512
+    hs = helpers.hidden(200, 20, 1, 1024, dim).to(DEV, dt)
+    enc = helpers.hidden(200, 21, 1, n_txt, dim).to(DEV, dt)
+    if hy:
+        mask = torch.zeros(1, 1, 1, 1024 + n_txt, dtype=torch.bool, device=DEV)
+        mask[..., :1024 + 200] = True
+        rope = tuple(t.to(DEV) for t in helpers.rope_tables(1024, hd))
+        proc = RectifiedHunyuanVideoSpaAttnProcessor2_0("flash", 2, None, 0.3, 0)
+        call = lambda: proc(a, hs, enc, mask, rope)
+    else:
+        rope = tuple(t.to(DEV) for t in helpers.rope_tables(1024 + n_txt, hd))
+        proc = RectifiedFluxSpaAttnProcessor2_0("flash", 2, None, 0.3, 40, n_txt)
+        if dual:
+            call = lambda: proc(a, hs, enc, None, rope)
+        else:
+            both = torch.cat([hs, enc], 1)
+            call = lambda: (proc(a, both, None, None, rope),)
+    assert op.FUSED_PRODUCER
+    fused = call()
+    op.FUSED_PRODUCER = False
+    try:
+        plain = call()
+    finally:
+        op.FUSED_PRODUCER = True
+    for f, p in zip(fused, plain):
+        if f is None:
+            continue
+        assert f.shape == p.shape
+        assert float((f.float() - p.float()).abs().max()) <= 3e-2
