@@ -248,8 +248,14 @@ __global__ __launch_bounds__(256) void pooled_scores_kernel(ScoreArgs a) {
 }
 
 // =====================================================================================================
-// K3: select_mask -- one workgroup (256 threads) per (bh, q-block) row.  Contract C5..C8.
-// dynamic LDS: float e[NS] | float pr[L] | u64 keys[N2] | u8 kept[NB_total(pad 4)]
+// K3: select_mask -- ONE WAVE per (bh, q-block) row (four rows per 256-thread workgroup, no workgroup barrier
+// anywhere).  Contract C5..C8.  The row's keys (probability bits << 32 | ~index) are sorted in REGISTERS:
+// lane l holds elements l*KPL .. l*KPL+KPL-1 of the bitonic network (N2 = 64*KPL), partner distances below KPL
+// are in-lane compare-swaps, larger ones exchange through lane shuffles.
+// The contract's 256 strided partial sums are kept as four accumulators per lane (partial t = lane + 64 w), reduced
+// per w across the lanes with the xor tree (strides 1..32) and combined as (u0+u1)+(u2+u3): bit-identical to the
+// 256-thread formulation of the oracle.
+// dynamic LDS per wave: float e[NS] | float pr[L] | u8 kept[NB_total]
 // =====================================================================================================
 struct SelectArgs {
     const float* scores;
@@ -258,132 +264,198 @@ struct SelectArgs {
     float *probs, *w, *R;
     uint32_t* bitmask;
     int32_t *cols, *counts;
-    int NBv, n_txt, NS, L, N2, NB_total, NW, text_end_block, ffb, top_k;
+    int NBv, n_txt, NS, L, N2, NB_total, NW, text_end_block, ffb, top_k, rows_total, lds_per_wave;
     float thr, scale;
 };
 
-__global__ __launch_bounds__(RSA_NT) void select_mask_kernel(SelectArgs a) {
+__device__ __forceinline__ float wave_tree4(const float (&part)[4]) {
+    float u[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        float v = part[w];
+        v = wave_xor_add(v, 1); v = wave_xor_add(v, 2); v = wave_xor_add(v, 4);
+        v = wave_xor_add(v, 8); v = wave_xor_add(v, 16); v = wave_xor_add(v, 32);
+        u[w] = v;
+    }
+    return (u[0] + u[1]) + (u[2] + u[3]);
+}
+
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
+    const unsigned lo = __shfl_xor((unsigned)v, m, 64);
+    const unsigned hi = __shfl_xor((unsigned)(v >> 32), m, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+template <int KPL>
+__global__ __launch_bounds__(256) void select_mask_kernel(SelectArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
-    float* e = reinterpret_cast<float*>(smem + (size_t)a.N2 * 8);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long row = (long)blockIdx.x * 4 + wv;
+    if (row >= a.rows_total) return;
+    const int qblk = (int)(row % a.NBv);
+    unsigned char* base = smem + (size_t)wv * a.lds_per_wave;
+    float* e = reinterpret_cast<float*>(base);
     float* pr = e + ((a.NS + 3) & ~3);
     uint8_t* kept = reinterpret_cast<uint8_t*>(pr + ((a.L + 3) & ~3));
-    __shared__ float red[4];
-    __shared__ int s_n;
-
-    const int t = threadIdx.x;
-    const int qblk = blockIdx.x;
-    const long row = (long)blockIdx.y * a.NBv + qblk;
     const float* sc = a.scores + row * a.NS;
     const bool has_txt = a.n_txt > 0;
 
     // scaled scores, max
     float mx = -INFINITY;
-    for (int j = t; j < a.NS; j += RSA_NT) {
+    for (int j = lane; j < a.NS; j += 64) {
         const float x = sc[j] * a.scale;
         e[j] = x;
         mx = fmaxf(mx, x);
     }
-    mx = block_max(mx, red);
-    float part = 0.0f;
-    for (int j = t; j < a.NS; j += RSA_NT) {
+    for (int m = 1; m < 64; m <<= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+    // exp and denominator: element j -> partial (j % 256) = lane + 64*((j >> 6) & 3), sequential in j
+    float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int j = lane, m = 0; j < a.NS; j += 64, ++m) {
         const float v = rsa_exp(e[j] - mx);
         e[j] = v;
-        part = part + v;
+        if ((m & 3) == 0) part[0] = part[0] + v;
+        else if ((m & 3) == 1) part[1] = part[1] + v;
+        else if ((m & 3) == 2) part[2] = part[2] + v;
+        else part[3] = part[3] + v;
     }
-    const float Z = block_tree_sum(part, red);
-    for (int j = t; j < a.NS; j += RSA_NT) e[j] = e[j] / Z;
-    __syncthreads();
+    const float Z = wave_tree4(part);
+    for (int j = lane; j < a.NS; j += 64) e[j] = e[j] / Z;
     if (has_txt) {  // IPAR
-        float pn = 0.0f, pt = 0.0f;
-        for (int j = t; j < a.NBv; j += RSA_NT) pn = pn + e[j];
-        for (int u = t; u < a.n_txt; u += RSA_NT) pt = pt + e[a.NBv + u];
-        const float normal_sum = block_tree_sum(pn, red);
-        const float text_sum = block_tree_sum(pt, red);
-        const float denom = normal_sum * 128.0f + text_sum;
-        for (int j = t; j < a.NBv; j += RSA_NT) pr[j] = (e[j] * 128.0f) / denom;
-        if (t == 0) pr[a.NBv] = text_sum / denom;
-    } else {
-        for (int j = t; j < a.NBv; j += RSA_NT) pr[j] = e[j];
-    }
-    __syncthreads();
-    // keys: (prob bits << 32) | (0xFFFFFFFF - idx); descending sort == prob desc, lower index first
-    for (int j = t; j < a.N2; j += RSA_NT) {
-        unsigned long long kk = 0ull;
-        if (j < a.L) {
-            const float pj = pr[j];
-            a.probs[row * a.L + j] = pj;
-            kk = ((unsigned long long)__float_as_uint(pj) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)j);
+        float pn[4] = {0.0f, 0.0f, 0.0f, 0.0f}, pt[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int j = lane, m = 0; j < a.NBv; j += 64, ++m) {
+            const float v = e[j];
+            if ((m & 3) == 0) pn[0] = pn[0] + v; else if ((m & 3) == 1) pn[1] = pn[1] + v;
+            else if ((m & 3) == 2) pn[2] = pn[2] + v; else pn[3] = pn[3] + v;
         }
-        keys[j] = kk;
+        for (int u = lane, m = 0; u < a.n_txt; u += 64, ++m) {
+            const float v = e[a.NBv + u];
+            if ((m & 3) == 0) pt[0] = pt[0] + v; else if ((m & 3) == 1) pt[1] = pt[1] + v;
+            else if ((m & 3) == 2) pt[2] = pt[2] + v; else pt[3] = pt[3] + v;
+        }
+        const float normal_sum = wave_tree4(pn);
+        const float text_sum = wave_tree4(pt);
+        const float denom = normal_sum * 128.0f + text_sum;
+        for (int j = lane; j < a.NBv; j += 64) pr[j] = (e[j] * 128.0f) / denom;
+        if (lane == 0) pr[a.NBv] = text_sum / denom;
+    } else {
+        for (int j = lane; j < a.NBv; j += 64) pr[j] = e[j];
     }
-    __syncthreads();
-    for (int k = 2; k <= a.N2; k <<= 1) {
+    for (int j = lane; j < a.L; j += 64) a.probs[row * a.L + j] = pr[j];
+
+    // keys into registers: element idx = lane*KPL + s
+    unsigned long long key[KPL];
+#pragma unroll
+    for (int s_ = 0; s_ < KPL; ++s_) {
+        const int idx = lane * KPL + s_;
+        unsigned long long kk = 0ull;
+        if (idx < a.L)
+            kk = ((unsigned long long)__float_as_uint(pr[idx]) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)idx);
+        key[s_] = kk;
+    }
+    // bitonic sort, descending
+    for (int k = 2; k <= 64 * KPL; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int idx = t; idx < (a.N2 >> 1); idx += RSA_NT) {
-                const int lo = ((idx & ~(j - 1)) << 1) | (idx & (j - 1));
-                const int hi = lo | j;
-                const bool desc = (lo & k) == 0;
-                const unsigned long long ka = keys[lo], kb = keys[hi];
-                if ((ka < kb) == desc) {
-                    keys[lo] = kb;
-                    keys[hi] = ka;
+            if (j >= KPL) {  // partner in another lane
+                const int lm = j / KPL;
+                const bool upper = (lane & lm) != 0;
+#pragma unroll
+                for (int s_ = 0; s_ < KPL; ++s_) {
+                    const int idx = lane * KPL + s_;
+                    const bool desc = (idx & k) == 0;
+                    const unsigned long long mine = key[s_], other = shfl_xor_u64(mine, lm);
+                    const bool take_max = (desc != upper);  // lower element of a descending pair keeps the max
+                    const bool other_gt = other > mine;
+                    key[s_] = (other_gt == take_max) ? other : mine;
+                }
+            } else {  // partner in this lane: static slot pairs
+#pragma unroll
+                for (int jj = 1; jj < KPL; jj <<= 1) {
+                    if (jj == j) {
+#pragma unroll
+                        for (int s_ = 0; s_ < KPL; ++s_) {
+                            if ((s_ & jj) == 0) {
+                                const int idx = lane * KPL + s_;
+                                const bool desc = (idx & k) == 0;
+                                const unsigned long long ka = key[s_], kb = key[s_ | jj];
+                                const bool sw = (ka < kb) == desc;
+                                key[s_] = sw ? kb : ka;
+                                key[s_ | jj] = sw ? ka : kb;
+                            }
+                        }
+                    }
                 }
             }
-            __syncthreads();
         }
     }
-    // sequential cumulative sum (C8); monotone, so stop at the first c > thr
-    if (t == 0) {
+    // sequential cumulative sum over the sorted order (C8), lane after lane, stop once it exceeds thr
+    int count = 0;
+    {
         float c = 0.0f;
-        int count = 0;
-        for (int k = 0; k < a.L; ++k) {
-            c = c + __uint_as_float((unsigned)(keys[k] >> 32));
-            if (c <= a.thr) ++count; else break;
+        bool done = false;
+        for (int ln = 0; ln < 64 && !done; ++ln) {
+            float cl = c;
+            int cnt = 0;
+            bool dl = false;
+#pragma unroll
+            for (int s_ = 0; s_ < KPL; ++s_) {
+                const int pos = ln * KPL + s_;
+                if (!dl && pos < a.L) {
+                    cl = cl + __uint_as_float((unsigned)(key[s_] >> 32));
+                    if (cl <= a.thr) ++cnt; else dl = true;
+                } else if (pos >= a.L) {
+                    dl = true;
+                }
+            }
+            // take lane ln's result
+            c = __shfl(cl, ln, 64);
+            count += __shfl(cnt, ln, 64);
+            done = __shfl((int)dl, ln, 64) != 0;
         }
-        int n = count + 1;
-        if (n < a.top_k) n = a.top_k;
-        if (n > a.L) n = a.L;
-        s_n = n;
     }
-    for (int j = t; j < a.NB_total; j += RSA_NT) kept[j] = 0;
-    __syncthreads();
-    const int n = s_n;
-    for (int k = t; k < n; k += RSA_NT) kept[0xFFFFFFFFu - (unsigned)(keys[k] & 0xFFFFFFFFull)] = 1;
-    __syncthreads();
-    for (int j = t; j < a.NB_total; j += RSA_NT) {
+    int n = count + 1;
+    if (n < a.top_k) n = a.top_k;
+    if (n > a.L) n = a.L;
+    for (int j = lane; j < a.NB_total; j += 64) kept[j] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+    for (int s_ = 0; s_ < KPL; ++s_) {
+        const int pos = lane * KPL + s_;
+        if (pos < n) kept[0xFFFFFFFFu - (unsigned)(key[s_] & 0xFFFFFFFFull)] = 1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int j = lane; j < a.NB_total; j += 64) {
         uint8_t kj = kept[j];
         if (j < a.NBv && a.neighbor) kj |= (a.neighbor[(long)qblk * a.NBv + j] != 0);
         if (has_txt && j >= a.NBv && j < a.text_end_block) kj = 1;
         if (qblk < a.ffb && j < a.ffb) kj = 1;
         kept[j] = kj;
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     // rectification factor and compensation weights
-    float pR = 0.0f;
-    for (int j = t; j < a.L; j += RSA_NT) {
-        bool m = kept[j] != 0;
-        if (j < a.NBv) m = m || (a.unrel[row * a.NBv + j] != 0);
+    float pR[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int j = lane, m = 0; j < a.L; j += 64, ++m) {
+        bool mm = kept[j] != 0;
+        if (j < a.NBv) mm = mm || (a.unrel[row * a.NBv + j] != 0);
         const float pj = pr[j];
-        pR = pR + (m ? pj : 0.0f);
-        a.w[row * a.L + j] = m ? 0.0f : pj;
+        const float v = mm ? pj : 0.0f;
+        if ((m & 3) == 0) pR[0] = pR[0] + v; else if ((m & 3) == 1) pR[1] = pR[1] + v;
+        else if ((m & 3) == 2) pR[2] = pR[2] + v; else pR[3] = pR[3] + v;
+        a.w[row * a.L + j] = mm ? 0.0f : pj;
     }
-    const float Rv = block_tree_sum(pR, red);
-    if (t == 0) a.R[row] = Rv;
-    // bitmask + ascending column list (wave 0)
-    if (t < 64) {
-        int off = 0;
-        for (int base = 0; base < a.NB_total; base += 64) {
-            const int j = base + t;
-            const bool f = j < a.NB_total && kept[j] != 0;
-            const unsigned long long m = __ballot(f);
-            if (f) a.cols[row * a.NB_total + off + __popcll(m & ((1ull << t) - 1ull))] = j;
-            off += __popcll(m);
-            const int wi = (base >> 5) + (t >> 5);
-            if ((t & 31) == 0 && wi < a.NW) a.bitmask[row * a.NW + wi] = (unsigned)(m >> (t & 32));
-        }
-        if (t == 0) a.counts[row] = off;
+    const float Rv = wave_tree4(pR);
+    if (lane == 0) a.R[row] = Rv;
+    // bitmask + ascending column list
+    int off = 0;
+    for (int b0 = 0; b0 < a.NB_total; b0 += 64) {
+        const int j = b0 + lane;
+        const bool f = j < a.NB_total && kept[j] != 0;
+        const unsigned long long m = __ballot(f);
+        if (f) a.cols[row * a.NB_total + off + __popcll(m & ((1ull << lane) - 1ull))] = j;
+        off += __popcll(m);
+        const int wi = (b0 >> 5) + (lane >> 5);
+        if ((lane & 31) == 0 && wi < a.NW) a.bitmask[row * a.NW + wi] = (unsigned)(m >> (lane & 32));
     }
+    if (lane == 0) a.counts[row] = off;
 }
 
 // =====================================================================================================
@@ -580,17 +652,29 @@ extern "C" int rsa_select_mask(const rsa_layout* l, const uint8_t* neighbor, int
     a.probs = buf->probs; a.w = buf->w; a.R = buf->R; a.bitmask = buf->bitmask; a.cols = buf->cols;
     a.counts = buf->counts;
     a.NBv = l->NBv; a.n_txt = l->n_txt; a.NS = l->NBv + l->n_txt; a.L = l->NBv + (l->n_txt > 0 ? 1 : 0);
-    int n2 = 2;
+    int n2 = 64;
     while (n2 < a.L) n2 <<= 1;
     a.N2 = n2; a.NB_total = l->NB_total; a.NW = (l->NB_total + 31) / 32;
     a.text_end_block = l->text_end_block; a.ffb = l->first_frame_blocks; a.top_k = top_k;
     a.thr = p_remain;
     a.scale = (float)(1.0 / sqrt((double)l->D));  // head_dim ** -0.5 rounded to fp32 (hunyuan :208)
-    const size_t lds = (size_t)a.N2 * 8 + (size_t)((a.NS + 3) & ~3) * 4 + (size_t)((a.L + 3) & ~3) * 4 +
-                       (size_t)((a.NB_total + 15) & ~15);
-    if (lds > 60 * 1024) return RSA_ERR_UNSUPPORTED;
-    dim3 grid(l->NBv, l->B * l->H);
-    select_mask_kernel<<<grid, RSA_NT, lds, static_cast<hipStream_t>(stream)>>>(a);
+    a.rows_total = l->B * l->H * l->NBv;
+    const size_t per_wave = (((size_t)((a.NS + 3) & ~3) * 4 + (size_t)((a.L + 3) & ~3) * 4 +
+                              (size_t)a.NB_total) + 15) & ~(size_t)15;
+    a.lds_per_wave = (int)per_wave;
+    const size_t lds = per_wave * 4;
+    if (lds > 64 * 1024 || n2 > 4096) return RSA_ERR_UNSUPPORTED;
+    dim3 grid((unsigned)((a.rows_total + 3) / 4));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (n2 / 64) {
+        case 1: select_mask_kernel<1><<<grid, 256, lds, s>>>(a); break;
+        case 2: select_mask_kernel<2><<<grid, 256, lds, s>>>(a); break;
+        case 4: select_mask_kernel<4><<<grid, 256, lds, s>>>(a); break;
+        case 8: select_mask_kernel<8><<<grid, 256, lds, s>>>(a); break;
+        case 16: select_mask_kernel<16><<<grid, 256, lds, s>>>(a); break;
+        case 32: select_mask_kernel<32><<<grid, 256, lds, s>>>(a); break;
+        default: select_mask_kernel<64><<<grid, 256, lds, s>>>(a); break;
+    }
     return rsa_launch_status();
 }
 
