@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 (MI355X_MICROARCH.md, chip-level parameters)
+MFMA_FP8_PEAK_TFLOPS = 5000.0   # MI355X dense fp8 (same table)
 
 WORKLOADS = {
     # name: (H, S_visual, text_pad, text_valid, top_k, variant)
@@ -30,6 +31,8 @@ WORKLOADS = {
     "flux_4096": dict(H=24, S_vis=65536, text=512, text_valid=512, top_k=51, variant="flux", latent=(1, 256, 256)),
     "wan21_720p_81f": dict(H=40, S_vis=75600, text=0, text_valid=0, top_k=147, variant="wan", ffb=28,
                            latent=(21, 45, 80)),
+    "wan22_ti2v_720p_121f": dict(H=24, S_vis=27280, text=0, text_valid=0, top_k=53, variant="wan", ffb=6,
+                                 latent=(31, 22, 40)),
     "tiny": dict(H=4, S_vis=4096, text=256, text_valid=200, top_k=6, variant="hunyuan", latent=(4, 32, 32)),
 }
 
@@ -93,6 +96,8 @@ def main():
     ap.add_argument("--neighbors", default="none",
                     help="block-neighbour matrix: 'none' (exactly top_k kept: the 10 %% regime), 'gilbert' (true "
                          "26-neighbourhood along the Gilbert curve of the workload's latent), or an int band width")
+    ap.add_argument("--qkv-fp8", action="store_true",
+                    help="K5 on e4m3 images of Q/K/V (fp8 MFMA); the quantisation pass is inside the timed step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather-output", action="store_true", help="all-gather O along heads inside the timed region")
     args = ap.parse_args()
@@ -137,10 +142,12 @@ def main():
         nbr = torch.from_numpy(synth.banded_neighbors(spec.NBv, int(args.neighbors)))
     top_k = wl["top_k"]
 
-    stages = _core.StagedCall(q, k, v, spec, top_k, args.p_remain, nbr)
+    stages = _core.StagedCall(q, k, v, spec, top_k, args.p_remain, nbr, qkv_fp8=args.qkv_fp8)
 
     def step(ev=None):
         stages.select()
+        if args.qkv_fp8:
+            stages.quantize()
         if ev is not None:
             ev[0].record()
         stages.attend()
@@ -188,16 +195,18 @@ def main():
     # the gfx950 x2 correction; tools/pmc_to_json.py) of this same command; it cannot be collected inside this process.
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "r01_k5_traffic.json")
-    if args.workload == "hunyuan_720p_128f" and args.neighbors == "none" and world == 1 and os.path.exists(tfile):
+    if (args.workload == "hunyuan_720p_128f" and args.neighbors == "none" and world == 1 and not args.qkv_fp8
+            and os.path.exists(tfile)):
         try:
             traffic = json.load(open(tfile)).get("traffic_bytes_per_launch")
         except (OSError, ValueError):
             traffic = None
+    peak = MFMA_FP8_PEAK_TFLOPS if args.qkv_fp8 else MFMA_BF16_PEAK_TFLOPS
     res = {
         "metric": "attention-layer TFLOPs/sec (rectified block-sparse attention, HunyuanVideo seq~120k d=128 bf16)",
         "value": round(value, 3), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic",
+        "dtype": "fp8_e4m3" if args.qkv_fp8 else "bf16", "data": "synthetic",
         "config": {"workload": f"{args.workload}: B=1 H={H} S={S} ({wl['S_vis']} visual + {wl['text']} text, "
                                f"{wl['text_valid']} valid) D={D}, top_k={top_k}, p_remain={args.p_remain}, "
                                f"neighbors={args.neighbors}",
@@ -205,12 +214,13 @@ def main():
                    "dense_equivalent_tflops": round(4.0 * S * S * D * H / (elapsed / args.steps) / 1e12, 1),
                    "gather_output": bool(args.gather_output), "parallelism": f"head-shard x{world}",
                    "per_rank_ms": [round(x / args.steps * 1e3, 3) for x in per_rank_s]},
-        "roofline": {"kernel": "bsfwd_kernel<128,bf16_tag,4,1,2> (K5 block_sparse_fwd)", "bound": "mfma",
-                     "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
+        "roofline": {"kernel": "bsfwd_fp8_kernel<2> (K5 block_sparse_fwd_fp8)" if args.qkv_fp8 else
+                     "bsfwd_kernel<128,bf16_tag,4,1,2> (K5 block_sparse_fwd)", "bound": "mfma",
+                     "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                     "frac": round(achieved / peak, 4), "traffic": traffic,
                      "traffic_note": "L2 memory-side bytes/launch from rocprofv3 PMC (profiles/r01_k5_traffic.json); "
                                      "includes Infinity-Cache hits; compulsory Q+K+V+O = 2.84e9",
-                     "k5_ms": round(k5_ms_local, 4), "select_pass_ms": round(ms_per_step - k5_ms, 4)},
+                     "k5_ms": round(k5_ms_local, 4), "select_pass_ms": round(ms_per_step - k5_ms, 4)},  # + the fp8 quantisation pass with --qkv-fp8
     }
     if not args.no_cpu_baseline and world == 1:
         res["cpu_baseline"] = cpu_baseline(S, D)

@@ -171,6 +171,37 @@ int rsa_permute_tokens(int B, int S, int C, const void* x, int64_t x_stride_b, i
 int rsa_qk_norm_rope(int B, int H, int S, int D, int dtype, rsa_tensor4 x, const float* weight, float eps,
                      int apply_norm, const float* cos, const float* sin, int S_rope, rsa_out4 y, void* stream);
 
+/* ---- fp8 operands for K5 (BASELINE config "fp8 Q/K/V on CDNA4 fp8 MFMA"; the reference has no fp8 path, its P/Q
+ * rounding rule "operands in the input dtype, fp32 statistics" (rectified_hunyuan_attn.py:61-62, :97) is kept) ---- */
+
+/* e4m3 (OCP e4m3fn) images of one call's Q, K, V, written by rsa_quantize_fp8 and read by rsa_block_sparse_fwd_fp8. */
+typedef struct rsa_fp8_operands {
+    uint8_t* q8;    /* [BH, NB_total*128, D]     rows >= S are zero                                            */
+    uint8_t* k8;    /* [BH, NB_total*128, D]     rows >= max(kv_valid, kv_text_valid) are zero                 */
+    uint8_t* v8t;   /* [BH, NB_total*2, D, 64]   V^T per 64-key tile, keys in the MFMA k-slot order (rsa_fp8.hip) */
+    float* scales;  /* [3, BH] dequantisation scales of q, k, v (amax/448), followed by 3*BH words of scratch   */
+} rsa_fp8_operands;
+
+/* Bytes of the four members (member order) and their 256-B-rounded sum.  D = 128 only. */
+int rsa_fp8_operand_bytes(const rsa_layout* lay, size_t sizes[4], size_t* total);
+int rsa_carve_fp8_operands(const rsa_layout* lay, void* ws, size_t ws_bytes, rsa_fp8_operands* out);
+
+/* Per-(b,h) amax of Q, K, V and the three e4m3 images: x/scale (IEEE), clamp +-448, round to nearest even. */
+int rsa_quantize_fp8(const rsa_layout* lay, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
+                     const rsa_fp8_operands* ops, void* stream);
+
+/* K5 on v_mfma_f32_32x32x64_f8f6f4: same lists, R, comp, text rows and output layout as rsa_block_sparse_fwd;
+ * lay->dtype selects the OUTPUT element type. */
+int rsa_block_sparse_fwd_fp8(const rsa_layout* lay, const rsa_fp8_operands* ops, const rsa_buffers* buf,
+                             rsa_out4 out, void* stream);
+
+/* The whole operator with fp8 K5: K1..K4 on the 2-byte inputs (the mask is the bf16 path's, bit for bit), then
+ * rsa_quantize_fp8 and rsa_block_sparse_fwd_fp8. */
+int rsa_rectified_attention_fp8(const rsa_layout* lay, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
+                                const uint8_t* neighbor, int top_k, float p_remain, void* workspace,
+                                size_t workspace_bytes, void* fp8_workspace, size_t fp8_workspace_bytes,
+                                rsa_out4 out, void* stream);
+
 /* Tuning / diagnostics hook, not part of the data path.  Keys: "k5_prio" (0/1: issue-priority raise inside K5's pipelined block). */
 int rsa_set_tuning(const char* key, int value);
 

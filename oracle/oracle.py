@@ -319,6 +319,122 @@ def rectified_attention(q, k, v, lay: Layout, top_k: int, p: float, neighbor=Non
     return (res, parts) if want_parts else res
 
 
+# ---------------------------------------------------------------------------------------------------------
+# fp8 operands (BASELINE config "fp8 Q/K/V on CDNA4 fp8 MFMA").  The reference has no fp8 code; its rule
+# "operands rounded to the input dtype, fp32 statistics" (rectified_hunyuan_attn.py:61-62, :97) is applied to
+# e4m3 (OCP e4m3fn: 4 exponent bits, bias 7, 3 mantissa bits, max 448, no infinity).
+# ---------------------------------------------------------------------------------------------------------
+E4M3_MAX = np.float32(448.0)
+
+
+def quantize_e4m3(y: np.ndarray) -> np.ndarray:
+    """fp32 -> e4m3 bytes: clamp to +-448, round to nearest even, subnormals (multiples of 2^-9) kept."""
+    y = np.clip(np.asarray(y, np.float32), -E4M3_MAX, E4M3_MAX)
+    sign = (np.signbit(y).astype(np.uint8)) << 7
+    a = np.abs(y).astype(np.float64)
+    m, e = np.frexp(a)                      # a = m * 2^e, m in [0.5, 1)
+    e = e - 1                               # a = (2m) * 2^e, 2m in [1, 2)
+    sub = e < -6                            # below the smallest normal 2^-6: fixed step 2^-9
+    step = np.where(sub, 2.0 ** -9, np.exp2(np.maximum(e, -6).astype(np.float64) - 3))
+    qv = np.rint(a / step)                  # np.rint = round half to even; a/step is exact (power-of-two step)
+    val = qv * step                         # representable magnitude (may have carried to the next binade)
+    m2, e2 = np.frexp(val)
+    e2 = e2 - 1
+    normal = val >= 2.0 ** -6
+    mant = np.where(normal, np.rint((m2 * 2 - 1) * 8), np.rint(val * 2.0 ** 9)).astype(np.int64)
+    expo = np.where(normal, e2 + 7, 0).astype(np.int64)
+    byte = ((expo << 3) | mant).astype(np.uint8)
+    byte = np.where(val == 0, 0, byte).astype(np.uint8)
+    return (byte | sign).astype(np.uint8)
+
+
+def dequantize_e4m3(b: np.ndarray) -> np.ndarray:
+    b = np.asarray(b, np.uint8)
+    sign = np.where(b & 0x80, -1.0, 1.0)
+    expo = ((b >> 3) & 0xF).astype(np.int64)
+    mant = (b & 7).astype(np.float64)
+    val = np.where(expo == 0, mant * 2.0 ** -9, (1 + mant / 8) * np.exp2(expo.astype(np.float64) - 7))
+    return (sign * val).astype(np.float32)
+
+
+def fp8_kslot_key(p: np.ndarray) -> np.ndarray:
+    """Key (0..63 inside a 64-key tile) stored at byte p of a V^T row (layout of rsa_fp8.hip)."""
+    p = np.asarray(p)
+    h, j = p >> 5, p & 31
+    return 32 * (j >> 4) + (j & 3) + 8 * ((j & 15) >> 2) + 4 * h
+
+
+def fp8_operands(q, k, v, lay: Layout):
+    """Per-(b,h) scales and e4m3 images exactly as rsa_quantize_fp8 writes them.
+    q, k, v: [B, H, S, D] fp32 -> dict(scales [3, BH], q8/k8 [BH, S_pad, D], v8t [BH, S_pad/64, D, 64])."""
+    B, H, S, D = q.shape
+    BH, SP = B * H, lay.NB_total * BLOCK
+    kv_lim = max(lay.kv_valid, lay.kv_text_valid)
+    valid = (S, kv_lim, kv_lim)
+    scales = np.ones((3, BH), np.float32)
+    imgs = []
+    for i, x in enumerate((q, k, v)):
+        x = np.asarray(x, np.float32).reshape(BH, S, D)
+        img = np.zeros((BH, SP, D), np.uint8)
+        for bh in range(BH):
+            xv = x[bh, : valid[i]]
+            amax = np.float32(np.max(np.abs(xv))) if xv.size else np.float32(0)
+            sc = np.float32(amax / E4M3_MAX) if amax > 0 else np.float32(1.0)
+            scales[i, bh] = sc
+            img[bh, : valid[i]] = quantize_e4m3((xv / sc).astype(np.float32))
+        imgs.append(img)
+    v8 = imgs[2].reshape(BH, SP // 64, 64, D)
+    v8t = np.ascontiguousarray(v8[:, :, fp8_kslot_key(np.arange(64)), :].transpose(0, 1, 3, 2))
+    return dict(scales=scales, q8=imgs[0], k8=imgs[1], v8t=v8t)
+
+
+def fp8_dequantized_qkv(q, k, v, lay: Layout):
+    """The values the fp8 K5 multiplies: dequantised e4m3 images cropped back to [B, H, S, D] fp32."""
+    B, H, S, D = q.shape
+    ops = fp8_operands(q, k, v, lay)
+    res = []
+    for i, name in enumerate(("q8", "k8")):
+        x = dequantize_e4m3(ops[name])[:, :S] * ops["scales"][i][:, None, None]
+        res.append(x.reshape(B, H, S, D).astype(np.float32))
+    inv = np.argsort(fp8_kslot_key(np.arange(64)))
+    vt = dequantize_e4m3(ops["v8t"])                             # [BH, T, D, 64 slots]
+    vv = vt[:, :, :, inv].transpose(0, 1, 3, 2).reshape(B * H, -1, D)[:, :S] * ops["scales"][2][:, None, None]
+    res.append(vv.reshape(B, H, S, D).astype(np.float32))
+    return res[0], res[1], res[2], ops
+
+
+def rectified_attention_fp8(q, k, v, lay: Layout, top_k: int, p: float, neighbor=None, want_parts: bool = False):
+    """Operator with fp8 K5 operands: mask statistics, R and comp from the 2-byte inputs (unchanged contract), the
+    sparse / text-row attention itself on the dequantised e4m3 values (P kept in fp64 here; the kernel rounds P to
+    e4m3 -- covered by the stated fp8 tolerance)."""
+    B, H, S, D = q.shape
+    q8, k8, v8, ops = fp8_dequantized_qkv(q, k, v, lay)
+    out = np.zeros((B, S, H, D), np.float32)
+    parts = []
+    nvis_tok = lay.NBv * BLOCK
+    for b in range(B):
+        for h in range(H):
+            qq, kk, vv = q[b, h], k[b, h], v[b, h]
+            if lay.pool_valid < S:
+                kk = kk.copy()
+                vv = vv.copy()
+                kk[lay.pool_valid:] = 0
+                vv[lay.pool_valid:] = 0
+            sel = select_head(qq, kk, vv, lay, top_k, p, neighbor)
+            o = sparse_attention_head(q8[b, h], k8[b, h], v8[b, h], lay, sel["kept"], sel["rows"])
+            o = o * sel["R"][:, None, None].astype(np.float64) + sel["comp"][:, None, :].astype(np.float64)
+            o = o.reshape(-1, D)[: min(S, nvis_tok)]
+            out[b, : o.shape[0], h] = o
+            if lay.q_text_valid > 0:
+                r0 = nvis_tok
+                ot = dense_attention(q8[b, h][r0: r0 + lay.q_text_valid], k8[b, h], v8[b, h], lay.kv_text_valid)
+                out[b, r0: r0 + lay.q_text_valid, h] = ot
+            if want_parts:
+                parts.append(sel)
+    res = out.reshape(B, S, H * D)
+    return (res, parts, ops) if want_parts else res
+
+
 def pack_bits(mask_u8: np.ndarray) -> np.ndarray:
     """[..., N] 0/1 -> [..., ceil(N/32)] uint32, bit j%32 of word j//32 (the library's bitmask format)."""
     n = mask_u8.shape[-1]

@@ -14,7 +14,7 @@ from typing import Dict, Optional
 import torch
 
 from . import _lib
-from ._lib import BLOCK, BUFFER_NAMES, RsaBuffers, RsaLayout, RsaOut4, RsaTensor4
+from ._lib import BLOCK, BUFFER_NAMES, RsaBuffers, RsaFp8Operands, RsaLayout, RsaOut4, RsaTensor4
 
 
 @dataclass
@@ -157,11 +157,24 @@ def neighbor_on_device(block_neighbor_list, NBv: int, device) -> Optional[torch.
     return hit
 
 
+def alloc_fp8_operands(spec: LayoutSpec, B: int, H: int, D: int, device) -> Dict[str, torch.Tensor]:
+    """e4m3 images of Q, K, V for the fp8 K5 (include/rsa.h::rsa_fp8_operands)."""
+    assert D == 128, "the fp8 block-sparse kernel is built for head_dim 128"
+    BH, SP = B * H, spec.NB_total * BLOCK
+    return dict(q8=torch.empty((BH, SP, D), dtype=torch.uint8, device=device),
+                k8=torch.empty((BH, SP, D), dtype=torch.uint8, device=device),
+                v8t=torch.empty((BH, SP // 64, D, 64), dtype=torch.uint8, device=device),
+                scales=torch.empty((2, 3, BH), dtype=torch.float32, device=device))  # [0] = scales, [1] = scratch
+
+
 class StagedCall:
     """One rectified-attention call with its buffers: select() runs K1..K4 (mask-selection pass), attend() runs
-    K5.  Both are asynchronous on the current stream.  q, k, v: [B, H, S, D] device tensors."""
+    K5.  Both are asynchronous on the current stream.  q, k, v: [B, H, S, D] device tensors.
+    qkv_fp8: K5 runs on e4m3 images of Q, K, V (quantize() + the fp8 MFMA kernel); the mask-selection pass is
+    unchanged, so the kept lists are the 2-byte path's bit for bit."""
 
-    def __init__(self, q, k, v, spec: LayoutSpec, top_k: int, p_remain: float, block_neighbor_list=None):
+    def __init__(self, q, k, v, spec: LayoutSpec, top_k: int, p_remain: float, block_neighbor_list=None,
+                 qkv_fp8: bool = False):
         _require_device(q, k, v)
         self.L = _lib.lib()
         B, H, S, D = q.shape
@@ -179,6 +192,16 @@ class StagedCall:
         self.o4 = RsaOut4(self.out.data_ptr(), self.out.stride(0), self.out.stride(2), self.out.stride(1))
         self.nbr = neighbor_on_device(block_neighbor_list, spec.NBv, q.device)
         self.t = (_t4(self.q), _t4(self.k), _t4(self.v))
+        self.fp8 = None
+        if qkv_fp8:
+            self.fp8 = alloc_fp8_operands(spec, B, H, D, q.device)
+            self.cf = RsaFp8Operands(*[self.fp8[n].data_ptr() for n in ("q8", "k8", "v8t", "scales")])
+
+    def quantize(self):
+        tq, tk, tv = self.t
+        with torch.cuda.device(self.q.device):
+            _lib.check(self.L.rsa_quantize_fp8(ctypes.byref(self.lay), tq, tk, tv, ctypes.byref(self.cf), _stream()),
+                       "rsa_quantize_fp8")
 
     def select(self):
         L, lay, cb, st = self.L, ctypes.byref(self.lay), ctypes.byref(self.cb), _stream()
@@ -192,6 +215,12 @@ class StagedCall:
 
     def attend(self):
         tq, tk, tv = self.t
+        if self.fp8 is not None:
+            with torch.cuda.device(self.q.device):
+                _lib.check(self.L.rsa_block_sparse_fwd_fp8(ctypes.byref(self.lay), ctypes.byref(self.cf),
+                                                           ctypes.byref(self.cb), self.o4, _stream()),
+                           "rsa_block_sparse_fwd_fp8")
+            return self.out
         with torch.cuda.device(self.q.device):
             _lib.check(self.L.rsa_block_sparse_fwd(ctypes.byref(self.lay), tq, tk, tv, ctypes.byref(self.cb),
                                                    self.o4, _stream()), "rsa_block_sparse_fwd")
@@ -200,18 +229,25 @@ class StagedCall:
 
 def rectified_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, spec: LayoutSpec, top_k: int,
                         p_remain: float, block_neighbor_list=None, return_parts: bool = False,
-                        shape_xfuse: bool = False):
+                        shape_xfuse: bool = False, qkv_fp8: bool = False):
     """q, k, v: [B, H, S, D] device tensors -> [B, S, H*D] (or [B, S, H, D] if shape_xfuse).
 
     K1 pool_stats -> K2 pooled_scores -> K3 select_mask -> K4 compensation -> K5 block_sparse_fwd on the
     current stream; no host synchronisation, no K/V mutation (the reference zeroes masked K/V rows in place,
     hunyuan :307-308; here they are treated as zero by predication)."""
-    call = StagedCall(q, k, v, spec, top_k, p_remain, block_neighbor_list)
+    call = StagedCall(q, k, v, spec, top_k, p_remain, block_neighbor_list, qkv_fp8=qkv_fp8)
     call.select()
+    if qkv_fp8:
+        call.quantize()
     out = call.attend()
     B, H, S, D = q.shape
     res = out if shape_xfuse else out.view(B, S, H * D)
-    return (res, call.bufs) if return_parts else res
+    if return_parts:
+        parts = dict(call.bufs)
+        if qkv_fp8:
+            parts.update(call.fp8)
+        return res, parts
+    return res
 
 
 def dense_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, q_split: Optional[int] = None,
@@ -243,7 +279,8 @@ def unpack_bitmask(bitmask: torch.Tensor, n: int) -> torch.Tensor:
 
 
 def rectified_attention_onecall(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, spec: LayoutSpec, top_k: int,
-                                p_remain: float, block_neighbor_list=None, workspace: Optional[torch.Tensor] = None):
+                                p_remain: float, block_neighbor_list=None, workspace: Optional[torch.Tensor] = None,
+                                qkv_fp8: bool = False):
     """Same operator through the single C entry point rsa_rectified_attention with one caller-provided workspace
     (what a non-Python host would call).  Returns ([B, S, H*D], workspace)."""
     _require_device(q, k, v)
@@ -259,6 +296,19 @@ def rectified_attention_onecall(q: torch.Tensor, k: torch.Tensor, v: torch.Tenso
     out = torch.empty((B, S, H, D), dtype=q.dtype, device=q.device)
     o4 = RsaOut4(out.data_ptr(), out.stride(0), out.stride(2), out.stride(1))
     nbr = neighbor_on_device(block_neighbor_list, spec.NBv, q.device)
+    if qkv_fp8:
+        s4 = (ctypes.c_size_t * 4)()
+        t8 = ctypes.c_size_t()
+        _lib.check(L.rsa_fp8_operand_bytes(ctypes.byref(lay), ctypes.byref(s4), ctypes.byref(t8)),
+                   "rsa_fp8_operand_bytes")
+        ws8 = torch.empty(t8.value, dtype=torch.uint8, device=q.device)
+        with torch.cuda.device(q.device):
+            _lib.check(L.rsa_rectified_attention_fp8(ctypes.byref(lay), _t4(q), _t4(k), _t4(v),
+                                                     nbr.data_ptr() if nbr is not None else None, int(top_k),
+                                                     float(p_remain), workspace.data_ptr(), workspace.numel(),
+                                                     ws8.data_ptr(), ws8.numel(), o4, _stream()),
+                       "rsa_rectified_attention_fp8")
+        return out.view(B, S, H * D), workspace
     with torch.cuda.device(q.device):
         _lib.check(L.rsa_rectified_attention(ctypes.byref(lay), _t4(q), _t4(k), _t4(v),
                                              nbr.data_ptr() if nbr is not None else None, int(top_k),

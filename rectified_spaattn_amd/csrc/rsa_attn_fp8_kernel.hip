@@ -1,0 +1,421 @@
+// K5, fp8 operands: block-sparse flash attention forward on v_mfma_f32_32x32x64_f8f6f4 (e4m3 x e4m3 -> f32, twice the
+// bf16 MFMA rate) with the rectification epilogue fused.  Same work mapping, per-row plan, kept lists and epilogue as
+// the 2-byte kernel (rsa_attn_kernel.hip); the operands are the images written by rsa_fp8.hip.
+//
+// One workgroup (4 waves, two workgroups per CU) owns one 128-row query block, wave w rows 32w..32w+31, "key on the
+// register, query row on the lane":
+//      S^T[key][q]  = K8 . Q8^T     A = K8 rows (2 x ds_read_b128 of a 128-byte row), B = Q8 (16 registers, loaded once)
+//      O^T[d][q]   += V8^T . P8^T   A = rows of the pre-transposed V tile (2 x ds_read_b128), B = P = the two 32-key score
+//                                   accumulators of a 64-key tile converted in place with v_cvt_pk_fp8_f32
+// The 64 k-slots of the PV product are (lane half h, byte j); rsa_fp8.hip stores V^T with the keys of a tile in exactly
+// that order, so neither operand needs a transposing read or any cross-lane traffic.
+// Scores: S_raw * c with c = scale_q * scale_k * sm_scale * log2(e) (one fma feeds exp2); P = exp2(S*c - m + 4) with the
+// deferred running max moving only when a row max grew by more than 2^4, so P <= 2^8 < 448 (e4m3 max) and keeps
+// 2^-9 * 2^-4 relative resolution below the row's reference; l is summed from the unrounded P (as the reference kernel
+// does for its 2-byte P, rectified_hunyuan_attn.py:93-97); the V scale and 1/l, R meet in the epilogue.
+//
+// Pipeline (per wave, 64-key tiles, S double-buffered): step t computes S(t+1) while P(t) and O += V(t) P(t) run.
+// Staging: K and V tiles are 8 KiB each; 4-slot rings; at the head of step t the wave issues its 2+2 LDS-DMA pieces of
+// K(t+3) and V(t+2) behind `s_waitcnt vmcnt(4)` + barrier, so every tile has two full steps to land.
+#include "rsa_attn.h"
+
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+struct Attn8Args {
+    const uint8_t *q8, *k8, *v8t;  // [BH, S_pad, 128], [BH, S_pad, 128], [BH, S_pad/64, 128, 64]
+    const float* scales;           // [3, BH]
+    unsigned short* out;
+    long osb, osh, oss;
+    const int32_t* cols;
+    const int32_t* counts;
+    const float* R;
+    const float* comp;
+    int mode, H, Sq, Sk, S_pad;
+    int NBv, NQB, NB_total;
+    int kv_valid, kv_text_valid, q_text_end;
+    int q_split, kv_split;
+    int n_heavy_pad, NBp, BH;
+    float sm_scale_log2e;
+    int out_fp16;
+};
+
+namespace {
+
+constexpr int D8 = 128;
+constexpr int TILE8 = 8192;   // bytes of one K tile (64 keys x 128) and of one V tile (128 d x 64 keys)
+constexpr int NSLOT = 4;
+constexpr float P_OFFSET = 4.0f, P_THRESH = 4.0f;
+
+__device__ __forceinline__ f32x16 mfma8(i32x8 a, i32x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0, 0, 0);  // e4m3 x e4m3, unscaled
+}
+
+template <int PIPE_OPT>
+__global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned short* lds_list = reinterpret_cast<unsigned short*>(lds + 2 * NSLOT * TILE8);
+
+    // ---------------- work mapping (as rsa_attn_kernel.hip) ----------------
+    int bh, qblk;
+    {
+        const int bid = blockIdx.x;
+        if (bid < a.n_heavy_pad) {
+            const int ntq = a.NQB - a.NBv;
+            if (ntq <= 0 || bid >= a.BH * ntq) return;
+            bh = bid / ntq;
+            qblk = a.NBv + bid % ntq;
+        } else {
+            const int v = bid - a.n_heavy_pad;
+            bh = v / a.NBp;
+            const int j = v % a.NBp;
+            const int chunk = a.NBp >> 3;
+            qblk = (j & 7) * chunk + (j >> 3);
+            if (qblk >= a.NBv) return;
+        }
+    }
+    const int b = bh / a.H, h = bh % a.H;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int grow = qblk * RSA_BLOCK + 32 * wv + r;
+
+    // ---------------- per-row plan ----------------
+    int lo_r = 0, hi_r = 0;
+    bool store_r = false, zero_r = false;
+    int n_items, first_blk = 0, lo_max, hi_min, hi_max;
+    const int32_t* list = nullptr;
+    bool rectify = false;
+    if (a.mode == MODE_SPARSE) {
+        if (qblk < a.NBv) {
+            const long rowi = (long)bh * a.NBv + qblk;
+            list = a.cols + rowi * a.NB_total;
+            n_items = a.counts[rowi];
+            lo_max = 0; hi_min = hi_max = a.kv_valid;
+            rectify = a.R != nullptr;
+            hi_r = a.kv_valid; store_r = grow < a.Sq;
+        } else {
+            n_items = (a.kv_text_valid + RSA_BLOCK - 1) / RSA_BLOCK;
+            lo_max = 0; hi_min = hi_max = a.kv_text_valid;
+            hi_r = a.kv_text_valid;
+            store_r = grow < a.q_text_end;
+            zero_r = !store_r && grow < a.Sq;
+        }
+    } else {
+        const int row0 = qblk * RSA_BLOCK, row1 = row0 + RSA_BLOCK;
+        if (grow < a.q_split) { lo_r = 0; hi_r = a.kv_split; }
+        else { lo_r = a.kv_split; hi_r = a.Sk; }
+        store_r = grow < a.Sq;
+        int lo_min;
+        if (row1 <= a.q_split) { lo_min = 0; lo_max = 0; hi_min = hi_max = a.kv_split; }
+        else if (row0 >= a.q_split) { lo_min = lo_max = a.kv_split; hi_min = hi_max = a.Sk; }
+        else { lo_min = 0; lo_max = a.kv_split; hi_min = a.kv_split; hi_max = a.Sk; }
+        first_blk = lo_min / RSA_BLOCK;
+        n_items = (hi_max + RSA_BLOCK - 1) / RSA_BLOCK - first_blk;
+        if (hi_max <= lo_min) n_items = 0;
+    }
+    n_items = __builtin_amdgcn_readfirstlane(n_items);
+    const bool use_list = list != nullptr;
+    if (use_list) {
+        for (int i = t; i < n_items; i += 256) lds_list[i] = (unsigned short)list[i];
+        __syncthreads();
+    }
+    auto blk_of = [&](int item) -> int { return use_list ? (int)lds_list[item] : first_blk + item; };
+    int n_tiles = 2 * n_items;
+    if (n_items > 0) {
+        const int last_blk = blk_of(n_items - 1);
+        if (last_blk * RSA_BLOCK + 64 >= hi_max) n_tiles -= 1;
+    }
+    n_tiles = __builtin_amdgcn_readfirstlane(n_tiles);
+    auto key0_of = [&](int tile) -> int {  // first key of tile `tile` (index clamped: callers guard tile < n_tiles)
+        const int it = tile >> 1;
+        const int blk = __builtin_amdgcn_readfirstlane(blk_of(it < n_items ? it : (n_items > 0 ? n_items - 1 : 0)));
+        return blk * RSA_BLOCK + (tile & 1) * 64;
+    };
+
+    // ---------------- scales, Q fragments ----------------
+    const float c_qk = a.scales[bh] * a.scales[a.BH + bh] * a.sm_scale_log2e;
+    const float s_v = a.scales[2 * a.BH + bh];
+    i32x8 qf[2];
+    {
+        const uint8_t* qp = a.q8 + ((long)bh * a.S_pad + grow) * D8 + 32 * hh;  // rows < S_pad always exist (zero-padded)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const i32x4 lo = *reinterpret_cast<const i32x4*>(qp + 64 * ks);
+            const i32x4 hi = *reinterpret_cast<const i32x4*>(qp + 64 * ks + 16);
+            qf[ks] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    }
+
+    // ---------------- LDS-DMA staging ----------------
+    // K tile [64 keys][128 B]: 1-KiB piece pc = rows 8pc..8pc+7; wave w moves pieces w and w+4 (same swizzle phase).
+    // V tile [128 d][64 B]:    1-KiB piece pc = rows 16pc..16pc+15; wave w moves pieces w and w+4.
+    // The LDS image is lane-linear, so the bank swizzle is applied to the SOURCE chunk.
+    const unsigned char* kbase = a.k8 + (long)bh * a.S_pad * D8;
+    const unsigned char* vbase = a.v8t + (long)bh * a.S_pad * D8;  // S_pad/64 tiles x 8192 bytes
+    const unsigned voffk = (unsigned)((lane >> 3) * 128 + (((lane & 7) ^ (4 * (wv & 1) + (lane >> 4))) << 4));
+    const unsigned voffv = (unsigned)((lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4));
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    auto dma2 = [&](const unsigned char* tile_src, unsigned lds_dst, unsigned voff) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                         :: "v"(voff), "s"(tile_src + (wv + 4 * j) * 1024), "s"(lds_dst + (wv + 4 * j) * 1024)
+                         : "memory");
+        }
+    };
+    auto dma_k = [&](int key0, int slot) { dma2(kbase + (long)key0 * D8, lds_base + slot * TILE8, voffk); };
+    auto dma_v = [&](int key0, int slot) {
+        dma2(vbase + (long)(key0 >> 6) * TILE8, lds_base + (NSLOT + slot) * TILE8, voffv);
+    };
+
+    // ---------------- state ----------------
+    f32x16 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[dt][i] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;
+
+    // per-lane read offsets (slot base added per step)
+    int koff[2][2][2];  // [sub][ks][chunk]
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+        const int row = 32 * sub + r;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2)
+                koff[sub][ks][c2] = row * 128 + (((4 * ks + 2 * hh + c2) ^ ((row >> 1) & 7)) << 4);
+    }
+    int voff_rd[2];  // row r of a 32-row d-tile; +2048 per d-tile
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2) voff_rd[c2] = r * 64 + (((2 * hh + c2) ^ ((r >> 2) & 3)) << 4);
+
+    auto ld32 = [&](const unsigned char* p0, const unsigned char* p1) -> i32x8 {
+        const i32x4 lo = *reinterpret_cast<const i32x4*>(p0);
+        const i32x4 hi = *reinterpret_cast<const i32x4*>(p1);
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    // S^T (two 32-key halves) of the tile in K slot `slot`
+    auto qk_tile = [&](int slot, f32x16 (&S)[2]) {
+        const unsigned char* kt_ = lds + slot * TILE8;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) S[sub][i] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                S[sub] = mfma8(ld32(kt_ + koff[sub][ks][0], kt_ + koff[sub][ks][1]), qf[ks], S[sub]);
+        }
+    };
+    auto rowmax_tile = [&](const f32x16 (&S)[2]) -> float {
+        float m = S[0][0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) m = fmaxf(m, S[0][i]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) m = fmaxf(m, S[1][i]);
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+        return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * c_qk;  // c_qk > 0
+    };
+    auto apply_mask = [&](f32x16 (&S)[2], int key0) {
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int kk = key0 + 32 * sub + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                if (kk < lo_r || kk >= hi_r) S[sub][i] = -INFINITY;
+            }
+    };
+
+    int kq1 = 0, kq2 = 0, kq3 = 0;  // first keys of tiles t+1, t+2, t+3
+
+    auto step = [&](int tile, int key0, f32x16 (&S_cur)[2], float& mx_cur, f32x16 (&S_nxt)[2], float& mx_nxt) {
+        if (tile + 2 < n_tiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tile + 3 < n_tiles) dma_k(kq3, (tile + 3) & (NSLOT - 1));
+        if (tile + 2 < n_tiles) dma_v(kq2, (tile + 2) & (NSLOT - 1));
+        // ---- head (rare branches): boundary mask, deferred rescale ----
+        if (key0 < lo_max || key0 + 64 > hi_min) {
+            apply_mask(S_cur, key0);
+            mx_cur = rowmax_tile(S_cur);
+        }
+        if (__builtin_amdgcn_ballot_w64(mx_cur > m_run + P_THRESH) != 0ull) {
+            const float m_new = fmaxf(m_run, mx_cur);
+            const float mu = (m_new == -INFINITY) ? 0.0f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - mu);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+        }
+        const float m_use = ((m_run == -INFINITY) ? 0.0f : m_run) - P_OFFSET;
+
+        // ---- pipelined block ----
+        if constexpr (PIPE_OPT & 2) __builtin_amdgcn_s_setprio(2);
+        qk_tile((tile + 1) & (NSLOT - 1), S_nxt);
+        i32x8 pb;
+        float ps = 0.0f;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) {
+                float p4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    p4[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(S_cur[sub][4 * w4 + e], c_qk, -m_use));
+                    ps += p4[e];
+                }
+                int word = 0;
+                word = __builtin_amdgcn_cvt_pk_fp8_f32(p4[0], p4[1], word, false);
+                word = __builtin_amdgcn_cvt_pk_fp8_f32(p4[2], p4[3], word, true);
+                pb[4 * sub + w4] = word;
+            }
+        l_run += ps;
+        const unsigned char* vt_ = lds + (NSLOT + (tile & (NSLOT - 1))) * TILE8;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+            o[dt] = mfma8(ld32(vt_ + dt * 2048 + voff_rd[0], vt_ + dt * 2048 + voff_rd[1]), pb, o[dt]);
+        mx_nxt = rowmax_tile(S_nxt);
+        if constexpr (PIPE_OPT & 2) __builtin_amdgcn_s_setprio(0);
+    };
+
+    // ---------------- prologue + main loop ----------------
+    f32x16 SA[2], SB[2];
+    float mxA = -INFINITY, mxB = -INFINITY;
+    int key0 = 0;
+    if (n_tiles > 0) {
+        key0 = key0_of(0);
+        kq1 = key0_of(1);
+        kq2 = key0_of(2);
+        kq3 = key0_of(3);
+        dma_k(key0, 0);
+        dma_v(key0, 0);
+        if (n_tiles > 1) { dma_k(kq1, 1); dma_v(kq1, 1); }
+        if (n_tiles > 2) dma_k(kq2, 2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        qk_tile(0, SA);
+        mxA = rowmax_tile(SA);
+    }
+    auto advance = [&](int tile) {  // after finishing `tile`: shift the key queue, fetch tile+4's first key
+        key0 = kq1;
+        kq1 = kq2;
+        kq2 = kq3;
+        kq3 = key0_of(tile + 4);
+    };
+    {
+        int tile = 0;
+        for (; tile + 1 < n_tiles; tile += 2) {
+            step(tile, key0, SA, mxA, SB, mxB);
+            advance(tile);
+            step(tile + 1, key0, SB, mxB, SA, mxA);
+            advance(tile + 1);
+        }
+        if (tile < n_tiles) step(tile, key0, SA, mxA, SB, mxB);
+    }
+
+    // ---------------- epilogue ----------------
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+    const float l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    if (!(store_r || zero_r)) return;
+    float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
+    float Rv = 1.0f;
+    const float* cp = nullptr;
+    if (rectify) {
+        const long rowi = (long)bh * a.NBv + qblk;
+        Rv = a.R[rowi];
+        cp = a.comp + rowi * D8;
+    }
+    if (zero_r) inv = 0.0f;
+    const float sc = inv * Rv * s_v;
+    unsigned short* op = a.out + (long)b * a.osb + (long)h * a.osh + (long)grow * a.oss;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d0 = 32 * dt + 8 * g + 4 * hh;
+            float4 c4 = make_float4(0, 0, 0, 0);
+            if (cp && !zero_r) c4 = *reinterpret_cast<const float4*>(cp + d0);
+            const float v0 = o[dt][4 * g + 0] * sc + c4.x;
+            const float v1 = o[dt][4 * g + 1] * sc + c4.y;
+            const float v2 = o[dt][4 * g + 2] * sc + c4.z;
+            const float v3 = o[dt][4 * g + 3] * sc + c4.w;
+            uint2 pk;
+            if (a.out_fp16) {
+                pk.x = (unsigned)Elem<fp16_tag>::from_f32(v0) | ((unsigned)Elem<fp16_tag>::from_f32(v1) << 16);
+                pk.y = (unsigned)Elem<fp16_tag>::from_f32(v2) | ((unsigned)Elem<fp16_tag>::from_f32(v3) << 16);
+            } else {
+                pk.x = (unsigned)Elem<bf16_tag>::from_f32(v0) | ((unsigned)Elem<bf16_tag>::from_f32(v1) << 16);
+                pk.y = (unsigned)Elem<bf16_tag>::from_f32(v2) | ((unsigned)Elem<bf16_tag>::from_f32(v3) << 16);
+            }
+            *reinterpret_cast<uint2*>(op + d0) = pk;
+        }
+    }
+}
+
+int launch_attn8(Attn8Args& a, int BH, hipStream_t s) {
+    const int ntq = a.NQB - a.NBv;
+    const int n_heavy = ntq > 0 ? BH * ntq : 0;
+    a.BH = BH;
+    a.n_heavy_pad = (n_heavy + 7) & ~7;
+    a.NBp = (a.NBv + 7) & ~7;
+    const long nblocks = (long)a.n_heavy_pad + (long)BH * a.NBp;
+    if (nblocks <= 0) return RSA_OK;
+    if (nblocks > 0x7FFFFFFF) return RSA_ERR_UNSUPPORTED;
+    if (a.NB_total > 8192) return RSA_ERR_UNSUPPORTED;
+    const size_t lds_bytes = (size_t)2 * NSLOT * TILE8 + (((size_t)a.NB_total * 2 + 15) & ~(size_t)15);
+    bsfwd_fp8_kernel<2><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a);
+    return rsa_launch_status();
+}
+
+int check_out8(const rsa_out4& o) {
+    if (!o.ptr || (reinterpret_cast<uintptr_t>(o.ptr) & 7)) return RSA_ERR_BAD_ARG;
+    if ((o.stride_b % 4) || (o.stride_h % 4) || (o.stride_s % 4)) return RSA_ERR_BAD_ARG;
+    return RSA_OK;
+}
+
+}  // namespace
+
+extern "C" int rsa_block_sparse_fwd_fp8(const rsa_layout* l, const rsa_fp8_operands* ops, const rsa_buffers* buf,
+                                        rsa_out4 out, void* stream) {
+    int st = rsa_check_layout(l);
+    if (st != RSA_OK) return st;
+    if (l->D != 128) return RSA_ERR_UNSUPPORTED;
+    if (!ops || !ops->q8 || !ops->k8 || !ops->v8t || !ops->scales) return RSA_ERR_BAD_ARG;
+    if ((st = check_out8(out))) return st;
+    if (!buf || (l->NBv > 0 && (!buf->cols || !buf->counts))) return RSA_ERR_BAD_ARG;
+    if ((buf->R == nullptr) != (buf->comp == nullptr)) return RSA_ERR_BAD_ARG;
+    Attn8Args a;
+    a.q8 = ops->q8; a.k8 = ops->k8; a.v8t = ops->v8t; a.scales = ops->scales;
+    a.out = static_cast<unsigned short*>(out.ptr); a.osb = out.stride_b; a.osh = out.stride_h; a.oss = out.stride_s;
+    a.cols = buf->cols; a.counts = buf->counts; a.R = buf->R; a.comp = buf->comp;
+    a.mode = MODE_SPARSE; a.H = l->H; a.Sq = l->S; a.Sk = l->S; a.S_pad = l->NB_total * RSA_BLOCK;
+    a.NBv = l->NBv; a.NQB = l->NB_total; a.NB_total = l->NB_total;
+    a.kv_valid = l->kv_valid; a.kv_text_valid = l->kv_text_valid;
+    a.q_text_end = l->NBv * RSA_BLOCK + l->q_text_valid;
+    a.q_split = 0; a.kv_split = 0;
+    a.sm_scale_log2e = (float)((1.0 / sqrt((double)l->D)) * 1.44269504);
+    a.out_fp16 = l->dtype == RSA_FP16;
+    return launch_attn8(a, l->B * l->H, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int rsa_rectified_attention_fp8(const rsa_layout* l, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
+                                           const uint8_t* neighbor, int top_k, float p_remain, void* workspace,
+                                           size_t workspace_bytes, void* fp8_workspace, size_t fp8_workspace_bytes,
+                                           rsa_out4 out, void* stream) {
+    rsa_buffers buf;
+    rsa_fp8_operands ops;
+    int st = rsa_carve_workspace(l, workspace, workspace_bytes, &buf);
+    if (st != RSA_OK) return st;
+    if ((st = rsa_carve_fp8_operands(l, fp8_workspace, fp8_workspace_bytes, &ops))) return st;
+    if ((st = rsa_pool_stats(l, q, k, v, &buf, stream))) return st;
+    if ((st = rsa_pooled_scores(l, k, &buf, stream))) return st;
+    if ((st = rsa_select_mask(l, neighbor, top_k, p_remain, &buf, stream))) return st;
+    if ((st = rsa_compensation(l, &buf, stream))) return st;
+    if ((st = rsa_quantize_fp8(l, q, k, v, &ops, stream))) return st;
+    return rsa_block_sparse_fwd_fp8(l, &ops, &buf, out, stream);
+}

@@ -1,0 +1,217 @@
+// FP8 operand producer for the fp8 K5 (rsa_attn_fp8_kernel.hip): per-(batch, head) absolute maxima of Q, K, V and
+// the e4m3 (OCP "e4m3fn", gfx950's native fp8) images the kernel stages:
+//      q8, k8 : [BH, NB_total*128, D]   row-major bytes, rows past the tensor's valid range are zero
+//      v8t    : [BH, NB_total*2, D, 64] V transposed per 64-key tile; byte p = 32*h + j of a (tile, d) row holds the
+//               key the f8f6f4 MFMA's k-slot (lane half h, byte j) meets in the P operand built from two 32-key
+//               score accumulators:   key = 32*(j >> 4) + (j & 3) + 8*((j & 15) >> 2) + 4*h
+//      scales : [3, BH] fp32 dequantisation scales (amax / 448; 1 when the tensor is all zero)
+// Numeric contract (bit-exact against oracle.quantize_e4m3): widen exactly to fp32, IEEE-divide by the scale, clamp
+// to +-448, convert with v_cvt_pk_fp8_f32 (round to nearest even, subnormals kept).
+#include "rsa_common.h"
+
+namespace {
+
+constexpr float E4M3_MAX = 448.0f;
+
+struct QuantArgs {
+    const unsigned short* src[3];
+    long sb[3], sh[3], ss[3];
+    int valid[3];        // rows >= valid[i] are zero in the image (and skipped by the amax)
+    unsigned* amax_bits; // [3, BH] fp32 bit patterns (non-negative floats order like unsigned ints)
+    float* scales;       // [3, BH]
+    uint8_t *q8, *k8, *v8t;
+    int H, BH, S_pad;    // S_pad = NB_total * 128
+};
+
+template <typename Tag>
+__global__ __launch_bounds__(256) void amax_kernel(QuantArgs a) {
+    const int which = blockIdx.z, bh = blockIdx.y;
+    const int b = bh / a.H, h = bh % a.H;
+    const unsigned short* base = a.src[which] + (long)b * a.sb[which] + (long)h * a.sh[which];
+    const int row0 = blockIdx.x * 1024;
+    const int row1 = min(row0 + 1024, a.valid[which]);
+    const int t = threadIdx.x, c = t & 15;
+    float m = 0.0f;
+    for (int row = row0 + (t >> 4); row < row1; row += 16) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(base + (long)row * a.ss[which] + 8 * c);
+        const unsigned w4[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            m = fmaxf(m, fabsf(rsa_to_f32<Tag>((unsigned short)(w4[e] & 0xFFFF))));
+            m = fmaxf(m, fabsf(rsa_to_f32<Tag>((unsigned short)(w4[e] >> 16))));
+        }
+    }
+    for (int s = 1; s < 64; s <<= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
+    if ((t & 63) == 0 && m > 0.0f) atomicMax(a.amax_bits + which * a.BH + bh, __float_as_uint(m));
+}
+
+__global__ void scales_kernel(const unsigned* amax_bits, float* scales, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float m = __uint_as_float(amax_bits[i]);
+    scales[i] = m > 0.0f ? m / E4M3_MAX : 1.0f;
+}
+
+__device__ __forceinline__ float q_clamp(float x, float scale) {
+    const float y = x / scale;
+    return fminf(fmaxf(y, -E4M3_MAX), E4M3_MAX);
+}
+
+// 8 two-byte elements (one uint4) -> 8 e4m3 bytes (uint2)
+template <typename Tag>
+__device__ __forceinline__ uint2 quant8(uint4 raw, float scale) {
+    const unsigned w4[4] = {raw.x, raw.y, raw.z, raw.w};
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        f[2 * e] = q_clamp(rsa_to_f32<Tag>((unsigned short)(w4[e] & 0xFFFF)), scale);
+        f[2 * e + 1] = q_clamp(rsa_to_f32<Tag>((unsigned short)(w4[e] >> 16)), scale);
+    }
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+    return make_uint2((unsigned)lo, (unsigned)hi);
+}
+
+// Q and K: 64 rows x D per workgroup, row-major bytes.  grid (S_pad / 64, BH, 2)
+template <int D, typename Tag>
+__global__ __launch_bounds__(256) void quant_rows_kernel(QuantArgs a) {
+    constexpr int TPR = D / 32;  // threads per row, 32 elements each
+    const int which = blockIdx.z, bh = blockIdx.y;
+    const int b = bh / a.H, h = bh % a.H;
+    const float scale = a.scales[which * a.BH + bh];
+    uint8_t* dst = (which == 0 ? a.q8 : a.k8) + (long)bh * a.S_pad * D;
+    const unsigned short* base = a.src[which] + (long)b * a.sb[which] + (long)h * a.sh[which];
+    const int t = threadIdx.x;
+    for (int rr = t / TPR; rr < 64; rr += 256 / TPR) {
+        const int row = blockIdx.x * 64 + rr, part = t % TPR;
+        uint2 o[4];
+        if (row < a.valid[which]) {
+            const unsigned short* p = base + (long)row * a.ss[which] + 32 * part;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = quant8<Tag>(*reinterpret_cast<const uint4*>(p + 8 * i), scale);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = make_uint2(0, 0);
+        }
+        uint4* out = reinterpret_cast<uint4*>(dst + (long)row * D + 32 * part);
+        out[0] = make_uint4(o[0].x, o[0].y, o[1].x, o[1].y);
+        out[1] = make_uint4(o[2].x, o[2].y, o[3].x, o[3].y);
+    }
+}
+
+// V: one 64-key tile per workgroup, transposed through LDS into the k-slot key order.  grid (S_pad / 64, BH)
+template <int D, typename Tag>
+__global__ __launch_bounds__(256) void quant_vt_kernel(QuantArgs a) {
+    constexpr int TPR = D / 32;
+    constexpr int LROW = D + 16;  // padded LDS row (bytes)
+    __shared__ __attribute__((aligned(16))) uint8_t tile[64 * LROW];
+    const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
+    const float scale = a.scales[2 * a.BH + bh];
+    const unsigned short* base = a.src[2] + (long)b * a.sb[2] + (long)h * a.sh[2];
+    const int t = threadIdx.x;
+    for (int rr = t / TPR; rr < 64; rr += 256 / TPR) {
+        const int row = blockIdx.x * 64 + rr, part = t % TPR;
+        uint2 o[4];
+        if (row < a.valid[2]) {
+            const unsigned short* p = base + (long)row * a.ss[2] + 32 * part;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = quant8<Tag>(*reinterpret_cast<const uint4*>(p + 8 * i), scale);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = make_uint2(0, 0);
+        }
+        uint4* out = reinterpret_cast<uint4*>(tile + rr * LROW + 32 * part);
+        out[0] = make_uint4(o[0].x, o[0].y, o[1].x, o[1].y);
+        out[1] = make_uint4(o[2].x, o[2].y, o[3].x, o[3].y);
+    }
+    __syncthreads();
+    uint8_t* dst = a.v8t + ((long)bh * (a.S_pad / 64) + blockIdx.x) * (long)(D * 64);
+    for (int item = t; item < D * 2; item += 256) {
+        const int d = item >> 1, hh = item & 1;
+        unsigned w[8];
+#pragma unroll
+        for (int j4 = 0; j4 < 8; ++j4) {
+            unsigned word = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = 4 * j4 + e;
+                const int key = 32 * (j >> 4) + (j & 3) + 8 * ((j & 15) >> 2) + 4 * hh;
+                word |= (unsigned)tile[key * LROW + d] << (8 * e);
+            }
+            w[j4] = word;
+        }
+        uint4* out = reinterpret_cast<uint4*>(dst + d * 64 + 32 * hh);
+        out[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        out[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace
+
+extern "C" int rsa_fp8_operand_bytes(const rsa_layout* l, size_t sizes[4], size_t* total) {
+    int st = rsa_check_layout(l);
+    if (st != RSA_OK) return st;
+    if (!sizes || !total) return RSA_ERR_BAD_ARG;
+    if (l->D != 128) return RSA_ERR_UNSUPPORTED;
+    const size_t BH = (size_t)l->B * l->H, SP = (size_t)l->NB_total * RSA_BLOCK, D = l->D;
+    const size_t s[4] = {BH * SP * D, BH * SP * D, BH * SP * D, 2 * 3 * BH * 4};  // scales + amax bit patterns
+    size_t tot = 0;
+    for (int i = 0; i < 4; ++i) { sizes[i] = s[i]; tot += align256(s[i]); }
+    *total = tot;
+    return RSA_OK;
+}
+
+extern "C" int rsa_carve_fp8_operands(const rsa_layout* l, void* ws, size_t ws_bytes, rsa_fp8_operands* out) {
+    size_t sizes[4], total;
+    int st = rsa_fp8_operand_bytes(l, sizes, &total);
+    if (st != RSA_OK) return st;
+    if (!ws || !out || (reinterpret_cast<uintptr_t>(ws) & 255)) return RSA_ERR_BAD_ARG;
+    if (ws_bytes < total) return RSA_ERR_WORKSPACE;
+    uint8_t* p = static_cast<uint8_t*>(ws);
+    out->q8 = p; p += align256(sizes[0]);
+    out->k8 = p; p += align256(sizes[1]);
+    out->v8t = p; p += align256(sizes[2]);
+    out->scales = reinterpret_cast<float*>(p);
+    return RSA_OK;
+}
+
+extern "C" int rsa_quantize_fp8(const rsa_layout* l, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
+                                const rsa_fp8_operands* ops, void* stream) {
+    int st = rsa_check_layout(l);
+    if (st != RSA_OK) return st;
+    if (l->D != 128) return RSA_ERR_UNSUPPORTED;
+    if (!ops || !ops->q8 || !ops->k8 || !ops->v8t || !ops->scales) return RSA_ERR_BAD_ARG;
+    if ((st = rsa_check_tensor(q)) || (st = rsa_check_tensor(k)) || (st = rsa_check_tensor(v))) return st;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    QuantArgs a;
+    const rsa_tensor4* ts[3] = {&q, &k, &v};
+    for (int i = 0; i < 3; ++i) {
+        a.src[i] = static_cast<const unsigned short*>(ts[i]->ptr);
+        a.sb[i] = ts[i]->stride_b; a.sh[i] = ts[i]->stride_h; a.ss[i] = ts[i]->stride_s;
+    }
+    const int kv_lim = l->kv_valid > l->kv_text_valid ? l->kv_valid : l->kv_text_valid;
+    a.valid[0] = l->S; a.valid[1] = kv_lim; a.valid[2] = kv_lim;
+    a.H = l->H; a.BH = l->B * l->H; a.S_pad = l->NB_total * RSA_BLOCK;
+    a.scales = ops->scales;
+    a.amax_bits = reinterpret_cast<unsigned*>(ops->scales + 3 * a.BH);
+    a.q8 = ops->q8; a.k8 = ops->k8; a.v8t = ops->v8t;
+    if (hipMemsetAsync(a.amax_bits, 0, (size_t)3 * a.BH * 4, s) != hipSuccess) return rsa_launch_status();
+    const dim3 g_amax((a.S_pad + 1023) / 1024, a.BH, 3), g_rows(a.S_pad / 64, a.BH, 2), g_vt(a.S_pad / 64, a.BH);
+    if (l->dtype == RSA_BF16) {
+        amax_kernel<bf16_tag><<<g_amax, 256, 0, s>>>(a);
+        scales_kernel<<<(3 * a.BH + 255) / 256, 256, 0, s>>>(a.amax_bits, a.scales, 3 * a.BH);
+        quant_rows_kernel<128, bf16_tag><<<g_rows, 256, 0, s>>>(a);
+        quant_vt_kernel<128, bf16_tag><<<g_vt, 256, 0, s>>>(a);
+    } else {
+        amax_kernel<fp16_tag><<<g_amax, 256, 0, s>>>(a);
+        scales_kernel<<<(3 * a.BH + 255) / 256, 256, 0, s>>>(a.amax_bits, a.scales, 3 * a.BH);
+        quant_rows_kernel<128, fp16_tag><<<g_rows, 256, 0, s>>>(a);
+        quant_vt_kernel<128, fp16_tag><<<g_vt, 256, 0, s>>>(a);
+    }
+    return rsa_launch_status();
+}

@@ -1,0 +1,111 @@
+"""fp8 (e4m3) K5 on the GPU (BASELINE config 5: fp8 Q/K/V on the CDNA4 fp8 MFMA).
+
+* the quantiser's images and scales equal oracle.fp8_operands byte for byte (integer / byte work: bit-exact)
+* the kept lists, R and comp are the 2-byte path's (the mask-selection pass does not see the fp8 images)
+* the kernel's output is within max|d| <= 4e-2, mean|d| <= 4e-3 of the fp8-aware oracle (same dequantised e4m3
+  operands, P kept exact) for N(0,1)-scale V -- measured 2.3e-2 / 2.5e-3, which is the e4m3 rounding of P
+* against the bf16 oracle (un-quantised inputs) the stated tolerance is max|d| <= 2e-1, mean|d| <= 2e-2: here the
+  e4m3 rounding of Q, K, V themselves dominates (the fp8-aware oracle alone is 5e-2..1.4e-1 / 1e-2 away from the bf16
+  oracle on this data, so SURVEY 8(d)'s provisional 8e-2 is not reachable by any per-head-scaled e4m3 operand set)
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+FP8_MAX_VS_BF16, FP8_MEAN_VS_BF16 = 2e-1, 2e-2
+FP8_MAX_VS_FP8, FP8_MEAN_VS_FP8 = 4e-2, 4e-3
+
+
+def _spec(lay):
+    from rectified_spaattn_amd import _core
+    return _core.LayoutSpec(lay.S, lay.NB_total, lay.NBv, lay.n_txt, lay.kv_valid, lay.pool_valid,
+                            lay.text_end_block, lay.ffb, lay.q_text_valid, lay.kv_text_valid)
+
+
+CASES = [
+    ("wan_ragged", lambda: orc.layout_wan(7 * 128 - 37, 2), 2, 3, 0.3, 1, torch.bfloat16),
+    ("wan_tiny", lambda: orc.layout_wan(100, 0), 1, 1, 0.5, -1, torch.bfloat16),
+    ("hunyuan", lambda: orc.layout_hunyuan(6 * 128 + 256, 6 * 128 + 200), 2, 2, 0.4, 1, torch.bfloat16),
+    ("flux", lambda: orc.layout_flux(9 * 128 + 512, 512), 1, 3, 0.2, 0, torch.float16),
+    ("wan_keep_all", lambda: orc.layout_wan(5 * 128, 0), 1, 99, 1.5, -1, torch.bfloat16),
+    ("wan_odd_tiles", lambda: orc.layout_wan(4 * 128 + 40, 1), 1, 2, 0.6, 1, torch.bfloat16),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: c[0])
+def test_fp8_operator(case):
+    from rectified_spaattn_amd import _core, synth
+    name, mk, H, top_k, p, nbw, dt = case
+    lay = mk()
+    q, k, v = synth.structured_qkv(4242 + len(name), 1, H, lay.S, 128, smooth=0.0)
+    nbr = synth.banded_neighbors(lay.NBv, nbw) if nbw >= 0 else None
+    tq, tk, tv = (torch.from_numpy(x).to(DEV, dt) for x in (q, k, v))
+    q, k, v = (x.float().cpu().numpy() for x in (tq, tk, tv))
+    tn = torch.from_numpy(nbr) if nbr is not None else None
+    out, parts = _core.rectified_attention(tq, tk, tv, _spec(lay), top_k, p, tn, return_parts=True, qkv_fp8=True)
+    out_ref, parts_ref = _core.rectified_attention(tq, tk, tv, _spec(lay), top_k, p, tn, return_parts=True)
+    # selection pass untouched by the fp8 option
+    for n in ("bitmask", "cols", "counts", "R", "comp", "probs"):
+        a, b = parts[n], parts_ref[n]
+        if n == "cols":  # only the first counts[] entries of a row are defined
+            cnt = parts["counts"].cpu().numpy().reshape(-1)
+            a2, b2 = a.cpu().numpy().reshape(len(cnt), -1), b.cpu().numpy().reshape(len(cnt), -1)
+            assert all(np.array_equal(a2[i, :c], b2[i, :c]) for i, c in enumerate(cnt))
+        else:
+            assert torch.equal(a, b), n
+    # byte-exact operand images
+    ref8, sel, ops = orc.rectified_attention_fp8(q, k, v, lay, top_k, p, nbr, want_parts=True)
+    assert np.array_equal(parts["scales"][0].cpu().numpy(), ops["scales"]), "scales"
+    assert np.array_equal(parts["q8"].cpu().numpy(), ops["q8"]), "q8"
+    assert np.array_equal(parts["k8"].cpu().numpy(), ops["k8"]), "k8"
+    assert np.array_equal(parts["v8t"].cpu().numpy(), ops["v8t"]), "v8t"
+    # output
+    o = out.float().cpu().numpy()
+    e8 = np.abs(o - ref8)
+    assert e8.max() <= FP8_MAX_VS_FP8 and e8.mean() <= FP8_MEAN_VS_FP8, f"vs fp8 oracle: {e8.max():.3e} {e8.mean():.3e}"
+    ref16 = orc.rectified_attention(q, k, v, lay, top_k, p, nbr)
+    e16 = np.abs(o - ref16)
+    assert e16.max() <= FP8_MAX_VS_BF16 and e16.mean() <= FP8_MEAN_VS_BF16, \
+        f"vs bf16 oracle: {e16.max():.3e} {e16.mean():.3e}"
+    assert np.isfinite(o).all()
+
+
+def test_fp8_onecall_matches_staged():
+    from rectified_spaattn_amd import _core, synth
+    lay = orc.layout_hunyuan(5 * 128 + 256, 5 * 128 + 131)
+    q, k, v = synth.structured_qkv(77, 1, 2, lay.S, 128, smooth=0.0)
+    tq, tk, tv = (torch.from_numpy(x).to(DEV, torch.bfloat16) for x in (q, k, v))
+    nbr = torch.from_numpy(synth.banded_neighbors(lay.NBv, 1))
+    a = _core.rectified_attention(tq, tk, tv, _spec(lay), 2, 0.3, nbr, qkv_fp8=True)
+    b, _ = _core.rectified_attention_onecall(tq, tk, tv, _spec(lay), 2, 0.3, nbr, qkv_fp8=True)
+    assert torch.equal(a, b)
+
+
+def test_fp8_rejects_head_dim_64():
+    from rectified_spaattn_amd import _core, synth
+    lay = orc.layout_wan(256, 0)
+    q, k, v = synth.structured_qkv(5, 1, 1, lay.S, 64, smooth=0.0)
+    tq, tk, tv = (torch.from_numpy(x).to(DEV, torch.bfloat16) for x in (q, k, v))
+    with pytest.raises(AssertionError):
+        _core.rectified_attention(tq, tk, tv, _spec(lay), 1, 0.3, None, qkv_fp8=True)
+
+
+def test_fp8_large_magnitudes_and_zero_tensor():
+    """Scales follow the data: x1000 inputs quantise to the same bytes; an all-zero V gives scale 1 and comp-only output."""
+    from rectified_spaattn_amd import _core, synth
+    lay = orc.layout_wan(3 * 128, 0)
+    q, k, v = synth.structured_qkv(9, 1, 1, lay.S, 128, smooth=0.0)
+    tq, tk, tv = (torch.from_numpy(x).to(DEV, torch.bfloat16) for x in (q, k, v))
+    _, p1 = _core.rectified_attention(tq, tk, tv, _spec(lay), 1, 0.3, None, return_parts=True, qkv_fp8=True)
+    _, p2 = _core.rectified_attention(tq, tk, tv * 1024, _spec(lay), 1, 0.3, None, return_parts=True, qkv_fp8=True)
+    assert torch.equal(p1["v8t"], p2["v8t"])  # power-of-two rescale: identical bytes
+    assert torch.equal(p1["scales"][0, 2] * 1024, p2["scales"][0, 2])
+    o, p3 = _core.rectified_attention(tq, tk, torch.zeros_like(tv), _spec(lay), 1, 0.3, None, return_parts=True,
+                                      qkv_fp8=True)
+    assert float(p3["scales"][0, 2, 0]) == 1.0
+    assert torch.count_nonzero(o) == 0
