@@ -366,22 +366,33 @@ def fp8_kslot_key(p: np.ndarray) -> np.ndarray:
 
 def fp8_operands(q, k, v, lay: Layout):
     """Per-(b,h) scales and e4m3 images exactly as rsa_quantize_fp8 writes them.
-    q, k, v: [B, H, S, D] fp32 -> dict(scales [3, BH], q8/k8 [BH, S_pad, D], v8t [BH, S_pad/64, D, 64])."""
+    q, k, v: [B, H, S, D] fp32 -> dict(scales [4, BH] (q, k, v, c), q8/k8 [BH, S_pad, D], v8t [BH, S_pad/64, D, 64])."""
     B, H, S, D = q.shape
     BH, SP = B * H, lay.NB_total * BLOCK
     kv_lim = max(lay.kv_valid, lay.kv_text_valid)
     valid = (S, kv_lim, kv_lim)
-    scales = np.ones((3, BH), np.float32)
+    xs = [np.asarray(x, np.float32).reshape(BH, S, D) for x in (q, k, v)]
+    scales = np.ones((4, BH), np.float32)
+    qk_const = np.float32((1.0 / np.sqrt(float(D))) * 1.44269504)
+    for bh in range(BH):
+        sc = []
+        for i in range(3):
+            xv = xs[i][bh, : valid[i]]
+            amax = np.float32(np.max(np.abs(xv))) if xv.size else np.float32(0)
+            sc.append(np.float32(amax / E4M3_MAX) if amax > 0 else np.float32(1.0))
+        # c = scale_q * scale_k * sm_scale * log2(e) rounded UP to a power of two by stretching scale_q (rsa_fp8.hip)
+        skc = np.float32(sc[1] * qk_const)
+        c0 = np.float32(sc[0] * skc)
+        mant, e = np.frexp(c0)
+        e = int(e) - (1 if mant == np.float32(0.5) else 0)
+        e = max(-120, min(120, e))
+        c = np.float32(np.ldexp(np.float32(1.0), e))
+        scales[:, bh] = (np.float32(c / skc), sc[1], sc[2], c)
     imgs = []
-    for i, x in enumerate((q, k, v)):
-        x = np.asarray(x, np.float32).reshape(BH, S, D)
+    for i in range(3):
         img = np.zeros((BH, SP, D), np.uint8)
         for bh in range(BH):
-            xv = x[bh, : valid[i]]
-            amax = np.float32(np.max(np.abs(xv))) if xv.size else np.float32(0)
-            sc = np.float32(amax / E4M3_MAX) if amax > 0 else np.float32(1.0)
-            scales[i, bh] = sc
-            img[bh, : valid[i]] = quantize_e4m3((xv / sc).astype(np.float32))
+            img[bh, : valid[i]] = quantize_e4m3((xs[i][bh, : valid[i]] / scales[i, bh]).astype(np.float32))
         imgs.append(img)
     v8 = imgs[2].reshape(BH, SP // 64, 64, D)
     v8t = np.ascontiguousarray(v8[:, :, fp8_kslot_key(np.arange(64)), :].transpose(0, 1, 3, 2))

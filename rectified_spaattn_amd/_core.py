@@ -164,7 +164,7 @@ def alloc_fp8_operands(spec: LayoutSpec, B: int, H: int, D: int, device) -> Dict
     return dict(q8=torch.empty((BH, SP, D), dtype=torch.uint8, device=device),
                 k8=torch.empty((BH, SP, D), dtype=torch.uint8, device=device),
                 v8t=torch.empty((BH, SP // 64, D, 64), dtype=torch.uint8, device=device),
-                scales=torch.empty((2, 3, BH), dtype=torch.float32, device=device))  # [0] = scales, [1] = scratch
+                scales=torch.empty((7, BH), dtype=torch.float32, device=device))  # rows 0..3 = scales q, k, v, c; 4..6 = scratch
 
 
 class StagedCall:

@@ -9,10 +9,14 @@
 //                                   accumulators of a 64-key tile converted in place with v_cvt_pk_fp8_f32
 // The 64 k-slots of the PV product are (lane half h, byte j); rsa_fp8.hip stores V^T with the keys of a tile in exactly
 // that order, so neither operand needs a transposing read or any cross-lane traffic.
-// Scores: S_raw * c with c = scale_q * scale_k * sm_scale * log2(e) (one fma feeds exp2); P = exp2(S*c - m + 4) with the
-// deferred running max moving only when a row max grew by more than 2^4, so P <= 2^8 < 448 (e4m3 max) and keeps
-// 2^-9 * 2^-4 relative resolution below the row's reference; l is summed from the unrounded P (as the reference kernel
-// does for its 2-byte P, rectified_hunyuan_attn.py:93-97); the V scale and 1/l, R meet in the epilogue.
+// Scores: the quantiser makes c = scale_q * scale_k * sm_scale * log2(e) an exact power of two (rsa_fp8.hip), which the
+// MFMA applies for free through its E8M0 block-scale operands, and the QK^T chain starts from a 16-register block that
+// holds 4 - m (m = the row's deferred running max), so the accumulator IS log2(P) and the softmax costs one v_exp_f32,
+// one add and half a v_cvt_pk_fp8_f32 per score -- the kernel is VALU-bound, not MFMA-bound.  The running max moves
+// only when a row max grew by more than 2^4, so P <= 2^8 < 448 (e4m3 max) and keeps 2^-9 * 2^-4 relative resolution
+// below the row's reference; that rare move also shifts the scores already computed for the next tile.  l is summed
+// from the unrounded P (as the reference kernel does for its 2-byte P, rectified_hunyuan_attn.py:93-97); the V scale,
+// 1/l and R meet in the epilogue.
 //
 // Pipeline (per wave, 64-key tiles, S double-buffered): step t computes S(t+1) while P(t) and O += V(t) P(t) run.
 // Staging: K and V tiles are 8 KiB each; 4-slot rings; at the head of step t the wave issues its 2+2 LDS-DMA pieces of
@@ -49,6 +53,10 @@ constexpr float P_OFFSET = 4.0f, P_THRESH = 4.0f;
 
 __device__ __forceinline__ f32x16 mfma8(i32x8 a, i32x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0, 0, 0);  // e4m3 x e4m3, unscaled
+}
+// same with E8M0 block scales 2^(sa-127) on A and 2^(sb-127) on B (byte 0 of each lane's scale register)
+__device__ __forceinline__ f32x16 mfma8s(i32x8 a, i32x8 b, f32x16 c, int sa, int sb) {
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, sa, 0, sb);
 }
 
 template <int PIPE_OPT>
@@ -134,7 +142,9 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     };
 
     // ---------------- scales, Q fragments ----------------
-    const float c_qk = a.scales[bh] * a.scales[a.BH + bh] * a.sm_scale_log2e;
+    // c = scale_q * scale_k * sm_scale * log2(e) = 2^e exactly (rsa_fp8.hip::scales_kernel): split over the two operands
+    const int c_exp = (int)((__float_as_uint(a.scales[3 * a.BH + bh]) >> 23) & 0xFF) - 127;
+    const int sc_a = 127 + (c_exp >> 1), sc_b = 127 + (c_exp - (c_exp >> 1));
     const float s_v = a.scales[2 * a.BH + bh];
     i32x8 qf[2];
     {
@@ -176,6 +186,9 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) o[dt][i] = 0.0f;
     float m_run = -INFINITY, l_run = 0.0f;
+    f32x16 mblk;  // P_OFFSET - m_eff in all 16 registers: the start value of every QK^T chain (m_eff = 0 while m_run = -inf)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mblk[i] = P_OFFSET;
 
     // per-lane read offsets (slot base added per step)
     int koff[2][2][2];  // [sub][ks][chunk]
@@ -202,11 +215,8 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
         const unsigned char* kt_ = lds + slot * TILE8;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) S[sub][i] = 0.0f;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                S[sub] = mfma8(ld32(kt_ + koff[sub][ks][0], kt_ + koff[sub][ks][1]), qf[ks], S[sub]);
+            S[sub] = mfma8s(ld32(kt_ + koff[sub][0][0], kt_ + koff[sub][0][1]), qf[0], mblk, sc_a, sc_b);
+            S[sub] = mfma8s(ld32(kt_ + koff[sub][1][0], kt_ + koff[sub][1][1]), qf[1], S[sub], sc_a, sc_b);
         }
     };
     auto rowmax_tile = [&](const f32x16 (&S)[2]) -> float {
@@ -216,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) m = fmaxf(m, S[1][i]);
         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
-        return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * c_qk;  // c_qk > 0
+        return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));  // = score_max - m_eff + P_OFFSET
     };
     auto apply_mask = [&](f32x16 (&S)[2], int key0) {
 #pragma unroll
@@ -230,33 +240,44 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
 
     int kq1 = 0, kq2 = 0, kq3 = 0;  // first keys of tiles t+1, t+2, t+3
 
-    auto step = [&](int tile, int key0, f32x16 (&S_cur)[2], float& mx_cur, f32x16 (&S_nxt)[2], float& mx_nxt) {
+    // TS = tile & 3 (compile-time: every LDS address is a loop-invariant VGPR plus an immediate)
+    auto step = [&](auto TS, int tile, int key0, f32x16 (&S_cur)[2], float& mx_cur, f32x16 (&S_nxt)[2], float& mx_nxt) {
+        const int ts = TS;  // integral_constant (static LDS addresses) or the runtime tile & 3
         if (tile + 2 < n_tiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tile + 3 < n_tiles) dma_k(kq3, (tile + 3) & (NSLOT - 1));
-        if (tile + 2 < n_tiles) dma_v(kq2, (tile + 2) & (NSLOT - 1));
+        if (tile + 3 < n_tiles) dma_k(kq3, (ts + 3) & (NSLOT - 1));
+        if (tile + 2 < n_tiles) dma_v(kq2, (ts + 2) & (NSLOT - 1));
         // ---- head (rare branches): boundary mask, deferred rescale ----
         if (key0 < lo_max || key0 + 64 > hi_min) {
             apply_mask(S_cur, key0);
             mx_cur = rowmax_tile(S_cur);
         }
-        if (__builtin_amdgcn_ballot_w64(mx_cur > m_run + P_THRESH) != 0ull) {
-            const float m_new = fmaxf(m_run, mx_cur);
-            const float mu = (m_new == -INFINITY) ? 0.0f : m_new;
-            const float alpha = __builtin_amdgcn_exp2f(m_run - mu);
+        // mx_cur and S_cur are relative to the block's reference: score - m_eff + P_OFFSET
+        const bool grow = (m_run == -INFINITY) ? (mx_cur > -INFINITY) : (mx_cur > P_THRESH + P_OFFSET);
+        if (__builtin_amdgcn_ballot_w64(grow) != 0ull) {
+            const float m_eff_old = (m_run == -INFINITY) ? 0.0f : m_run;
+            const float m_new = fmaxf(m_run, mx_cur - P_OFFSET + m_eff_old);
+            const float m_eff = (m_new == -INFINITY) ? 0.0f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_eff);
+            const float shift = m_eff - m_eff_old;
             m_run = m_new;
             l_run *= alpha;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) S_cur[sub][i] -= shift;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mblk[i] = P_OFFSET - m_eff;
         }
-        const float m_use = ((m_run == -INFINITY) ? 0.0f : m_run) - P_OFFSET;
 
         // ---- pipelined block ----
         if constexpr (PIPE_OPT & 2) __builtin_amdgcn_s_setprio(2);
-        qk_tile((tile + 1) & (NSLOT - 1), S_nxt);
+        qk_tile((ts + 1) & (NSLOT - 1), S_nxt);
         i32x8 pb;
         float ps = 0.0f;
 #pragma unroll
@@ -266,16 +287,17 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
                 float p4[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    p4[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(S_cur[sub][4 * w4 + e], c_qk, -m_use));
+                    p4[e] = __builtin_amdgcn_exp2f(S_cur[sub][4 * w4 + e]);
                     ps += p4[e];
                 }
-                int word = 0;
+                // the packed word is built in a score register that is dead by now (no zero-initialised temporary)
+                int word = __float_as_int(S_cur[0][4 * sub + w4]);
                 word = __builtin_amdgcn_cvt_pk_fp8_f32(p4[0], p4[1], word, false);
                 word = __builtin_amdgcn_cvt_pk_fp8_f32(p4[2], p4[3], word, true);
                 pb[4 * sub + w4] = word;
             }
         l_run += ps;
-        const unsigned char* vt_ = lds + (NSLOT + (tile & (NSLOT - 1))) * TILE8;
+        const unsigned char* vt_ = lds + (NSLOT + ts) * TILE8;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
             o[dt] = mfma8(ld32(vt_ + dt * 2048 + voff_rd[0], vt_ + dt * 2048 + voff_rd[1]), pb, o[dt]);
@@ -310,12 +332,12 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     {
         int tile = 0;
         for (; tile + 1 < n_tiles; tile += 2) {
-            step(tile, key0, SA, mxA, SB, mxB);
+            step(tile & 3, tile, key0, SA, mxA, SB, mxB);
             advance(tile);
-            step(tile + 1, key0, SB, mxB, SA, mxA);
+            step((tile + 1) & 3, tile + 1, key0, SB, mxB, SA, mxA);
             advance(tile + 1);
         }
-        if (tile < n_tiles) step(tile, key0, SA, mxA, SB, mxB);
+        if (tile < n_tiles) step(tile & 3, tile, key0, SA, mxA, SB, mxB);
     }
 
     // ---------------- epilogue ----------------

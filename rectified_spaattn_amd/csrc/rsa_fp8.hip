@@ -4,9 +4,12 @@
 //      v8t    : [BH, NB_total*2, D, 64] V transposed per 64-key tile; byte p = 32*h + j of a (tile, d) row holds the
 //               key the f8f6f4 MFMA's k-slot (lane half h, byte j) meets in the P operand built from two 32-key
 //               score accumulators:   key = 32*(j >> 4) + (j & 3) + 8*((j & 15) >> 2) + 4*h
-//      scales : [3, BH] fp32 dequantisation scales (amax / 448; 1 when the tensor is all zero)
-// Numeric contract (bit-exact against oracle.quantize_e4m3): widen exactly to fp32, IEEE-divide by the scale, clamp
-// to +-448, convert with v_cvt_pk_fp8_f32 (round to nearest even, subnormals kept).
+//      scales : [4, BH] fp32: dequantisation scales of q, k, v, then c = scale_q * scale_k * sm_scale * log2(e)
+// Numeric contract (bit-exact against oracle.fp8_operands): scale = amax / 448 (1 when the tensor is all zero) for K and
+// V; for Q the scale is stretched by less than 2x so that c is an exact power of two -- c = the smallest power of two
+// >= (amax_q/448 * scale_k) * qk_const, scale_q = c / (scale_k * qk_const), all in fp32 -- which costs e4m3 (a floating
+// point format) no precision and lets the kernel apply c through the MFMA's E8M0 scale operands.  Elements: widen
+// exactly to fp32, IEEE-divide by the scale, clamp to +-448, v_cvt_pk_fp8_f32 (round to nearest even, subnormals kept).
 #include "rsa_common.h"
 
 namespace {
@@ -18,7 +21,8 @@ struct QuantArgs {
     long sb[3], sh[3], ss[3];
     int valid[3];        // rows >= valid[i] are zero in the image (and skipped by the amax)
     unsigned* amax_bits; // [3, BH] fp32 bit patterns (non-negative floats order like unsigned ints)
-    float* scales;       // [3, BH]
+    float* scales;       // [4, BH]
+    float qk_const;      // sm_scale * log2(e)
     uint8_t *q8, *k8, *v8t;
     int H, BH, S_pad;    // S_pad = NB_total * 128
 };
@@ -32,24 +36,48 @@ __global__ __launch_bounds__(256) void amax_kernel(QuantArgs a) {
     const int row1 = min(row0 + 1024, a.valid[which]);
     const int t = threadIdx.x, c = t & 15;
     float m = 0.0f;
-    for (int row = row0 + (t >> 4); row < row1; row += 16) {
-        const uint4 raw = *reinterpret_cast<const uint4*>(base + (long)row * a.ss[which] + 8 * c);
+    auto fold = [&](uint4 raw) {
         const unsigned w4[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             m = fmaxf(m, fabsf(rsa_to_f32<Tag>((unsigned short)(w4[e] & 0xFFFF))));
             m = fmaxf(m, fabsf(rsa_to_f32<Tag>((unsigned short)(w4[e] >> 16))));
         }
+    };
+    const long ss = a.ss[which];
+    int row = row0 + (t >> 4);
+    for (; row + 112 < row1; row += 128) {  // 8 independent 16-byte loads in flight per lane
+        uint4 raw[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) raw[u] = *reinterpret_cast<const uint4*>(base + (long)(row + 16 * u) * ss + 8 * c);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) fold(raw[u]);
     }
+    for (; row < row1; row += 16) fold(*reinterpret_cast<const uint4*>(base + (long)row * ss + 8 * c));
     for (int s = 1; s < 64; s <<= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
     if ((t & 63) == 0 && m > 0.0f) atomicMax(a.amax_bits + which * a.BH + bh, __float_as_uint(m));
 }
 
-__global__ void scales_kernel(const unsigned* amax_bits, float* scales, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float m = __uint_as_float(amax_bits[i]);
-    scales[i] = m > 0.0f ? m / E4M3_MAX : 1.0f;
+__global__ void scales_kernel(const unsigned* amax_bits, float* scales, int BH, float qk_const) {
+    const int bh = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bh >= BH) return;
+    float sc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float m = __uint_as_float(amax_bits[i * BH + bh]);
+        sc[i] = m > 0.0f ? m / E4M3_MAX : 1.0f;
+    }
+    const float skc = sc[1] * qk_const;
+    const float c0 = sc[0] * skc;
+    int e;
+    const float mant = frexpf(c0, &e);              // c0 = mant * 2^e, mant in [0.5, 1)
+    if (mant == 0.5f) e -= 1;                        // already a power of two
+    e = e < -120 ? -120 : (e > 120 ? 120 : e);
+    const float c = ldexpf(1.0f, e);
+    scales[bh] = c / skc;
+    scales[BH + bh] = sc[1];
+    scales[2 * BH + bh] = sc[2];
+    scales[3 * BH + bh] = c;
 }
 
 __device__ __forceinline__ float q_clamp(float x, float scale) {
@@ -159,7 +187,7 @@ extern "C" int rsa_fp8_operand_bytes(const rsa_layout* l, size_t sizes[4], size_
     if (!sizes || !total) return RSA_ERR_BAD_ARG;
     if (l->D != 128) return RSA_ERR_UNSUPPORTED;
     const size_t BH = (size_t)l->B * l->H, SP = (size_t)l->NB_total * RSA_BLOCK, D = l->D;
-    const size_t s[4] = {BH * SP * D, BH * SP * D, BH * SP * D, 2 * 3 * BH * 4};  // scales + amax bit patterns
+    const size_t s[4] = {BH * SP * D, BH * SP * D, BH * SP * D, (4 + 3) * BH * 4};  // scales + amax bit patterns
     size_t tot = 0;
     for (int i = 0; i < 4; ++i) { sizes[i] = s[i]; tot += align256(s[i]); }
     *total = tot;
@@ -198,18 +226,19 @@ extern "C" int rsa_quantize_fp8(const rsa_layout* l, rsa_tensor4 q, rsa_tensor4 
     a.valid[0] = l->S; a.valid[1] = kv_lim; a.valid[2] = kv_lim;
     a.H = l->H; a.BH = l->B * l->H; a.S_pad = l->NB_total * RSA_BLOCK;
     a.scales = ops->scales;
-    a.amax_bits = reinterpret_cast<unsigned*>(ops->scales + 3 * a.BH);
+    a.amax_bits = reinterpret_cast<unsigned*>(ops->scales + 4 * a.BH);
+    a.qk_const = (float)((1.0 / sqrt((double)l->D)) * 1.44269504);
     a.q8 = ops->q8; a.k8 = ops->k8; a.v8t = ops->v8t;
     if (hipMemsetAsync(a.amax_bits, 0, (size_t)3 * a.BH * 4, s) != hipSuccess) return rsa_launch_status();
     const dim3 g_amax((a.S_pad + 1023) / 1024, a.BH, 3), g_rows(a.S_pad / 64, a.BH, 2), g_vt(a.S_pad / 64, a.BH);
     if (l->dtype == RSA_BF16) {
         amax_kernel<bf16_tag><<<g_amax, 256, 0, s>>>(a);
-        scales_kernel<<<(3 * a.BH + 255) / 256, 256, 0, s>>>(a.amax_bits, a.scales, 3 * a.BH);
+        scales_kernel<<<(a.BH + 255) / 256, 256, 0, s>>>(a.amax_bits, a.scales, a.BH, a.qk_const);
         quant_rows_kernel<128, bf16_tag><<<g_rows, 256, 0, s>>>(a);
         quant_vt_kernel<128, bf16_tag><<<g_vt, 256, 0, s>>>(a);
     } else {
         amax_kernel<fp16_tag><<<g_amax, 256, 0, s>>>(a);
-        scales_kernel<<<(3 * a.BH + 255) / 256, 256, 0, s>>>(a.amax_bits, a.scales, 3 * a.BH);
+        scales_kernel<<<(a.BH + 255) / 256, 256, 0, s>>>(a.amax_bits, a.scales, a.BH, a.qk_const);
         quant_rows_kernel<128, fp16_tag><<<g_rows, 256, 0, s>>>(a);
         quant_vt_kernel<128, fp16_tag><<<g_vt, 256, 0, s>>>(a);
     }

@@ -60,7 +60,9 @@ def test_fp8_operator(case):
             assert torch.equal(a, b), n
     # byte-exact operand images
     ref8, sel, ops = orc.rectified_attention_fp8(q, k, v, lay, top_k, p, nbr, want_parts=True)
-    assert np.array_equal(parts["scales"][0].cpu().numpy(), ops["scales"]), "scales"
+    assert np.array_equal(parts["scales"][:4].cpu().numpy(), ops["scales"]), "scales"
+    c = ops["scales"][3]
+    assert (np.frexp(c)[0] == 0.5).all(), "c must be a power of two"
     assert np.array_equal(parts["q8"].cpu().numpy(), ops["q8"]), "q8"
     assert np.array_equal(parts["k8"].cpu().numpy(), ops["k8"]), "k8"
     assert np.array_equal(parts["v8t"].cpu().numpy(), ops["v8t"]), "v8t"
@@ -104,8 +106,8 @@ def test_fp8_large_magnitudes_and_zero_tensor():
     _, p1 = _core.rectified_attention(tq, tk, tv, _spec(lay), 1, 0.3, None, return_parts=True, qkv_fp8=True)
     _, p2 = _core.rectified_attention(tq, tk, tv * 1024, _spec(lay), 1, 0.3, None, return_parts=True, qkv_fp8=True)
     assert torch.equal(p1["v8t"], p2["v8t"])  # power-of-two rescale: identical bytes
-    assert torch.equal(p1["scales"][0, 2] * 1024, p2["scales"][0, 2])
+    assert torch.equal(p1["scales"][2] * 1024, p2["scales"][2])
     o, p3 = _core.rectified_attention(tq, tk, torch.zeros_like(tv), _spec(lay), 1, 0.3, None, return_parts=True,
                                       qkv_fp8=True)
-    assert float(p3["scales"][0, 2, 0]) == 1.0
+    assert float(p3["scales"][2, 0]) == 1.0
     assert torch.count_nonzero(o) == 0

@@ -54,10 +54,16 @@ def main():
         S = wl["S_vis"] + wl["text"]
         spec = _core.LayoutSpec.hunyuan(S, wl["S_vis"] + wl["text_valid"])
         q, k, v = gen_qkv(H, 0, S, wl["S_vis"], D, dev)
-        call = _core.StagedCall(q, k, v, spec, wl["top_k"], 0.0, None)
+        fp8 = os.environ.get("RSA_PERF_FP8", "0") == "1"
+        call = _core.StagedCall(q, k, v, spec, wl["top_k"], 0.0, None, qkv_fp8=fp8)
         for _ in range(2):
             call.select()
+            if fp8:
+                call.quantize()
             call.attend()
+        if fp8:
+            torch.cuda.synchronize()
+            return
         Sd = 16384
         qd = torch.randn(1, H, Sd, D, device=dev).to(torch.bfloat16)
         for _ in range(2):

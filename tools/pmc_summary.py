@@ -10,9 +10,9 @@ for pat in sys.argv[1:]:
     for f in glob.glob(pat, recursive=True):
         for r in csv.DictReader(open(f)):
             name = r.get("Kernel_Name", "")
-            if not any(k in name for k in ("bsfwd", "select_mask", "pool_stats", "pooled_scores", "compensation")):
+            if not any(k in name for k in ("bsfwd", "select_mask", "pool_stats", "pooled_scores", "compensation", "quant", "amax")):
                 continue
-            short = name.split("(")[0].replace("void ", "")
+            short = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
             if "bsfwd" in short:
                 short += " grid=" + r.get("Grid_Size", "?")
             a = acc[(short, r["Counter_Name"])]

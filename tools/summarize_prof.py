@@ -5,7 +5,8 @@ import csv
 import sys
 
 OURS = ("bsfwd_kernel", "select_mask_kernel", "compensation_kernel", "pool_stats_kernel", "pooled_scores_kernel",
-        "gapr_compare_kernel")
+        "gapr_compare_kernel", "bsfwd_fp8_kernel", "amax_kernel", "scales_kernel", "quant_rows_kernel", "quant_vt_kernel",
+        "permute_tokens_kernel", "qk_norm_rope_kernel")
 rows = list(csv.DictReader(open(sys.argv[1])))
 title = sys.argv[2] if len(sys.argv) > 2 else sys.argv[1]
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
@@ -17,7 +18,7 @@ other = [0, 0.0]
 for r in rows:
     name = r["Name"]
     if any(o in name for o in OURS):
-        short = name.replace("void ", "")
+        short = name.replace("void ", "").replace("(anonymous namespace)::", "")
         print(f"| `{short[:90]}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['MinNs'])/1e3:.1f} | "
               f"{float(r['MaxNs'])/1e3:.1f} | {float(r['TotalDurationNs'])/1e6:.2f} | "
               f"{100*float(r['TotalDurationNs'])/tot:.2f} |")
