@@ -100,3 +100,66 @@ def test_wan22_ti2v_full_size():
     from rectified_spaattn_amd import _core
     S = 27280
     _check_config("wan22", _core.LayoutSpec.wan(S, 6), orc.layout_wan(S, 6), 4, 53, 0.3, None, [0, 100, 213])
+
+
+def _check_config_fp8(name, spec, lay, H, top_k, p, nbr, sample_rows, seed=77):
+    """fp8 K5 at full size: operand images byte-exact on the sampled heads, kept lists identical to the 2-byte path,
+    sampled query blocks against the fp8-aware oracle (tolerances of tests/test_gpu_fp8.py)."""
+    from rectified_spaattn_amd import _core
+    D = 128
+    q, k, v = _gen(H, lay.S, D, seed)
+    tn = torch.from_numpy(nbr) if nbr is not None else None
+    out, parts = _core.rectified_attention(q, k, v, spec, top_k, p, tn, return_parts=True, qkv_fp8=True)
+    _, parts16 = _core.rectified_attention(q, k, v, spec, top_k, p, tn, return_parts=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all(), f"{name}: non-finite output"
+    assert torch.equal(parts["bitmask"], parts16["bitmask"]) and torch.equal(parts["counts"], parts16["counts"])
+    assert torch.equal(parts["R"], parts16["R"]) and torch.equal(parts["comp"], parts16["comp"])
+    kept = _core.unpack_bitmask(parts["bitmask"], lay.NB_total).cpu().numpy()
+    o = out.view(1, lay.S, H, D)
+    for bh in (0, H - 1):
+        qh, kh, vh = (x[0, bh].float().cpu().numpy() for x in (q, k, v))
+        q8, k8, v8, ops = orc.fp8_dequantized_qkv(qh[None, None], kh[None, None], vh[None, None], lay)
+        assert np.array_equal(parts["scales"][:4, bh].cpu().numpy(), ops["scales"][:, 0]), f"{name}: scales"
+        assert np.array_equal(parts["q8"][bh].cpu().numpy(), ops["q8"][0]), f"{name}: q8"
+        assert np.array_equal(parts["k8"][bh].cpu().numpy(), ops["k8"][0]), f"{name}: k8"
+        assert np.array_equal(parts["v8t"][bh].cpu().numpy(), ops["v8t"][0]), f"{name}: v8t"
+        if lay.pool_valid < lay.S:
+            kh[lay.pool_valid:] = 0
+            vh[lay.pool_valid:] = 0
+        sel = orc.select_head(qh, kh, vh, lay, top_k, p, nbr, rows=sample_rows)
+        for a, i in enumerate(sample_rows):
+            assert np.array_equal(kept[bh, i], sel["kept"][a].astype(bool)), f"{name}: mask row {i} head {bh}"
+        ref = orc.sparse_attention_head(q8[0, 0], k8[0, 0], v8[0, 0], lay, sel["kept"], sample_rows)
+        ref = ref * sel["R"][:, None, None] + sel["comp"][:, None, :]
+        for a, i in enumerate(sample_rows):
+            n = min(128, lay.S - i * 128)
+            got = o[0, i * 128: i * 128 + n, bh].float().cpu().numpy()
+            err = np.abs(got - ref[a, :n])
+            # mean bound 6e-3 here (4e-3 in test_gpu_fp8.py): with this generator's sharper attention rows a few keys
+            # carry the row, and the e4m3 rounding of their P (2^-4 relative) shows undiluted against the unrounded l
+            assert err.max() <= 4e-2 and err.mean() <= 6e-3, f"{name}: fp8 O row-block {i}: {err.max():.3e} {err.mean():.3e}"
+        if lay.q_text_valid > 0:
+            r0 = lay.NBv * 128
+            rows = [r0, r0 + lay.q_text_valid - 1]
+            reft = orc.dense_attention(q8[0, 0][rows], k8[0, 0], v8[0, 0], lay.kv_text_valid)
+            assert np.abs(o[0, rows, bh].float().cpu().numpy() - reft).max() <= 4e-2
+            if r0 + lay.q_text_valid < lay.S:
+                assert float(o[0, r0 + lay.q_text_valid:, bh].abs().max()) == 0.0
+
+
+def test_wan22_ti2v_fp8_full_size():
+    """BASELINE configs[4]: Wan2.2-TI2V 720p with fp8 Q/K/V on the fp8 MFMA: S = 27 280, top_k = 53, ffb = 6."""
+    from rectified_spaattn_amd import _core
+    S = 27280
+    _check_config_fp8("wan22-fp8", _core.LayoutSpec.wan(S, 6), orc.layout_wan(S, 6), 4, 53, 0.3, None, [0, 100, 213])
+
+
+def test_hunyuan_720p_fp8_full_size():
+    """HunyuanVideo 720p shape with fp8 operands (text tail, masked keys, Gilbert neighbours); 2 heads."""
+    from rectified_spaattn_amd import _core
+    from rectified_spaattn_amd.utils import jenga_gilbert
+    S, nt = 115456, 115400
+    nbr = jenga_gilbert.gilbert_block_neighbor_mapping(32, 45, 80).numpy()
+    _check_config_fp8("hunyuan-fp8", _core.LayoutSpec.hunyuan(S, nt), orc.layout_hunyuan(S, nt), 2, 90, 0.05, nbr,
+                      [0, 437, 899])
