@@ -12,3 +12,10 @@ Module names mirror the reference package `rectified_spaattn`:
 Device work goes through librsa_hip.so (C-ABI in include/rsa.h); nothing here falls back to PyTorch kernels.
 """
 __version__ = "0.1.0"
+
+
+def set_qkv_fp8(enabled: bool) -> bool:
+    """Run the block-sparse kernel of every sparse operator / processor call on e4m3 images of Q, K, V (fp8 MFMA,
+    head_dim 128); returns the previous setting.  Default off = the reference's input-dtype behaviour."""
+    from . import _operator
+    return _operator.set_qkv_fp8(enabled)

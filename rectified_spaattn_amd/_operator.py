@@ -27,6 +27,20 @@ def _check_blocks(bm: int, bn: int):
                                   "(the only value the reference scripts use)")
 
 
+# K5 operand precision for every operator call that goes through run(): False = the input dtype (bf16/fp16, the
+# reference's behaviour), True = e4m3 images of Q, K, V on the fp8 MFMA (head_dim 128 only; other head dims keep the
+# 2-byte kernel).  Set with rectified_spaattn_amd.set_qkv_fp8(); the reference has no such switch (fp8 is its TODO).
+QKV_FP8 = False
+
+
+def set_qkv_fp8(enabled: bool) -> bool:
+    """Switch the sparse operator (and therefore every processor's sparse steps) to fp8 K5 operands.  Returns the
+    previous setting."""
+    global QKV_FP8
+    old, QKV_FP8 = QKV_FP8, bool(enabled)
+    return old
+
+
 def run(variant: str, query, key, value, top_k, prob_threshold, block_neighbor_list, shape_xfuse,
         cu_seqlens_q=None, cu_seqlens_kv=None, text_length: int = 256, first_frame_blocks=None,
         block_size_M: int = 128, block_size_N: int = 128):
@@ -43,7 +57,7 @@ def run(variant: str, query, key, value, top_k, prob_threshold, block_neighbor_l
     else:
         raise ValueError(variant)
     return _core.rectified_attention(query, key, value, spec, int(top_k), float(prob_threshold),
-                                     block_neighbor_list, shape_xfuse=shape_xfuse)
+                                     block_neighbor_list, shape_xfuse=shape_xfuse, qkv_fp8=QKV_FP8 and D == 128)
 
 
 # ---- small helpers shared by the processors ---------------------------------------------------------

@@ -14,17 +14,23 @@
 // holds 4 - m (m = the row's deferred running max), so the accumulator IS log2(P) and the softmax costs one v_exp_f32,
 // one add and half a v_cvt_pk_fp8_f32 per score -- the kernel is VALU-bound, not MFMA-bound.  The running max moves
 // only when a row max grew by more than 2^4, so P <= 2^8 < 448 (e4m3 max) and keeps 2^-9 * 2^-4 relative resolution
-// below the row's reference; that rare move also shifts the scores already computed for the next tile.  l is summed
-// from the unrounded P (as the reference kernel does for its 2-byte P, rectified_hunyuan_attn.py:93-97); the V scale,
-// 1/l and R meet in the epilogue.
+// below the row's reference; that rare move also shifts the scores already computed for the next tile.  The row sum l
+// comes from the matrix pipe too: one v_mfma_f32_16x16x128_f8f6f4 per tile multiplies the SAME packed P operand by a
+// ones/zeros pattern (read from a 64-byte LDS table) chosen so that every lane's accumulator receives the full 64-key sum
+// of its own query row (tools/probes/fp8_rowsum_probe.hip).  So l sums the e4m3-ROUNDED P that the PV product uses --
+// numerator and denominator round together (the reference kernel sums its P before the 2-byte rounding,
+// rectified_hunyuan_attn.py:93-97; with 3 mantissa bits that mismatch would be a 2^-4 relative error on rows carried
+// by a few keys) -- and 32 v_add_f32 per tile leave the VALU.  The V scale, 1/l and R meet in the epilogue.
 //
 // Pipeline (per wave, 64-key tiles, S double-buffered): step t computes S(t+1) while P(t) and O += V(t) P(t) run.
 // Staging: K and V tiles are 8 KiB each; 4-slot rings; at the head of step t the wave issues its 2+2 LDS-DMA pieces of
-// K(t+3) and V(t+2) behind `s_waitcnt vmcnt(4)` + barrier, so every tile has two full steps to land.
+// K(t+3) and V(t+2) behind `s_waitcnt vmcnt(4)` + barrier, so every tile has two full steps to land.  (Issuing them
+// before the barrier wait -- legal with four slots -- measured the same: 9.71 vs 9.66 ms.)
 #include "rsa_attn.h"
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct Attn8Args {
     const uint8_t *q8, *k8, *v8t;  // [BH, S_pad, 128], [BH, S_pad, 128], [BH, S_pad/64, 128, 64]
@@ -62,7 +68,8 @@ __device__ __forceinline__ f32x16 mfma8s(i32x8 a, i32x8 b, f32x16 c, int sa, int
 template <int PIPE_OPT>
 __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    unsigned short* lds_list = reinterpret_cast<unsigned short*>(lds + 2 * NSLOT * TILE8);
+    unsigned char* lds_ones = lds + 2 * NSLOT * TILE8;  // 32 bytes of e4m3 1.0, then 32 bytes of 0
+    unsigned short* lds_list = reinterpret_cast<unsigned short*>(lds + 2 * NSLOT * TILE8 + 64);
 
     // ---------------- work mapping (as rsa_attn_kernel.hip) ----------------
     int bh, qblk;
@@ -124,10 +131,11 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     }
     n_items = __builtin_amdgcn_readfirstlane(n_items);
     const bool use_list = list != nullptr;
+    if (t < 16) reinterpret_cast<unsigned*>(lds_ones)[t] = t < 8 ? 0x38383838u : 0u;
     if (use_list) {
         for (int i = t; i < n_items; i += 256) lds_list[i] = (unsigned short)list[i];
-        __syncthreads();
     }
+    __syncthreads();
     auto blk_of = [&](int item) -> int { return use_list ? (int)lds_list[item] : first_blk + item; };
     int n_tiles = 2 * n_items;
     if (n_items > 0) {
@@ -185,7 +193,12 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) o[dt][i] = 0.0f;
-    float m_run = -INFINITY, l_run = 0.0f;
+    float m_run = -INFINITY;
+    f32x4 lacc = {0.0f, 0.0f, 0.0f, 0.0f};  // row sum of the rounded P (all four registers hold the lane's own row)
+    // A operand of the row-sum product: lane (row a = l & 15, k-block b = l >> 4) is all ones iff (b & 1) == ((a >> 2) & 1);
+    // B k-block b of column c is P of query row c + 16 (b & 1), lane half b >> 1, so C[a][c] = l(row c + 16 ((a >> 2) & 1))
+    // and the lane that owns C rows 4 (l >> 4) .. +3 of column l & 15 is exactly the lane of that query row.
+    const int ones_off = ((((lane >> 4) & 1) == ((lane >> 2) & 1)) ? 0 : 32);
     f32x16 mblk;  // P_OFFSET - m_eff in all 16 registers: the start value of every QK^T chain (m_eff = 0 while m_run = -inf)
 #pragma unroll
     for (int i = 0; i < 16; ++i) mblk[i] = P_OFFSET;
@@ -262,7 +275,8 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_eff);
             const float shift = m_eff - m_eff_old;
             m_run = m_new;
-            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lacc[i] *= alpha;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -279,24 +293,21 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
         if constexpr (PIPE_OPT & 2) __builtin_amdgcn_s_setprio(2);
         qk_tile((ts + 1) & (NSLOT - 1), S_nxt);
         i32x8 pb;
-        float ps = 0.0f;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int w4 = 0; w4 < 4; ++w4) {
                 float p4[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    p4[e] = __builtin_amdgcn_exp2f(S_cur[sub][4 * w4 + e]);
-                    ps += p4[e];
-                }
+                for (int e = 0; e < 4; ++e) p4[e] = __builtin_amdgcn_exp2f(S_cur[sub][4 * w4 + e]);
                 // the packed word is built in a score register that is dead by now (no zero-initialised temporary)
                 int word = __float_as_int(S_cur[0][4 * sub + w4]);
                 word = __builtin_amdgcn_cvt_pk_fp8_f32(p4[0], p4[1], word, false);
                 word = __builtin_amdgcn_cvt_pk_fp8_f32(p4[2], p4[3], word, true);
                 pb[4 * sub + w4] = word;
             }
-        l_run += ps;
+        lacc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ld32(lds_ones + ones_off, lds_ones + ones_off + 16), pb,
+                                                                lacc, 0, 0, 0, 0, 0, 0);
         const unsigned char* vt_ = lds + (NSLOT + ts) * TILE8;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
@@ -341,8 +352,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     }
 
     // ---------------- epilogue ----------------
-    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
-    const float l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    const float l_tot = lacc[0];
     if (!(store_r || zero_r)) return;
     float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
     float Rv = 1.0f;
@@ -389,7 +399,7 @@ int launch_attn8(Attn8Args& a, int BH, hipStream_t s) {
     if (nblocks <= 0) return RSA_OK;
     if (nblocks > 0x7FFFFFFF) return RSA_ERR_UNSUPPORTED;
     if (a.NB_total > 8192) return RSA_ERR_UNSUPPORTED;
-    const size_t lds_bytes = (size_t)2 * NSLOT * TILE8 + (((size_t)a.NB_total * 2 + 15) & ~(size_t)15);
+    const size_t lds_bytes = (size_t)2 * NSLOT * TILE8 + 64 + (((size_t)a.NB_total * 2 + 15) & ~(size_t)15);
     bsfwd_fp8_kernel<2><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a);
     return rsa_launch_status();
 }

@@ -111,3 +111,24 @@ def test_fp8_large_magnitudes_and_zero_tensor():
                                       qkv_fp8=True)
     assert float(p3["scales"][2, 0]) == 1.0
     assert torch.count_nonzero(o) == 0
+
+
+def test_fp8_switch_reaches_the_reference_shaped_operator():
+    """set_qkv_fp8(True) routes rectified_block_sparse_attention (and so the processors) through the fp8 K5."""
+    import rectified_spaattn_amd as rsa
+    from rectified_spaattn_amd import _core, synth
+    from rectified_spaattn_amd.rectified_wan21_attn import rectified_block_sparse_attention
+    lay = orc.layout_wan(6 * 128, 1)
+    q, k, v = synth.structured_qkv(31, 1, 2, lay.S, 128, smooth=0.0)
+    tq, tk, tv = (torch.from_numpy(x).to(DEV, torch.bfloat16) for x in (q, k, v))
+    nbr = torch.from_numpy(synth.banded_neighbors(lay.NBv, 1))
+    kw = dict(block_neighbor_list=nbr, p_remain_rates=0.3, first_frame_blocks=1)
+    o16 = rectified_block_sparse_attention(tq, tk, tv, None, 2, **kw)
+    old = rsa.set_qkv_fp8(True)
+    try:
+        o8 = rectified_block_sparse_attention(tq, tk, tv, None, 2, **kw)
+    finally:
+        rsa.set_qkv_fp8(old)
+    want = _core.rectified_attention(tq, tk, tv, _spec(lay), 2, 0.3, nbr, qkv_fp8=True)
+    assert torch.equal(o8, want) and not torch.equal(o8, o16)
+    assert torch.equal(rectified_block_sparse_attention(tq, tk, tv, None, 2, **kw), o16)
