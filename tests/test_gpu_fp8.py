@@ -132,3 +132,26 @@ def test_fp8_switch_reaches_the_reference_shaped_operator():
     want = _core.rectified_attention(tq, tk, tv, _spec(lay), 2, 0.3, nbr, qkv_fp8=True)
     assert torch.equal(o8, want) and not torch.equal(o8, o16)
     assert torch.equal(rectified_block_sparse_attention(tq, tk, tv, None, 2, **kw), o16)
+
+
+def test_fp8_batch_and_strided_views():
+    """B = 2 and q/k/v handed over as strided views of one packed [B, S, 3, H, D] projection (no copies)."""
+    from rectified_spaattn_amd import _core, synth
+    lay = orc.layout_flux(4 * 128 + 256, 256)
+    B, H, D = 2, 3, 128
+    q, k, v = synth.structured_qkv(2025, B, H, lay.S, D, smooth=0.0)
+    packed = torch.empty(B, lay.S, 3, H, D, dtype=torch.bfloat16, device=DEV)
+    for i, x in enumerate((q, k, v)):
+        packed[:, :, i] = torch.from_numpy(x).to(DEV, torch.bfloat16).permute(0, 2, 1, 3)
+    tq, tk, tv = (packed[:, :, i].permute(0, 2, 1, 3) for i in range(3))       # [B, H, S, D] views
+    assert not tq.is_contiguous()
+    out, parts = _core.rectified_attention(tq, tk, tv, _spec(lay), 2, 0.3, None, return_parts=True, qkv_fp8=True)
+    qf, kf, vf = (t.float().cpu().numpy() for t in (tq, tk, tv))
+    ref, sel, ops = orc.rectified_attention_fp8(qf, kf, vf, lay, 2, 0.3, None, want_parts=True)
+    assert np.array_equal(parts["scales"][:4].cpu().numpy(), ops["scales"])
+    assert np.array_equal(parts["k8"].cpu().numpy(), ops["k8"]) and np.array_equal(parts["v8t"].cpu().numpy(), ops["v8t"])
+    err = np.abs(out.float().cpu().numpy() - ref)
+    assert err.max() <= FP8_MAX_VS_FP8 and err.mean() <= FP8_MEAN_VS_FP8, f"{err.max():.3e} {err.mean():.3e}"
+    same = _core.rectified_attention(tq.contiguous(), tk.contiguous(), tv.contiguous(), _spec(lay), 2, 0.3, None,
+                                     qkv_fp8=True)
+    assert torch.equal(out, same)
