@@ -177,10 +177,10 @@ int rsa_qk_norm_rope(int B, int H, int S, int D, int dtype, rsa_tensor4 x, const
 /* e4m3 (OCP e4m3fn) images of one call's Q, K, V, written by rsa_quantize_fp8 and read by rsa_block_sparse_fwd_fp8. */
 typedef struct rsa_fp8_operands {
     uint8_t* q8;    /* [BH, NB_total*128, D]     rows >= S are zero                                            */
-    uint8_t* k8;    /* [BH, NB_total*128, D]     rows >= max(kv_valid, kv_text_valid) are zero                 */
+    uint8_t* k8;    /* [BH, NB_total*128, D]     rows >= pool_valid are zero (needs pool_valid >= kv_valid, kv_text_valid) */
     uint8_t* v8t;   /* [BH, NB_total*2, D, 64]   V^T per 64-key tile, keys in the MFMA k-slot order (rsa_fp8.hip) */
     float* scales;  /* [4, BH] dequantisation scales of q, k, v and c = scale_q*scale_k*sm_scale*log2(e) (a power of
-                     * two by construction, see rsa_fp8.hip), followed by 3*BH words of scratch                  */
+                     * two by construction, see rsa_fp8.hip), followed by (3 + 3*NB_total)*BH words of scratch   */
 } rsa_fp8_operands;
 
 /* Bytes of the four members (member order) and their 256-B-rounded sum.  D = 128 only. */
@@ -192,13 +192,21 @@ int rsa_carve_fp8_operands(const rsa_layout* lay, void* ws, size_t ws_bytes, rsa
 int rsa_quantize_fp8(const rsa_layout* lay, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
                      const rsa_fp8_operands* ops, void* stream);
 
+/* The same in two halves that fuse into the mask-selection pass: rsa_pool_stats_fp8 = K1 (rsa_pool_stats) with the
+ * |x| maxima as a side product of the rows it reads anyway, a small amax launch over the text-tail rows of Q and K,
+ * and the scales; rsa_fp8_images = the three images from those scales.  Bit-identical to rsa_quantize_fp8. */
+int rsa_pool_stats_fp8(const rsa_layout* lay, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v, const rsa_buffers* buf,
+                       const rsa_fp8_operands* ops, void* stream);
+int rsa_fp8_images(const rsa_layout* lay, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v, const rsa_fp8_operands* ops,
+                   void* stream);
+
 /* K5 on v_mfma_f32_32x32x64_f8f6f4: same lists, R, comp, text rows and output layout as rsa_block_sparse_fwd;
  * lay->dtype selects the OUTPUT element type. */
 int rsa_block_sparse_fwd_fp8(const rsa_layout* lay, const rsa_fp8_operands* ops, const rsa_buffers* buf,
                              rsa_out4 out, void* stream);
 
-/* The whole operator with fp8 K5: K1..K4 on the 2-byte inputs (the mask is the bf16 path's, bit for bit), then
- * rsa_quantize_fp8 and rsa_block_sparse_fwd_fp8. */
+/* The whole operator with fp8 K5: K1..K4 on the 2-byte inputs (the mask is the bf16 path's, bit for bit; K1 in its
+ * rsa_pool_stats_fp8 form), then rsa_fp8_images and rsa_block_sparse_fwd_fp8. */
 int rsa_rectified_attention_fp8(const rsa_layout* lay, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
                                 const uint8_t* neighbor, int top_k, float p_remain, void* workspace,
                                 size_t workspace_bytes, void* fp8_workspace, size_t fp8_workspace_bytes,

@@ -369,8 +369,8 @@ def fp8_operands(q, k, v, lay: Layout):
     q, k, v: [B, H, S, D] fp32 -> dict(scales [4, BH] (q, k, v, c), q8/k8 [BH, S_pad, D], v8t [BH, S_pad/64, D, 64])."""
     B, H, S, D = q.shape
     BH, SP = B * H, lay.NB_total * BLOCK
-    kv_lim = max(lay.kv_valid, lay.kv_text_valid)
-    valid = (S, kv_lim, kv_lim)
+    assert lay.pool_valid >= max(lay.kv_valid, lay.kv_text_valid)
+    valid = (S, lay.pool_valid, lay.pool_valid)  # the rows the pooling pass counts
     xs = [np.asarray(x, np.float32).reshape(BH, S, D) for x in (q, k, v)]
     scales = np.ones((4, BH), np.float32)
     qk_const = np.float32((1.0 / np.sqrt(float(D))) * 1.44269504)

@@ -164,7 +164,8 @@ def alloc_fp8_operands(spec: LayoutSpec, B: int, H: int, D: int, device) -> Dict
     return dict(q8=torch.empty((BH, SP, D), dtype=torch.uint8, device=device),
                 k8=torch.empty((BH, SP, D), dtype=torch.uint8, device=device),
                 v8t=torch.empty((BH, SP // 64, D, 64), dtype=torch.uint8, device=device),
-                scales=torch.empty((7, BH), dtype=torch.float32, device=device))  # rows 0..3 = scales q, k, v, c; 4..6 = scratch
+                scales=torch.empty((7 + 3 * spec.NB_total, BH), dtype=torch.float32, device=device))  # rows 0..3: scales
+    # of q, k, v and c; the rest is scratch (amax words, K1's per-block maxima)
 
 
 class StagedCall:
@@ -197,17 +198,23 @@ class StagedCall:
             self.fp8 = alloc_fp8_operands(spec, B, H, D, q.device)
             self.cf = RsaFp8Operands(*[self.fp8[n].data_ptr() for n in ("q8", "k8", "v8t", "scales")])
 
-    def quantize(self):
+    def quantize(self, standalone: bool = False):
+        """e4m3 images of Q, K, V.  After select() the scales are already there (K1 produced the maxima as a side
+        product); standalone=True runs the self-contained producer (own amax pass) instead."""
         tq, tk, tv = self.t
+        fn, name = ((self.L.rsa_quantize_fp8, "rsa_quantize_fp8") if standalone
+                    else (self.L.rsa_fp8_images, "rsa_fp8_images"))
         with torch.cuda.device(self.q.device):
-            _lib.check(self.L.rsa_quantize_fp8(ctypes.byref(self.lay), tq, tk, tv, ctypes.byref(self.cf), _stream()),
-                       "rsa_quantize_fp8")
+            _lib.check(fn(ctypes.byref(self.lay), tq, tk, tv, ctypes.byref(self.cf), _stream()), name)
 
     def select(self):
         L, lay, cb, st = self.L, ctypes.byref(self.lay), ctypes.byref(self.cb), _stream()
         tq, tk, tv = self.t
         with torch.cuda.device(self.q.device):
-            _lib.check(L.rsa_pool_stats(lay, tq, tk, tv, cb, st), "rsa_pool_stats")
+            if self.fp8 is not None:
+                _lib.check(L.rsa_pool_stats_fp8(lay, tq, tk, tv, cb, ctypes.byref(self.cf), st), "rsa_pool_stats_fp8")
+            else:
+                _lib.check(L.rsa_pool_stats(lay, tq, tk, tv, cb, st), "rsa_pool_stats")
             _lib.check(L.rsa_pooled_scores(lay, tk, cb, st), "rsa_pooled_scores")
             _lib.check(L.rsa_select_mask(lay, self.nbr.data_ptr() if self.nbr is not None else None, self.top_k,
                                          self.p, cb, st), "rsa_select_mask")

@@ -444,10 +444,10 @@ extern "C" int rsa_rectified_attention_fp8(const rsa_layout* l, rsa_tensor4 q, r
     int st = rsa_carve_workspace(l, workspace, workspace_bytes, &buf);
     if (st != RSA_OK) return st;
     if ((st = rsa_carve_fp8_operands(l, fp8_workspace, fp8_workspace_bytes, &ops))) return st;
-    if ((st = rsa_pool_stats(l, q, k, v, &buf, stream))) return st;
+    if ((st = rsa_pool_stats_fp8(l, q, k, v, &buf, &ops, stream))) return st;
     if ((st = rsa_pooled_scores(l, k, &buf, stream))) return st;
     if ((st = rsa_select_mask(l, neighbor, top_k, p_remain, &buf, stream))) return st;
     if ((st = rsa_compensation(l, &buf, stream))) return st;
-    if ((st = rsa_quantize_fp8(l, q, k, v, &ops, stream))) return st;
+    if ((st = rsa_fp8_images(l, q, k, v, &ops, stream))) return st;
     return rsa_block_sparse_fwd_fp8(l, &ops, &buf, out, stream);
 }

@@ -89,6 +89,11 @@ static inline int rsa_check_tensor(const rsa_tensor4& t) {
     return RSA_OK;
 }
 
+// K1 with an optional side product for the fp8 path: max |x| of every block it reads, amax_part[3][BH][NB_total]
+// (q blocks < NBv, k blocks < NBv with rows >= pool_valid as zero, v blocks < NB_total likewise).  rsa_stats.hip.
+int rsa_pool_stats_amax(const rsa_layout* l, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v, const rsa_buffers* buf,
+                        float* amax_part, void* stream);
+
 // last HIP error seen by a launch of this library (for rsa_last_hip_error); defined in rsa_stats.hip
 extern int g_rsa_last_hip_error;
 static inline int rsa_launch_status() {

@@ -1,6 +1,7 @@
 // FP8 operand producer for the fp8 K5 (rsa_attn_fp8_kernel.hip): per-(batch, head) absolute maxima of Q, K, V and
 // the e4m3 (OCP "e4m3fn", gfx950's native fp8) images the kernel stages:
-//      q8, k8 : [BH, NB_total*128, D]   row-major bytes, rows past the tensor's valid range are zero
+//      q8, k8 : [BH, NB_total*128, D]   row-major bytes, rows past the tensor's valid range (q: S, k and v: pool_valid,
+//               the rows the pooling pass counts) are zero
 //      v8t    : [BH, NB_total*2, D, 64] V transposed per 64-key tile; byte p = 32*h + j of a (tile, d) row holds the
 //               key the f8f6f4 MFMA's k-slot (lane half h, byte j) meets in the P operand built from two 32-key
 //               score accumulators:   key = 32*(j >> 4) + (j & 3) + 8*((j & 15) >> 2) + 4*h
@@ -20,6 +21,7 @@ struct QuantArgs {
     const unsigned short* src[3];
     long sb[3], sh[3], ss[3];
     int valid[3];        // rows >= valid[i] are zero in the image (and skipped by the amax)
+    int lo[3];           // first row the amax kernel reads (rows below were covered by K1's side product)
     unsigned* amax_bits; // [3, BH] fp32 bit patterns (non-negative floats order like unsigned ints)
     float* scales;       // [4, BH]
     float qk_const;      // sm_scale * log2(e)
@@ -32,7 +34,7 @@ __global__ __launch_bounds__(256) void amax_kernel(QuantArgs a) {
     const int which = blockIdx.z, bh = blockIdx.y;
     const int b = bh / a.H, h = bh % a.H;
     const unsigned short* base = a.src[which] + (long)b * a.sb[which] + (long)h * a.sh[which];
-    const int row0 = blockIdx.x * 1024;
+    const int row0 = a.lo[which] + blockIdx.x * 1024;
     const int row1 = min(row0 + 1024, a.valid[which]);
     const int t = threadIdx.x, c = t & 15;
     float m = 0.0f;
@@ -58,15 +60,22 @@ __global__ __launch_bounds__(256) void amax_kernel(QuantArgs a) {
     if ((t & 63) == 0 && m > 0.0f) atomicMax(a.amax_bits + which * a.BH + bh, __float_as_uint(m));
 }
 
-__global__ void scales_kernel(const unsigned* amax_bits, float* scales, int BH, float qk_const) {
-    const int bh = blockIdx.x * blockDim.x + threadIdx.x;
-    if (bh >= BH) return;
+// one wave per (b,h): amax = max(atomic word, per-block maxima written by K1) -> scales
+__global__ __launch_bounds__(64) void scales_kernel(const unsigned* amax_bits, const float* amax_part, int NB_total,
+                                                    int nb_q, int nb_k, int nb_v, float* scales, int BH,
+                                                    float qk_const) {
+    const int bh = blockIdx.x, lane = threadIdx.x;
     float sc[3];
+    const int nb[3] = {nb_q, nb_k, nb_v};
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const float m = __uint_as_float(amax_bits[i * BH + bh]);
+        float m = __uint_as_float(amax_bits[i * BH + bh]);
+        if (amax_part != nullptr)
+            for (int j = lane; j < nb[i]; j += 64) m = fmaxf(m, amax_part[((long)i * BH + bh) * NB_total + j]);
+        for (int s = 1; s < 64; s <<= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
         sc[i] = m > 0.0f ? m / E4M3_MAX : 1.0f;
     }
+    if (lane != 0) return;
     const float skc = sc[1] * qk_const;
     const float c0 = sc[0] * skc;
     int e;
@@ -187,7 +196,8 @@ extern "C" int rsa_fp8_operand_bytes(const rsa_layout* l, size_t sizes[4], size_
     if (!sizes || !total) return RSA_ERR_BAD_ARG;
     if (l->D != 128) return RSA_ERR_UNSUPPORTED;
     const size_t BH = (size_t)l->B * l->H, SP = (size_t)l->NB_total * RSA_BLOCK, D = l->D;
-    const size_t s[4] = {BH * SP * D, BH * SP * D, BH * SP * D, (4 + 3) * BH * 4};  // scales + amax bit patterns
+    const size_t s[4] = {BH * SP * D, BH * SP * D, BH * SP * D,
+                         (4 + 3 + 3 * (size_t)l->NB_total) * BH * 4};  // scales, amax words, per-block maxima
     size_t tot = 0;
     for (int i = 0; i < 4; ++i) { sizes[i] = s[i]; tot += align256(s[i]); }
     *total = tot;
@@ -208,39 +218,94 @@ extern "C" int rsa_carve_fp8_operands(const rsa_layout* l, void* ws, size_t ws_b
     return RSA_OK;
 }
 
-extern "C" int rsa_quantize_fp8(const rsa_layout* l, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
-                                const rsa_fp8_operands* ops, void* stream) {
+namespace {
+
+int fill_args(const rsa_layout* l, const rsa_tensor4& q, const rsa_tensor4& k, const rsa_tensor4& v,
+              const rsa_fp8_operands* ops, QuantArgs& a) {
     int st = rsa_check_layout(l);
     if (st != RSA_OK) return st;
     if (l->D != 128) return RSA_ERR_UNSUPPORTED;
     if (!ops || !ops->q8 || !ops->k8 || !ops->v8t || !ops->scales) return RSA_ERR_BAD_ARG;
     if ((st = rsa_check_tensor(q)) || (st = rsa_check_tensor(k)) || (st = rsa_check_tensor(v))) return st;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    QuantArgs a;
+    // every key K5 may read unmasked must be a row the images hold
+    if (l->pool_valid < l->kv_valid || l->pool_valid < l->kv_text_valid) return RSA_ERR_BAD_ARG;
     const rsa_tensor4* ts[3] = {&q, &k, &v};
     for (int i = 0; i < 3; ++i) {
         a.src[i] = static_cast<const unsigned short*>(ts[i]->ptr);
         a.sb[i] = ts[i]->stride_b; a.sh[i] = ts[i]->stride_h; a.ss[i] = ts[i]->stride_s;
+        a.lo[i] = 0;
     }
-    const int kv_lim = l->kv_valid > l->kv_text_valid ? l->kv_valid : l->kv_text_valid;
-    a.valid[0] = l->S; a.valid[1] = kv_lim; a.valid[2] = kv_lim;
+    a.valid[0] = l->S; a.valid[1] = l->pool_valid; a.valid[2] = l->pool_valid;
     a.H = l->H; a.BH = l->B * l->H; a.S_pad = l->NB_total * RSA_BLOCK;
     a.scales = ops->scales;
     a.amax_bits = reinterpret_cast<unsigned*>(ops->scales + 4 * a.BH);
     a.qk_const = (float)((1.0 / sqrt((double)l->D)) * 1.44269504);
     a.q8 = ops->q8; a.k8 = ops->k8; a.v8t = ops->v8t;
-    if (hipMemsetAsync(a.amax_bits, 0, (size_t)3 * a.BH * 4, s) != hipSuccess) return rsa_launch_status();
-    const dim3 g_amax((a.S_pad + 1023) / 1024, a.BH, 3), g_rows(a.S_pad / 64, a.BH, 2), g_vt(a.S_pad / 64, a.BH);
-    if (l->dtype == RSA_BF16) {
-        amax_kernel<bf16_tag><<<g_amax, 256, 0, s>>>(a);
-        scales_kernel<<<(a.BH + 255) / 256, 256, 0, s>>>(a.amax_bits, a.scales, a.BH, a.qk_const);
+    return RSA_OK;
+}
+
+void launch_amax(const QuantArgs& a, int dtype, int ntensors, hipStream_t s) {
+    int rows = 0;
+    for (int i = 0; i < ntensors; ++i) rows = a.valid[i] - a.lo[i] > rows ? a.valid[i] - a.lo[i] : rows;
+    if (rows <= 0) return;
+    const dim3 g((rows + 1023) / 1024, a.BH, ntensors);
+    if (dtype == RSA_BF16) amax_kernel<bf16_tag><<<g, 256, 0, s>>>(a);
+    else amax_kernel<fp16_tag><<<g, 256, 0, s>>>(a);
+}
+
+int launch_images(const QuantArgs& a, int dtype, hipStream_t s) {
+    const dim3 g_rows(a.S_pad / 64, a.BH, 2), g_vt(a.S_pad / 64, a.BH);
+    if (dtype == RSA_BF16) {
         quant_rows_kernel<128, bf16_tag><<<g_rows, 256, 0, s>>>(a);
         quant_vt_kernel<128, bf16_tag><<<g_vt, 256, 0, s>>>(a);
     } else {
-        amax_kernel<fp16_tag><<<g_amax, 256, 0, s>>>(a);
-        scales_kernel<<<(a.BH + 255) / 256, 256, 0, s>>>(a.amax_bits, a.scales, a.BH, a.qk_const);
         quant_rows_kernel<128, fp16_tag><<<g_rows, 256, 0, s>>>(a);
         quant_vt_kernel<128, fp16_tag><<<g_vt, 256, 0, s>>>(a);
     }
     return rsa_launch_status();
+}
+
+}  // namespace
+
+// stand-alone producer: amax pass + scales + images
+extern "C" int rsa_quantize_fp8(const rsa_layout* l, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
+                                const rsa_fp8_operands* ops, void* stream) {
+    QuantArgs a;
+    int st = fill_args(l, q, k, v, ops, a);
+    if (st != RSA_OK) return st;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(a.amax_bits, 0, (size_t)3 * a.BH * 4, s) != hipSuccess) return rsa_launch_status();
+    launch_amax(a, l->dtype, 3, s);
+    scales_kernel<<<a.BH, 64, 0, s>>>(a.amax_bits, nullptr, 0, 0, 0, 0, a.scales, a.BH, a.qk_const);
+    return launch_images(a, l->dtype, s);
+}
+
+// K1 (pool statistics) with the |x| maxima folded in: K1 already reads every Q (visual), K (visual) and V row, so
+// only the text-tail rows of Q and K need a (tiny) extra amax launch; then the scales.  Same scales, bit for bit, as
+// the stand-alone pass (a max does not depend on the order).
+extern "C" int rsa_pool_stats_fp8(const rsa_layout* l, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
+                                  const rsa_buffers* buf, const rsa_fp8_operands* ops, void* stream) {
+    QuantArgs a;
+    int st = fill_args(l, q, k, v, ops, a);
+    if (st != RSA_OK) return st;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(a.amax_bits, 0, (size_t)3 * a.BH * 4, s) != hipSuccess) return rsa_launch_status();
+    float* amax_part = reinterpret_cast<float*>(a.amax_bits + 3 * a.BH);
+    if ((st = rsa_pool_stats_amax(l, q, k, v, buf, amax_part, stream))) return st;
+    const int vis_tok = l->NBv * RSA_BLOCK;
+    a.lo[0] = vis_tok < l->S ? vis_tok : l->S;                    // q rows K1 did not read
+    a.lo[1] = vis_tok < l->pool_valid ? vis_tok : l->pool_valid;  // k rows K1 did not read
+    launch_amax(a, l->dtype, 2, s);
+    scales_kernel<<<a.BH, 64, 0, s>>>(a.amax_bits, amax_part, l->NB_total, l->NBv, l->NBv, l->NB_total, a.scales, a.BH,
+                                      a.qk_const);
+    return rsa_launch_status();
+}
+
+// the three e4m3 images from scales that are already in ops->scales (after rsa_pool_stats_fp8)
+extern "C" int rsa_fp8_images(const rsa_layout* l, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
+                              const rsa_fp8_operands* ops, void* stream) {
+    QuantArgs a;
+    int st = fill_args(l, q, k, v, ops, a);
+    if (st != RSA_OK) return st;
+    return launch_images(a, l->dtype, static_cast<hipStream_t>(stream));
 }

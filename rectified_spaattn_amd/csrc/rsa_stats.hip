@@ -19,6 +19,8 @@ struct PoolArgs {
     int nblk[3];     // blocks to produce per tensor
     int valid[3];    // rows >= valid are zero
     int H;
+    float* amax_part;  // optional [3, BH, NB_total]: max |x| of each block this launch reads (fp8 scales); plain stores
+    int BH, NB_total;
 };
 
 template <int D, typename Tag>
@@ -50,6 +52,17 @@ __global__ __launch_bounds__(D * 2) void pool_stats_kernel(PoolArgs a) {
             x[i][2 * e + 1] = rsa_to_f32<Tag>((unsigned short)(w[e] >> 16));
         }
     }
+    __shared__ float amx[NW];
+    if (a.amax_part != nullptr) {  // side product for the fp8 path: the block is in registers anyway
+        float m = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(x[i][e]));
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) m = fmaxf(m, __shfl_xor(m, sft, 64));
+        if ((t & 63) == 0) amx[t >> 6] = m;  // combined after the first barrier below
+    }
     __shared__ float red[NW][D];
     float mean[8];
     // ---- sum -> mean
@@ -70,6 +83,12 @@ __global__ __launch_bounds__(D * 2) void pool_stats_kernel(PoolArgs a) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) red[t >> 6][c * 8 + e] = s[e];
         __syncthreads();
+        if (a.amax_part != nullptr && t == 0) {
+            float m = amx[0];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) m = fmaxf(m, amx[w]);
+            a.amax_part[((long)which * a.BH + bh) * a.NB_total + blk] = m;
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float tot;
@@ -582,8 +601,9 @@ extern "C" int rsa_carve_workspace(const rsa_layout* l, void* ws, size_t ws_byte
     return RSA_OK;
 }
 
-extern "C" int rsa_pool_stats(const rsa_layout* l, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
-                              const rsa_buffers* buf, void* stream) {
+// K1 with the optional |x| maxima (rsa_common.h); rsa_pool_stats is the amax-less public form
+int rsa_pool_stats_amax(const rsa_layout* l, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v, const rsa_buffers* buf,
+                        float* amax_part, void* stream) {
     int st = rsa_check_layout(l);
     if (st != RSA_OK) return st;
     if (!buf || !buf->qbar || !buf->aq || !buf->kbar || !buf->ak || !buf->vbar) return RSA_ERR_BAD_ARG;
@@ -601,6 +621,7 @@ extern "C" int rsa_pool_stats(const rsa_layout* l, rsa_tensor4 q, rsa_tensor4 k,
     a.valid[1] = l->pool_valid < vis_tok ? l->pool_valid : vis_tok;
     a.mean[2] = buf->vbar; a.mad[2] = nullptr; a.nblk[2] = l->NB_total; a.valid[2] = l->pool_valid;
     a.H = l->H;
+    a.amax_part = amax_part; a.BH = l->B * l->H; a.NB_total = l->NB_total;
     dim3 grid(l->NB_total, l->B * l->H, 3);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (l->D == 128) {
@@ -611,6 +632,11 @@ extern "C" int rsa_pool_stats(const rsa_layout* l, rsa_tensor4 q, rsa_tensor4 k,
         else pool_stats_kernel<64, fp16_tag><<<grid, 128, 0, s>>>(a);
     }
     return rsa_launch_status();
+}
+
+extern "C" int rsa_pool_stats(const rsa_layout* l, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
+                              const rsa_buffers* buf, void* stream) {
+    return rsa_pool_stats_amax(l, q, k, v, buf, nullptr, stream);
 }
 
 extern "C" int rsa_pooled_scores(const rsa_layout* l, rsa_tensor4 k, const rsa_buffers* buf, void* stream) {
@@ -705,6 +731,7 @@ extern "C" int rsa_estimate_pr_gain(int BH, int NQ, int NK, int D, int dtype, co
     hipStream_t s = static_cast<hipStream_t>(stream);
     for (int which = 0; which < 2; ++which) {
         PoolArgs a;
+        a.amax_part = nullptr; a.BH = BH; a.NB_total = 0;
         const int N = which == 0 ? NQ : NK;
         float* scratch = which == 0 ? scratch_aq : scratch_ak;
         for (int i = 0; i < 3; ++i) {

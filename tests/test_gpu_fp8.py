@@ -155,3 +155,27 @@ def test_fp8_batch_and_strided_views():
     same = _core.rectified_attention(tq.contiguous(), tk.contiguous(), tv.contiguous(), _spec(lay), 2, 0.3, None,
                                      qkv_fp8=True)
     assert torch.equal(out, same)
+
+
+@pytest.mark.parametrize("mk", [lambda: orc.layout_hunyuan(4 * 128 + 256, 4 * 128 + 77), lambda: orc.layout_wan(300, 0),
+                                lambda: orc.layout_flux(3 * 128 + 128, 128)], ids=["hunyuan", "wan", "flux"])
+def test_fp8_fused_amax_equals_standalone_producer(mk):
+    """rsa_pool_stats_fp8 (maxima as K1's side product + text-tail rows) + rsa_fp8_images == rsa_quantize_fp8."""
+    from rectified_spaattn_amd import _core, synth
+    lay = mk()
+    q, k, v = synth.structured_qkv(808, 1, 2, lay.S, 128, smooth=0.0)
+    q[0, 1, lay.S - 1, 5] = 37.0          # the largest |q| sits in the last row (text tail / ragged end)
+    k[0, 0, min(lay.NBv * 128, lay.S) - 1, 9] = -41.0
+    tq, tk, tv = (torch.from_numpy(x).to(DEV, torch.bfloat16) for x in (q, k, v))
+    call = _core.StagedCall(tq, tk, tv, _spec(lay), 2, 0.3, None, qkv_fp8=True)
+    call.select()
+    call.quantize()
+    fused = {n: t.clone() for n, t in call.fp8.items()}
+    for t in call.fp8.values():
+        t.zero_()
+    call.quantize(standalone=True)
+    for n in ("q8", "k8", "v8t"):
+        assert torch.equal(fused[n], call.fp8[n]), n
+    assert torch.equal(fused["scales"][:4], call.fp8["scales"][:4])
+    ops = orc.fp8_operands(*(t.float().cpu().numpy() for t in (tq, tk, tv)), lay)
+    assert np.array_equal(fused["scales"][:4].cpu().numpy(), ops["scales"])
