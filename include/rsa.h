@@ -212,6 +212,12 @@ int rsa_rectified_attention_fp8(const rsa_layout* lay, rsa_tensor4 q, rsa_tensor
                                 size_t workspace_bytes, void* fp8_workspace, size_t fp8_workspace_bytes,
                                 rsa_out4 out, void* stream);
 
+/* rsa_dense_fwd with e4m3 operands (per-(b,h) scales computed inside): quantisation pass + the fp8 kernel in dense
+ * mode.  workspace: >= *total of rsa_dense_fp8_bytes, 256-B aligned.  D = 128 only. */
+int rsa_dense_fp8_bytes(int B, int H, int Sq, int Sk, int D, size_t* total);
+int rsa_dense_fwd_fp8(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
+                      int q_split, int kv_split, void* workspace, size_t workspace_bytes, rsa_out4 out, void* stream);
+
 /* Tuning / diagnostics hook, not part of the data path.  Keys: "k5_prio" (0/1: issue-priority raise inside K5's pipelined block). */
 int rsa_set_tuning(const char* key, int value);
 

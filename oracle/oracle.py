@@ -364,6 +364,45 @@ def fp8_kslot_key(p: np.ndarray) -> np.ndarray:
     return 32 * (j >> 4) + (j & 3) + 8 * ((j & 15) >> 2) + 4 * h
 
 
+def _fp8_scales(amax3, D: int):
+    """(scale_q, scale_k, scale_v, c) from the three maxima -- the arithmetic of rsa_fp8.hip::scales_kernel."""
+    qk_const = np.float32((1.0 / np.sqrt(float(D))) * 1.44269504)
+    sc = [np.float32(a / E4M3_MAX) if a > 0 else np.float32(1.0) for a in amax3]
+    # c = scale_q * scale_k * sm_scale * log2(e) rounded UP to a power of two by stretching scale_q
+    skc = np.float32(sc[1] * qk_const)
+    c0 = np.float32(sc[0] * skc)
+    mant, e = np.frexp(c0)
+    e = int(e) - (1 if mant == np.float32(0.5) else 0)
+    e = max(-120, min(120, e))
+    c = np.float32(np.ldexp(np.float32(1.0), e))
+    return np.float32(c / skc), sc[1], sc[2], c
+
+
+def _fp8_images(xs, valid, pads, D):
+    """xs: three [BH, S_i, D] fp32 arrays -> scales [4, BH], images [BH, pads[i], D] (rows >= valid[i] zero)."""
+    BH = xs[0].shape[0]
+    scales = np.ones((4, BH), np.float32)
+    for bh in range(BH):
+        amax = []
+        for i in range(3):
+            xv = xs[i][bh, : valid[i]]
+            amax.append(np.float32(np.max(np.abs(xv))) if xv.size else np.float32(0))
+        scales[:, bh] = _fp8_scales(amax, D)
+    imgs = []
+    for i in range(3):
+        img = np.zeros((BH, pads[i], D), np.uint8)
+        for bh in range(BH):
+            img[bh, : valid[i]] = quantize_e4m3((xs[i][bh, : valid[i]] / scales[i, bh]).astype(np.float32))
+        imgs.append(img)
+    return scales, imgs
+
+
+def _v8t_from_image(v8):
+    BH, SP, D = v8.shape
+    v8 = v8.reshape(BH, SP // 64, 64, D)
+    return np.ascontiguousarray(v8[:, :, fp8_kslot_key(np.arange(64)), :].transpose(0, 1, 3, 2))
+
+
 def fp8_operands(q, k, v, lay: Layout):
     """Per-(b,h) scales and e4m3 images exactly as rsa_quantize_fp8 writes them.
     q, k, v: [B, H, S, D] fp32 -> dict(scales [4, BH] (q, k, v, c), q8/k8 [BH, S_pad, D], v8t [BH, S_pad/64, D, 64])."""
@@ -372,31 +411,30 @@ def fp8_operands(q, k, v, lay: Layout):
     assert lay.pool_valid >= max(lay.kv_valid, lay.kv_text_valid)
     valid = (S, lay.pool_valid, lay.pool_valid)  # the rows the pooling pass counts
     xs = [np.asarray(x, np.float32).reshape(BH, S, D) for x in (q, k, v)]
-    scales = np.ones((4, BH), np.float32)
-    qk_const = np.float32((1.0 / np.sqrt(float(D))) * 1.44269504)
-    for bh in range(BH):
-        sc = []
-        for i in range(3):
-            xv = xs[i][bh, : valid[i]]
-            amax = np.float32(np.max(np.abs(xv))) if xv.size else np.float32(0)
-            sc.append(np.float32(amax / E4M3_MAX) if amax > 0 else np.float32(1.0))
-        # c = scale_q * scale_k * sm_scale * log2(e) rounded UP to a power of two by stretching scale_q (rsa_fp8.hip)
-        skc = np.float32(sc[1] * qk_const)
-        c0 = np.float32(sc[0] * skc)
-        mant, e = np.frexp(c0)
-        e = int(e) - (1 if mant == np.float32(0.5) else 0)
-        e = max(-120, min(120, e))
-        c = np.float32(np.ldexp(np.float32(1.0), e))
-        scales[:, bh] = (np.float32(c / skc), sc[1], sc[2], c)
-    imgs = []
-    for i in range(3):
-        img = np.zeros((BH, SP, D), np.uint8)
-        for bh in range(BH):
-            img[bh, : valid[i]] = quantize_e4m3((xs[i][bh, : valid[i]] / scales[i, bh]).astype(np.float32))
-        imgs.append(img)
-    v8 = imgs[2].reshape(BH, SP // 64, 64, D)
-    v8t = np.ascontiguousarray(v8[:, :, fp8_kslot_key(np.arange(64)), :].transpose(0, 1, 3, 2))
-    return dict(scales=scales, q8=imgs[0], k8=imgs[1], v8t=v8t)
+    scales, imgs = _fp8_images(xs, valid, (SP, SP, SP), D)
+    return dict(scales=scales, q8=imgs[0], k8=imgs[1], v8t=_v8t_from_image(imgs[2]))
+
+
+def dense_attention_fp8(q, k, v, q_split: Optional[int] = None, kv_split: Optional[int] = None):
+    """Dense attention of ONE head on e4m3 operands as rsa_dense_fwd_fp8 quantises them (per-head scales over all Sq /
+    Sk rows), two-segment semantics of attn.py:107-120.  q [Sq, D], k/v [Sk, D] fp32 -> [Sq, D]."""
+    Sq, D = q.shape
+    Sk = k.shape[0]
+    pad = lambda n: (n + BLOCK - 1) // BLOCK * BLOCK
+    scales, imgs = _fp8_images([q[None], k[None], v[None]], (Sq, Sk, Sk), (pad(Sq), pad(Sk), pad(Sk)), D)
+    qd = dequantize_e4m3(imgs[0][0, :Sq]) * scales[0, 0]
+    kd = dequantize_e4m3(imgs[1][0, :Sk]) * scales[1, 0]
+    vd = dequantize_e4m3(imgs[2][0, :Sk]) * scales[2, 0]
+    q_split = Sq if q_split is None else q_split
+    kv_split = Sk if kv_split is None else kv_split
+    out = np.zeros((Sq, D), np.float64)
+    sm = float(D) ** -0.5
+    cols = np.arange(Sk)
+    if q_split > 0:
+        out[:q_split] = _masked_attention_rows(qd[:q_split], kd, vd, cols < kv_split, sm)
+    if q_split < Sq:
+        out[q_split:] = _masked_attention_rows(qd[q_split:], kd, vd, cols >= kv_split, sm)
+    return out
 
 
 def fp8_dequantized_qkv(q, k, v, lay: Layout):

@@ -19,3 +19,10 @@ def set_qkv_fp8(enabled: bool) -> bool:
     head_dim 128); returns the previous setting.  Default off = the reference's input-dtype behaviour."""
     from . import _operator
     return _operator.set_qkv_fp8(enabled)
+
+
+def set_dense_fp8(enabled: bool) -> bool:
+    """Run fullattn's device path (dense attention, head_dim 128) on e4m3 images of Q, K, V; returns the previous
+    setting.  Default off."""
+    from . import _operator
+    return _operator.set_dense_fp8(enabled)

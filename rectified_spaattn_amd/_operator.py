@@ -41,6 +41,17 @@ def set_qkv_fp8(enabled: bool) -> bool:
     return old
 
 
+# Same switch for the dense kernel behind fullattn(mode="flash" | device "torch"/"vanilla") -- separate because the dense
+# (warm-up) steps are the ones a pipeline keeps exact on purpose.
+DENSE_FP8 = False
+
+
+def set_dense_fp8(enabled: bool) -> bool:
+    global DENSE_FP8
+    old, DENSE_FP8 = DENSE_FP8, bool(enabled)
+    return old
+
+
 def run(variant: str, query, key, value, top_k, prob_threshold, block_neighbor_list, shape_xfuse,
         cu_seqlens_q=None, cu_seqlens_kv=None, text_length: int = 256, first_frame_blocks=None,
         block_size_M: int = 128, block_size_N: int = 128):

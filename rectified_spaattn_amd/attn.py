@@ -13,7 +13,7 @@ import math
 import torch
 import torch.nn.functional as F
 
-from . import _core
+from . import _core, _operator
 from ._lib import RsaError
 
 # pre/post layout adapters kept for API parity (attn.py:18-31).  "flash" packs [b,a,s,d] -> [(b s), a, d].
@@ -62,9 +62,10 @@ def _to_list(x):
 def _device_dense(q, k, v, splits):
     """q [b,a,s,d], k/v [b,a,s1,d]; splits: per batch item (q_split, kv_split).  Returns [b,a,s,d] view."""
     B = q.shape[0]
+    fp8 = _operator.DENSE_FP8 and q.shape[-1] == 128  # set_dense_fp8(): e4m3 operands on the fp8 MFMA
     if len(set(splits)) == 1:
-        return _core.dense_attention(q, k, v, splits[0][0], splits[0][1]).transpose(1, 2)
-    outs = [_core.dense_attention(q[i:i + 1], k[i:i + 1], v[i:i + 1], *splits[i]) for i in range(B)]
+        return _core.dense_attention(q, k, v, splits[0][0], splits[0][1], qkv_fp8=fp8).transpose(1, 2)
+    outs = [_core.dense_attention(q[i:i + 1], k[i:i + 1], v[i:i + 1], *splits[i], qkv_fp8=fp8) for i in range(B)]
     return torch.cat(outs, 0).transpose(1, 2)
 
 

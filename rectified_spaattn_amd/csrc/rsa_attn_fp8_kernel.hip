@@ -41,7 +41,7 @@ struct Attn8Args {
     const int32_t* counts;
     const float* R;
     const float* comp;
-    int mode, H, Sq, Sk, S_pad;
+    int mode, H, Sq, Sk, Sq_pad, Sk_pad;  // padded rows of q8 and of k8 / v8t
     int NBv, NQB, NB_total;
     int kv_valid, kv_text_valid, q_text_end;
     int q_split, kv_split;
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     const float s_v = a.scales[2 * a.BH + bh];
     i32x8 qf[2];
     {
-        const uint8_t* qp = a.q8 + ((long)bh * a.S_pad + grow) * D8 + 32 * hh;  // rows < S_pad always exist (zero-padded)
+        const uint8_t* qp = a.q8 + ((long)bh * a.Sq_pad + grow) * D8 + 32 * hh;  // rows < Sq_pad always exist (zero-padded)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const i32x4 lo = *reinterpret_cast<const i32x4*>(qp + 64 * ks);
@@ -169,8 +169,8 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     // K tile [64 keys][128 B]: 1-KiB piece pc = rows 8pc..8pc+7; wave w moves pieces w and w+4 (same swizzle phase).
     // V tile [128 d][64 B]:    1-KiB piece pc = rows 16pc..16pc+15; wave w moves pieces w and w+4.
     // The LDS image is lane-linear, so the bank swizzle is applied to the SOURCE chunk.
-    const unsigned char* kbase = a.k8 + (long)bh * a.S_pad * D8;
-    const unsigned char* vbase = a.v8t + (long)bh * a.S_pad * D8;  // S_pad/64 tiles x 8192 bytes
+    const unsigned char* kbase = a.k8 + (long)bh * a.Sk_pad * D8;
+    const unsigned char* vbase = a.v8t + (long)bh * a.Sk_pad * D8;  // Sk_pad/64 tiles x 8192 bytes
     const unsigned voffk = (unsigned)((lane >> 3) * 128 + (((lane & 7) ^ (4 * (wv & 1) + (lane >> 4))) << 4));
     const unsigned voffv = (unsigned)((lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4));
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
@@ -425,7 +425,8 @@ extern "C" int rsa_block_sparse_fwd_fp8(const rsa_layout* l, const rsa_fp8_opera
     a.q8 = ops->q8; a.k8 = ops->k8; a.v8t = ops->v8t; a.scales = ops->scales;
     a.out = static_cast<unsigned short*>(out.ptr); a.osb = out.stride_b; a.osh = out.stride_h; a.oss = out.stride_s;
     a.cols = buf->cols; a.counts = buf->counts; a.R = buf->R; a.comp = buf->comp;
-    a.mode = MODE_SPARSE; a.H = l->H; a.Sq = l->S; a.Sk = l->S; a.S_pad = l->NB_total * RSA_BLOCK;
+    a.mode = MODE_SPARSE; a.H = l->H; a.Sq = l->S; a.Sk = l->S;
+    a.Sq_pad = a.Sk_pad = l->NB_total * RSA_BLOCK;
     a.NBv = l->NBv; a.NQB = l->NB_total; a.NB_total = l->NB_total;
     a.kv_valid = l->kv_valid; a.kv_text_valid = l->kv_text_valid;
     a.q_text_end = l->NBv * RSA_BLOCK + l->q_text_valid;
@@ -450,4 +451,34 @@ extern "C" int rsa_rectified_attention_fp8(const rsa_layout* l, rsa_tensor4 q, r
     if ((st = rsa_compensation(l, &buf, stream))) return st;
     if ((st = rsa_fp8_images(l, q, k, v, &ops, stream))) return st;
     return rsa_block_sparse_fwd_fp8(l, &ops, &buf, out, stream);
+}
+
+// Dense attention (two-segment varlen semantics of rsa_dense_fwd) with fp8 operands: quantise, then the same kernel in
+// its dense mode.  Workspace: rsa_dense_fp8_bytes.
+extern "C" int rsa_dense_fwd_fp8(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k,
+                                 rsa_tensor4 v, int q_split, int kv_split, void* workspace, size_t workspace_bytes,
+                                 rsa_out4 out, void* stream) {
+    if (B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0) return RSA_ERR_BAD_ARG;
+    if (D != 128) return RSA_ERR_UNSUPPORTED;
+    if (dtype != RSA_BF16 && dtype != RSA_FP16) return RSA_ERR_UNSUPPORTED;
+    if (q_split < 0 || q_split > Sq || kv_split < 0 || kv_split > Sk) return RSA_ERR_BAD_ARG;
+    int st;
+    if ((st = rsa_check_tensor(q)) || (st = rsa_check_tensor(k)) || (st = rsa_check_tensor(v)) ||
+        (st = check_out8(out)))
+        return st;
+    rsa_fp8_operands ops;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if ((st = rsa_dense_quantize_fp8(B, H, Sq, Sk, D, dtype, q, k, v, workspace, workspace_bytes, &ops, s))) return st;
+    Attn8Args a;
+    a.q8 = ops.q8; a.k8 = ops.k8; a.v8t = ops.v8t; a.scales = ops.scales;
+    a.out = static_cast<unsigned short*>(out.ptr); a.osb = out.stride_b; a.osh = out.stride_h; a.oss = out.stride_s;
+    a.cols = nullptr; a.counts = nullptr; a.R = nullptr; a.comp = nullptr;
+    a.mode = MODE_DENSE; a.H = H; a.Sq = Sq; a.Sk = Sk;
+    a.NQB = (Sq + RSA_BLOCK - 1) / RSA_BLOCK; a.NBv = a.NQB; a.NB_total = (Sk + RSA_BLOCK - 1) / RSA_BLOCK;
+    a.Sq_pad = a.NQB * RSA_BLOCK; a.Sk_pad = a.NB_total * RSA_BLOCK;
+    a.kv_valid = Sk; a.kv_text_valid = Sk; a.q_text_end = 0;
+    a.q_split = q_split; a.kv_split = kv_split;
+    a.sm_scale_log2e = (float)((1.0 / sqrt((double)D)) * 1.44269504);
+    a.out_fp16 = dtype == RSA_FP16;
+    return launch_attn8(a, B * H, s);
 }

@@ -94,6 +94,10 @@ static inline int rsa_check_tensor(const rsa_tensor4& t) {
 int rsa_pool_stats_amax(const rsa_layout* l, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v, const rsa_buffers* buf,
                         float* amax_part, void* stream);
 
+// e4m3 images for the dense fp8 kernel, carved out of `ws` (rsa_fp8.hip)
+int rsa_dense_quantize_fp8(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
+                           void* ws, size_t ws_bytes, rsa_fp8_operands* ops, hipStream_t s);
+
 // last HIP error seen by a launch of this library (for rsa_last_hip_error); defined in rsa_stats.hip
 extern int g_rsa_last_hip_error;
 static inline int rsa_launch_status() {

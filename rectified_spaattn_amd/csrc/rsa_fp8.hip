@@ -26,7 +26,8 @@ struct QuantArgs {
     float* scales;       // [4, BH]
     float qk_const;      // sm_scale * log2(e)
     uint8_t *q8, *k8, *v8t;
-    int H, BH, S_pad;    // S_pad = NB_total * 128
+    int H, BH;
+    int S_pad[3];        // padded rows of each image (multiple of 128)
 };
 
 template <typename Tag>
@@ -119,7 +120,8 @@ __global__ __launch_bounds__(256) void quant_rows_kernel(QuantArgs a) {
     const int which = blockIdx.z, bh = blockIdx.y;
     const int b = bh / a.H, h = bh % a.H;
     const float scale = a.scales[which * a.BH + bh];
-    uint8_t* dst = (which == 0 ? a.q8 : a.k8) + (long)bh * a.S_pad * D;
+    if (blockIdx.x * 64 >= a.S_pad[which]) return;
+    uint8_t* dst = (which == 0 ? a.q8 : a.k8) + (long)bh * a.S_pad[which] * D;
     const unsigned short* base = a.src[which] + (long)b * a.sb[which] + (long)h * a.sh[which];
     const int t = threadIdx.x;
     for (int rr = t / TPR; rr < 64; rr += 256 / TPR) {
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(256) void quant_vt_kernel(QuantArgs a) {
         out[1] = make_uint4(o[2].x, o[2].y, o[3].x, o[3].y);
     }
     __syncthreads();
-    uint8_t* dst = a.v8t + ((long)bh * (a.S_pad / 64) + blockIdx.x) * (long)(D * 64);
+    uint8_t* dst = a.v8t + ((long)bh * (a.S_pad[2] / 64) + blockIdx.x) * (long)(D * 64);
     for (int item = t; item < D * 2; item += 256) {
         const int d = item >> 1, hh = item & 1;
         unsigned w[8];
@@ -236,7 +238,8 @@ int fill_args(const rsa_layout* l, const rsa_tensor4& q, const rsa_tensor4& k, c
         a.lo[i] = 0;
     }
     a.valid[0] = l->S; a.valid[1] = l->pool_valid; a.valid[2] = l->pool_valid;
-    a.H = l->H; a.BH = l->B * l->H; a.S_pad = l->NB_total * RSA_BLOCK;
+    a.H = l->H; a.BH = l->B * l->H;
+    a.S_pad[0] = a.S_pad[1] = a.S_pad[2] = l->NB_total * RSA_BLOCK;
     a.scales = ops->scales;
     a.amax_bits = reinterpret_cast<unsigned*>(ops->scales + 4 * a.BH);
     a.qk_const = (float)((1.0 / sqrt((double)l->D)) * 1.44269504);
@@ -254,7 +257,8 @@ void launch_amax(const QuantArgs& a, int dtype, int ntensors, hipStream_t s) {
 }
 
 int launch_images(const QuantArgs& a, int dtype, hipStream_t s) {
-    const dim3 g_rows(a.S_pad / 64, a.BH, 2), g_vt(a.S_pad / 64, a.BH);
+    const int sp = a.S_pad[0] > a.S_pad[1] ? a.S_pad[0] : a.S_pad[1];
+    const dim3 g_rows(sp / 64, a.BH, 2), g_vt(a.S_pad[2] / 64, a.BH);
     if (dtype == RSA_BF16) {
         quant_rows_kernel<128, bf16_tag><<<g_rows, 256, 0, s>>>(a);
         quant_vt_kernel<128, bf16_tag><<<g_vt, 256, 0, s>>>(a);
@@ -308,4 +312,55 @@ extern "C" int rsa_fp8_images(const rsa_layout* l, rsa_tensor4 q, rsa_tensor4 k,
     int st = fill_args(l, q, k, v, ops, a);
     if (st != RSA_OK) return st;
     return launch_images(a, l->dtype, static_cast<hipStream_t>(stream));
+}
+
+// ---- dense attention operands (rsa_dense_fwd_fp8): q [B,H,Sq,D], k/v [B,H,Sk,D]; workspace carved here ----
+static size_t dense_fp8_carve(int BH, int Sq, int Sk, int D, void* ws, rsa_fp8_operands* ops, int* sqp, int* skp) {
+    const size_t SQ = (size_t)((Sq + RSA_BLOCK - 1) / RSA_BLOCK) * RSA_BLOCK;
+    const size_t SK = (size_t)((Sk + RSA_BLOCK - 1) / RSA_BLOCK) * RSA_BLOCK;
+    const size_t s[4] = {align256(BH * SQ * D), align256(BH * SK * D), align256(BH * SK * D), align256((size_t)7 * BH * 4)};
+    if (ops) {
+        uint8_t* p = static_cast<uint8_t*>(ws);
+        ops->q8 = p; p += s[0];
+        ops->k8 = p; p += s[1];
+        ops->v8t = p; p += s[2];
+        ops->scales = reinterpret_cast<float*>(p);
+    }
+    if (sqp) *sqp = (int)SQ;
+    if (skp) *skp = (int)SK;
+    return s[0] + s[1] + s[2] + s[3];
+}
+
+extern "C" int rsa_dense_fp8_bytes(int B, int H, int Sq, int Sk, int D, size_t* total) {
+    if (B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0 || !total) return RSA_ERR_BAD_ARG;
+    if (D != 128) return RSA_ERR_UNSUPPORTED;
+    *total = dense_fp8_carve(B * H, Sq, Sk, D, nullptr, nullptr, nullptr, nullptr);
+    return RSA_OK;
+}
+
+// internal: producer for the dense kernel (declared in rsa_common.h)
+int rsa_dense_quantize_fp8(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
+                           void* ws, size_t ws_bytes, rsa_fp8_operands* ops, hipStream_t s) {
+    if (D != 128) return RSA_ERR_UNSUPPORTED;
+    if (!ws || (reinterpret_cast<uintptr_t>(ws) & 255)) return RSA_ERR_BAD_ARG;
+    int sqp, skp;
+    if (ws_bytes < dense_fp8_carve(B * H, Sq, Sk, D, ws, ops, &sqp, &skp)) return RSA_ERR_WORKSPACE;
+    QuantArgs a;
+    const rsa_tensor4* ts[3] = {&q, &k, &v};
+    for (int i = 0; i < 3; ++i) {
+        a.src[i] = static_cast<const unsigned short*>(ts[i]->ptr);
+        a.sb[i] = ts[i]->stride_b; a.sh[i] = ts[i]->stride_h; a.ss[i] = ts[i]->stride_s;
+        a.lo[i] = 0;
+    }
+    a.valid[0] = Sq; a.valid[1] = Sk; a.valid[2] = Sk;
+    a.S_pad[0] = sqp; a.S_pad[1] = skp; a.S_pad[2] = skp;
+    a.H = H; a.BH = B * H;
+    a.scales = ops->scales;
+    a.amax_bits = reinterpret_cast<unsigned*>(ops->scales + 4 * a.BH);
+    a.qk_const = (float)((1.0 / sqrt((double)D)) * 1.44269504);
+    a.q8 = ops->q8; a.k8 = ops->k8; a.v8t = ops->v8t;
+    if (hipMemsetAsync(a.amax_bits, 0, (size_t)3 * a.BH * 4, s) != hipSuccess) return rsa_launch_status();
+    launch_amax(a, dtype, 3, s);
+    scales_kernel<<<a.BH, 64, 0, s>>>(a.amax_bits, nullptr, 0, 0, 0, 0, a.scales, a.BH, a.qk_const);
+    return launch_images(a, dtype, s);
 }

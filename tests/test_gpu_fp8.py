@@ -179,3 +179,40 @@ def test_fp8_fused_amax_equals_standalone_producer(mk):
     assert torch.equal(fused["scales"][:4], call.fp8["scales"][:4])
     ops = orc.fp8_operands(*(t.float().cpu().numpy() for t in (tq, tk, tv)), lay)
     assert np.array_equal(fused["scales"][:4].cpu().numpy(), ops["scales"])
+
+
+@pytest.mark.parametrize("Sq,Sk,qs,ks", [(300, 520, None, None), (384, 384, 256, 200), (129, 1000, 1, 64)],
+                         ids=["plain", "two_segment", "ragged"])
+def test_fp8_dense_kernel(Sq, Sk, qs, ks):
+    """rsa_dense_fwd_fp8 (fullattn's device path with e4m3 operands) vs the fp8-aware dense oracle."""
+    from rectified_spaattn_amd import _core
+    g = torch.Generator().manual_seed(Sq * 7 + Sk)
+    H = 2
+    q = torch.randn(1, H, Sq, 128, generator=g).to(DEV, torch.bfloat16)
+    k = torch.randn(1, H, Sk, 128, generator=g).to(DEV, torch.bfloat16)
+    v = torch.randn(1, H, Sk, 128, generator=g).to(DEV, torch.bfloat16)
+    out = _core.dense_attention(q, k, v, qs, ks, qkv_fp8=True)          # [1, Sq, H, D]
+    ref16 = _core.dense_attention(q, k, v, qs, ks)
+    assert torch.isfinite(out.float()).all()
+    for h in range(H):
+        ref = orc.dense_attention_fp8(*(t[0, h].float().cpu().numpy() for t in (q, k, v)), qs, ks)
+        err = np.abs(out[0, :, h].float().cpu().numpy() - ref)
+        assert err.max() <= FP8_MAX_VS_FP8 and err.mean() <= FP8_MEAN_VS_FP8, f"{err.max():.3e} {err.mean():.3e}"
+    d16 = (out.float() - ref16.float()).abs()
+    assert d16.max() <= FP8_MAX_VS_BF16 and d16.mean() <= FP8_MEAN_VS_BF16
+
+
+def test_fullattn_dense_fp8_switch():
+    import rectified_spaattn_amd as rsa
+    from rectified_spaattn_amd.attn import fullattn
+    g = torch.Generator().manual_seed(3)
+    q, k, v = (torch.randn(1, 3, 500, 128, generator=g).to(DEV, torch.bfloat16) for _ in range(3))
+    o16 = fullattn(q, k, v, mode="torch")
+    old = rsa.set_dense_fp8(True)
+    try:
+        o8 = fullattn(q, k, v, mode="torch")
+    finally:
+        rsa.set_dense_fp8(old)
+    assert o8.shape == o16.shape and not torch.equal(o8, o16)
+    assert (o8.float() - o16.float()).abs().max() <= FP8_MAX_VS_BF16
+    assert torch.equal(fullattn(q, k, v, mode="torch"), o16)

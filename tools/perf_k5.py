@@ -102,7 +102,7 @@ def main():
                       f"{fld/medd/1e9:7.1f} TF/s | max|d vs opt0| {err:.2e}", flush=True)
         return
     if "dense" in what:
-        for S in (8192, 16384, 32768):
+        for S in (8192, 16384, 32768, 65536):
             H = 24
             q = torch.randn(1, H, S, D, device=dev).to(torch.bfloat16)
             k = torch.randn(1, H, S, D, device=dev).to(torch.bfloat16)
@@ -110,6 +110,8 @@ def main():
             med, mn = timeit(lambda: _core.dense_attention(q, k, v), n=3, warm=1)
             fl = 4.0 * S * S * D * H
             print(f"dense S={S} H={H}: median {med:.3f} ms  {fl/med/1e9:.1f} TFLOP/s")
+            med8, _ = timeit(lambda: _core.dense_attention(q, k, v, qkv_fp8=True), n=3, warm=1)
+            print(f"dense fp8 (incl. quantisation) S={S} H={H}: median {med8:.3f} ms  {fl/med8/1e9:.1f} TFLOP/s")
 
 
 if __name__ == "__main__":
