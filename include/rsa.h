@@ -218,7 +218,8 @@ int rsa_dense_fp8_bytes(int B, int H, int Sq, int Sk, int D, size_t* total);
 int rsa_dense_fwd_fp8(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
                       int q_split, int kv_split, void* workspace, size_t workspace_bytes, rsa_out4 out, void* stream);
 
-/* Tuning / diagnostics hook, not part of the data path.  Keys: "k5_prio" (0/1: issue-priority raise inside K5's pipelined block). */
+/* Tuning / diagnostics hook, not part of the data path.  Keys: "k5_prio" (0/1: issue-priority raise inside K5's
+ * pipelined block), "dense256" (0/1: rsa_dense_fwd on 256-row query tiles, 8 waves per workgroup; same results). */
 int rsa_set_tuning(const char* key, int value);
 
 const char* rsa_status_string(int status);

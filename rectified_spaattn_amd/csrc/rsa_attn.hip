@@ -6,6 +6,7 @@
 // host side
 // =====================================================================================================
 static int g_k5_prio = 1;  // tuning hook: 1 = raise the wave's issue priority inside the pipelined block
+static int g_dense256 = 0;  // tuning hook: dense mode on 256-row query tiles (8 waves, one workgroup per CU)
 
 int rsa_launch_bsfwd(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int dtype, int prio, hipStream_t s);
 
@@ -13,10 +14,11 @@ int rsa_launch_bsfwd(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int 
 extern "C" int rsa_set_tuning(const char* key, int value) {
     if (!key) return RSA_ERR_BAD_ARG;
     if (strcmp(key, "k5_prio") == 0) { g_k5_prio = value != 0; return RSA_OK; }
+    if (strcmp(key, "dense256") == 0) { g_dense256 = value != 0; return RSA_OK; }
     return RSA_ERR_BAD_ARG;
 }
 
-static int launch_attn(AttnArgs& a, int BH, int D, int dtype, hipStream_t s) {
+static int launch_attn(AttnArgs& a, int BH, int D, int dtype, hipStream_t s, int variant = -1) {
     const int ntq = a.NQB - a.NBv;
     const int n_heavy = ntq > 0 ? BH * ntq : 0;
     a.BH = BH;
@@ -27,7 +29,7 @@ static int launch_attn(AttnArgs& a, int BH, int D, int dtype, hipStream_t s) {
     if (nblocks > 0x7FFFFFFF) return RSA_ERR_UNSUPPORTED;
     if (a.NB_total > 8192) return RSA_ERR_UNSUPPORTED;  // kept list lives in LDS as u16, 16 KiB max
     const size_t lds_bytes = (size_t)4 * 64 * D * 2 + (((size_t)a.NB_total * 2 + 15) & ~(size_t)15);
-    return rsa_launch_bsfwd(a, dim3((unsigned)nblocks), lds_bytes, D, dtype, g_k5_prio, s);
+    return rsa_launch_bsfwd(a, dim3((unsigned)nblocks), lds_bytes, D, dtype, variant >= 0 ? variant : g_k5_prio, s);
 }
 
 static void fill_qkv(AttnArgs& a, const rsa_tensor4& q, const rsa_tensor4& k, const rsa_tensor4& v,
@@ -83,6 +85,10 @@ extern "C" int rsa_dense_fwd(int B, int H, int Sq, int Sk, int D, int dtype, rsa
     a.kv_valid = Sk; a.kv_text_valid = Sk; a.q_text_end = 0;
     a.q_split = q_split; a.kv_split = kv_split;
     a.qk_scale = (float)((1.0 / sqrt((double)D)) * 1.44269504);
+    if (g_dense256) {  // 256 query rows per workgroup: K/V tiles staged once per 256 rows
+        a.NQB = (Sq + 255) / 256; a.NBv = a.NQB;
+        return launch_attn(a, B * H, D, dtype, static_cast<hipStream_t>(stream), 8);
+    }
     return launch_attn(a, B * H, D, dtype, static_cast<hipStream_t>(stream));
 }
 

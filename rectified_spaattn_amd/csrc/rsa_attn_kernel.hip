@@ -46,14 +46,16 @@
 // compiler's own order -- softmax VALU first, then the MFMA cluster -- lets the two co-resident waves alternate.)
 template <int D, typename Tag, int NW, int QT, int PIPE_OPT>
 __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bsfwd_kernel(AttnArgs a) {
-    static_assert(NW * QT == 4, "a workgroup owns one 128-row query block");
+    static_assert(NW * QT == 4 || (NW == 8 && QT == 1), "128-row query block, or the 256-row dense tile (8 waves)");
+    constexpr int QROWS = 32 * NW * QT;          // query rows per workgroup
     constexpr int KS = D / 16;
     constexpr int DT = D / 32;
     constexpr int CHR = D / 8;
     constexpr int RPI = 1024 / (D * 2);     // rows per 1-KiB piece
     constexpr int TILE_BYTES = 64 * D * 2;
     constexpr int NPC = TILE_BYTES / 1024 / NW;  // 1-KiB pieces per wave per tile operand
-    constexpr int PG = 4 / NW;                  // pieces of each group of 4 that this wave moves (1 or 2)
+    constexpr int PG = NW >= 4 ? 1 : 4 / NW;    // pieces of each group of 4 that this wave moves (1 or 2)
+    constexpr int TEAMS = NW >= 4 ? NW / 4 : 1; // wave teams that alternate over the groups of 4 pieces
     using E = Elem<Tag>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned short* lds_list = reinterpret_cast<unsigned short*>(lds + 4 * TILE_BYTES);
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
     const int r = lane & 31, hh = lane >> 5;
     int grow[QT];
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) grow[qt] = qblk * RSA_BLOCK + 32 * QT * wv + 32 * qt + r;
+    for (int qt = 0; qt < QT; ++qt) grow[qt] = qblk * QROWS + 32 * QT * wv + 32 * qt + r;
 
     // ---------------- per-row plan ----------------
     int lo_r[QT], hi_r[QT];
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
             }
         }
     } else {
-        const int row0 = qblk * RSA_BLOCK, row1 = row0 + RSA_BLOCK;
+        const int row0 = qblk * QROWS, row1 = row0 + QROWS;
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             if (grow[qt] < a.q_split) { lo_r[qt] = 0; hi_r[qt] = a.kv_split; }
@@ -171,14 +173,15 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
     // ---------------- LDS-DMA staging ----------------
     const unsigned char* kbase = reinterpret_cast<const unsigned char*>(a.k + (long)b * a.ksb + (long)h * a.ksh);
     const unsigned char* vbase = reinterpret_cast<const unsigned char*>(a.v + (long)b * a.vsb + (long)h * a.vsh);
-    // piece pc = 4*(j/PG) + PG*wv + (j%PG), j = 0..NPC-1: tile rows pc*RPI .. +RPI-1.  The source-chunk swizzle
-    // depends on pc & 3 = PG*wv + (j%PG): PG per-lane offsets per operand.
+    // piece pc = 4*grp + PG*wslot + (j%PG), grp = TEAMS*(j/PG) + team, j = 0..NPC-1: tile rows pc*RPI .. +RPI-1.  The
+    // source-chunk swizzle depends on pc & 3 = PG*wslot + (j%PG): PG per-lane offsets per operand.
+    const int wslot = NW >= 4 ? (wv & 3) : wv, team = NW >= 4 ? (wv >> 2) : 0;
     const int rsub = lane / CHR, cl = lane % CHR;
     unsigned voffk[PG], voffv[PG];
     int gsw[PG];
 #pragma unroll
     for (int par = 0; par < PG; ++par) {
-        const int rowl = (PG * wv + par) * RPI + rsub;  // row inside the first group of 4 pieces
+        const int rowl = (PG * wslot + par) * RPI + rsub;  // row inside the first group of 4 pieces
         if constexpr (D == 128) gsw[par] = cl ^ (((rowl & 3) << 2) | ((rowl >> 2) & 3));
         else gsw[par] = cl ^ ((rowl >> 1) & 7);
         voffk[par] = (unsigned)(((long)rowl * a.kss + gsw[par] * 8) * 2);
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
     const long kstep = (long)(4 * RPI) * a.kss * 2, vstep = (long)(4 * RPI) * a.vss * 2;  // bytes per 4 pieces
     // is_v: 0 = K tile into K slot `slot`, 1 = V tile into V slot `slot`
     auto dma = [&](int is_v, int key0, int slot) {
-        const unsigned ld0 = lds_base + (is_v ? 2 : 0) * TILE_BYTES + slot * TILE_BYTES + (PG * wv) * 1024;
+        const unsigned ld0 = lds_base + (is_v ? 2 : 0) * TILE_BYTES + slot * TILE_BYTES + (PG * wslot) * 1024;
         const unsigned char* base = is_v ? vbase : kbase;
         const long ss = is_v ? a.vss : a.kss;
         if (key0 + 64 <= kv_limit) {
@@ -198,18 +201,20 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
             for (int j = 0; j < NPC; ++j) {
                 const unsigned vo = is_v ? voffv[j % PG] : voffk[j % PG];
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                             :: "v"(vo), "s"(tb + (j / PG) * step), "s"(ld0 + (j / PG) * 4096 + (j % PG) * 1024)
+                             :: "v"(vo), "s"(tb + (TEAMS * (j / PG) + team) * step),
+                                "s"(ld0 + (TEAMS * (j / PG) + team) * 4096 + (j % PG) * 1024)
                              : "memory");
             }
         } else {
 #pragma unroll
             for (int j = 0; j < NPC; ++j) {
-                const int rowl = (PG * wv + (j % PG)) * RPI + rsub;
-                int krow = key0 + (j / PG) * 4 * RPI + rowl;
+                const int rowl = (PG * wslot + (j % PG)) * RPI + rsub;
+                int krow = key0 + (TEAMS * (j / PG) + team) * 4 * RPI + rowl;
                 krow = krow < kv_limit ? krow : kv_limit - 1;
                 const unsigned vo = (unsigned)(((long)krow * ss + gsw[j % PG] * 8) * 2);
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                             :: "v"(vo), "s"(base), "s"(ld0 + (j / PG) * 4096 + (j % PG) * 1024) : "memory");
+                             :: "v"(vo), "s"(base), "s"(ld0 + (TEAMS * (j / PG) + team) * 4096 + (j % PG) * 1024)
+                             : "memory");
             }
         }
     };
@@ -289,7 +294,8 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
         if (tile + 1 < n_tiles) {
             if constexpr (NPC == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else if constexpr (NPC == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if constexpr (NPC == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -449,7 +455,8 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
 int rsa_launch_bsfwd(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int dtype, int prio, hipStream_t s) {
 #define RSA_K5(DD, TT) \
     do { \
-        if (prio) bsfwd_kernel<DD, TT, 4, 1, 2><<<grid, 256, lds_bytes, s>>>(a); \
+        if (prio == 8) bsfwd_kernel<DD, TT, 8, 1, 2><<<grid, 512, lds_bytes, s>>>(a); \
+        else if (prio) bsfwd_kernel<DD, TT, 4, 1, 2><<<grid, 256, lds_bytes, s>>>(a); \
         else bsfwd_kernel<DD, TT, 4, 1, 0><<<grid, 256, lds_bytes, s>>>(a); \
     } while (0)
     if (D == 128) {

@@ -101,6 +101,26 @@ def main():
                 print(f"round {rnd} opt {opt:2d}: sparse {med:7.3f} ms {flops/med/1e9:7.1f} TF/s | dense16k {medd:6.3f} ms "
                       f"{fld/medd/1e9:7.1f} TF/s | max|d vs opt0| {err:.2e}", flush=True)
         return
+    if "dense256" in what:  # A/B of the 256-row dense tile (tuning key "dense256") against the 128-row kernel
+        from rectified_spaattn_amd import _lib
+        L = _lib.lib()
+        for S in (4096, 16384, 65536, 115456):
+            H = 24 if S < 100000 else 8
+            q, k, v = (torch.randn(1, H, S, D, device=dev).to(torch.bfloat16) for _ in range(3))
+            fl = 4.0 * S * S * D * H
+            res = {}
+            for flag in (0, 1, 0, 1):
+                assert L.rsa_set_tuning(b"dense256", flag) == 0
+                med, _ = timeit(lambda: _core.dense_attention(q, k, v), n=3, warm=1)
+                res.setdefault(flag, []).append(med)
+                if flag:
+                    o1 = _core.dense_attention(q, k, v).float()
+                else:
+                    o0 = _core.dense_attention(q, k, v).float()
+            L.rsa_set_tuning(b"dense256", 0)
+            print(f"dense S={S} H={H}: 128-row {min(res[0]):.3f} ms {fl/min(res[0])/1e9:.0f} TF/s | 256-row {min(res[1]):.3f} ms "
+                  f"{fl/min(res[1])/1e9:.0f} TF/s | max|d| {(o0-o1).abs().max().item():.2e}", flush=True)
+        return
     if "dense" in what:
         for S in (8192, 16384, 32768, 65536):
             H = 24
