@@ -194,9 +194,9 @@ def main():
     # HBM-side traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE with
     # the gfx950 x2 correction; tools/pmc_to_json.py) of this same command; it cannot be collected inside this process.
     traffic = None
-    tfile = os.path.join(ROOT, "profiles", "r01_k5_traffic.json")
-    if (args.workload == "hunyuan_720p_128f" and args.neighbors == "none" and world == 1 and not args.qkv_fp8
-            and os.path.exists(tfile)):
+    tname = "r01_k5_fp8_traffic.json" if args.qkv_fp8 else "r01_k5_traffic.json"
+    tfile = os.path.join(ROOT, "profiles", tname)
+    if args.workload == "hunyuan_720p_128f" and args.neighbors == "none" and world == 1 and os.path.exists(tfile):
         try:
             traffic = json.load(open(tfile)).get("traffic_bytes_per_launch")
         except (OSError, ValueError):
@@ -218,7 +218,7 @@ def main():
                      "bsfwd_kernel<128,bf16_tag,4,1,2> (K5 block_sparse_fwd)", "bound": "mfma",
                      "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                      "frac": round(achieved / peak, 4), "traffic": traffic,
-                     "traffic_note": "L2 memory-side bytes/launch from rocprofv3 PMC (profiles/r01_k5_traffic.json); "
+                     "traffic_note": f"L2 memory-side bytes/launch from rocprofv3 PMC (profiles/{tname}); "
                                      "includes Infinity-Cache hits; compulsory Q+K+V+O = 2.84e9",
                      "k5_ms": round(k5_ms_local, 4), "select_pass_ms": round(ms_per_step - k5_ms, 4)},  # + the fp8 quantisation pass with --qkv-fp8
     }
