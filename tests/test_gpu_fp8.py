@@ -216,3 +216,28 @@ def test_fullattn_dense_fp8_switch():
     assert o8.shape == o16.shape and not torch.equal(o8, o16)
     assert (o8.float() - o16.float()).abs().max() <= FP8_MAX_VS_BF16
     assert torch.equal(fullattn(q, k, v, mode="torch"), o16)
+
+
+def test_fp8_hip_graph_capture_and_replay():
+    """The fp8 path (K1 with maxima, scales, images, fp8 K5; one memset node) is capturable and replays on new data."""
+    from rectified_spaattn_amd import _core, synth
+    qa, ka, va = (torch.from_numpy(x).to(DEV, torch.bfloat16) for x in synth.structured_qkv(41, 1, 2, 1024, 128))
+    qb, kb, vb = (torch.from_numpy(x * 3.0).to(DEV, torch.bfloat16) for x in synth.structured_qkv(42, 1, 2, 1024, 128))
+    spec = _core.LayoutSpec.wan(1024, 1)
+    q, k, v = qa.clone(), ka.clone(), va.clone()
+    call = _core.StagedCall(q, k, v, spec, 3, 0.3, None, qkv_fp8=True)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        call.select(); call.quantize(); call.attend()   # warm-up outside capture
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        call.select()
+        call.quantize()
+        call.attend()
+    q.copy_(qb); k.copy_(kb); v.copy_(vb)
+    g.replay()
+    torch.cuda.synchronize()
+    eager = _core.rectified_attention(qb, kb, vb, spec, 3, 0.3, None, qkv_fp8=True)
+    assert torch.equal(call.out.view(1, 1024, 256), eager)
