@@ -13,7 +13,7 @@ int rsa_launch_bsfwd(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int 
 // Tuning / diagnostics hook (not part of the data path).
 extern "C" int rsa_set_tuning(const char* key, int value) {
     if (!key) return RSA_ERR_BAD_ARG;
-    if (strcmp(key, "k5_prio") == 0) { g_k5_prio = value; return RSA_OK; }  // 0 / 1, 3 = 1 + relative score accumulators
+    if (strcmp(key, "k5_prio") == 0) { g_k5_prio = value != 0; return RSA_OK; }
     if (strcmp(key, "dense256") == 0) { g_dense256 = value != 0; return RSA_OK; }
     return RSA_ERR_BAD_ARG;
 }

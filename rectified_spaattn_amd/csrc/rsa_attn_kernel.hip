@@ -230,14 +230,6 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
     float m_run[QT], l_run[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) { m_run[qt] = -INFINITY; l_run[qt] = 0.0f; }
-    // PIPE_OPT & 64: every QK^T chain starts from a block holding -m_eff (m_eff = 0 while m_run = -inf), so the score
-    // accumulators are already relative to the row's reference and the softmax needs no subtraction
-    constexpr bool REL = (PIPE_OPT & 64) != 0;
-    f32x16 mblk[QT];
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) mblk[qt][i] = 0.0f;
 
     // per-lane read addressing
     const int kswz = ((r & 3) << 2) | ((r >> 2) & 3);
@@ -258,17 +250,15 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
     auto qk_sub = [&](auto KSLOT, auto SUB, f32x16 (&S)[QT]) {
         constexpr int slot = decltype(KSLOT)::value, sub = decltype(SUB)::value;
         const unsigned char* kt_ = lds + slot * TILE_BYTES;
-        if constexpr (!REL) {
 #pragma unroll
-            for (int qt = 0; qt < QT; ++qt)
+        for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) S[qt][i] = 0.0f;
-        }
+            for (int i = 0; i < 16; ++i) S[qt][i] = 0.0f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const s16x8 a0 = *reinterpret_cast<const s16x8*>(kt_ + k_off(ks, sub));
 #pragma unroll
-            for (int qt = 0; qt < QT; ++qt) S[qt] = E::mfma(a0, qf[qt][ks], (REL && ks == 0) ? mblk[qt] : S[qt]);
+            for (int qt = 0; qt < QT; ++qt) S[qt] = E::mfma(a0, qf[qt][ks], S[qt]);
         }
     };
     auto rowmax_sub = [&](const f32x16 (&S)[QT], float (&mx)[QT]) {
@@ -323,15 +313,11 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
         }
         bool grow_any = false;
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            if constexpr (REL) grow_any |= (m_run[qt] == -INFINITY) ? (mx_cur[qt] > -INFINITY) : (mx_cur[qt] > 8.0f);
-            else grow_any |= mx_cur[qt] > m_run[qt] + 8.0f;
-        }
+        for (int qt = 0; qt < QT; ++qt) grow_any |= mx_cur[qt] > m_run[qt] + 8.0f;
         if (__builtin_amdgcn_ballot_w64(grow_any) != 0ull) {
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
-                const float m_eff_old = (m_run[qt] == -INFINITY) ? 0.0f : m_run[qt];
-                const float m_new = fmaxf(m_run[qt], REL ? mx_cur[qt] + m_eff_old : mx_cur[qt]);
+                const float m_new = fmaxf(m_run[qt], mx_cur[qt]);
                 const float mu = (m_new == -INFINITY) ? 0.0f : m_new;
                 const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - mu);
                 m_run[qt] = m_new;
@@ -340,18 +326,11 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
                 for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) o[dt][qt][i] *= alpha;
-                if constexpr (REL) {
-                    const float shift = mu - m_eff_old;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) S_cur[qt][i] -= shift;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) mblk[qt][i] = -mu;
-                }
             }
         }
         float m_use[QT];
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt) m_use[qt] = REL ? 0.0f : ((m_run[qt] == -INFINITY) ? 0.0f : m_run[qt]);
+        for (int qt = 0; qt < QT; ++qt) m_use[qt] = (m_run[qt] == -INFINITY) ? 0.0f : m_run[qt];
 
         // ---- pipelined block (branch-free on purpose: the scheduler interleaves the MFMA and VALU streams) ----
         if constexpr (PIPE_OPT & 2) __builtin_amdgcn_s_setprio(2);
@@ -366,7 +345,7 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
                 float pv8[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    pv8[i] = __builtin_amdgcn_exp2f(REL ? S_cur[qt][8 * half + i] : S_cur[qt][8 * half + i] - m_use[qt]);
+                    pv8[i] = __builtin_amdgcn_exp2f(S_cur[qt][8 * half + i] - m_use[qt]);
                     ps += pv8[i];
                 }
                 pb[qt][half] = E::cvt8(pv8);
@@ -477,7 +456,6 @@ int rsa_launch_bsfwd(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int 
 #define RSA_K5(DD, TT) \
     do { \
         if (prio == 8) bsfwd_kernel<DD, TT, 8, 1, 2><<<grid, 512, lds_bytes, s>>>(a); \
-        else if (prio == 3) bsfwd_kernel<DD, TT, 4, 1, 66><<<grid, 256, lds_bytes, s>>>(a); \
         else if (prio) bsfwd_kernel<DD, TT, 4, 1, 2><<<grid, 256, lds_bytes, s>>>(a); \
         else bsfwd_kernel<DD, TT, 4, 1, 0><<<grid, 256, lds_bytes, s>>>(a); \
     } while (0)
