@@ -207,7 +207,8 @@ class StagedCall:
         with torch.cuda.device(self.q.device):
             _lib.check(fn(ctypes.byref(self.lay), tq, tk, tv, ctypes.byref(self.cf), _stream()), name)
 
-    def select(self):
+    def select_pool(self):
+        """K1 (with the fp8 maxima + scales when qkv_fp8)."""
         L, lay, cb, st = self.L, ctypes.byref(self.lay), ctypes.byref(self.cb), _stream()
         tq, tk, tv = self.t
         with torch.cuda.device(self.q.device):
@@ -215,10 +216,20 @@ class StagedCall:
                 _lib.check(L.rsa_pool_stats_fp8(lay, tq, tk, tv, cb, ctypes.byref(self.cf), st), "rsa_pool_stats_fp8")
             else:
                 _lib.check(L.rsa_pool_stats(lay, tq, tk, tv, cb, st), "rsa_pool_stats")
+
+    def select_rest(self):
+        """K2..K4 (need only K1's statistics)."""
+        L, lay, cb, st = self.L, ctypes.byref(self.lay), ctypes.byref(self.cb), _stream()
+        tk = self.t[1]
+        with torch.cuda.device(self.q.device):
             _lib.check(L.rsa_pooled_scores(lay, tk, cb, st), "rsa_pooled_scores")
             _lib.check(L.rsa_select_mask(lay, self.nbr.data_ptr() if self.nbr is not None else None, self.top_k,
                                          self.p, cb, st), "rsa_select_mask")
             _lib.check(L.rsa_compensation(lay, cb, st), "rsa_compensation")
+
+    def select(self):
+        self.select_pool()
+        self.select_rest()
 
     def attend(self):
         tq, tk, tv = self.t
