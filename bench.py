@@ -215,7 +215,7 @@ def main():
                    "gather_output": bool(args.gather_output), "parallelism": f"head-shard x{world}",
                    "per_rank_ms": [round(x / args.steps * 1e3, 3) for x in per_rank_s]},
         "roofline": {"kernel": "bsfwd_fp8_kernel<2> (K5 block_sparse_fwd_fp8)" if args.qkv_fp8 else
-                     "bsfwd_kernel<128,bf16_tag,4,1,2> (K5 block_sparse_fwd)", "bound": "mfma",
+                     "bsfwd_kernel<128,bf16_tag,4,1,258> (K5 block_sparse_fwd)", "bound": "mfma",
                      "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                      "frac": round(achieved / peak, 4), "traffic": traffic,
                      "traffic_note": f"L2 memory-side bytes/launch from rocprofv3 PMC (profiles/{tname}); "

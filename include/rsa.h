@@ -219,7 +219,8 @@ int rsa_dense_fwd_fp8(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor
                       int q_split, int kv_split, void* workspace, size_t workspace_bytes, rsa_out4 out, void* stream);
 
 /* Tuning / diagnostics hook, not part of the data path.  Keys: "k5_prio" (0/1: issue-priority raise inside K5's
- * pipelined block), "dense256" (0/1: rsa_dense_fwd on 256-row query tiles, 8 waves per workgroup; same results). */
+ * pipelined block + LLVM's iglp_opt(0) interleave), "dense256" (0/1: rsa_dense_fwd on 256-row query tiles, 8 waves
+ * per workgroup; same results), "fp8_variant" (0..4: iglp_opt strategy of the fp8 kernel's block; 0 = none). */
 int rsa_set_tuning(const char* key, int value);
 
 const char* rsa_status_string(int status);

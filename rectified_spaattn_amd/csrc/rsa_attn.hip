@@ -8,13 +8,15 @@
 static int g_k5_prio = 1;  // tuning hook: 1 = raise the wave's issue priority inside the pipelined block
 static int g_dense256 = 0;  // tuning hook: dense mode on 256-row query tiles (8 waves, one workgroup per CU)
 
+void rsa_set_fp8_variant(int v);
 int rsa_launch_bsfwd(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int dtype, int prio, hipStream_t s);
 
 // Tuning / diagnostics hook (not part of the data path).
 extern "C" int rsa_set_tuning(const char* key, int value) {
     if (!key) return RSA_ERR_BAD_ARG;
-    if (strcmp(key, "k5_prio") == 0) { g_k5_prio = value != 0; return RSA_OK; }
+    if (strcmp(key, "k5_prio") == 0) { g_k5_prio = value; return RSA_OK; }
     if (strcmp(key, "dense256") == 0) { g_dense256 = value != 0; return RSA_OK; }
+    if (strcmp(key, "fp8_variant") == 0) { rsa_set_fp8_variant(value); return RSA_OK; }
     return RSA_ERR_BAD_ARG;
 }
 

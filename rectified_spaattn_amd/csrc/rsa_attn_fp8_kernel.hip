@@ -291,6 +291,10 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
 
         // ---- pipelined block ----
         if constexpr (PIPE_OPT & 2) __builtin_amdgcn_s_setprio(2);
+        if constexpr ((PIPE_OPT >> 8) == 1) __builtin_amdgcn_iglp_opt(0);
+        if constexpr ((PIPE_OPT >> 8) == 2) __builtin_amdgcn_iglp_opt(1);
+        if constexpr ((PIPE_OPT >> 8) == 3) __builtin_amdgcn_iglp_opt(2);
+        if constexpr ((PIPE_OPT >> 8) == 4) __builtin_amdgcn_iglp_opt(3);
         qk_tile((ts + 1) & (NSLOT - 1), S_nxt);
         i32x8 pb;
 #pragma unroll
@@ -389,6 +393,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     }
 }
 
+int g_fp8_variant = 0;
 int launch_attn8(Attn8Args& a, int BH, hipStream_t s) {
     const int ntq = a.NQB - a.NBv;
     const int n_heavy = ntq > 0 ? BH * ntq : 0;
@@ -400,7 +405,13 @@ int launch_attn8(Attn8Args& a, int BH, hipStream_t s) {
     if (nblocks > 0x7FFFFFFF) return RSA_ERR_UNSUPPORTED;
     if (a.NB_total > 8192) return RSA_ERR_UNSUPPORTED;
     const size_t lds_bytes = (size_t)2 * NSLOT * TILE8 + 64 + (((size_t)a.NB_total * 2 + 15) & ~(size_t)15);
-    bsfwd_fp8_kernel<2><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a);
+    switch (g_fp8_variant) {
+        case 1: bsfwd_fp8_kernel<2 + 256><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a); break;
+        case 2: bsfwd_fp8_kernel<2 + 512><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a); break;
+        case 3: bsfwd_fp8_kernel<2 + 768><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a); break;
+        case 4: bsfwd_fp8_kernel<2 + 1024><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a); break;
+        default: bsfwd_fp8_kernel<2><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a); break;
+    }
     return rsa_launch_status();
 }
 
@@ -411,6 +422,8 @@ int check_out8(const rsa_out4& o) {
 }
 
 }  // namespace
+
+void rsa_set_fp8_variant(int v) { g_fp8_variant = v; }
 
 extern "C" int rsa_block_sparse_fwd_fp8(const rsa_layout* l, const rsa_fp8_operands* ops, const rsa_buffers* buf,
                                         rsa_out4 out, void* stream) {

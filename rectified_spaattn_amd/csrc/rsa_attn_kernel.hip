@@ -41,7 +41,9 @@
 // register class, i.e. an asm-level body.
 #include "rsa_attn.h"
 
-// PIPE_OPT bits (tuning experiments): 2 = issue priority 2 for this wave while it is inside the pipelined block.
+// PIPE_OPT bits (tuning experiments): 2 = issue priority 2 for this wave while it is inside the pipelined block;
+// 256 = __builtin_amdgcn_iglp_opt(0) on the pipelined block (+1.7 % sparse, +2.7 % dense 16k; strategies 1, 2 (the
+// "exp interleave" meant for attention) and 3 measured -0.5 ... -3 %).
 // (Pinning a per-MFMA interleave {2 LDS reads, 1 MFMA, 1 exp, 4 VALU} with sched_group_barrier measured -3.5 %: the
 // compiler's own order -- softmax VALU first, then the MFMA cluster -- lets the two co-resident waves alternate.)
 template <int D, typename Tag, int NW, int QT, int PIPE_OPT>
@@ -334,6 +336,7 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
 
         // ---- pipelined block (branch-free on purpose: the scheduler interleaves the MFMA and VALU streams) ----
         if constexpr (PIPE_OPT & 2) __builtin_amdgcn_s_setprio(2);
+        if constexpr (PIPE_OPT & 256) __builtin_amdgcn_iglp_opt(0);  // LLVM's small-GEMM MFMA/DS interleave for this region
         if constexpr (sub == 0) qk_sub(std::integral_constant<int, vs>{}, std::integral_constant<int, 1>{}, S_nxt);
         else qk_sub(std::integral_constant<int, vs ^ 1>{}, std::integral_constant<int, 0>{}, S_nxt);
         s16x8 pb[QT][2];
@@ -455,8 +458,8 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
 int rsa_launch_bsfwd(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int dtype, int prio, hipStream_t s) {
 #define RSA_K5(DD, TT) \
     do { \
-        if (prio == 8) bsfwd_kernel<DD, TT, 8, 1, 2><<<grid, 512, lds_bytes, s>>>(a); \
-        else if (prio) bsfwd_kernel<DD, TT, 4, 1, 2><<<grid, 256, lds_bytes, s>>>(a); \
+        if (prio == 8) bsfwd_kernel<DD, TT, 8, 1, 2 + 256><<<grid, 512, lds_bytes, s>>>(a); \
+        else if (prio) bsfwd_kernel<DD, TT, 4, 1, 2 + 256><<<grid, 256, lds_bytes, s>>>(a); \
         else bsfwd_kernel<DD, TT, 4, 1, 0><<<grid, 256, lds_bytes, s>>>(a); \
     } while (0)
     if (D == 128) {

@@ -101,6 +101,29 @@ def main():
                 print(f"round {rnd} opt {opt:2d}: sparse {med:7.3f} ms {flops/med/1e9:7.1f} TF/s | dense16k {medd:6.3f} ms "
                       f"{fld/medd/1e9:7.1f} TF/s | max|d vs opt0| {err:.2e}", flush=True)
         return
+    if "fp8variants" in what:
+        from rectified_spaattn_amd import _lib
+        L = _lib.lib()
+        H = 24
+        wl = WORKLOADS["hunyuan_720p_128f"]
+        S = wl["S_vis"] + wl["text"]
+        spec = _core.LayoutSpec.hunyuan(S, wl["S_vis"] + wl["text_valid"])
+        q, k, v = gen_qkv(H, 0, S, wl["S_vis"], D, dev)
+        call = _core.StagedCall(q, k, v, spec, wl["top_k"], 0.0, None, qkv_fp8=True)
+        call.select(); call.quantize()
+        pairs = call.bufs["counts"].sum().item()
+        flops = 4.0 * D * 128 * 128 * pairs + 4.0 * D * spec.q_text_valid * spec.kv_text_valid * H
+        ref = None
+        for rnd in range(2):
+            for opt in [int(x) for x in os.environ.get("RSA_PERF_OPTS", "0,1,2,3,4").split(",")]:
+                assert L.rsa_set_tuning(b"fp8_variant", opt) == 0
+                med, mn = timeit(call.attend, n=4, warm=1)
+                o = call.out.float()
+                if ref is None:
+                    ref = o.clone()
+                print(f"round {rnd} fp8 variant {opt}: {med:7.3f} ms {flops/med/1e9:7.1f} TF/s | max|d| {(o-ref).abs().max().item():.2e}", flush=True)
+        L.rsa_set_tuning(b"fp8_variant", 0)
+        return
     if "dense256" in what:  # A/B of the 256-row dense tile (tuning key "dense256") against the 128-row kernel
         from rectified_spaattn_amd import _lib
         L = _lib.lib()
