@@ -167,3 +167,28 @@ def test_cabi_library_exports_every_declared_symbol():
     assert lib.rsa_buffer_bytes(ctypes.byref(lay), ctypes.byref(sizes), ctypes.byref(tot)) == 0 and tot.value > 0
     lay.NB_total = 7
     assert lib.rsa_buffer_bytes(ctypes.byref(lay), ctypes.byref(sizes), ctypes.byref(tot)) == -1
+
+
+def test_cabi_fp8_entry_points_validate_on_the_host():
+    """The fp8 entry points reject bad layouts / head dims / workspaces before any launch (runs without a GPU)."""
+    import ctypes
+    from rectified_spaattn_amd import _lib
+    lib = _lib.lib()
+    lay = _lib.RsaLayout(1, 2, 128, 256, 2, 2, 0, 256, 256, 2, 0, 0, 256, 0)
+    s4, tot = (ctypes.c_size_t * 4)(), ctypes.c_size_t()
+    assert lib.rsa_fp8_operand_bytes(ctypes.byref(lay), ctypes.byref(s4), ctypes.byref(tot)) == 0
+    assert list(s4)[:3] == [2 * 256 * 128] * 3 and tot.value >= 3 * 2 * 256 * 128
+    lay64 = _lib.RsaLayout(1, 2, 64, 256, 2, 2, 0, 256, 256, 2, 0, 0, 256, 0)
+    assert lib.rsa_fp8_operand_bytes(ctypes.byref(lay64), ctypes.byref(s4), ctypes.byref(tot)) == -2   # head_dim 64
+    ops = _lib.RsaFp8Operands()
+    assert lib.rsa_carve_fp8_operands(ctypes.byref(lay), None, 0, ctypes.byref(ops)) == -1             # null workspace
+    assert lib.rsa_carve_fp8_operands(ctypes.byref(lay), ctypes.c_void_p(4096), 16, ctypes.byref(ops)) == -3  # too small
+    t = _lib.RsaTensor4(0, 0, 0, 0)
+    assert lib.rsa_quantize_fp8(ctypes.byref(lay), t, t, t, None, None) == -1                          # null operands
+    assert lib.rsa_fp8_images(ctypes.byref(lay), t, t, t, ctypes.byref(ops), None) == -1               # null images
+    d = ctypes.c_size_t()
+    assert lib.rsa_dense_fp8_bytes(1, 2, 300, 500, 128, ctypes.byref(d)) == 0
+    assert d.value >= 2 * (384 + 2 * 512) * 128
+    assert lib.rsa_dense_fp8_bytes(1, 2, 300, 500, 64, ctypes.byref(d)) == -2
+    assert lib.rsa_dense_fp8_bytes(0, 2, 300, 500, 128, ctypes.byref(d)) == -1
+    assert lib.rsa_set_tuning(b"no_such_key", 1) == -1
