@@ -241,3 +241,34 @@ def test_fp8_hip_graph_capture_and_replay():
     torch.cuda.synchronize()
     eager = _core.rectified_attention(qb, kb, vb, spec, 3, 0.3, None, qkv_fp8=True)
     assert torch.equal(call.out.view(1, 1024, 256), eager)
+
+
+def _random_fp8_cases():
+    import test_gpu_random_layouts as R
+    return [c for c in R._cases() if c[2] == 128]
+
+
+@pytest.mark.parametrize("case", _random_fp8_cases(), ids=lambda c: f"{c[0]}-{c[1]}")
+def test_fp8_random_layouts(case):
+    """The randomised layouts of test_gpu_random_layouts (head_dim 128 ones) through the fp8 K5: same mask as the 2-byte
+    path, byte-exact images, output within the fp8 tolerance of the fp8-aware oracle, no NaN in the awkward corners."""
+    from rectified_spaattn_amd import _core, synth
+    i, variant, D, H, lay, top_k, p, nbw = case
+    q, k, v = synth.structured_qkv(1000 + i, 1, H, lay.S, D, smooth=0.5 if i % 3 == 0 else 0.0)
+    nbr = synth.banded_neighbors(lay.NBv, nbw) if nbw >= 0 else None
+    dt = torch.bfloat16 if i % 2 == 0 else torch.float16
+    tq, tk, tv = (torch.from_numpy(x).to(DEV, dt) for x in (q, k, v))
+    q, k, v = (x.float().cpu().numpy() for x in (tq, tk, tv))
+    tn = torch.from_numpy(nbr) if nbr is not None else None
+    out, parts = _core.rectified_attention(tq, tk, tv, _spec(lay), top_k, p, tn, return_parts=True, qkv_fp8=True)
+    ref8, sel, ops = orc.rectified_attention_fp8(q, k, v, lay, top_k, p, nbr, want_parts=True)
+    for bh in range(H):
+        kept = orc.unpack_bits(parts["bitmask"][bh].cpu().numpy().view(np.uint32), lay.NB_total)
+        assert np.array_equal(kept, sel[bh]["kept"]), f"mask (case {i})"
+    assert np.array_equal(parts["scales"][:4].cpu().numpy(), ops["scales"])
+    for n in ("q8", "k8", "v8t"):
+        assert np.array_equal(parts[n].cpu().numpy(), ops[n]), n
+    o = out.float().cpu().numpy()
+    assert np.isfinite(o).all()
+    err = np.abs(o - ref8)
+    assert err.max() <= 6e-2 and err.mean() <= 6e-3, f"case {i}: max {err.max():.3e} mean {err.mean():.3e}"
