@@ -177,17 +177,18 @@ int rsa_qk_norm_rope(int B, int H, int S, int D, int dtype, rsa_tensor4 x, const
 /* e4m3 (OCP e4m3fn) images of one call's Q, K, V, written by rsa_quantize_fp8 and read by rsa_block_sparse_fwd_fp8. */
 typedef struct rsa_fp8_operands {
     uint8_t* q8;    /* [BH, NB_total*128, D]     rows >= S are zero                                            */
-    uint8_t* k8;    /* [BH, NB_total*128, D]     rows >= pool_valid are zero (needs pool_valid >= kv_valid, kv_text_valid) */
+    uint8_t* k8;    /* [BH, NB_total*128, D]     rows >= pool_valid are zero (needs pool_valid >= kv_valid, kv_text_valid);
+                     * in the fused form K minus its per-head mean ("smooth K", exact under softmax; rsa_fp8.hip)   */
     uint8_t* v8t;   /* [BH, NB_total*2, D, 64]   V^T per 64-key tile, keys in the MFMA k-slot order (rsa_fp8.hip) */
     float* scales;  /* [4, BH] dequantisation scales of q, k, v and c = scale_q*scale_k*sm_scale*log2(e) (a power of
-                     * two by construction, see rsa_fp8.hip), followed by (3 + 3*NB_total)*BH words of scratch   */
+                     * two by construction, see rsa_fp8.hip), followed by (3 + 3*NB_total + D)*BH words of scratch / K mean */
 } rsa_fp8_operands;
 
 /* Bytes of the four members (member order) and their 256-B-rounded sum.  D = 128 only. */
 int rsa_fp8_operand_bytes(const rsa_layout* lay, size_t sizes[4], size_t* total);
 int rsa_carve_fp8_operands(const rsa_layout* lay, void* ws, size_t ws_bytes, rsa_fp8_operands* out);
 
-/* Per-(b,h) amax of Q, K, V, the scales, and the three e4m3 images: x/scale (IEEE), clamp +-448, round to nearest
+/* Per-(b,h) amax of Q, K, V, the scales, and the three e4m3 images: x * fl(1/scale), clamp +-448, round to nearest
  * even. */
 int rsa_quantize_fp8(const rsa_layout* lay, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
                      const rsa_fp8_operands* ops, void* stream);

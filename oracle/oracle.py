@@ -378,23 +378,50 @@ def _fp8_scales(amax3, D: int):
     return np.float32(c / skc), sc[1], sc[2], c
 
 
-def _fp8_images(xs, valid, pads, D):
-    """xs: three [BH, S_i, D] fp32 arrays -> scales [4, BH], images [BH, pads[i], D] (rows >= valid[i] zero)."""
+def _fp8_images(xs, valid, pads, D, kmean=None):
+    """xs: three [BH, S_i, D] fp32 arrays -> scales [4, BH], images [BH, pads[i], D] (rows >= valid[i] zero).
+    kmean [BH, D] (optional, "smooth K"): subtracted from K before quantisation; the K scale then uses the bound
+    amax|k| + max|mu| exactly as rsa_fp8.hip::scales_kernel does."""
     BH = xs[0].shape[0]
     scales = np.ones((4, BH), np.float32)
     for bh in range(BH):
         amax = []
         for i in range(3):
             xv = xs[i][bh, : valid[i]]
-            amax.append(np.float32(np.max(np.abs(xv))) if xv.size else np.float32(0))
+            a = np.float32(np.max(np.abs(xv))) if xv.size else np.float32(0)
+            if i == 1 and kmean is not None:
+                a = np.float32(a + np.float32(np.max(np.abs(kmean[bh]))))
+            amax.append(a)
         scales[:, bh] = _fp8_scales(amax, D)
     imgs = []
     for i in range(3):
         img = np.zeros((BH, pads[i], D), np.uint8)
         for bh in range(BH):
-            img[bh, : valid[i]] = quantize_e4m3((xs[i][bh, : valid[i]] / scales[i, bh]).astype(np.float32))
+            xv = xs[i][bh, : valid[i]]
+            if i == 1 and kmean is not None:
+                xv = (xv - kmean[bh][None, :]).astype(np.float32)
+            inv = np.float32(np.float32(1.0) / scales[i, bh])   # the kernels multiply by the reciprocal
+            img[bh, : valid[i]] = quantize_e4m3((xv * inv).astype(np.float32))
         imgs.append(img)
     return scales, imgs
+
+
+def fp8_kmean(k, lay: Layout):
+    """"Smooth K" vector of one head from the pooled K block means (contract of rsa_fp8.hip::kmean_kernel):
+    mu[d] = tree16(P_0..P_15) / NBv, P_g = sum in block order of kbar[j][d] over j = g (mod 16), tree16 = xor tree with
+    strides 1, 2, 4, 8 (as contract C6), all in fp32."""
+    nq = lay.NBv
+    D = k.shape[1]
+    if nq == 0:
+        return np.zeros(D, np.float32)
+    kk = np.asarray(k, np.float32)
+    kbar, _ = pool(kk[: nq * BLOCK], min(lay.pool_valid, nq * BLOCK), nq, False)
+    part = np.zeros((16, D), np.float32)
+    for j in range(nq):
+        part[j % 16] = (part[j % 16] + kbar[j]).astype(np.float32)
+    for stride in (1, 2, 4, 8):
+        part = (part + part[np.arange(16) ^ stride]).astype(np.float32)
+    return (part[0] / np.float32(nq)).astype(np.float32)
 
 
 def _v8t_from_image(v8):
@@ -403,16 +430,24 @@ def _v8t_from_image(v8):
     return np.ascontiguousarray(v8[:, :, fp8_kslot_key(np.arange(64)), :].transpose(0, 1, 3, 2))
 
 
-def fp8_operands(q, k, v, lay: Layout):
-    """Per-(b,h) scales and e4m3 images exactly as rsa_quantize_fp8 writes them.
-    q, k, v: [B, H, S, D] fp32 -> dict(scales [4, BH] (q, k, v, c), q8/k8 [BH, S_pad, D], v8t [BH, S_pad/64, D, 64])."""
+def fp8_operands(q, k, v, lay: Layout, smooth_k: bool = True):
+    """Per-(b,h) scales and e4m3 images exactly as rsa_pool_stats_fp8 + rsa_fp8_images write them (smooth_k=True, the
+    operator's path) or as the stand-alone rsa_quantize_fp8 does (smooth_k=False: no K mean).
+    q, k, v: [B, H, S, D] fp32 -> dict(scales [4, BH] (q, k, v, c), kmean [BH, D], q8/k8 [BH, S_pad, D],
+    v8t [BH, S_pad/64, D, 64])."""
     B, H, S, D = q.shape
     BH, SP = B * H, lay.NB_total * BLOCK
     assert lay.pool_valid >= max(lay.kv_valid, lay.kv_text_valid)
     valid = (S, lay.pool_valid, lay.pool_valid)  # the rows the pooling pass counts
     xs = [np.asarray(x, np.float32).reshape(BH, S, D) for x in (q, k, v)]
-    scales, imgs = _fp8_images(xs, valid, (SP, SP, SP), D)
-    return dict(scales=scales, q8=imgs[0], k8=imgs[1], v8t=_v8t_from_image(imgs[2]))
+    kmean = None
+    if smooth_k:
+        kz = xs[1].copy()
+        kz[:, lay.pool_valid:] = 0                  # rows the pooling pass counts as zero (hunyuan :307-308)
+        kmean = np.stack([fp8_kmean(kz[bh], lay) for bh in range(BH)])
+    scales, imgs = _fp8_images(xs, valid, (SP, SP, SP), D, kmean)
+    return dict(scales=scales, kmean=kmean if kmean is not None else np.zeros((BH, D), np.float32), q8=imgs[0],
+                k8=imgs[1], v8t=_v8t_from_image(imgs[2]))
 
 
 def dense_attention_fp8(q, k, v, q_split: Optional[int] = None, kv_split: Optional[int] = None):
@@ -437,13 +472,14 @@ def dense_attention_fp8(q, k, v, q_split: Optional[int] = None, kv_split: Option
     return out
 
 
-def fp8_dequantized_qkv(q, k, v, lay: Layout):
+def fp8_dequantized_qkv(q, k, v, lay: Layout, smooth_k: bool = True):
     """The values the fp8 K5 multiplies: dequantised e4m3 images cropped back to [B, H, S, D] fp32."""
     B, H, S, D = q.shape
-    ops = fp8_operands(q, k, v, lay)
+    ops = fp8_operands(q, k, v, lay, smooth_k)
     res = []
     for i, name in enumerate(("q8", "k8")):
         x = dequantize_e4m3(ops[name])[:, :S] * ops["scales"][i][:, None, None]
+        # (k8 holds k - mu: every score of a query row is shifted by q.mu, which no softmax sees)
         res.append(x.reshape(B, H, S, D).astype(np.float32))
     inv = np.argsort(fp8_kslot_key(np.arange(64)))
     vt = dequantize_e4m3(ops["v8t"])                             # [BH, T, D, 64 slots]
@@ -452,12 +488,13 @@ def fp8_dequantized_qkv(q, k, v, lay: Layout):
     return res[0], res[1], res[2], ops
 
 
-def rectified_attention_fp8(q, k, v, lay: Layout, top_k: int, p: float, neighbor=None, want_parts: bool = False):
+def rectified_attention_fp8(q, k, v, lay: Layout, top_k: int, p: float, neighbor=None, want_parts: bool = False,
+                            smooth_k: bool = True):
     """Operator with fp8 K5 operands: mask statistics, R and comp from the 2-byte inputs (unchanged contract), the
     sparse / text-row attention itself on the dequantised e4m3 values (P kept in fp64 here; the kernel rounds P to
     e4m3 -- covered by the stated fp8 tolerance)."""
     B, H, S, D = q.shape
-    q8, k8, v8, ops = fp8_dequantized_qkv(q, k, v, lay)
+    q8, k8, v8, ops = fp8_dequantized_qkv(q, k, v, lay, smooth_k)
     out = np.zeros((B, S, H, D), np.float32)
     parts = []
     nvis_tok = lay.NBv * BLOCK

@@ -164,8 +164,8 @@ def alloc_fp8_operands(spec: LayoutSpec, B: int, H: int, D: int, device) -> Dict
     return dict(q8=torch.empty((BH, SP, D), dtype=torch.uint8, device=device),
                 k8=torch.empty((BH, SP, D), dtype=torch.uint8, device=device),
                 v8t=torch.empty((BH, SP // 64, D, 64), dtype=torch.uint8, device=device),
-                scales=torch.empty((7 + 3 * spec.NB_total, BH), dtype=torch.float32, device=device))  # rows 0..3: scales
-    # of q, k, v and c; the rest is scratch (amax words, K1's per-block maxima)
+                scales=torch.empty((7 + 3 * spec.NB_total + D, BH), dtype=torch.float32, device=device))  # rows 0..3:
+    # scales of q, k, v and c; then scratch (amax words, K1's per-block maxima) and the [BH, D] K mean at the end
 
 
 class StagedCall:

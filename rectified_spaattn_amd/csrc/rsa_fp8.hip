@@ -6,11 +6,18 @@
 //               key the f8f6f4 MFMA's k-slot (lane half h, byte j) meets in the P operand built from two 32-key
 //               score accumulators:   key = 32*(j >> 4) + (j & 3) + 8*((j & 15) >> 2) + 4*h
 //      scales : [4, BH] fp32: dequantisation scales of q, k, v, then c = scale_q * scale_k * sm_scale * log2(e)
+//      kmean  : [BH, D] fp32 ("smooth K"): in the fused form (rsa_pool_stats_fp8) the mean over the visual blocks of
+//               K1's block means is subtracted from every K row before quantisation.  q.(k - mu) = q.k - q.mu shifts all
+//               scores of a query row by the same amount, so every softmax -- kept-block, text-row, dense -- is unchanged
+//               in exact arithmetic, while the common component real K tensors carry no longer eats the e4m3 mantissa.
+//               The K scale uses the bound amax|k - mu| <= amax|k| + max|mu| (no second pass; free for a float format).
+//               The stand-alone producer (rsa_quantize_fp8, dense path) uses mu = 0.
 // Numeric contract (bit-exact against oracle.fp8_operands): scale = amax / 448 (1 when the tensor is all zero) for K and
 // V; for Q the scale is stretched by less than 2x so that c is an exact power of two -- c = the smallest power of two
 // >= (amax_q/448 * scale_k) * qk_const, scale_q = c / (scale_k * qk_const), all in fp32 -- which costs e4m3 (a floating
 // point format) no precision and lets the kernel apply c through the MFMA's E8M0 scale operands.  Elements: widen
-// exactly to fp32, IEEE-divide by the scale, clamp to +-448, v_cvt_pk_fp8_f32 (round to nearest even, subnormals kept).
+// exactly to fp32, (subtract the K mean,) multiply by inv = fl(1 / scale), clamp to +-448, v_cvt_pk_fp8_f32 (round to
+// nearest even, subnormals kept).
 #include "rsa_common.h"
 
 namespace {
@@ -25,6 +32,7 @@ struct QuantArgs {
     unsigned* amax_bits; // [3, BH] fp32 bit patterns (non-negative floats order like unsigned ints)
     float* scales;       // [4, BH]
     float qk_const;      // sm_scale * log2(e)
+    const float* kmean;  // [BH, D] or nullptr (no smoothing)
     uint8_t *q8, *k8, *v8t;
     int H, BH;
     int S_pad[3];        // padded rows of each image (multiple of 128)
@@ -61,11 +69,30 @@ __global__ __launch_bounds__(256) void amax_kernel(QuantArgs a) {
     if ((t & 63) == 0 && m > 0.0f) atomicMax(a.amax_bits + which * a.BH + bh, __float_as_uint(m));
 }
 
-// one wave per (b,h): amax = max(atomic word, per-block maxima written by K1) -> scales
+// "smooth K" vector: mu[bh][d] = tree16(P_0..P_15) / NBv, P_g = sum in block order of kbar[j][d] over j = g (mod 16);
+// tree16 = the xor-tree of contract C6 (strides 1, 2, 4, 8).  grid (D / 16, BH), 256 threads = 16 g x 16 d.
+__global__ __launch_bounds__(256) void kmean_kernel(const float* kbar, int NBv, int D, float* kmean) {
+    const int bh = blockIdx.y, t = threadIdx.x;
+    const int g = t & 15, d = blockIdx.x * 16 + (t >> 4);  // the 16 partial sums of one d sit in 16 adjacent lanes
+    float p = 0.0f;
+    for (int j = g; j < NBv; j += 16) p = p + kbar[((long)bh * NBv + j) * D + d];
+    p = p + __shfl_xor(p, 1, 64);
+    p = p + __shfl_xor(p, 2, 64);
+    p = p + __shfl_xor(p, 4, 64);
+    p = p + __shfl_xor(p, 8, 64);
+    if (g == 0) kmean[(long)bh * D + d] = NBv > 0 ? p / (float)NBv : 0.0f;
+}
+
+// one wave per (b,h): amax = max(atomic word, per-block maxima written by K1) -> scales (K: + max |mu| when smoothing)
 __global__ __launch_bounds__(64) void scales_kernel(const unsigned* amax_bits, const float* amax_part, int NB_total,
                                                     int nb_q, int nb_k, int nb_v, float* scales, int BH,
-                                                    float qk_const) {
+                                                    float qk_const, int D, const float* kmean) {
     const int bh = blockIdx.x, lane = threadIdx.x;
+    float mu_max = 0.0f;
+    if (kmean != nullptr) {
+        for (int d = lane; d < D; d += 64) mu_max = fmaxf(mu_max, fabsf(kmean[(long)bh * D + d]));
+        for (int s = 1; s < 64; s <<= 1) mu_max = fmaxf(mu_max, __shfl_xor(mu_max, s, 64));
+    }
     float sc[3];
     const int nb[3] = {nb_q, nb_k, nb_v};
 #pragma unroll
@@ -74,6 +101,7 @@ __global__ __launch_bounds__(64) void scales_kernel(const unsigned* amax_bits, c
         if (amax_part != nullptr)
             for (int j = lane; j < nb[i]; j += 64) m = fmaxf(m, amax_part[((long)i * BH + bh) * NB_total + j]);
         for (int s = 1; s < 64; s <<= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
+        if (i == 1) m = m + mu_max;  // bound on amax |k - mu|
         sc[i] = m > 0.0f ? m / E4M3_MAX : 1.0f;
     }
     if (lane != 0) return;
@@ -90,20 +118,23 @@ __global__ __launch_bounds__(64) void scales_kernel(const unsigned* amax_bits, c
     scales[3 * BH + bh] = c;
 }
 
-__device__ __forceinline__ float q_clamp(float x, float scale) {
-    const float y = x / scale;
+// `inv` = 1 / scale (one IEEE division per thread); the per-element step is a single multiply
+__device__ __forceinline__ float q_clamp(float x, float inv) {
+    const float y = x * inv;
     return fminf(fmaxf(y, -E4M3_MAX), E4M3_MAX);
 }
 
-// 8 two-byte elements (one uint4) -> 8 e4m3 bytes (uint2)
+// 8 two-byte elements (one uint4) -> 8 e4m3 bytes (uint2); mu (8 floats) is subtracted first when given
 template <typename Tag>
-__device__ __forceinline__ uint2 quant8(uint4 raw, float scale) {
+__device__ __forceinline__ uint2 quant8(uint4 raw, float inv, const float* mu = nullptr) {
     const unsigned w4[4] = {raw.x, raw.y, raw.z, raw.w};
     float f[8];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        f[2 * e] = q_clamp(rsa_to_f32<Tag>((unsigned short)(w4[e] & 0xFFFF)), scale);
-        f[2 * e + 1] = q_clamp(rsa_to_f32<Tag>((unsigned short)(w4[e] >> 16)), scale);
+        float lo = rsa_to_f32<Tag>((unsigned short)(w4[e] & 0xFFFF)), hi = rsa_to_f32<Tag>((unsigned short)(w4[e] >> 16));
+        if (mu != nullptr) { lo = lo - mu[2 * e]; hi = hi - mu[2 * e + 1]; }
+        f[2 * e] = q_clamp(lo, inv);
+        f[2 * e + 1] = q_clamp(hi, inv);
     }
     int lo = 0, hi = 0;
     lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
@@ -113,28 +144,48 @@ __device__ __forceinline__ uint2 quant8(uint4 raw, float scale) {
     return make_uint2((unsigned)lo, (unsigned)hi);
 }
 
-// Q and K: 64 rows x D per workgroup, row-major bytes.  grid (S_pad / 64, BH, 2)
-template <int D, typename Tag>
+// Q and K: 256 rows x D per workgroup, row-major bytes.  grid (ceil(S_pad / 256), BH, 2); a thread owns one 32-element
+// column slice (so the K mean slice is loaded once) of four rows
+template <int D, typename Tag, bool SMOOTH_K>
 __global__ __launch_bounds__(256) void quant_rows_kernel(QuantArgs a) {
     constexpr int TPR = D / 32;  // threads per row, 32 elements each
     const int which = blockIdx.z, bh = blockIdx.y;
+    if (blockIdx.x * 256 >= a.S_pad[which]) return;
     const int b = bh / a.H, h = bh % a.H;
-    const float scale = a.scales[which * a.BH + bh];
-    if (blockIdx.x * 64 >= a.S_pad[which]) return;
+    const float scale = 1.0f / a.scales[which * a.BH + bh];  // reciprocal: elements are multiplied
     uint8_t* dst = (which == 0 ? a.q8 : a.k8) + (long)bh * a.S_pad[which] * D;
     const unsigned short* base = a.src[which] + (long)b * a.sb[which] + (long)h * a.sh[which];
-    const int t = threadIdx.x;
-    for (int rr = t / TPR; rr < 64; rr += 256 / TPR) {
-        const int row = blockIdx.x * 64 + rr, part = t % TPR;
-        uint2 o[4];
-        if (row < a.valid[which]) {
-            const unsigned short* p = base + (long)row * a.ss[which] + 32 * part;
+    const int t = threadIdx.x, part = t % TPR;
+    const bool smooth = SMOOTH_K && which == 1;
+    float mu[32];
+    if (smooth) {
+        const float4* mp = reinterpret_cast<const float4*>(a.kmean + (long)bh * D + 32 * part);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = quant8<Tag>(*reinterpret_cast<const uint4*>(p + 8 * i), scale);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = make_uint2(0, 0);
+        for (int i = 0; i < 8; ++i) {
+            const float4 m4 = mp[i];
+            mu[4 * i] = m4.x; mu[4 * i + 1] = m4.y; mu[4 * i + 2] = m4.z; mu[4 * i + 3] = m4.w;
         }
+    }
+    constexpr int NR = 256 / (256 / TPR);  // rows per thread (4 at D = 128)
+    uint4 raw[NR][4];
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {  // all loads first: 16 x 16 B in flight per lane
+        const int row = blockIdx.x * 256 + t / TPR + u * (256 / TPR);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            raw[u][i] = make_uint4(0, 0, 0, 0);
+            if (row < a.valid[which])
+                raw[u][i] = *reinterpret_cast<const uint4*>(base + (long)row * a.ss[which] + 32 * part + 8 * i);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+        const int row = blockIdx.x * 256 + t / TPR + u * (256 / TPR);
+        if (row >= a.S_pad[which]) break;
+        uint2 o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)  // rows >= valid were loaded as zeros; 0 - mu must still give a zero byte there
+            o[i] = row < a.valid[which] ? quant8<Tag>(raw[u][i], scale, smooth ? mu + 8 * i : nullptr) : make_uint2(0, 0);
         uint4* out = reinterpret_cast<uint4*>(dst + (long)row * D + 32 * part);
         out[0] = make_uint4(o[0].x, o[0].y, o[1].x, o[1].y);
         out[1] = make_uint4(o[2].x, o[2].y, o[3].x, o[3].y);
@@ -148,7 +199,7 @@ __global__ __launch_bounds__(256) void quant_vt_kernel(QuantArgs a) {
     constexpr int LROW = D + 16;  // padded LDS row (bytes)
     __shared__ __attribute__((aligned(16))) uint8_t tile[64 * LROW];
     const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
-    const float scale = a.scales[2 * a.BH + bh];
+    const float scale = 1.0f / a.scales[2 * a.BH + bh];  // reciprocal: elements are multiplied
     const unsigned short* base = a.src[2] + (long)b * a.sb[2] + (long)h * a.sh[2];
     const int t = threadIdx.x;
     for (int rr = t / TPR; rr < 64; rr += 256 / TPR) {
@@ -199,7 +250,7 @@ extern "C" int rsa_fp8_operand_bytes(const rsa_layout* l, size_t sizes[4], size_
     if (l->D != 128) return RSA_ERR_UNSUPPORTED;
     const size_t BH = (size_t)l->B * l->H, SP = (size_t)l->NB_total * RSA_BLOCK, D = l->D;
     const size_t s[4] = {BH * SP * D, BH * SP * D, BH * SP * D,
-                         (4 + 3 + 3 * (size_t)l->NB_total) * BH * 4};  // scales, amax words, per-block maxima
+                         (4 + 3 + 3 * (size_t)l->NB_total + D) * BH * 4};  // scales, amax words, per-block maxima, K mean
     size_t tot = 0;
     for (int i = 0; i < 4; ++i) { sizes[i] = s[i]; tot += align256(s[i]); }
     *total = tot;
@@ -244,7 +295,13 @@ int fill_args(const rsa_layout* l, const rsa_tensor4& q, const rsa_tensor4& k, c
     a.amax_bits = reinterpret_cast<unsigned*>(ops->scales + 4 * a.BH);
     a.qk_const = (float)((1.0 / sqrt((double)l->D)) * 1.44269504);
     a.q8 = ops->q8; a.k8 = ops->k8; a.v8t = ops->v8t;
+    a.kmean = nullptr;
     return RSA_OK;
+}
+
+// the K mean lives behind the scales, the amax words and K1's per-block maxima
+float* kmean_ptr(const rsa_layout* l, const QuantArgs& a) {
+    return reinterpret_cast<float*>(a.amax_bits) + (size_t)(3 + 3 * l->NB_total) * a.BH;
 }
 
 void launch_amax(const QuantArgs& a, int dtype, int ntensors, hipStream_t s) {
@@ -258,12 +315,14 @@ void launch_amax(const QuantArgs& a, int dtype, int ntensors, hipStream_t s) {
 
 int launch_images(const QuantArgs& a, int dtype, hipStream_t s) {
     const int sp = a.S_pad[0] > a.S_pad[1] ? a.S_pad[0] : a.S_pad[1];
-    const dim3 g_rows(sp / 64, a.BH, 2), g_vt(a.S_pad[2] / 64, a.BH);
+    const dim3 g_rows((sp + 255) / 256, a.BH, 2), g_vt(a.S_pad[2] / 64, a.BH);
     if (dtype == RSA_BF16) {
-        quant_rows_kernel<128, bf16_tag><<<g_rows, 256, 0, s>>>(a);
+        if (a.kmean) quant_rows_kernel<128, bf16_tag, true><<<g_rows, 256, 0, s>>>(a);
+        else quant_rows_kernel<128, bf16_tag, false><<<g_rows, 256, 0, s>>>(a);
         quant_vt_kernel<128, bf16_tag><<<g_vt, 256, 0, s>>>(a);
     } else {
-        quant_rows_kernel<128, fp16_tag><<<g_rows, 256, 0, s>>>(a);
+        if (a.kmean) quant_rows_kernel<128, fp16_tag, true><<<g_rows, 256, 0, s>>>(a);
+        else quant_rows_kernel<128, fp16_tag, false><<<g_rows, 256, 0, s>>>(a);
         quant_vt_kernel<128, fp16_tag><<<g_vt, 256, 0, s>>>(a);
     }
     return rsa_launch_status();
@@ -280,7 +339,7 @@ extern "C" int rsa_quantize_fp8(const rsa_layout* l, rsa_tensor4 q, rsa_tensor4 
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (hipMemsetAsync(a.amax_bits, 0, (size_t)3 * a.BH * 4, s) != hipSuccess) return rsa_launch_status();
     launch_amax(a, l->dtype, 3, s);
-    scales_kernel<<<a.BH, 64, 0, s>>>(a.amax_bits, nullptr, 0, 0, 0, 0, a.scales, a.BH, a.qk_const);
+    scales_kernel<<<a.BH, 64, 0, s>>>(a.amax_bits, nullptr, 0, 0, 0, 0, a.scales, a.BH, a.qk_const, 0, nullptr);
     return launch_images(a, l->dtype, s);
 }
 
@@ -300,8 +359,9 @@ extern "C" int rsa_pool_stats_fp8(const rsa_layout* l, rsa_tensor4 q, rsa_tensor
     a.lo[0] = vis_tok < l->S ? vis_tok : l->S;                    // q rows K1 did not read
     a.lo[1] = vis_tok < l->pool_valid ? vis_tok : l->pool_valid;  // k rows K1 did not read
     launch_amax(a, l->dtype, 2, s);
+    kmean_kernel<<<dim3(l->D / 16, a.BH), 256, 0, s>>>(buf->kbar, l->NBv, l->D, kmean_ptr(l, a));
     scales_kernel<<<a.BH, 64, 0, s>>>(a.amax_bits, amax_part, l->NB_total, l->NBv, l->NBv, l->NB_total, a.scales, a.BH,
-                                      a.qk_const);
+                                      a.qk_const, l->D, kmean_ptr(l, a));
     return rsa_launch_status();
 }
 
@@ -311,6 +371,7 @@ extern "C" int rsa_fp8_images(const rsa_layout* l, rsa_tensor4 q, rsa_tensor4 k,
     QuantArgs a;
     int st = fill_args(l, q, k, v, ops, a);
     if (st != RSA_OK) return st;
+    a.kmean = kmean_ptr(l, a);  // written by rsa_pool_stats_fp8
     return launch_images(a, l->dtype, static_cast<hipStream_t>(stream));
 }
 
@@ -361,6 +422,7 @@ int rsa_dense_quantize_fp8(int B, int H, int Sq, int Sk, int D, int dtype, rsa_t
     a.q8 = ops->q8; a.k8 = ops->k8; a.v8t = ops->v8t;
     if (hipMemsetAsync(a.amax_bits, 0, (size_t)3 * a.BH * 4, s) != hipSuccess) return rsa_launch_status();
     launch_amax(a, dtype, 3, s);
-    scales_kernel<<<a.BH, 64, 0, s>>>(a.amax_bits, nullptr, 0, 0, 0, 0, a.scales, a.BH, a.qk_const);
+    a.kmean = nullptr;
+    scales_kernel<<<a.BH, 64, 0, s>>>(a.amax_bits, nullptr, 0, 0, 0, 0, a.scales, a.BH, a.qk_const, 0, nullptr);
     return launch_images(a, dtype, s);
 }

@@ -159,8 +159,10 @@ def test_fp8_batch_and_strided_views():
 
 @pytest.mark.parametrize("mk", [lambda: orc.layout_hunyuan(4 * 128 + 256, 4 * 128 + 77), lambda: orc.layout_wan(300, 0),
                                 lambda: orc.layout_flux(3 * 128 + 128, 128)], ids=["hunyuan", "wan", "flux"])
-def test_fp8_fused_amax_equals_standalone_producer(mk):
-    """rsa_pool_stats_fp8 (maxima as K1's side product + text-tail rows) + rsa_fp8_images == rsa_quantize_fp8."""
+def test_fp8_fused_and_standalone_producers(mk):
+    """Fused form (rsa_pool_stats_fp8: maxima as K1's side product + text-tail rows, K mean from K1's block means;
+    rsa_fp8_images) and the stand-alone rsa_quantize_fp8 (own amax pass, no K mean) against their oracle contracts:
+    the V image and scale agree between the two."""
     from rectified_spaattn_amd import _core, synth
     lay = mk()
     q, k, v = synth.structured_qkv(808, 1, 2, lay.S, 128, smooth=0.0)
@@ -174,11 +176,41 @@ def test_fp8_fused_amax_equals_standalone_producer(mk):
     for t in call.fp8.values():
         t.zero_()
     call.quantize(standalone=True)
-    for n in ("q8", "k8", "v8t"):
-        assert torch.equal(fused[n], call.fp8[n]), n
-    assert torch.equal(fused["scales"][:4], call.fp8["scales"][:4])
-    ops = orc.fp8_operands(*(t.float().cpu().numpy() for t in (tq, tk, tv)), lay)
-    assert np.array_equal(fused["scales"][:4].cpu().numpy(), ops["scales"])
+    alone = call.fp8
+    qf, kf, vf = (t.float().cpu().numpy() for t in (tq, tk, tv))
+    of, oa = orc.fp8_operands(qf, kf, vf, lay, smooth_k=True), orc.fp8_operands(qf, kf, vf, lay, smooth_k=False)
+    BH = 2
+    for got, want, tag in ((fused, of, "fused"), (alone, oa, "stand-alone")):
+        assert np.array_equal(got["scales"][:4].cpu().numpy(), want["scales"]), tag
+        for n in ("q8", "k8", "v8t"):
+            assert np.array_equal(got[n].cpu().numpy(), want[n]), f"{tag} {n}"
+    kmean = fused["scales"].flatten()[-BH * 128:].view(BH, 128).cpu().numpy()
+    assert np.array_equal(kmean, of["kmean"])
+    # V is untouched by the smoothing; Q is not (its scale is stretched against the K scale to make c a power of two)
+    assert torch.equal(fused["v8t"], alone["v8t"]) and torch.equal(fused["scales"][2], alone["scales"][2])
+
+
+def test_fp8_smooth_k_removes_a_common_key_component():
+    """Real K tensors carry a large component shared by all tokens; q.(k - mu) only shifts each row's scores, so the
+    fused producer subtracts the per-head mean before quantising.  With a bias of ~6 sigma added to every key the
+    smoothed path stays at the unbiased error level while the unsmoothed images are several times worse."""
+    from rectified_spaattn_amd import _core, synth
+    lay = orc.layout_wan(6 * 128, 0)
+    q, k, v = synth.structured_qkv(515, 1, 2, lay.S, 128, smooth=0.0)
+    bias = np.random.default_rng(5).standard_normal(128).astype(np.float32) * 6.0
+    kb = k + bias[None, None, None, :]
+    tq, tk, tv = (torch.from_numpy(x).to(DEV, torch.bfloat16) for x in (q, kb, v))
+    qf, kf, vf = (t.float().cpu().numpy() for t in (tq, tk, tv))
+    ref16 = orc.rectified_attention(qf, kf, vf, lay, 99, 1.5, None)          # keep-all: the mask plays no role
+    call = _core.StagedCall(tq, tk, tv, _spec(lay), 99, 1.5, None, qkv_fp8=True)
+    call.select(); call.quantize()
+    smooth = call.attend().float().cpu().numpy().reshape(ref16.shape)
+    call.quantize(standalone=True)                                            # same scales for q and v, no K mean
+    plain = call.attend().float().cpu().numpy().reshape(ref16.shape)
+    e_s, e_p = np.abs(smooth - ref16).mean(), np.abs(plain - ref16).mean()
+    ref8 = orc.rectified_attention_fp8(qf, kf, vf, lay, 99, 1.5, None)
+    assert np.abs(smooth - ref8).max() <= FP8_MAX_VS_FP8
+    assert e_s <= FP8_MEAN_VS_BF16 and e_p >= 2.0 * e_s, f"smooth {e_s:.3e} plain {e_p:.3e}"
 
 
 @pytest.mark.parametrize("Sq,Sk,qs,ks", [(300, 520, None, None), (384, 384, 256, 200), (129, 1000, 1, 64)],

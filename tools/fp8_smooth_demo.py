@@ -1,0 +1,19 @@
+import sys, numpy as np, torch
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+from oracle import oracle as orc
+from rectified_spaattn_amd import _core, synth
+import test_gpu_fp8 as T
+lay = orc.layout_wan(6 * 128, 0)
+q, k, v = synth.structured_qkv(515, 1, 2, lay.S, 128, smooth=0.0)
+for scale in (0.0, 2.0, 6.0, 12.0):
+    bias = np.random.default_rng(5).standard_normal(128).astype(np.float32) * scale
+    kb = k + bias[None, None, None, :]
+    tq, tk, tv = (torch.from_numpy(x).to("cuda:0", torch.bfloat16) for x in (q, kb, v))
+    qf, kf, vf = (t.float().cpu().numpy() for t in (tq, tk, tv))
+    ref16 = orc.rectified_attention(qf, kf, vf, lay, 99, 1.5, None)
+    call = _core.StagedCall(tq, tk, tv, T._spec(lay), 99, 1.5, None, qkv_fp8=True)
+    call.select(); call.quantize()
+    smooth = call.attend().float().cpu().numpy().reshape(ref16.shape)
+    call.quantize(standalone=True)
+    plain = call.attend().float().cpu().numpy().reshape(ref16.shape)
+    print(f"K bias {scale:4.1f} sigma: mean|dO| vs bf16 oracle: smooth-K {np.abs(smooth-ref16).mean():.3e}  plain {np.abs(plain-ref16).mean():.3e}")
