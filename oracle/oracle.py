@@ -450,13 +450,35 @@ def fp8_operands(q, k, v, lay: Layout, smooth_k: bool = True):
                 k8=imgs[1], v8t=_v8t_from_image(imgs[2]))
 
 
+def fp8_dense_kmean(k):
+    """"Smooth K" vector of the dense fp8 path (contract of rsa_fp8.hip::amax_kernel's column sums + colmean_kernel):
+    per 1024-row chunk, P_g = sum in row order over the chunk's rows g, g+16, ...; wave w adds its four partial sums as
+    (P_4w + P_4w+1) + (P_4w+2 + P_4w+3); the chunk sum is (W0 + W1) + (W2 + W3); mu = (sum over chunks in order) / Sk."""
+    k = np.asarray(k, np.float32)
+    Sk, D = k.shape
+    tot = np.zeros(D, np.float32)
+    for r0 in range(0, Sk, 1024):
+        chunk = k[r0: r0 + 1024]
+        P = np.zeros((16, D), np.float32)
+        for i in range(0, chunk.shape[0], 16):           # rows i + g: one add per g, in row order
+            blk = chunk[i: i + 16]
+            P[: blk.shape[0]] = (P[: blk.shape[0]] + blk).astype(np.float32)
+        W = [((P[4 * w] + P[4 * w + 1]).astype(np.float32) + (P[4 * w + 2] + P[4 * w + 3]).astype(np.float32)).astype(np.float32)
+             for w in range(4)]
+        cs = ((W[0] + W[1]).astype(np.float32) + (W[2] + W[3]).astype(np.float32)).astype(np.float32)
+        tot = (tot + cs).astype(np.float32)
+    return (tot / np.float32(Sk)).astype(np.float32)
+
+
 def dense_attention_fp8(q, k, v, q_split: Optional[int] = None, kv_split: Optional[int] = None):
     """Dense attention of ONE head on e4m3 operands as rsa_dense_fwd_fp8 quantises them (per-head scales over all Sq /
-    Sk rows), two-segment semantics of attn.py:107-120.  q [Sq, D], k/v [Sk, D] fp32 -> [Sq, D]."""
+    Sk rows, K minus its column mean), two-segment semantics of attn.py:107-120.  q [Sq, D], k/v [Sk, D] fp32 -> [Sq, D].
+    (With two segments the shift q.mu is still one constant per query row, so both softmaxes are unchanged.)"""
     Sq, D = q.shape
     Sk = k.shape[0]
     pad = lambda n: (n + BLOCK - 1) // BLOCK * BLOCK
-    scales, imgs = _fp8_images([q[None], k[None], v[None]], (Sq, Sk, Sk), (pad(Sq), pad(Sk), pad(Sk)), D)
+    kmean = fp8_dense_kmean(k)[None]
+    scales, imgs = _fp8_images([q[None], k[None], v[None]], (Sq, Sk, Sk), (pad(Sq), pad(Sk), pad(Sk)), D, kmean)
     qd = dequantize_e4m3(imgs[0][0, :Sq]) * scales[0, 0]
     kd = dequantize_e4m3(imgs[1][0, :Sk]) * scales[1, 0]
     vd = dequantize_e4m3(imgs[2][0, :Sk]) * scales[2, 0]

@@ -11,7 +11,8 @@
 //               scores of a query row by the same amount, so every softmax -- kept-block, text-row, dense -- is unchanged
 //               in exact arithmetic, while the common component real K tensors carry no longer eats the e4m3 mantissa.
 //               The K scale uses the bound amax|k - mu| <= amax|k| + max|mu| (no second pass; free for a float format).
-//               The stand-alone producer (rsa_quantize_fp8, dense path) uses mu = 0.
+//               The dense path (rsa_dense_fwd_fp8) gets mu from column sums its amax pass takes along; the stand-alone
+//               rsa_quantize_fp8 uses mu = 0.
 // Numeric contract (bit-exact against oracle.fp8_operands): scale = amax / 448 (1 when the tensor is all zero) for K and
 // V; for Q the scale is stretched by less than 2x so that c is an exact power of two -- c = the smallest power of two
 // >= (amax_q/448 * scale_k) * qk_const, scale_q = c / (scale_k * qk_const), all in fp32 -- which costs e4m3 (a floating
@@ -33,6 +34,8 @@ struct QuantArgs {
     float* scales;       // [4, BH]
     float qk_const;      // sm_scale * log2(e)
     const float* kmean;  // [BH, D] or nullptr (no smoothing)
+    float* colsum_part;  // optional [BH, nchunk, D]: column sums of K per 1024-row chunk (dense path's K mean)
+    int nchunk;
     uint8_t *q8, *k8, *v8t;
     int H, BH;
     int S_pad[3];        // padded rows of each image (multiple of 128)
@@ -56,17 +59,58 @@ __global__ __launch_bounds__(256) void amax_kernel(QuantArgs a) {
         }
     };
     const long ss = a.ss[which];
+    const bool sums = which == 1 && a.colsum_part != nullptr;
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto fold_sum = [&](uint4 raw) {  // column sums of K in row order (this thread: rows g, g + 16, ...)
+        const unsigned w4[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            cs[2 * e] = cs[2 * e] + rsa_to_f32<Tag>((unsigned short)(w4[e] & 0xFFFF));
+            cs[2 * e + 1] = cs[2 * e + 1] + rsa_to_f32<Tag>((unsigned short)(w4[e] >> 16));
+        }
+    };
     int row = row0 + (t >> 4);
     for (; row + 112 < row1; row += 128) {  // 8 independent 16-byte loads in flight per lane
         uint4 raw[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) raw[u] = *reinterpret_cast<const uint4*>(base + (long)(row + 16 * u) * ss + 8 * c);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) fold(raw[u]);
+        for (int u = 0; u < 8; ++u) {
+            fold(raw[u]);
+            if (sums) fold_sum(raw[u]);
+        }
     }
-    for (; row < row1; row += 16) fold(*reinterpret_cast<const uint4*>(base + (long)row * ss + 8 * c));
+    for (; row < row1; row += 16) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(base + (long)row * ss + 8 * c);
+        fold(raw);
+        if (sums) fold_sum(raw);
+    }
     for (int s = 1; s < 64; s <<= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
     if ((t & 63) == 0 && m > 0.0f) atomicMax(a.amax_bits + which * a.BH + bh, __float_as_uint(m));
+    if (a.colsum_part != nullptr) {  // uniform per launch: every workgroup reaches the barrier
+        __shared__ float red[4][128];
+        if (sums) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                cs[e] = cs[e] + __shfl_xor(cs[e], 16, 64);
+                cs[e] = cs[e] + __shfl_xor(cs[e], 32, 64);
+            }
+            if ((t & 63) < 16)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) red[t >> 6][8 * c + e] = cs[e];
+        }
+        __syncthreads();
+        if (sums && t < 128 && (int)blockIdx.x < a.nchunk)
+            a.colsum_part[((long)bh * a.nchunk + blockIdx.x) * 128 + t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+    }
+}
+
+// dense path's "smooth K": mu[bh][d] = (sum over the 1024-row chunks, in order, of the chunk column sums) / rows
+__global__ __launch_bounds__(128) void colmean_kernel(const float* part, int nchunk, int rows, float* kmean) {
+    const int bh = blockIdx.x, d = threadIdx.x;
+    float sum = 0.0f;
+    for (int cidx = 0; cidx < nchunk; ++cidx) sum = sum + part[((long)bh * nchunk + cidx) * 128 + d];
+    kmean[(long)bh * 128 + d] = rows > 0 ? sum / (float)rows : 0.0f;
 }
 
 // "smooth K" vector: mu[bh][d] = tree16(P_0..P_15) / NBv, P_g = sum in block order of kbar[j][d] over j = g (mod 16);
@@ -295,7 +339,7 @@ int fill_args(const rsa_layout* l, const rsa_tensor4& q, const rsa_tensor4& k, c
     a.amax_bits = reinterpret_cast<unsigned*>(ops->scales + 4 * a.BH);
     a.qk_const = (float)((1.0 / sqrt((double)l->D)) * 1.44269504);
     a.q8 = ops->q8; a.k8 = ops->k8; a.v8t = ops->v8t;
-    a.kmean = nullptr;
+    a.kmean = nullptr; a.colsum_part = nullptr; a.nchunk = 0;
     return RSA_OK;
 }
 
@@ -379,7 +423,9 @@ extern "C" int rsa_fp8_images(const rsa_layout* l, rsa_tensor4 q, rsa_tensor4 k,
 static size_t dense_fp8_carve(int BH, int Sq, int Sk, int D, void* ws, rsa_fp8_operands* ops, int* sqp, int* skp) {
     const size_t SQ = (size_t)((Sq + RSA_BLOCK - 1) / RSA_BLOCK) * RSA_BLOCK;
     const size_t SK = (size_t)((Sk + RSA_BLOCK - 1) / RSA_BLOCK) * RSA_BLOCK;
-    const size_t s[4] = {align256(BH * SQ * D), align256(BH * SK * D), align256(BH * SK * D), align256((size_t)7 * BH * 4)};
+    const size_t nchunk = (SK + 1023) / 1024;
+    const size_t s[4] = {align256(BH * SQ * D), align256(BH * SK * D), align256(BH * SK * D),
+                         align256((size_t)(7 + D + nchunk * D) * BH * 4)};  // scales, amax words, K mean, chunk sums
     if (ops) {
         uint8_t* p = static_cast<uint8_t*>(ws);
         ops->q8 = p; p += s[0];
@@ -421,8 +467,14 @@ int rsa_dense_quantize_fp8(int B, int H, int Sq, int Sk, int D, int dtype, rsa_t
     a.qk_const = (float)((1.0 / sqrt((double)D)) * 1.44269504);
     a.q8 = ops->q8; a.k8 = ops->k8; a.v8t = ops->v8t;
     if (hipMemsetAsync(a.amax_bits, 0, (size_t)3 * a.BH * 4, s) != hipSuccess) return rsa_launch_status();
-    launch_amax(a, dtype, 3, s);
+    // smooth K: the amax pass also sums K's columns per 1024-row chunk; mu = their ordered sum / Sk
+    float* kmean = reinterpret_cast<float*>(a.amax_bits) + 3 * a.BH;
+    a.colsum_part = kmean + (size_t)D * a.BH;
+    a.nchunk = (Sk + 1023) / 1024;
     a.kmean = nullptr;
-    scales_kernel<<<a.BH, 64, 0, s>>>(a.amax_bits, nullptr, 0, 0, 0, 0, a.scales, a.BH, a.qk_const, 0, nullptr);
+    launch_amax(a, dtype, 3, s);
+    colmean_kernel<<<a.BH, 128, 0, s>>>(a.colsum_part, a.nchunk, Sk, kmean);
+    a.kmean = kmean;
+    scales_kernel<<<a.BH, 64, 0, s>>>(a.amax_bits, nullptr, 0, 0, 0, 0, a.scales, a.BH, a.qk_const, D, kmean);
     return launch_images(a, dtype, s);
 }

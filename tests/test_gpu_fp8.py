@@ -304,3 +304,23 @@ def test_fp8_random_layouts(case):
     assert np.isfinite(o).all()
     err = np.abs(o - ref8)
     assert err.max() <= 6e-2 and err.mean() <= 6e-3, f"case {i}: max {err.max():.3e} mean {err.mean():.3e}"
+
+
+def test_fp8_dense_smooth_k():
+    """Dense fp8 with a common component of 8 sigma on every key: stays at the unbiased error level."""
+    from rectified_spaattn_amd import _core
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn(1, 2, 700, 128, generator=g)
+    k = torch.randn(1, 2, 2300, 128, generator=g)
+    v = torch.randn(1, 2, 2300, 128, generator=g)
+    bias = torch.randn(128, generator=g) * 8.0
+    errs = []
+    for kk in (k, k + bias):
+        tq, tk, tv = (x.to(DEV, torch.bfloat16) for x in (q, kk, v))
+        o8 = _core.dense_attention(tq, tk, tv, qkv_fp8=True).float()
+        o16 = _core.dense_attention(tq, tk, tv).float()
+        errs.append((o8 - o16).abs().mean().item())
+        ref = orc.dense_attention_fp8(*(t[0, 1].float().cpu().numpy() for t in (tq, tk, tv)))
+        e = np.abs(o8[0, :, 1].cpu().numpy() - ref)
+        assert e.max() <= FP8_MAX_VS_FP8 and e.mean() <= FP8_MEAN_VS_FP8, f"{e.max():.3e} {e.mean():.3e}"
+    assert errs[1] <= 1.5 * errs[0] + 1e-3, errs
