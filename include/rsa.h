@@ -213,6 +213,11 @@ int rsa_rectified_attention_fp8(const rsa_layout* lay, rsa_tensor4 q, rsa_tensor
                                 size_t workspace_bytes, void* fp8_workspace, size_t fp8_workspace_bytes,
                                 rsa_out4 out, void* stream);
 
+/* TeaCache's step-skipping statistic (scripts/main_hunyuan.py:120, main_wan21t2v.py:112): out2[0] =
+ * sum |a - b|, out2[1] = sum |b| over two equal-length 2-byte tensors (n elements, 16-B aligned) in one HBM pass
+ * instead of the reference's five elementwise/reduction launches; scratch: >= 2048 floats.  DEVICE pointers. */
+int rsa_rel_l1(const void* a, const void* b, int64_t n, int dtype, float* out2, float* scratch, void* stream);
+
 /* rsa_dense_fwd with e4m3 operands (per-(b,h) scales computed inside): quantisation pass + the fp8 kernel in dense
  * mode.  workspace: >= *total of rsa_dense_fp8_bytes, 256-B aligned.  D = 128 only. */
 int rsa_dense_fp8_bytes(int B, int H, int Sq, int Sk, int D, size_t* total);

@@ -9,6 +9,7 @@ Module names mirror the reference package `rectified_spaattn`:
     rectified_wan22_attn      RectifiedWan{TI2V,T2V,I2V}SpaAttnProcessor2_0
     rectified_cogvideo_attn   rectified_block_sparse_attention, RectifiedCogVideoXVideoSpaAttnProcessor2_0
     attn_processor            get_attn_processors, set_attn_processor
+    teacache                  TeaCache step-skipping controller (scripts' teacache_forward bookkeeping), rel_l1_distance
 Device work goes through librsa_hip.so (C-ABI in include/rsa.h); nothing here falls back to PyTorch kernels.
 """
 __version__ = "0.1.0"

@@ -160,3 +160,68 @@ extern "C" int rsa_qk_norm_rope(int B, int H, int S, int D, int dtype, rsa_tenso
     }
     return rsa_launch_status();
 }
+
+// =====================================================================================================
+// rsa_rel_l1: sum |a - b| and sum |b| over two equal-length 2-byte tensors in ONE pass (TeaCache's step-skipping
+// statistic, scripts/main_hunyuan.py:120: ((x - prev).abs().mean() / prev.abs().mean()) is their ratio).  Fixed
+// reduction order: per thread in address order, per workgroup the C6 tree, then the workgroup partials in order.
+// =====================================================================================================
+namespace {
+constexpr int RL1_WGS = 1024;
+
+template <typename Tag>
+__global__ __launch_bounds__(256) void rel_l1_partial_kernel(const uint4* a, const uint4* b, long n16, float* part) {
+    __shared__ float red[4];
+    float sd = 0.0f, sb = 0.0f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) {
+        const uint4 ra = a[i], rb = b[i];
+        const unsigned wa[4] = {ra.x, ra.y, ra.z, ra.w}, wb[4] = {rb.x, rb.y, rb.z, rb.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a0 = rsa_to_f32<Tag>((unsigned short)(wa[e] & 0xFFFF)), a1 = rsa_to_f32<Tag>((unsigned short)(wa[e] >> 16));
+            const float b0 = rsa_to_f32<Tag>((unsigned short)(wb[e] & 0xFFFF)), b1 = rsa_to_f32<Tag>((unsigned short)(wb[e] >> 16));
+            sd = sd + fabsf(a0 - b0); sd = sd + fabsf(a1 - b1);
+            sb = sb + fabsf(b0); sb = sb + fabsf(b1);
+        }
+    }
+    const float td = block_tree_sum(sd, red);
+    const float tb = block_tree_sum(sb, red);
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = td; part[2 * blockIdx.x + 1] = tb; }
+}
+
+template <typename Tag>
+__global__ void rel_l1_final_kernel(const float* part, int nwg, const unsigned short* a, const unsigned short* b,
+                                    long tail0, long n, float* out2) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float sd = 0.0f, sb = 0.0f;
+    for (int i = 0; i < nwg; ++i) { sd = sd + part[2 * i]; sb = sb + part[2 * i + 1]; }
+    for (long i = tail0; i < n; ++i) {  // < 8 leftover elements
+        const float x = rsa_to_f32<Tag>(a[i]), y = rsa_to_f32<Tag>(b[i]);
+        sd = sd + fabsf(x - y); sb = sb + fabsf(y);
+    }
+    out2[0] = sd; out2[1] = sb;
+}
+}  // namespace
+
+extern "C" int rsa_rel_l1(const void* a, const void* b, int64_t n, int dtype, float* out2, float* scratch,
+                          void* stream) {
+    if (!a || !b || !out2 || !scratch || n < 0) return RSA_ERR_BAD_ARG;
+    if (dtype != RSA_BF16 && dtype != RSA_FP16) return RSA_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(a) & 15) || (reinterpret_cast<uintptr_t>(b) & 15)) return RSA_ERR_BAD_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long n16 = n / 8;
+    long want = (n16 + 256 * 8 - 1) / (256 * 8);
+    const int nwg = (int)(want < 1 ? 1 : (want > RL1_WGS ? RL1_WGS : want));
+    const uint4* pa = static_cast<const uint4*>(a);
+    const uint4* pb = static_cast<const uint4*>(b);
+    const unsigned short* ea = static_cast<const unsigned short*>(a);
+    const unsigned short* eb = static_cast<const unsigned short*>(b);
+    if (dtype == RSA_BF16) {
+        rel_l1_partial_kernel<bf16_tag><<<nwg, 256, 0, s>>>(pa, pb, n16, scratch);
+        rel_l1_final_kernel<bf16_tag><<<1, 64, 0, s>>>(scratch, nwg, ea, eb, n16 * 8, n, out2);
+    } else {
+        rel_l1_partial_kernel<fp16_tag><<<nwg, 256, 0, s>>>(pa, pb, n16, scratch);
+        rel_l1_final_kernel<fp16_tag><<<1, 64, 0, s>>>(scratch, nwg, ea, eb, n16 * 8, n, out2);
+    }
+    return rsa_launch_status();
+}

@@ -117,3 +117,38 @@ def test_processors_fused_producer_equals_unfused(which):
             continue
         assert f.shape == p.shape
         assert float((f.float() - p.float()).abs().max()) <= 3e-2
+
+
+@pytest.mark.parametrize("n,dt", [(8 * 1000 + 5, torch.bfloat16), (3, torch.float16), (1 * 4096 * 3072, torch.bfloat16)],
+                         ids=["ragged", "tiny", "large"])
+def test_rel_l1_reduction(n, dt):
+    """rsa_rel_l1 (TeaCache statistic, one pass) vs the reference expression evaluated in float64."""
+    from rectified_spaattn_amd.teacache import rel_l1_distance
+    g = torch.Generator().manual_seed(n % 1000)
+    a = torch.randn(n, generator=g).to(DEV, dt)
+    b = (a.float().cpu() + 0.1 * torch.randn(n, generator=g)).to(DEV, dt)
+    want = ((a.double() - b.double()).abs().mean() / b.double().abs().mean()).item()
+    got = rel_l1_distance(a, b)
+    assert abs(got - want) <= 2e-5 * want, (got, want)
+    assert rel_l1_distance(a, b) == got            # fixed reduction order: repeatable to the bit
+
+
+def test_teacache_on_device_skips_and_restores():
+    from rectified_spaattn_amd.teacache import TeaCache
+    tc = TeaCache.hunyuan(num_steps=10, rel_l1_thresh=0.5)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 4096, 256, generator=g).to(DEV, torch.bfloat16)
+    hidden = torch.zeros(1, 64, 32, device=DEV, dtype=torch.bfloat16)
+    decisions = []
+    for step in range(10):
+        x = x + 0.002 * torch.randn_like(x)
+        if tc.should_compute(x):
+            h_in = hidden.clone()
+            hidden = hidden + 1.0
+            tc.store_residual(hidden, h_in)
+            decisions.append(True)
+        else:
+            hidden = tc.apply_residual(hidden)
+            decisions.append(False)
+    assert decisions[0] and decisions[-1] and not all(decisions)
+    assert float(hidden.float().mean()) == 10.0     # a skipped step replays the cached residual (+1)
