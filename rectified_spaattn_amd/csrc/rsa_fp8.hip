@@ -188,52 +188,48 @@ __device__ __forceinline__ uint2 quant8(uint4 raw, float inv, const float* mu = 
     return make_uint2((unsigned)lo, (unsigned)hi);
 }
 
-// Q and K: 256 rows x D per workgroup, row-major bytes.  grid (ceil(S_pad / 256), BH, 2); a thread owns one 32-element
-// column slice (so the K mean slice is loaded once) of four rows
+// Q and K: 64 rows x D per workgroup, row-major bytes.  grid (S_pad / 64, BH, 2); a thread owns 32 elements of one row
 template <int D, typename Tag, bool SMOOTH_K>
 __global__ __launch_bounds__(256) void quant_rows_kernel(QuantArgs a) {
-    constexpr int TPR = D / 32;  // threads per row, 32 elements each
+    constexpr int TPR = D / 32;  // threads per row
     const int which = blockIdx.z, bh = blockIdx.y;
-    if (blockIdx.x * 256 >= a.S_pad[which]) return;
+    if (blockIdx.x * 64 >= a.S_pad[which]) return;
     const int b = bh / a.H, h = bh % a.H;
     const float scale = 1.0f / a.scales[which * a.BH + bh];  // reciprocal: elements are multiplied
     uint8_t* dst = (which == 0 ? a.q8 : a.k8) + (long)bh * a.S_pad[which] * D;
     const unsigned short* base = a.src[which] + (long)b * a.sb[which] + (long)h * a.sh[which];
     const int t = threadIdx.x, part = t % TPR;
-    const bool smooth = SMOOTH_K && which == 1;
-    float mu[32];
-    if (smooth) {
-        const float4* mp = reinterpret_cast<const float4*>(a.kmean + (long)bh * D + 32 * part);
+    const int row = blockIdx.x * 64 + t / TPR;
+    __shared__ __attribute__((aligned(16))) float smu[D];
+    if (SMOOTH_K && which == 1) {  // the head's K mean: one global read per workgroup, LDS reads per thread
+        if (t < D) smu[t] = a.kmean[(long)bh * D + t];
+        __syncthreads();
+    }
+    uint2 o[4];
+    if (row < a.valid[which]) {
+        const unsigned short* p = base + (long)row * a.ss[which] + 32 * part;
+        uint4 raw[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float4 m4 = mp[i];
-            mu[4 * i] = m4.x; mu[4 * i + 1] = m4.y; mu[4 * i + 2] = m4.z; mu[4 * i + 3] = m4.w;
+        for (int i = 0; i < 4; ++i) raw[i] = *reinterpret_cast<const uint4*>(p + 8 * i);
+        if (SMOOTH_K && which == 1) {
+            const float4* mp = reinterpret_cast<const float4*>(smu + 32 * part);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 m0 = mp[2 * i], m1 = mp[2 * i + 1];
+                const float mu[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+                o[i] = quant8<Tag>(raw[i], scale, mu);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = quant8<Tag>(raw[i], scale);
         }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = make_uint2(0, 0);
     }
-    constexpr int NR = 256 / (256 / TPR);  // rows per thread (4 at D = 128)
-    uint4 raw[NR][4];
-#pragma unroll
-    for (int u = 0; u < NR; ++u) {  // all loads first: 16 x 16 B in flight per lane
-        const int row = blockIdx.x * 256 + t / TPR + u * (256 / TPR);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            raw[u][i] = make_uint4(0, 0, 0, 0);
-            if (row < a.valid[which])
-                raw[u][i] = *reinterpret_cast<const uint4*>(base + (long)row * a.ss[which] + 32 * part + 8 * i);
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < NR; ++u) {
-        const int row = blockIdx.x * 256 + t / TPR + u * (256 / TPR);
-        if (row >= a.S_pad[which]) break;
-        uint2 o[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)  // rows >= valid were loaded as zeros; 0 - mu must still give a zero byte there
-            o[i] = row < a.valid[which] ? quant8<Tag>(raw[u][i], scale, smooth ? mu + 8 * i : nullptr) : make_uint2(0, 0);
-        uint4* out = reinterpret_cast<uint4*>(dst + (long)row * D + 32 * part);
-        out[0] = make_uint4(o[0].x, o[0].y, o[1].x, o[1].y);
-        out[1] = make_uint4(o[2].x, o[2].y, o[3].x, o[3].y);
-    }
+    uint4* out = reinterpret_cast<uint4*>(dst + (long)row * D + 32 * part);
+    out[0] = make_uint4(o[0].x, o[0].y, o[1].x, o[1].y);
+    out[1] = make_uint4(o[2].x, o[2].y, o[3].x, o[3].y);
 }
 
 // V: one 64-key tile per workgroup, transposed through LDS into the k-slot key order.  grid (S_pad / 64, BH)
@@ -359,7 +355,7 @@ void launch_amax(const QuantArgs& a, int dtype, int ntensors, hipStream_t s) {
 
 int launch_images(const QuantArgs& a, int dtype, hipStream_t s) {
     const int sp = a.S_pad[0] > a.S_pad[1] ? a.S_pad[0] : a.S_pad[1];
-    const dim3 g_rows((sp + 255) / 256, a.BH, 2), g_vt(a.S_pad[2] / 64, a.BH);
+    const dim3 g_rows(sp / 64, a.BH, 2), g_vt(a.S_pad[2] / 64, a.BH);
     if (dtype == RSA_BF16) {
         if (a.kmean) quant_rows_kernel<128, bf16_tag, true><<<g_rows, 256, 0, s>>>(a);
         else quant_rows_kernel<128, bf16_tag, false><<<g_rows, 256, 0, s>>>(a);
