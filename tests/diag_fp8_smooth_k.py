@@ -1,5 +1,8 @@
+"""Diagnostic script (uses the oracle, hence kept under tests/): run on the GPU box with python tests/diag_fp8_smooth_k.py."""
 import sys, numpy as np, torch
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import oracle as orc
 from rectified_spaattn_amd import _core, synth
 import test_gpu_fp8 as T
