@@ -1,4 +1,5 @@
-// Shared declarations of the K5 attention kernels (rsa_attn.hip: 4 waves x 32 rows; rsa_attn64.hip: 2 waves x 64 rows).
+// Shared declarations of the K5 attention kernels (rsa_attn_kernel.hip: bf16 / fp16; rsa_attn_fp8_kernel.hip: e4m3)
+// and their host sides (rsa_attn.hip).
 #pragma once
 #include <string.h>
 

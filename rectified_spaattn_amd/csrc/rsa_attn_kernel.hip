@@ -62,7 +62,7 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned short* lds_list = reinterpret_cast<unsigned short*>(lds + 4 * TILE_BYTES);
 
-    // ---------------- work mapping (same as the 4x32 kernel) ----------------
+    // ---------------- work mapping: dense text-row blocks first, then the sparse blocks chunked per XCD ----------------
     int bh, qblk;
     {
         const int bid = blockIdx.x;
