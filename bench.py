@@ -2,30 +2,40 @@
 """Attention-layer benchmark for the rectified block-sparse attention path (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One step = one pass of the whole hot path (K1 pool_stats .. K5 block_sparse_fwd) over one synthetic
 HunyuanVideo-720p attention call: B=1, H=24, S=115 200 visual + 256 text (200 valid), D=128, bf16, top_k = 90
-of 900 visual blocks (10 % kept), inputs already resident in HBM.  With N GPUs the 24 heads are sharded
-contiguously (24/N per rank, strong scaling, no data-path collective); time = max over ranks.
-Rank 0 prints ONE JSON line.
+of 900 visual blocks (10 % kept), inputs already resident in HBM, generated on the device by the counter-based
+generator of rectified_spaattn_amd/synth_device.py.
+
+--gpus N > 1: the 24 heads are sharded contiguously (24/N per rank, strong scaling, no data-path collective);
+time = max over ranks.  Launched without an outer launcher, this process never touches the GPU: it starts
+`python -m torch.distributed.run --nproc-per-node N` as a CHILD and exits with its code; launched under
+torch.distributed.run (WORLD_SIZE set) it is a rank.  Rank 0 prints ONE JSON line.
+
+The line's `value` is regime R2 of SURVEY.md 8(d) (exactly top_k kept visual blocks + the text blocks, independent
+block centroids).  Sub-records measured in the same run (N = 1): `regimes.r1` (Gilbert neighbours, p = 0.05),
+`regimes.locality` (spatially smooth centroids -> neighbouring query blocks keep overlapping lists, Gilbert
+neighbours, p = 0.05), `api` (the public operator and a processor __call__ end to end), `sustained` (>= 2 s of
+back-to-back steps), `cpu_baseline` (reference dense path + the rectified sparse path on the same mask, host cores).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 (MI355X_MICROARCH.md, chip-level parameters)
 MFMA_FP8_PEAK_TFLOPS = 5000.0   # MI355X dense fp8 (same table)
+SEED = 20251212                 # SURVEY 8(d): seed + global head index
 
 WORKLOADS = {
-    # name: (H, S_visual, text_pad, text_valid, top_k, variant)
     "hunyuan_720p_128f": dict(H=24, S_vis=115200, text=256, text_valid=200, top_k=90, variant="hunyuan",
                               latent=(32, 45, 80)),
     "flux_4096": dict(H=24, S_vis=65536, text=512, text_valid=512, top_k=51, variant="flux", latent=(1, 256, 256)),
@@ -36,29 +46,68 @@ WORKLOADS = {
     "tiny": dict(H=4, S_vis=4096, text=256, text_valid=200, top_k=6, variant="hunyuan", latent=(4, 32, 32)),
 }
 
-
-def gen_qkv(H_local, head0, S, S_vis, D, dev, seed=20251212, c=1.5, sigma=0.5):
-    """Structured synthetic Q/K/V (SURVEY 8(d)): per 128-token block a shared centroid for Q and K, V ~ N(0,1);
-    generated on device per head (seed + global head index)."""
-    q = torch.empty(1, H_local, S, D, dtype=torch.bfloat16, device=dev)
-    k = torch.empty_like(q)
-    v = torch.empty_like(q)
-    nb = (S + 127) // 128
-    for hl in range(H_local):
-        g = torch.Generator(device=dev)
-        g.manual_seed(seed + head0 + hl)
-        u = torch.randn(nb, D, generator=g, device=dev)
-        cent = u.repeat_interleave(128, dim=0)[:S] * c
-        q[0, hl] = (cent + sigma * torch.randn(S, D, generator=g, device=dev)).to(torch.bfloat16)
-        k[0, hl] = (cent + sigma * torch.randn(S, D, generator=g, device=dev)).to(torch.bfloat16)
-        v[0, hl] = torch.randn(S, D, generator=g, device=dev).to(torch.bfloat16)
-    return q, k, v
+# regime -> (centroid model, neighbour matrix, p_remain)
+REGIMES = {
+    "r2": ("iid", "none", 0.0),            # controlled: exactly top_k kept visual blocks per row (+ text blocks)
+    "r1": ("iid", "gilbert", 0.05),        # algorithmic: cumulative-probability rule + true Gilbert neighbours
+    "locality": ("spatial", "gilbert", 0.05),  # as r1 on spatially smooth centroids (overlapping kept lists)
+}
+K5_SOURCES = ("rsa_attn_kernel.hip", "rsa_attn.hip", "rsa_attn.h", "rsa_attn_fp8_kernel.hip")
 
 
-def cpu_baseline(S, D, budget_s=25.0):
+def kernel_source_sha() -> str:
+    """sha256 over the K5 sources: profiles/*traffic*.json carry the value they were collected with."""
+    h = hashlib.sha256()
+    for n in K5_SOURCES:
+        with open(os.path.join(ROOT, "rectified_spaattn_amd", "csrc", n), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def make_spec(wl):
+    from rectified_spaattn_amd import _core
+    S = wl["S_vis"] + wl["text"]
+    if wl["variant"] == "hunyuan":
+        return _core.LayoutSpec.hunyuan(S, wl["S_vis"] + wl["text_valid"])
+    if wl["variant"] == "flux":
+        return _core.LayoutSpec.flux(S, wl["text"])
+    return _core.LayoutSpec.wan(S, wl.get("ffb", 0))
+
+
+def make_neighbors(wl, spec, kind):
+    import torch
+    if kind == "none":
+        return None
+    if kind == "gilbert":
+        from rectified_spaattn_amd.utils import jenga_gilbert
+        return jenga_gilbert.gilbert_block_neighbor_mapping(*wl["latent"], axis_order=("w", "h", "t"))
+    from rectified_spaattn_amd import synth
+    return torch.from_numpy(synth.banded_neighbors(spec.NBv, int(kind)))
+
+
+def gen_qkv(H_local, head0, S, S_vis, D, dev, seed=SEED, centroid_fn=None):
+    """Structured synthetic Q/K/V from the counter-based generator, on the device, per head
+    (seed + global head index): per 128-token block a centroid shared by Q and K, V ~ N(0,1)."""
+    from rectified_spaattn_amd import synth_device
+    return synth_device.structured_qkv_device(seed, H_local, head0, S, D, dev, centroid_fn=centroid_fn)
+
+
+def gen_inputs(wl, H_local, head0, dev, centroids="iid", D=128, corr_len=6.0):
+    """Inputs of one regime: 'iid' block centroids (R2 / R1) or the spatially smooth field ('spatial', locality)."""
+    from rectified_spaattn_amd import synth_device
+    S = wl["S_vis"] + wl["text"]
+    fn = None
+    if centroids == "spatial":
+        field = synth_device.SpatialField(wl["latent"], (S + 127) // 128, corr_len=corr_len)
+        fn = lambda seed: field.centroids(seed, D)  # noqa: E731
+    return gen_qkv(H_local, head0, S, wl["S_vis"], D, dev, centroid_fn=fn)
+
+
+def cpu_baseline_dense(S, D, budget_s=20.0):
     """The reference's CPU dense path (fullattn mode='torch' = SDPA, attn.py:101-106) restated in
     oracle/dense_cpu.py, timed on this host's cores on a bounded sample: 1 head, as many query rows as fit the
     time budget, all S keys, bf16."""
+    import torch
     from oracle import dense_cpu
     ncores = os.cpu_count() or 1
     torch.set_num_threads(ncores)
@@ -71,7 +120,6 @@ def cpu_baseline(S, D, budget_s=25.0):
     t0 = time.perf_counter()
     dense_cpu.fullattn_torch_cpu(q, k, v)
     dt = time.perf_counter() - t0
-    # scale the sample towards the budget (bounded by the full S rows)
     rows2 = int(min(S, max(rows, rows * budget_s * 0.5 / max(dt, 1e-3))))
     if rows2 > rows * 2:
         q = torch.randn(1, 1, rows2, D, generator=g).to(torch.bfloat16)
@@ -85,150 +133,404 @@ def cpu_baseline(S, D, budget_s=25.0):
                        f"D={D}: {dt:.2f} s")
 
 
+def capture_sparse_sample(call):
+    """Head 0 of a finished call, copied to the host: inputs + the mask / rectification terms the GPU produced."""
+    return tuple(t[0, 0].cpu() for t in (call.q, call.k, call.v)) + tuple(
+        call.bufs[n][0].cpu() for n in ("cols", "counts", "R", "comp"))
+
+
+def cpu_baseline_sparse(sample, spec, D, budget_s=10.0):
+    """The rectified SPARSE path on the same mask the GPU used (oracle/sparse_cpu.py: per query block exact attention
+    over its kept blocks, then *R + comp), head 0 of this rank, a bounded sample of query blocks, bf16, host cores."""
+    import torch
+    from oracle import sparse_cpu
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    q, k, v, cols, counts, R, comp = sample
+    nb = 16
+    step = max(1, spec.NBv // nb)
+    blocks = list(range(0, spec.NBv, step))[:nb]
+    sparse_cpu.rectified_sparse_blocks_cpu(q, k, v, cols, counts, R, comp, spec.kv_valid, blocks[:2])  # warm-up
+    t0 = time.perf_counter()
+    sparse_cpu.rectified_sparse_blocks_cpu(q, k, v, cols, counts, R, comp, spec.kv_valid, blocks)
+    dt = time.perf_counter() - t0
+    nb2 = int(min(spec.NBv, max(nb, nb * budget_s * 0.6 / max(dt, 1e-3))))
+    if nb2 > nb * 2:
+        step = max(1, spec.NBv // nb2)
+        blocks = list(range(0, spec.NBv, step))[:nb2]
+        t0 = time.perf_counter()
+        sparse_cpu.rectified_sparse_blocks_cpu(q, k, v, cols, counts, R, comp, spec.kv_valid, blocks)
+        dt = time.perf_counter() - t0
+    pairs = int(counts[torch.tensor(blocks)].sum().item())
+    flops = 4.0 * D * 128 * 128 * pairs
+    return dict(value=flops / dt / 1e12, unit="TFLOP/s", cores=ncores, kind="port",
+                sample=f"rectified sparse path, same mask as the GPU run, head 0, {len(blocks)} query blocks "
+                       f"({pairs} kept block pairs), bf16 SDPA over gathered kept blocks + R/comp: {dt:.2f} s")
+
+
+# --------------------------------------------------------------------------------------------------------------
+# multi-process plumbing
+# --------------------------------------------------------------------------------------------------------------
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(args, argv) -> int:
+    """Parent of an N-rank run.  Nothing here imports torch.cuda or touches the GPU; the ranks are children of a
+    `torch.distributed.run` CHILD process (never an exec of this one)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_ADDR"] = "127.0.0.1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
+
+
+class Comm:
+    """torch.distributed in one place: nccl (= RCCL) on GPUs, gloo for --dry."""
+
+    def __init__(self, dry):
+        import torch
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dry = dry
+        self.dist = None
+        if dry:
+            self.dev = torch.device("cpu")
+        else:
+            self.dev = torch.device("cuda", self.local_rank)
+            torch.cuda.set_device(self.dev)
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if dry:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=self.dev)
+            self.dist = dist
+
+    def local_sync(self):
+        import torch
+        if not self.dry:
+            torch.cuda.synchronize()
+
+    def sync(self):
+        self.local_sync()
+        if self.dist is not None:
+            self.dist.barrier()
+        self.local_sync()
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+def timed_steps(comm, step, steps, warmup, events=None, want_busy=False):
+    """W untimed warm-up steps, then EXACTLY `steps` steps between barrier + synchronize on both sides.  Returns the
+    bracketed time (and, with want_busy, this rank's own time up to its local synchronize, before the closing
+    barrier -- what shows the imbalance between ranks)."""
+    for _ in range(warmup):
+        step(None)
+    comm.sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(events[i] if events is not None else None)
+    comm.local_sync()
+    busy = time.perf_counter() - t0
+    comm.sync()
+    total = time.perf_counter() - t0
+    return (total, busy) if want_busy else total
+
+
+# --------------------------------------------------------------------------------------------------------------
+def run_regime(comm, args, wl, regime, q, k, v, spec, steps, warmup, want_call=False):
+    """Times the staged hot path (select -> [quantize] -> attend) for one regime; returns the record (+ the call)."""
+    import torch
+    from rectified_spaattn_amd import _core, parallel
+    D = q.shape[-1]
+    _, nbr_kind, p = REGIMES[regime]
+    if args.neighbors is not None and regime == "r2":
+        nbr_kind = args.neighbors
+    if args.p_remain is not None and regime == "r2":
+        p = args.p_remain
+    nbr = make_neighbors(wl, spec, nbr_kind)
+    call = _core.StagedCall(q, k, v, spec, wl["top_k"], p, nbr, qkv_fp8=args.qkv_fp8)
+
+    def step(ev):
+        call.select()
+        if args.qkv_fp8:
+            call.quantize()
+        if ev is not None:
+            ev[0].record()
+        call.attend()
+        if ev is not None:
+            ev[1].record()
+
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    elapsed, busy = timed_steps(comm, step, steps, warmup, evs, want_busy=True)
+    k5_ms = sum(a.elapsed_time(b) for a, b in evs) / max(1, steps)
+    H_local = q.shape[1]
+    counts = float(call.bufs["counts"].sum().item())  # kept (q-block, k-block) pairs over local heads
+    local_flops = 4.0 * D * 128 * 128 * counts + 4.0 * D * spec.q_text_valid * spec.kv_text_valid * H_local
+    el_max, fl_sum, pairs_sum, k5_max, per_rank = parallel.reduce_step_stats(elapsed, local_flops, counts, k5_ms,
+                                                                            comm.dev, busy_s=busy)
+    H = wl["H"]
+    rec = dict(regime=regime, neighbors=nbr_kind, p_remain=p,
+               ms_per_step=el_max / steps * 1e3, value=fl_sum / (el_max / steps) / 1e12,
+               kept_block_fraction=pairs_sum / (H * spec.NBv * spec.NB_total),
+               k5_ms=k5_ms, k5_tflops=local_flops / (k5_ms * 1e-3) / 1e12,
+               select_pass_ms=el_max / steps * 1e3 - k5_max, per_rank_ms=[x / steps * 1e3 for x in per_rank],
+               flops=fl_sum, elapsed=el_max)
+    return (rec, call) if want_call else rec
+
+
+def api_record(comm, wl, spec, q, k, v, steps, warmup, staged_ms, with_processor):
+    """The PUBLIC entry points end to end (what a diffusers pipeline calls), regime r2: the reference-shaped operator
+    rectified_hunyuan_attn.rectified_block_sparse_attention and, optionally, a processor __call__ on a stand-in
+    attention module (random-init projections of the HunyuanVideo width)."""
+    import torch
+    from rectified_spaattn_amd import rectified_hunyuan_attn as rh
+    S = q.shape[2]
+    num_true = wl["S_vis"] + wl["text_valid"]
+    cu = [0, num_true, S]
+
+    def op_step(_):
+        rh.rectified_block_sparse_attention(q, k, v, attn_mask=None, top_k=wl["top_k"], cu_seqlens_q=cu,
+                                            cu_seqlens_kv=cu, max_seqlen_q=S, max_seqlen_kv=S,
+                                            block_neighbor_list=None, p_remain_rates=0.0)
+
+    el = timed_steps(comm, op_step, steps, warmup)
+    rec = dict(operator_ms=round(el / steps * 1e3, 4), staged_ms=round(staged_ms, 4),
+               operator_over_staged=round(el / steps * 1e3 / staged_ms, 4))
+    if with_processor:
+        import types
+        H, D = q.shape[1], q.shape[3]
+        dim = H * D
+        dev, dt = q.device, q.dtype
+        g = torch.Generator(device=dev).manual_seed(7)
+
+        def lin():
+            m = torch.nn.Linear(dim, dim, bias=True, device=dev, dtype=dt)
+            with torch.no_grad():
+                m.weight.copy_(torch.randn(dim, dim, generator=g, device=dev, dtype=torch.float32) * dim ** -0.5)
+                m.bias.zero_()
+            return m
+
+        attn = types.SimpleNamespace(heads=H, to_q=lin(), to_k=lin(), to_v=lin(),
+                                     to_out=torch.nn.ModuleList([lin(), torch.nn.Identity()]), norm_q=None,
+                                     norm_k=None, add_q_proj=None, add_k_proj=None, add_v_proj=None,
+                                     norm_added_q=None, norm_added_k=None, to_add_out=None)
+        proc = rh.RectifiedHunyuanVideoSpaAttnProcessor2_0("sparse", wl["top_k"], None, 0.0, 0)
+        hs = torch.randn(1, wl["S_vis"], dim, generator=g, device=dev, dtype=torch.float32).to(dt)
+        ehs = torch.randn(1, wl["text"], dim, generator=g, device=dev, dtype=torch.float32).to(dt)
+        mask = (torch.arange(S, device=dev) < num_true)[None, None, None, :]
+
+        def proc_step(_):
+            with torch.no_grad():
+                proc(attn, hs, encoder_hidden_states=ehs, attention_mask=mask)
+
+        def gemm_step(_):  # the projections alone (what the processor adds around the operator)
+            with torch.no_grad():
+                x = torch.cat([hs, ehs], dim=1)
+                attn.to_q(x), attn.to_k(x), attn.to_v(x)
+                attn.to_out[0](x[:, :wl["S_vis"]])
+
+        n = max(3, steps // 4)
+        elp = timed_steps(comm, proc_step, n, 2)
+        elg = timed_steps(comm, gemm_step, n, 2)
+        rec.update(processor_ms=round(elp / n * 1e3, 4), projections_ms=round(elg / n * 1e3, 4),
+                   processor_minus_projections_ms=round((elp - elg) / n * 1e3, 4))
+    return rec
+
+
+def load_traffic(name):
+    """PMC-derived memory-side bytes per launch of the dominant kernel, only if the json was collected from the kernel
+    sources that are built now (otherwise the number would silently go stale)."""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None, f"profiles/{name} not collected yet"
+    try:
+        d = json.load(open(path))
+    except (OSError, ValueError):
+        return None, f"profiles/{name} unreadable"
+    if d.get("kernel_source_sha") != kernel_source_sha():
+        return None, (f"profiles/{name} was collected from other kernel sources (sha {d.get('kernel_source_sha')} != "
+                      f"{kernel_source_sha()}); re-run tools/pmc_passes.sh")
+    return d.get("traffic_bytes_per_launch"), (f"L2 memory-side bytes/launch from rocprofv3 PMC passes "
+                                               f"(profiles/{name}, FETCH_SIZE x2 + WRITE_SIZE); includes Infinity-Cache "
+                                               f"hits; l2_hit_rate {d.get('l2_hit_rate')}")
+
+
+def dry_worker(args, comm):
+    """Host logic only (gloo, no GPU): sharding, barriers, max-over-ranks timing, the JSON line."""
+    from rectified_spaattn_amd import parallel
+    wl = WORKLOADS[args.workload]
+    H = wl["H"]
+    _, H_local = parallel.head_shard(H, comm.world, comm.rank)
+    spec = make_spec(wl)
+    pairs = float(H_local * spec.NBv * (wl["top_k"] + spec.NB_total - spec.NBv))
+    flops = 4.0 * 128 * 128 * 128 * pairs
+    elapsed, busy = timed_steps(comm, lambda ev: time.sleep(0.001 * (1 + comm.rank)), args.steps, args.warmup,
+                                want_busy=True)
+    el_max, fl_sum, _, _, per_rank = parallel.reduce_step_stats(elapsed, flops, pairs, 0.0, comm.dev, busy_s=busy)
+    if comm.rank == 0:
+        print(json.dumps({"metric": "dry run (host logic only, no GPU work)", "value": fl_sum / (el_max / args.steps) / 1e12,
+                          "unit": "TFLOP/s", "n_gpus": comm.world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": el_max / args.steps * 1e3, "dry": True, "heads_per_gpu": H_local,
+                          "per_rank_ms": [x / args.steps * 1e3 for x in per_rank],
+                          "imbalance": max(per_rank) / (sum(per_rank) / len(per_rank))}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="hunyuan_720p_128f", choices=list(WORKLOADS))
-    ap.add_argument("--p-remain", type=float, default=0.0,
-                    help="cumulative-probability threshold; 0 keeps exactly top_k visual blocks per row")
-    ap.add_argument("--neighbors", default="none",
-                    help="block-neighbour matrix: 'none' (exactly top_k kept: the 10 %% regime), 'gilbert' (true "
-                         "26-neighbourhood along the Gilbert curve of the workload's latent), or an int band width")
+    ap.add_argument("--regime", default="r2", choices=list(REGIMES), help="regime of the headline value")
+    ap.add_argument("--p-remain", type=float, default=None, help="override the cumulative-probability threshold (r2)")
+    ap.add_argument("--neighbors", default=None, help="override the block-neighbour matrix (r2): none | gilbert | <band>")
     ap.add_argument("--qkv-fp8", action="store_true",
                     help="K5 on e4m3 images of Q/K/V (fp8 MFMA); the quantisation pass is inside the timed step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gather-output", action="store_true", help="all-gather O along heads inside the timed region")
+    ap.add_argument("--no-extras", action="store_true", help="only the headline regime (no r1/locality/api/sustained)")
+    ap.add_argument("--via-api", action="store_true", help="also time a processor __call__ end to end")
+    ap.add_argument("--gather-output", action="store_true",
+                    help="N > 1: report only the variant with the all-gather of O along heads inside the timed region "
+                         "(default: both variants are measured and reported)")
+    ap.add_argument("--dry", action="store_true", help="host logic only (gloo, CPU): for the multi-process tests")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if args.gpus != world:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
-                  file=sys.stderr)
-        args.gpus = world
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
 
-    from rectified_spaattn_amd import _core, parallel, synth
-
-    wl = WORKLOADS[args.workload]
-    D = 128
-    H = wl["H"]
-    head0, H_local = parallel.head_shard(H, world, rank)
-    S = wl["S_vis"] + wl["text"]
-    if wl["variant"] == "hunyuan":
-        num_true = wl["S_vis"] + wl["text_valid"]
-        spec = _core.LayoutSpec.hunyuan(S, num_true)
-    elif wl["variant"] == "flux":
-        spec = _core.LayoutSpec.flux(S, wl["text"])
-    else:
-        spec = _core.LayoutSpec.wan(S, wl.get("ffb", 0))
-    q, k, v = gen_qkv(H_local, head0, S, wl["S_vis"], D, dev)
-    if args.neighbors == "none":
-        nbr = None
-    elif args.neighbors == "gilbert":
-        from rectified_spaattn_amd.utils import jenga_gilbert
-        nbr = jenga_gilbert.gilbert_block_neighbor_mapping(*wl["latent"], axis_order=("w", "h", "t"))
-    else:
-        nbr = torch.from_numpy(synth.banded_neighbors(spec.NBv, int(args.neighbors)))
-    top_k = wl["top_k"]
-
-    stages = _core.StagedCall(q, k, v, spec, top_k, args.p_remain, nbr, qkv_fp8=args.qkv_fp8)
-
-    def step(ev=None):
-        stages.select()
-        if args.qkv_fp8:
-            stages.quantize()
-        if ev is not None:
-            ev[0].record()
-        stages.attend()
-        if ev is not None:
-            ev[1].record()
-        if args.gather_output and world > 1:
-            parallel.gather_heads(stages.out)
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(evs[i])
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    k5_ms = sum(a.elapsed_time(b) for a, b in evs) / max(1, args.steps)
-
-    # work actually done (from the mask the selection kernels produced)
-    counts = stages.bufs["counts"].sum().item()  # kept (q-block, k-block) pairs over local heads
-    pair_flops = 4.0 * D * 128 * 128
-    text_flops = 4.0 * D * spec.q_text_valid * spec.kv_text_valid * H_local
-    local_flops = pair_flops * counts + text_flops
-    k5_ms_local = k5_ms
-    elapsed, total_flops, total_pairs, k5_ms, per_rank_s = parallel.reduce_step_stats(
-        elapsed, local_flops, float(counts), k5_ms, dev)
-    if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+    comm = Comm(args.dry)
+    if args.gpus != comm.world:
+        if comm.rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={comm.world}; using {comm.world}", file=sys.stderr)
+        args.gpus = comm.world
+    if args.dry:
+        dry_worker(args, comm)
+        comm.close()
         return
 
-    ms_per_step = elapsed / args.steps * 1e3
-    value = total_flops / (elapsed / args.steps) / 1e12
-    kept_frac = total_pairs / (H * spec.NBv * spec.NB_total)
-    k5_flops_local = local_flops  # rank-0 launch
-    achieved = k5_flops_local / (k5_ms_local * 1e-3) / 1e12
-    # HBM-side traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE with
-    # the gfx950 x2 correction; tools/pmc_to_json.py) of this same command; it cannot be collected inside this process.
-    traffic = None
-    tname = "r01_k5_fp8_traffic.json" if args.qkv_fp8 else "r01_k5_traffic.json"
-    tfile = os.path.join(ROOT, "profiles", tname)
-    if args.workload == "hunyuan_720p_128f" and args.neighbors == "none" and world == 1 and os.path.exists(tfile):
-        try:
-            traffic = json.load(open(tfile)).get("traffic_bytes_per_launch")
-        except (OSError, ValueError):
-            traffic = None
+    import torch
+    from rectified_spaattn_amd import parallel
+    world, rank, dev = comm.world, comm.rank, comm.dev
+    wl = WORKLOADS[args.workload]
+    D, H = 128, wl["H"]
+    head0, H_local = parallel.head_shard(H, world, rank)
+    S = wl["S_vis"] + wl["text"]
+    spec = make_spec(wl)
+
+    main_regime = args.regime
+    q, k, v = gen_inputs(wl, H_local, head0, dev, REGIMES[main_regime][0])
+    rec, call = run_regime(comm, args, wl, main_regime, q, k, v, spec, args.steps, args.warmup, want_call=True)
+    sample = capture_sparse_sample(call) if (world == 1 and not args.no_cpu_baseline) else None
+
+    extras = {}
+    gather = None
+    if world > 1:  # the optional exchange step at the layer boundary: all-gather of O along the head axis
+        def gstep(_):
+            call.select()
+            if args.qkv_fp8:
+                call.quantize()
+            call.attend()
+            parallel.gather_heads(call.out)
+        elg = timed_steps(comm, gstep, args.steps, max(1, args.warmup))
+        elg, _, _, _, per_rank_g = parallel.reduce_step_stats(elg, 0.0, 0.0, 0.0, dev)
+        gather = dict(ms_per_step=round(elg / args.steps * 1e3, 4),
+                      value=round(rec["flops"] / (elg / args.steps) / 1e12, 3),
+                      bytes_per_rank=int(call.out.numel() * call.out.element_size()),
+                      transport="torch.distributed all_gather (RCCL)")
+    if world == 1 and not args.no_extras:
+        # sustained: >= 2 s of back-to-back steps of the headline regime (what a power / utilisation sampler can see)
+        n_sus = max(args.steps, int(2.2 / max(rec["ms_per_step"] * 1e-3, 1e-4)))
+
+        def sstep(_):
+            call.select()
+            if args.qkv_fp8:
+                call.quantize()
+            call.attend()
+        els = timed_steps(comm, sstep, n_sus, 0)
+        extras["sustained"] = dict(steps=n_sus, seconds=round(els, 3), ms_per_step=round(els / n_sus * 1e3, 4),
+                                   value=round(rec["flops"] / (els / n_sus) / 1e12, 3))
+        if not args.qkv_fp8 and wl["variant"] == "hunyuan" and main_regime == "r2":
+            extras["api"] = api_record(comm, wl, spec, q, k, v, args.steps, args.warmup, rec["ms_per_step"],
+                                       args.via_api)
+        regs = {}
+        for rg in REGIMES:
+            if rg == main_regime:
+                continue
+            if REGIMES[rg][0] != REGIMES[main_regime][0]:
+                del call
+                q = k = v = None
+                torch.cuda.empty_cache()
+                q, k, v = gen_inputs(wl, H_local, head0, dev, REGIMES[rg][0])
+                r2, call = run_regime(comm, args, wl, rg, q, k, v, spec, max(5, args.steps // 2), 2, want_call=True)
+            else:
+                r2 = run_regime(comm, args, wl, rg, q, k, v, spec, max(5, args.steps // 2), 2)
+            peak_ = MFMA_FP8_PEAK_TFLOPS if args.qkv_fp8 else MFMA_BF16_PEAK_TFLOPS
+            regs[rg] = dict(neighbors=r2["neighbors"], p_remain=r2["p_remain"],
+                            kept_block_fraction=round(r2["kept_block_fraction"], 4),
+                            ms_per_step=round(r2["ms_per_step"], 4), value=round(r2["value"], 3),
+                            k5_ms=round(r2["k5_ms"], 4), k5_tflops=round(r2["k5_tflops"], 2),
+                            k5_frac=round(r2["k5_tflops"] / peak_, 4), select_pass_ms=round(r2["select_pass_ms"], 4))
+            tb, _ = load_traffic(f"r02_k5_traffic_{rg}.json")
+            regs[rg]["traffic"] = tb
+        extras["regimes"] = regs
+
+    if rank != 0:
+        comm.close()
+        return
+
     peak = MFMA_FP8_PEAK_TFLOPS if args.qkv_fp8 else MFMA_BF16_PEAK_TFLOPS
+    tname = f"r02_k5_traffic_{main_regime}{'_fp8' if args.qkv_fp8 else ''}.json"
+    traffic, tnote = (None, "N > 1: traffic is collected at N = 1")
+    if world == 1 and args.workload == "hunyuan_720p_128f":
+        traffic, tnote = load_traffic(tname)
+    per_rank_ms = [round(x, 3) for x in rec["per_rank_ms"]]
     res = {
         "metric": "attention-layer TFLOPs/sec (rectified block-sparse attention, HunyuanVideo seq~120k d=128 bf16)",
-        "value": round(value, 3), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "fp8_e4m3" if args.qkv_fp8 else "bf16", "data": "synthetic",
+        "value": round(rec["value"], 3), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(rec["ms_per_step"], 4), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "fp8_e4m3" if args.qkv_fp8 else "bf16",
+        "data": "synthetic (counter-based SplitMix64/Box-Muller generator on the device, seed 20251212 + head)",
         "config": {"workload": f"{args.workload}: B=1 H={H} S={S} ({wl['S_vis']} visual + {wl['text']} text, "
-                               f"{wl['text_valid']} valid) D={D}, top_k={top_k}, p_remain={args.p_remain}, "
-                               f"neighbors={args.neighbors}",
-                   "kept_block_fraction": round(kept_frac, 4), "heads_per_gpu": H_local,
-                   "dense_equivalent_tflops": round(4.0 * S * S * D * H / (elapsed / args.steps) / 1e12, 1),
-                   "gather_output": bool(args.gather_output), "parallelism": f"head-shard x{world}",
-                   "per_rank_ms": [round(x / args.steps * 1e3, 3) for x in per_rank_s]},
-        "roofline": {"kernel": "bsfwd_fp8_kernel<2> (K5 block_sparse_fwd_fp8)" if args.qkv_fp8 else
-                     "bsfwd_kernel<128,bf16_tag,4,1,258> (K5 block_sparse_fwd)", "bound": "mfma",
-                     "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                     "frac": round(achieved / peak, 4), "traffic": traffic,
-                     "traffic_note": f"L2 memory-side bytes/launch from rocprofv3 PMC (profiles/{tname}); "
-                                     "includes Infinity-Cache hits; compulsory Q+K+V+O = 2.84e9",
-                     "k5_ms": round(k5_ms_local, 4), "select_pass_ms": round(ms_per_step - k5_ms, 4)},  # + the fp8 quantisation pass with --qkv-fp8
+                               f"{wl['text_valid']} valid) D={D}, top_k={wl['top_k']}, regime={main_regime} "
+                               f"(p_remain={rec['p_remain']}, neighbors={rec['neighbors']})",
+                   "kept_block_fraction": round(rec["kept_block_fraction"], 4), "heads_per_gpu": H_local,
+                   "dense_equivalent_tflops": round(4.0 * S * S * D * H / (rec["elapsed"] / args.steps) / 1e12, 1),
+                   "parallelism": f"head-shard x{world}", "per_rank_ms": per_rank_ms,
+                   "imbalance": round(max(per_rank_ms) / (sum(per_rank_ms) / len(per_rank_ms)), 4),
+                   "gather_output": gather},
+        "roofline": {"kernel": "bsfwd_fp8_kernel (K5 block_sparse_fwd_fp8)" if args.qkv_fp8 else
+                     "bsfwd_kernel<128,bf16_tag,...> (K5 block_sparse_fwd)", "bound": "mfma",
+                     "achieved": round(rec["k5_tflops"], 2), "peak": peak, "unit": "TFLOP/s",
+                     "frac": round(rec["k5_tflops"] / peak, 4), "traffic": traffic, "traffic_note": tnote,
+                     "compulsory_bytes": 4 * 2 * H_local * S * D,
+                     "k5_ms": round(rec["k5_ms"], 4), "select_pass_ms": round(rec["select_pass_ms"], 4),
+                     "select_pass_tbps": round(2.0 * H_local * D * (wl["S_vis"] + 2 * S) /
+                                               max(rec["select_pass_ms"], 1e-6) / 1e9, 3)},
     }
-    if not args.no_cpu_baseline and world == 1:
-        res["cpu_baseline"] = cpu_baseline(S, D)
-    elif world == 1:
-        res["cpu_baseline"] = None
+    if args.gather_output and gather is not None:  # headline = the gather-inclusive variant on request
+        res["value"], res["ms_per_step"] = gather["value"], gather["ms_per_step"]
+    res.update(extras)
+    if world == 1:
+        if args.no_cpu_baseline:
+            res["cpu_baseline"] = None
+        else:
+            cb = cpu_baseline_dense(S, D)
+            try:
+                cb["sparse"] = cpu_baseline_sparse(sample, spec, D)
+            except Exception as e:  # noqa: BLE001  (the dense column must survive a failure of the sampled port)
+                cb["sparse"] = {"error": repr(e)}
+            res["cpu_baseline"] = cb
     print(json.dumps(res))
-    if world > 1:
-        dist.destroy_process_group()
+    comm.close()
 
 
 if __name__ == "__main__":

@@ -81,6 +81,15 @@ class LayoutSpec:
                          dtype_code(dtype))
 
 
+def check_head_dim(D: int) -> None:
+    """The reference asserts head_dim in {16, 32, 64, 128} (rectified_hunyuan_attn.py:119-121); the gfx950 kernels are
+    built for 64 and 128 (every model the reference ships: 128, CogVideoX 64).  16 / 32 are rejected here, before
+    anything is allocated, with the same AssertionError type."""
+    assert D in (16, 32, 64, 128), "head_dim must be in {16, 32, 64, 128}"  # reference :121
+    assert D in (64, 128), (f"head_dim {D}: the MI355X kernels are built for head_dim 64 and 128 "
+                            "(no reference pipeline uses 16 or 32)")
+
+
 def dtype_code(dtype: torch.dtype) -> int:
     if dtype == torch.bfloat16:
         return _lib.RSA_BF16
@@ -126,6 +135,34 @@ def buffer_shapes(spec: LayoutSpec, B: int, H: int, D: int) -> Dict[str, tuple]:
 
 def alloc_buffers(spec: LayoutSpec, B: int, H: int, D: int, device) -> Dict[str, torch.Tensor]:
     return {n: torch.empty(s, dtype=_BUF_DTYPES[n], device=device) for n, s in buffer_shapes(spec, B, H, D).items()}
+
+
+# Statistics / mask buffers are reused across calls of the same geometry on the same stream (a pipeline calls the
+# operator once per layer with identical shapes: 14 allocations + a ctypes struct per call otherwise).  Only
+# intermediates are cached -- the output tensor is always fresh, as in the reference.  Stream-ordered reuse is safe;
+# a different stream gets its own set.  A few entries at most (0.4 GB each at the HunyuanVideo shape).
+_BUF_CACHE: "Dict[tuple, Dict[str, torch.Tensor]]" = {}
+_BUF_CACHE_MAX = 4
+BUFFER_CACHE = True
+
+
+def cached_buffers(spec: LayoutSpec, B: int, H: int, D: int, device) -> Dict[str, torch.Tensor]:
+    if not BUFFER_CACHE:
+        return alloc_buffers(spec, B, H, D, device)
+    dev = torch.device(device)
+    stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
+    key = (dev.type, dev.index, stream, B, H, D, spec.S, spec.NB_total, spec.NBv, spec.n_txt)
+    hit = _BUF_CACHE.pop(key, None)
+    if hit is None:
+        while len(_BUF_CACHE) >= _BUF_CACHE_MAX:
+            _BUF_CACHE.pop(next(iter(_BUF_CACHE)))
+        hit = alloc_buffers(spec, B, H, D, device)
+    _BUF_CACHE[key] = hit  # most recently used last
+    return hit
+
+
+def clear_buffer_cache() -> None:
+    _BUF_CACHE.clear()
 
 
 def _c_buffers(bufs: Dict[str, torch.Tensor]) -> RsaBuffers:
@@ -175,19 +212,19 @@ class StagedCall:
     unchanged, so the kept lists are the 2-byte path's bit for bit."""
 
     def __init__(self, q, k, v, spec: LayoutSpec, top_k: int, p_remain: float, block_neighbor_list=None,
-                 qkv_fp8: bool = False):
+                 qkv_fp8: bool = False, reuse_buffers: bool = False):
         _require_device(q, k, v)
         self.L = _lib.lib()
         B, H, S, D = q.shape
         assert k.shape == q.shape and v.shape == q.shape, "q, k, v must have equal shapes (self-attention)"
-        assert D in (16, 32, 64, 128), "head_dim must be in {16, 32, 64, 128}"  # reference :121
+        check_head_dim(D)
         assert k.dtype == q.dtype and v.dtype == q.dtype
         if S != spec.S:
             raise ValueError(f"layout S={spec.S} does not match tensors S={S}")
         self.q, self.k, self.v = _as_bhsd(q), _as_bhsd(k), _as_bhsd(v)
         self.spec, self.top_k, self.p = spec, int(top_k), float(p_remain)
         self.lay = spec.to_c(B, H, D, q.dtype)
-        self.bufs = alloc_buffers(spec, B, H, D, q.device)
+        self.bufs = cached_buffers(spec, B, H, D, q.device) if reuse_buffers else alloc_buffers(spec, B, H, D, q.device)
         self.cb = _c_buffers(self.bufs)
         self.out = torch.empty((B, S, H, D), dtype=q.dtype, device=q.device)
         self.o4 = RsaOut4(self.out.data_ptr(), self.out.stride(0), self.out.stride(2), self.out.stride(1))
@@ -253,7 +290,9 @@ def rectified_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, spec:
     K1 pool_stats -> K2 pooled_scores -> K3 select_mask -> K4 compensation -> K5 block_sparse_fwd on the
     current stream; no host synchronisation, no K/V mutation (the reference zeroes masked K/V rows in place,
     hunyuan :307-308; here they are treated as zero by predication)."""
-    call = StagedCall(q, k, v, spec, top_k, p_remain, block_neighbor_list, qkv_fp8=qkv_fp8)
+    # return_parts hands the buffers to the caller, so those calls get their own set
+    call = StagedCall(q, k, v, spec, top_k, p_remain, block_neighbor_list, qkv_fp8=qkv_fp8,
+                      reuse_buffers=not return_parts)
     call.select()
     if qkv_fp8:
         call.quantize()
@@ -277,7 +316,7 @@ def dense_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, q_split: 
     B, H, Sq, D = q.shape
     Sk = k.shape[2]
     assert k.shape == v.shape and k.shape[0] == B and k.shape[1] == H and k.shape[3] == D
-    assert D in (16, 32, 64, 128), "head_dim must be in {16, 32, 64, 128}"
+    check_head_dim(D)
     q, k, v = _as_bhsd(q), _as_bhsd(k), _as_bhsd(v)
     q_split = Sq if q_split is None else int(q_split)
     kv_split = Sk if kv_split is None else int(kv_split)

@@ -91,9 +91,28 @@ def rotary(x: torch.Tensor, freqs):
         return (x.float() * cos + rot.float() * sin).to(x.dtype)
 
 
-def valid_keys(attention_mask, default: int) -> int:
-    """attention_mask.sum().item() -- the one host sync per call the reference also has (hunyuan :502)."""
-    return default if attention_mask is None else int(attention_mask.sum().item())
+_VALID_KEYS_MEMO = [None, -1, 0]  # weakref to the last mask tensor, its _version, its count
+
+
+def valid_keys(attention_mask, default: int, num_true: Optional[int] = None) -> int:
+    """attention_mask.sum().item() -- the host sync the reference pays in every layer (hunyuan :502).  Here it is paid
+    once per forward: the transformer hands the SAME mask tensor object to all of its blocks
+    (scripts/main_hunyuan.py:95-103, :128-150), so the count is remembered for that object (identity through a weak
+    reference + the tensor's in-place version counter).  A caller that already knows the count passes num_true."""
+    if num_true is not None:
+        return int(num_true)
+    if attention_mask is None:
+        return default
+    ref, ver, cnt = _VALID_KEYS_MEMO
+    if ref is not None and ref() is attention_mask and ver == attention_mask._version:
+        return cnt
+    cnt = int(attention_mask.sum().item())
+    import weakref
+    try:
+        _VALID_KEYS_MEMO[:] = [weakref.ref(attention_mask), attention_mask._version, cnt]
+    except TypeError:
+        _VALID_KEYS_MEMO[:] = [None, -1, 0]
+    return cnt
 
 
 # ---- fused producer path (SURVEY 8(f-3)) --------------------------------------------------------------

@@ -32,14 +32,17 @@ def gather_heads(out_local: torch.Tensor, group=None) -> torch.Tensor:
     return torch.cat(parts, dim=-1)
 
 
-def reduce_step_stats(elapsed_s: float, flops: float, pairs: float, k5_ms: float, device, group=None):
-    """(max elapsed, sum flops, sum kept pairs, max K5 ms, per-rank elapsed list) over all ranks."""
-    t = torch.tensor([elapsed_s, flops, pairs, k5_ms], dtype=torch.float64, device=device)
+def reduce_step_stats(elapsed_s: float, flops: float, pairs: float, k5_ms: float, device, group=None,
+                      busy_s: float = None):
+    """(max elapsed, sum flops, sum kept pairs, max K5 ms, per-rank list) over all ranks.  The per-rank list holds
+    each rank's own busy time `busy_s` (measured before the closing barrier; default: elapsed_s)."""
+    busy_s = elapsed_s if busy_s is None else busy_s
+    t = torch.tensor([busy_s, flops, pairs, k5_ms, elapsed_s], dtype=torch.float64, device=device)
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return elapsed_s, flops, pairs, k5_ms, [elapsed_s]
+        return elapsed_s, flops, pairs, k5_ms, [busy_s]
     tmax, tsum = t.clone(), t.clone()
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=group)
     dist.all_reduce(tsum, op=dist.ReduceOp.SUM, group=group)
     per_rank = [torch.empty_like(t) for _ in range(dist.get_world_size(group))]
     dist.all_gather(per_rank, t, group=group)
-    return tmax[0].item(), tsum[1].item(), tsum[2].item(), tmax[3].item(), [p[0].item() for p in per_rank]
+    return tmax[4].item(), tsum[1].item(), tsum[2].item(), tmax[3].item(), [p[0].item() for p in per_rank]

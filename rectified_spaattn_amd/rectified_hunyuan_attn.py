@@ -48,7 +48,10 @@ class RectifiedHunyuanVideoSpaAttnProcessor2_0:
         self.processor_id = processor_id
 
     def __call__(self, attn, hidden_states: torch.Tensor, encoder_hidden_states: Optional[torch.Tensor] = None,
-                 attention_mask: Optional[torch.Tensor] = None, image_rotary_emb=None):
+                 attention_mask: Optional[torch.Tensor] = None, image_rotary_emb=None,
+                 num_true: Optional[int] = None):
+        """num_true (optional, not in the reference): the count of valid keys = attention_mask.sum(), for callers that
+        computed it once per forward; without it the count is taken from the mask (one host sync per mask object)."""
         single_stream = attn.add_q_proj is None and encoder_hidden_states is not None
         n_txt = encoder_hidden_states.shape[1] if encoder_hidden_states is not None else 0
         if single_stream:  # single-stream blocks project the concatenated sequence
@@ -101,7 +104,7 @@ class RectifiedHunyuanVideoSpaAttnProcessor2_0:
                 q, k, v = torch.cat([q, eq], 2), torch.cat([k, ek], 2), torch.cat([v, ev], 2)
 
         B, H, S, D = q.shape
-        num_true = op.valid_keys(attention_mask, S)
+        num_true = op.valid_keys(attention_mask, S, num_true)
         cu = [0, num_true, S]
         if self.mode == "sparse":
             out = rectified_block_sparse_attention(q, k, v, attn_mask=attention_mask, top_k=self.select_block_num,

@@ -50,3 +50,22 @@ def test_head_shard_rules():
         parallel.head_shard(24, 5, 0)
     x = torch.zeros(1, 3, 2, 4)
     assert parallel.gather_heads(x).shape == (1, 3, 8)  # world of one: reshape only
+
+
+def test_bench_starts_its_own_ranks_dry():
+    """`python bench.py --gpus 2` with no outer launcher: the parent starts a torch.distributed.run child with two
+    ranks (gloo, --dry: host logic only) and rank 0 prints one JSON line for n_gpus = 2."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry", "--steps", "4",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 4 and rec["warmup"] == 1 and rec["heads_per_gpu"] == 12
+    assert len(rec["per_rank_ms"]) == 2 and rec["per_rank_ms"][1] > rec["per_rank_ms"][0]  # rank 1 sleeps longer
+    assert rec["imbalance"] > 1.05 and rec["ms_per_step"] >= max(rec["per_rank_ms"]) * 0.99

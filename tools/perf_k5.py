@@ -10,7 +10,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from bench import WORKLOADS, gen_qkv  # noqa: E402
+from bench import REGIMES, WORKLOADS, gen_inputs, gen_qkv, make_neighbors, make_spec  # noqa: E402
 from rectified_spaattn_amd import _core  # noqa: E402
 
 
@@ -28,10 +28,46 @@ def timeit(fn, n=5, warm=2):
     return ts[len(ts) // 2], ts[0]
 
 
+def regime_call(regime, H, dev, fp8=False):
+    """StagedCall of the Hunyuan bench workload in one of bench.REGIMES (inputs generated on the device)."""
+    wl = WORKLOADS["hunyuan_720p_128f"]
+    spec = make_spec(wl)
+    cent, nbr_kind, p = REGIMES[regime]
+    q, k, v = gen_inputs(wl, H, 0, dev, cent)
+    call = _core.StagedCall(q, k, v, spec, wl["top_k"], p, make_neighbors(wl, spec, nbr_kind), qkv_fp8=fp8)
+    return call, spec
+
+
+def call_flops(call, spec, H, D=128):
+    pairs = call.bufs["counts"].sum().item()
+    return 4.0 * D * 128 * 128 * pairs + 4.0 * D * spec.q_text_valid * spec.kv_text_valid * H, pairs
+
+
 def main():
     dev = torch.device("cuda:0")
     what = sys.argv[1:] or ["sparse", "dense"]
     D = 128
+    if "regimes" in what:  # K5 + select pass in every regime; kept-list overlap of adjacent query blocks
+        H = int(os.environ.get("RSA_PERF_H", "24"))
+        for regime in os.environ.get("RSA_PERF_REGIMES", "r2,r1,locality").split(","):
+            call, spec = regime_call(regime, H, dev)
+            call.select()
+            torch.cuda.synchronize()
+            flops, pairs = call_flops(call, spec, H)
+            med, mn = timeit(call.attend, n=7, warm=2)
+            msel, _ = timeit(call.select, n=5, warm=1)
+            bm = _core.unpack_bitmask(call.bufs["bitmask"][0], spec.NB_total)[:, :spec.NBv]
+            inter = (bm[:-1] & bm[1:]).sum(1).float()
+            uni = (bm[:-1] | bm[1:]).sum(1).float()
+            cnt = call.bufs["counts"].float()
+            print(f"regime {regime}: K5 median {med:.3f} ms (min {mn:.3f}) {flops/med/1e9:.1f} TFLOP/s pairs={pairs} "
+                  f"kept={pairs/(H*spec.NBv*spec.NB_total):.4f} counts min/mean/max {cnt.min().item():.0f}/"
+                  f"{cnt.mean().item():.1f}/{cnt.max().item():.0f} | select {msel:.3f} ms | adjacent-list overlap "
+                  f"(head 0) inter/union {(inter/uni).mean().item():.3f}, inter/own {(inter/bm[:-1].sum(1).float()).mean().item():.3f}",
+                  flush=True)
+            del call
+            torch.cuda.empty_cache()
+        return
     if "sparse" in what:
         H = int(os.environ.get("RSA_PERF_H", "24"))
         wl = WORKLOADS["hunyuan_720p_128f"]
@@ -48,14 +84,18 @@ def main():
         msel, _ = timeit(call.select)
         print(f"select pass: {msel:.3f} ms")
         del q, k, v, call
-    if "pmc" in what:  # few launches, for rocprofv3 --pmc passes
+    if "pmc" in what:  # few launches, for rocprofv3 --pmc passes (env RSA_PERF_REGIME selects the regime)
         H = 24
-        wl = WORKLOADS["hunyuan_720p_128f"]
-        S = wl["S_vis"] + wl["text"]
-        spec = _core.LayoutSpec.hunyuan(S, wl["S_vis"] + wl["text_valid"])
-        q, k, v = gen_qkv(H, 0, S, wl["S_vis"], D, dev)
         fp8 = os.environ.get("RSA_PERF_FP8", "0") == "1"
-        call = _core.StagedCall(q, k, v, spec, wl["top_k"], 0.0, None, qkv_fp8=fp8)
+        call, spec = regime_call(os.environ.get("RSA_PERF_REGIME", "r2"), H, dev, fp8=fp8)
+        if os.environ.get("RSA_PERF_NODENSE", "0") == "1":
+            for _ in range(3):
+                call.select()
+                if fp8:
+                    call.quantize()
+                call.attend()
+            torch.cuda.synchronize()
+            return
         for _ in range(2):
             call.select()
             if fp8:
