@@ -59,6 +59,37 @@ def _to_list(x):
     return [int(i) for i in x]
 
 
+def _splits_from_cu(cq, ck, B, S, S1):
+    """cu_seqlens_q / cu_seqlens_kv are segment boundaries over the packed [(b s), a, d] rows that
+    flash_attn_varlen_func receives (attn.py:107-120): segment j = q rows [cq[j], cq[j+1]) attending kv rows
+    [ck[j], ck[j+1]).  The HIP dense kernel serves, per batch item, one or two such segments: rows < q_split attend
+    kv [0, kv_split), rows >= q_split attend kv [kv_split, S1).  Accepted forms (all the reference builds):
+    get_cu_seqlens' 2B+1 entries (:34-57), the processors' 3 entries -- [0, valid, S] for B = 1 (hunyuan :503) and
+    [0, S, S*B] (cogvideo :481, flux, wan) where every batch item is one full segment -- and B+1 entries."""
+    if len(cq) != len(ck):
+        raise NotImplementedError(f"cu_seqlens_q / cu_seqlens_kv of different lengths ({len(cq)}, {len(ck)})")
+    segs = [(cq[j], cq[j + 1], ck[j], ck[j + 1]) for j in range(len(cq) - 1) if cq[j + 1] > cq[j]]
+    splits = []
+    for i in range(B):
+        q0, q1, k0, k1 = i * S, (i + 1) * S, i * S1, (i + 1) * S1
+        mine = [sg for sg in segs if sg[0] < q1 and sg[1] > q0]
+        ok = bool(mine) and mine[0][0] == q0 and mine[-1][1] == q1 and len(mine) <= 2
+        if ok and len(mine) == 1:
+            a, b, c, d = mine[0]
+            ok = c == k0 and k0 <= d <= k1
+            splits.append((S, d - k0))
+        elif ok:
+            (a, b, c, d), (a2, b2, c2, d2) = mine
+            ok = b == a2 and c == k0 and d == c2 and d2 == k1 and k0 <= d <= k1
+            splits.append((b - q0, d - k0))
+        if not ok:
+            raise NotImplementedError(
+                f"fullattn(mode='flash') on device: cu_seqlens_q={cq}, cu_seqlens_kv={ck} do not describe one or two "
+                f"segments per batch item (B={B}, S={S}, S1={S1}); supported: get_cu_seqlens' 2B+1 entries, "
+                f"[0, valid, S] for B = 1, [0, S, S*B], or B+1 entries")
+    return splits
+
+
 def _device_dense(q, k, v, splits):
     """q [b,a,s,d], k/v [b,a,s1,d]; splits: per batch item (q_split, kv_split).  Returns [b,a,s,d] view."""
     B = q.shape[0]
@@ -102,8 +133,8 @@ def fullattn(q, k, v, mode="flash", drop_rate=0, attn_mask=None, causal=False, c
             cq, ck = _to_list(cu_seqlens_q), _to_list(cu_seqlens_kv)
             if cq is None or ck is None:
                 splits = [(S, S1)] * B
-            else:  # segment pair i: [cu[2i], cu[2i+1]) and [cu[2i+1], cu[2i+2]) inside batch item i
-                splits = [(cq[2 * i + 1] - i * S, ck[2 * i + 1] - i * S1) for i in range(B)]
+            else:
+                splits = _splits_from_cu(cq, ck, B, S, S1)
         else:
             if attn_mask is None:
                 splits = [(S, S1)] * B

@@ -30,6 +30,22 @@ OP_CASES = ["wan_640", "wan_pad_1450", "wan_d64_1100", "wan_nonbr_1024", "hunyua
             "hunyuan_full_1536", "flux_1536", "cogvideo_994", "wan_smooth_2048"]
 
 
+# batch of two per layout (round 2).  wan has none: the reference operator cannot run B > 1 (rectified_wan21_attn.py:329
+# indexes with a per-batch tensor); tests/test_gpu_parity.py covers B = 2 for wan against the oracle alone.
+B2_CASES = ["b2_hunyuan_1280", "b2_flux_1280", "b2_cogvideo_994"]
+
+
+def reference_rows(meta, lay):
+    """bool [B, S]: rows of a golden `out` that the reference computes for that batch item.  B = 1: all.  B = 2: the
+    visual rows of both items, the text rows of item 0 only -- the reference's text-row flash call gets the 3-entry
+    cu_seqlens its callers build (rectified_hunyuan_attn.py:371-380), which describes ONE batch item of the packed
+    [(b s), a, d] tensor; item 1's text rows are checked against the oracle instead."""
+    ok = np.ones((meta["B"], meta["S"]), bool)
+    if meta["B"] > 1:
+        ok[1:, lay.NBv * 128:] = False
+    return ok
+
+
 def case_inputs(meta):
     """Regenerate the fixture's inputs (counter-based PRNG) and its oracle Layout + neighbour matrix."""
     from oracle import oracle as orc

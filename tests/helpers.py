@@ -82,3 +82,41 @@ def wan_freqs(S, head_dim):
     pos = torch.arange(S, dtype=torch.float64)[:, None]
     inv = 1.0 / (10000 ** (torch.arange(0, head_dim, 2, dtype=torch.float64) / head_dim))
     return torch.polar(torch.ones(S, head_dim // 2, dtype=torch.float64), pos * inv[None, :])[None, None]
+
+
+def wan22_rope(S, head_dim):
+    """(freqs_cos, freqs_sin) [1, S, 1, head_dim] as diffusers' Wan2.2 rotary module hands them over: every angle
+    repeated for its (even, odd) channel pair; the processor reads cos[..., 0::2] and sin[..., 1::2]."""
+    pos = torch.arange(S, dtype=torch.float32)[:, None]
+    inv = 1.0 / (10000 ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+    ang = (pos * inv[None, :]).repeat_interleave(2, dim=1)
+    return ang.cos()[None, :, None, :], ang.sin()[None, :, None, :]
+
+
+def fake_attn_wan_i2v(seed, heads, head_dim):
+    """Wan I2V cross-attention module: text keys + an image context through add_k_proj / add_v_proj / norm_added_k."""
+    a = fake_attn(seed, heads, head_dim, wan=True)
+    dim = heads * head_dim
+    a.add_k_proj, a.add_v_proj = _linear(seed, 6, dim, dim), _linear(seed, 7, dim, dim)
+    a.norm_added_k = RMS(dim)
+    a.modules_ += [a.add_k_proj, a.add_v_proj, a.norm_added_k]
+    return a
+
+
+# TeaCache pinning cases (tests/golden/make_golden.py::teacache ran the reference's own forwards on these sequences)
+TEACACHE_HUNYUAN_CASES = [  # (seed, drift, rel_l1_thresh, num_steps)
+    (1, 0.02, 0.15, 20), (2, 0.05, 0.1, 20), (3, 0.2, 0.3, 12)]
+TEACACHE_WAN_CASES = [  # (seed, drift, teacache_thresh, steps, model size key of the script, use_ret_steps)
+    (7, 0.004, 0.2, 12, "14B", True), (8, 0.05, 0.2, 12, "14B", False), (9, 0.003, 0.1, 10, "1.3B", True),
+    (10, 0.02, 0.08, 10, "1.3B", False)]
+
+
+def teacache_sequence(seed, n, drift, shape):
+    """Deterministic drifting tensor sequence (counter-based generator): x_i = x_{i-1} + drift*(1+0.5 sin i)*noise_i."""
+    x = torch.from_numpy(synth.normal(seed, 0, shape).astype(np.float32))
+    seq = []
+    for i in range(n):
+        x = x + float(drift * (1.0 + 0.5 * np.sin(i))) * torch.from_numpy(
+            synth.normal(seed, i + 1, shape).astype(np.float32))
+        seq.append(x.clone())
+    return seq

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import OP_CASES, case_inputs, load_op_case
+from conftest import B2_CASES, OP_CASES, case_inputs, load_op_case, reference_rows
 from oracle import oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -33,7 +33,7 @@ def _run(q, k, v, lay, top_k, p, nbr, dt):
     return out.float().cpu().numpy(), {n: t.cpu().numpy() for n, t in bufs.items()}, seen
 
 
-@pytest.mark.parametrize("name", OP_CASES)
+@pytest.mark.parametrize("name", OP_CASES + B2_CASES)
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 def test_operator_vs_oracle_and_golden(name, dt):
     meta, gold = load_op_case(name)
@@ -67,7 +67,7 @@ def test_operator_vs_oracle_and_golden(name, dt):
     err = np.abs(out - ref)
     assert err.max() <= mx and err.mean() <= mean, f"{name}: max {err.max():.3e} mean {err.mean():.3e}"
     if dt == torch.bfloat16:
-        e2 = np.abs(out - gold["out"])
+        e2 = np.abs(out - gold["out"])[reference_rows(meta, lay)]
         assert e2.max() <= mx and e2.mean() <= mean
 
 

@@ -1,0 +1,138 @@
+"""Round-2 processor coverage on the device: the three Wan2.2 processors (dense warm-up AND sparse branch), the CogVideoX
+sparse branch and CogVideoX with a batch of two (dense warm-up through fullattn 'flash' with cu_seqlens [0, S, 2S]).
+
+Checkers: (a) reference vectors (tests/golden/processors_r2.npz, produced by the reference's own processors on CPU in
+fp32) for everything dense -- tolerance 6e-2 because the device modules run bf16 linear layers; (b) for the sparse
+branches the oracle on the q / k / v the processor itself handed to the operator (captured), tolerance 2e-2 / 2e-3 as
+everywhere, plus the reference's sparse vector as a distance report (bf16 projections can flip near-tied blocks, so that
+one is asserted on the mean only)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from conftest import GOLDEN
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+G2 = np.load(os.path.join(GOLDEN, "processors_r2.npz"))
+heads, hd = 2, 128
+dim = heads * hd
+
+
+def _capture(module, fn_name="rectified_block_sparse_attention"):
+    captured = {}
+    orig = getattr(module, fn_name)
+
+    def spy(q, k, v, **kw):
+        captured["qkv"] = tuple(x.float().cpu().numpy() for x in (q, k, v))
+        captured["kw"] = kw
+        captured["out"] = orig(q, k, v, **kw)
+        return captured["out"]
+
+    setattr(module, fn_name, spy)
+    return captured, lambda: setattr(module, fn_name, orig)
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("which", ["ti2v", "t2v", "i2v"])
+def test_wan22_processors_on_device(which):
+    from rectified_spaattn_amd import rectified_wan21_attn as w21
+    from rectified_spaattn_amd import rectified_wan22_attn as w22
+    from rectified_spaattn_amd import synth
+    S = 900
+    a = helpers.attn_to(helpers.fake_attn(111, heads, hd, wan=True), DEV, torch.bfloat16)
+    hs = helpers.hidden(111, 20, 1, S, dim).to(DEV, torch.bfloat16)
+    rope = tuple(t.to(DEV) for t in helpers.wan22_rope(S, hd))
+    nbr = torch.from_numpy(synth.banded_neighbors(8, 1))
+    if which == "ti2v":
+        p = w22.RectifiedWanTI2VSpaAttnProcessor2_0("sparse", 2, nbr, 0.3, 3, 1)
+        top_k, pr, ffb, vec = 2, 0.3, 1, "w22_ti2v_sparse"
+        warm = p(a, hs, None, None, rope)      # step counter 0 < 10: dense warm-up through fullattn "flash"
+        assert np.abs(warm.float().cpu().numpy() - G2["w22_ti2v_warm"].astype(np.float32)).max() <= 6e-2
+        p.current_step = 10
+    elif which == "t2v":
+        p = w22.RectifiedWanT2VSpaAttnProcessor2_0("sparse", 3, nbr, 0.4, 5, 0, warm_steps=2)
+        top_k, pr, ffb, vec = 3, 0.4, 0, "w22_t2v_sparse"
+        p40 = w22.RectifiedWanT2VSpaAttnProcessor2_0("sparse", 3, nbr, 0.4, 40, 0, warm_steps=0)
+        d40 = p40(a, hs, None, None, rope)     # layer 40 (first layer of the second expert) stays dense
+        assert np.abs(d40.float().cpu().numpy() - G2["w22_t2v_layer40_dense"].astype(np.float32)).max() <= 6e-2
+        p.current_step = 2
+    else:
+        p = w22.RectifiedWanI2VSpaAttnProcessor2_0("sparse", 2, nbr, 0.3, 7, 2, warm_steps=0)
+        top_k, pr, ffb, vec = 2, 0.3, 2, "w22_i2v_sparse"
+    # _WanProcessorBase looks the operator up in rectified_wan21_attn's namespace
+    captured, restore = _capture(w21)
+    try:
+        o = p(a, hs, None, None, rope)
+    finally:
+        restore()
+    assert "qkv" in captured, "the sparse branch did not run"
+    q, k, v = captured["qkv"]
+    ref = orc.rectified_attention(q, k, v, orc.layout_wan(S, ffb), top_k, pr, nbr.numpy())
+    err = np.abs(captured["out"].float().cpu().numpy() - ref)
+    assert err.max() <= 2e-2 and err.mean() <= 2e-3, (which, err.max(), err.mean())
+    want = a.to_out[0](captured["out"])
+    assert torch.allclose(o.float(), want.float(), atol=1e-2)
+    dist = np.abs(o.float().cpu().numpy() - G2[vec].astype(np.float32))
+    assert dist.mean() <= 2e-2, (which, dist.mean(), dist.max())   # vs the reference's own sparse output (fp32 CPU run)
+    # cross attention of the same block type
+    pc = w22.RectifiedWanT2VSpaAttnProcessor2_0("flash", 2, None, 0.3, 5, 0)
+    oc = pc(a, hs, helpers.hidden(111, 23, 1, 512, dim).to(DEV, torch.bfloat16), None, None)
+    assert np.abs(oc.float().cpu().numpy() - G2["w22_cross"].astype(np.float32)).max() <= 6e-2
+
+
+@torch.no_grad()
+def test_cogvideo_sparse_branch_on_device():
+    from rectified_spaattn_amd import rectified_cogvideo_attn as cog
+    from rectified_spaattn_amd import synth
+    a = helpers.attn_to(helpers.fake_attn(106, 4, 64, added=False), DEV, torch.bfloat16)
+    hs = helpers.hidden(106, 20, 1, 768, 256).to(DEV, torch.bfloat16)
+    enc = helpers.hidden(106, 21, 1, 226, 256).to(DEV, torch.bfloat16)
+    rope = tuple(t.to(DEV) for t in helpers.rope_tables(768, 64))
+    nbr = torch.from_numpy(synth.banded_neighbors(6, 1))
+    p = cog.RectifiedCogVideoXVideoSpaAttnProcessor2_0("sparse", 2, nbr, 0.3, 0)
+    p.current_step = 5
+    captured, restore = _capture(cog)
+    try:
+        o, e = p(a, hs, enc, None, rope)
+    finally:
+        restore()
+    assert p.current_step == 6 and "qkv" in captured
+    q, k, v = captured["qkv"]
+    ref = orc.rectified_attention(q, k, v, orc.layout_cogvideo(994, 226), 2, 0.3, nbr.numpy())
+    err = np.abs(captured["out"].float().cpu().numpy() - ref)
+    assert err.max() <= 2e-2 and err.mean() <= 2e-3, (err.max(), err.mean())
+    assert o.shape == (1, 768, 256) and e.shape == (1, 226, 256)
+    full = torch.cat([o, e], 1).float().cpu().numpy()
+    gold = np.concatenate([G2["cog_sparse_out"], G2["cog_sparse_enc"]], 1).astype(np.float32)
+    assert np.abs(full - gold).mean() <= 2e-2
+
+
+@torch.no_grad()
+def test_cogvideo_batch_of_two_dense_warmup_on_device():
+    """fullattn(mode='flash') with the reference's 3-entry cu_seqlens [0, S, S*B] and B = 2."""
+    from rectified_spaattn_amd import rectified_cogvideo_attn as cog
+    a = helpers.attn_to(helpers.fake_attn(106, 4, 64, added=False), DEV, torch.bfloat16)
+    hs = helpers.hidden(106, 30, 2, 768, 256).to(DEV, torch.bfloat16)
+    enc = helpers.hidden(106, 31, 2, 226, 256).to(DEV, torch.bfloat16)
+    rope = tuple(t.to(DEV) for t in helpers.rope_tables(768, 64))
+    p = cog.RectifiedCogVideoXVideoSpaAttnProcessor2_0("sparse", 2, None, 0.3, 0)   # step 0 < 5: dense "flash"
+    o, e = p(a, hs, enc, None, rope)
+    assert np.abs(o.float().cpu().numpy() - G2["cog_b2_out"].astype(np.float32)).max() <= 6e-2
+    assert np.abs(e.float().cpu().numpy() - G2["cog_b2_enc"].astype(np.float32)).max() <= 6e-2
+
+
+def test_fullattn_flash_cu_seqlens_forms_on_device():
+    from rectified_spaattn_amd import attn, synth
+    q, k, v = (torch.from_numpy(x).to(DEV, torch.bfloat16) for x in synth.structured_qkv(5, 2, 2, 300, 64))
+    full = attn.fullattn(q, k, v, mode="torch")
+    for cu in ([0, 300, 600], torch.tensor([0, 300, 600], dtype=torch.int32, device=DEV), [0, 300, 300, 600, 600]):
+        got = attn.fullattn(q, k, v, mode="flash", cu_seqlens_q=cu, cu_seqlens_kv=cu, max_seqlen_q=300,
+                            max_seqlen_kv=300, batch_size=2)
+        assert torch.equal(got, full)
+    with pytest.raises(NotImplementedError):
+        attn.fullattn(q, k, v, mode="flash", cu_seqlens_q=[0, 300, 600], cu_seqlens_kv=[0, 450, 600])

@@ -192,3 +192,66 @@ def test_cabi_fp8_entry_points_validate_on_the_host():
     assert lib.rsa_dense_fp8_bytes(1, 2, 300, 500, 64, ctypes.byref(d)) == -2
     assert lib.rsa_dense_fp8_bytes(0, 2, 300, 500, 128, ctypes.byref(d)) == -1
     assert lib.rsa_set_tuning(b"no_such_key", 1) == -1
+
+
+# ---- round 2: Wan2.2 processors and B = 2 against reference vectors (tests/golden/processors_r2.npz) ------------------
+G2 = np.load(os.path.join(GOLDEN, "processors_r2.npz"))
+
+
+def close2(a, name, atol=3e-3):
+    np.testing.assert_allclose(a.detach().numpy(), G2[name].astype(np.float32), atol=atol, rtol=2e-3)
+
+
+@torch.no_grad()
+def test_wan22_processors_dense_cpu():
+    """RectifiedWan{TI2V,T2V,I2V}SpaAttnProcessor2_0.__call__ (reference rectified_wan22_attn.py:29-163, :181-288,
+    :306-413): projections through the non-fused helper, full-width RMSNorm, cos/sin RoPE on [B,S,H,D], dense CPU."""
+    from rectified_spaattn_amd import rectified_wan22_attn as w22
+    a = helpers.fake_attn(111, heads, hd, wan=True)
+    hs = helpers.hidden(111, 20, 1, 900, dim)
+    rope = helpers.wan22_rope(900, hd)
+    for cls, args in ((w22.RectifiedWanTI2VSpaAttnProcessor2_0, (3, 1)), (w22.RectifiedWanT2VSpaAttnProcessor2_0, (5, 0, 2)),
+                      (w22.RectifiedWanI2VSpaAttnProcessor2_0, (7, 2, 0))):
+        p = cls("torch", 2, None, 0.3, *args)
+        close2(p(a, hs, None, None, rope), "w22_ti2v_dense")      # dense attention: the same value for every class
+        assert p.current_step == 1
+    # cross attention (the reference ran it in "flash" mode = exact attention over the 512 text keys)
+    p = w22.RectifiedWanT2VSpaAttnProcessor2_0("torch", 2, None, 0.3, 5, 0)
+    close2(p(a, hs, helpers.hidden(111, 23, 1, 512, dim), None, None), "w22_cross")
+    # warm-up layers / steps of a "sparse" processor are dense: same numbers as the dense vector
+    assert np.abs(G2["w22_ti2v_warm"].astype(np.float32) - G2["w22_ti2v_dense"].astype(np.float32)).max() < 2e-3
+    assert np.abs(G2["w22_t2v_layer40_dense"].astype(np.float32) - G2["w22_ti2v_dense"].astype(np.float32)).max() < 2e-3
+
+
+@torch.no_grad()
+def test_wan_image_context_branch_is_the_intended_attention():
+    """Deliberate deviation: the reference's Wan2.2 image-context branch passes query as [B,S,H,D] to
+    SDPA against [B,H,S_img,D] keys (rectified_wan22_attn.py:94-97) and raises unless S == H (recorded by
+    make_golden.py: w22_imgctx_reference_runs == 0); Wan2.1's branch (rectified_wan21_attn.py:443-449) transposes first.
+    This package uses the Wan2.1 form for both: out = attention(q, text keys) + attention(q, image keys)."""
+    from rectified_spaattn_amd import rectified_wan22_attn as w22
+    assert int(G2["w22_imgctx_reference_runs"]) == 0
+    a = helpers.fake_attn_wan_i2v(112, heads, hd)
+    hs, enc = helpers.hidden(111, 20, 1, 300, dim), helpers.hidden(112, 24, 1, 512 + 17, dim)
+    p = w22.RectifiedWanI2VSpaAttnProcessor2_0("torch", 2, None, 0.3, 7, 0)
+    got = p(a, hs, enc, None, None)      # cross attention: no RoPE
+    # the same thing written out with plain torch ops
+    q = a.norm_q(a.to_q(hs)).unflatten(2, (heads, -1))
+    k = a.norm_k(a.to_k(enc[:, 17:])).unflatten(2, (heads, -1))
+    v = a.to_v(enc[:, 17:]).unflatten(2, (heads, -1))
+    ki = a.norm_added_k(a.add_k_proj(enc[:, :17])).unflatten(2, (heads, -1))
+    vi = a.add_v_proj(enc[:, :17]).unflatten(2, (heads, -1))
+    sd = torch.nn.functional.scaled_dot_product_attention
+    o = sd(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)) + sd(q.transpose(1, 2), ki.transpose(1, 2),
+                                                                          vi.transpose(1, 2))
+    want = a.to_out[0](o.transpose(1, 2).flatten(2, 3))
+    np.testing.assert_allclose(got.numpy(), want.numpy(), atol=2e-5)
+
+
+@torch.no_grad()
+def test_cogvideo_batch_of_two_dense():
+    """CogVideoX under classifier-free guidance: B = 2, cu_seqlens [0, S, 2S] (reference :478-498)."""
+    p = RectifiedCogVideoXVideoSpaAttnProcessor2_0("torch", 2, None, 0.3, 0)
+    o, e = p(helpers.fake_attn(106, 4, 64, added=False), helpers.hidden(106, 30, 2, 768, 256),
+             helpers.hidden(106, 31, 2, 226, 256), None, helpers.rope_tables(768, 64))
+    close2(o, "cog_b2_out"); close2(e, "cog_b2_enc")
