@@ -112,6 +112,10 @@ def lib():
                  "rsa_select_mask", "rsa_compensation", "rsa_block_sparse_fwd", "rsa_rectified_attention",
                  "rsa_dense_fwd", "rsa_estimate_pr_gain"):
         getattr(L, name).restype = i32
+    for key in ("k5_pp", "k5_prio"):   # kernel-variant switches for A/B runs and the test suite (debug hooks)
+        val = os.environ.get("RSA_" + key.upper())
+        if val is not None:
+            L.rsa_set_tuning(key.encode(), int(val))
     _lib = L
     return L
 

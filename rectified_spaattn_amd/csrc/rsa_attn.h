@@ -21,6 +21,12 @@ struct Elem<bf16_tag> {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
                                                        c, 0, 0, 0);
     }
+    // D = A.B + C with D and C in DIFFERENT registers (hipcc ties them and copies C first when given the builtin)
+    static __device__ __forceinline__ f32x16 mfma_from(s16x8 a, s16x8 b, const f32x16& c) {
+        f32x16 d;
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+        return d;
+    }
     static __device__ __forceinline__ unsigned short from_f32(float f) {
         return __builtin_bit_cast(unsigned short, (__bf16)f);
     }
@@ -36,6 +42,11 @@ struct Elem<fp16_tag> {
     static __device__ __forceinline__ f32x16 mfma(s16x8 a, s16x8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c,
                                                       0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x16 mfma_from(s16x8 a, s16x8 b, const f32x16& c) {
+        f32x16 d;
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+        return d;
     }
     static __device__ __forceinline__ unsigned short from_f32(float f) {
         return __builtin_bit_cast(unsigned short, (_Float16)f);
@@ -64,6 +75,7 @@ struct AttnArgs {
     int kv_valid, kv_text_valid, q_text_end;  // sparse mode (q_text_end = NBv*128 + q_text_valid)
     int q_split, kv_split;                    // dense mode
     int n_heavy_pad, NBp, BH;                 // work mapping
+    int NPp, list_cap;                        // ping-pong kernel: q-block pairs per head (padded to x8), list capacity
     float qk_scale;
 };
 

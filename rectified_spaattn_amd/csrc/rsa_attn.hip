@@ -7,20 +7,41 @@
 // =====================================================================================================
 static int g_k5_prio = 1;  // tuning hook: 1 = raise the wave's issue priority inside the pipelined block
 static int g_dense256 = 0;  // tuning hook: dense mode on 256-row query tiles (8 waves, one workgroup per CU)
+static int g_k5_pp = 0;     // 1 = the ping-pong kernel (rsa_attn_pp_kernel.hip): two query blocks per 8-wave workgroup
 
 void rsa_set_fp8_variant(int v);
 int rsa_launch_bsfwd(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int dtype, int prio, hipStream_t s);
+int rsa_launch_bsfwd_pp(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int dtype, int opt, hipStream_t s);
 
 // Tuning / diagnostics hook (not part of the data path).
 extern "C" int rsa_set_tuning(const char* key, int value) {
     if (!key) return RSA_ERR_BAD_ARG;
     if (strcmp(key, "k5_prio") == 0) { g_k5_prio = value; return RSA_OK; }
     if (strcmp(key, "dense256") == 0) { g_dense256 = value != 0; return RSA_OK; }
+    if (strcmp(key, "k5_pp") == 0) { g_k5_pp = value; return RSA_OK; }
     if (strcmp(key, "fp8_variant") == 0) { rsa_set_fp8_variant(value); return RSA_OK; }
     return RSA_ERR_BAD_ARG;
 }
 
+// ping-pong kernel: one workgroup per PAIR of query blocks
+static int launch_attn_pp(AttnArgs& a, int BH, int D, int dtype, hipStream_t s) {
+    const int ntq = a.NQB - a.NBv;
+    const int n_heavy = ntq > 0 ? BH * ((ntq + 1) / 2) : 0;
+    a.BH = BH;
+    a.n_heavy_pad = (n_heavy + 7) & ~7;
+    a.NPp = (((a.NBv + 1) / 2) + 7) & ~7;
+    a.NBp = (a.NBv + 7) & ~7;
+    a.list_cap = (a.NB_total + 7) & ~7;
+    const long nblocks = (long)a.n_heavy_pad + (long)BH * a.NPp;
+    if (nblocks <= 0) return RSA_OK;
+    if (nblocks > 0x7FFFFFFF) return RSA_ERR_UNSUPPORTED;
+    if (a.NB_total > 8192) return RSA_ERR_UNSUPPORTED;
+    const size_t lds_bytes = (size_t)8 * 64 * D * 2 + (size_t)4 * a.list_cap + 16;
+    return rsa_launch_bsfwd_pp(a, dim3((unsigned)nblocks), lds_bytes, D, dtype, g_k5_pp, s);
+}
+
 static int launch_attn(AttnArgs& a, int BH, int D, int dtype, hipStream_t s, int variant = -1) {
+    if (g_k5_pp && variant < 0) return launch_attn_pp(a, BH, D, dtype, s);
     const int ntq = a.NQB - a.NBv;
     const int n_heavy = ntq > 0 ? BH * ntq : 0;
     a.BH = BH;

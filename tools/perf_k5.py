@@ -68,6 +68,40 @@ def main():
             del call
             torch.cuda.empty_cache()
         return
+    if "pp" in what:  # A/B of the ping-pong K5 (tuning key k5_pp) against the 4-wave kernel, per regime, one process
+        from rectified_spaattn_amd import _lib
+        L = _lib.lib()
+        H = int(os.environ.get("RSA_PERF_H", "24"))
+        opts = [int(x) for x in os.environ.get("RSA_PERF_OPTS", "0,2").split(",")]
+        for regime in os.environ.get("RSA_PERF_REGIMES", "r2,locality").split(","):
+            call, spec = regime_call(regime, H, dev)
+            call.select()
+            torch.cuda.synchronize()
+            flops, pairs = call_flops(call, spec, H)
+            ref = None
+            for rnd in range(2):
+                for opt in opts:
+                    assert L.rsa_set_tuning(b"k5_pp", opt) == 0
+                    med, mn = timeit(call.attend, n=5, warm=2)
+                    o = call.out.float()
+                    if ref is None:
+                        ref = o.clone()
+                    d = (o - ref).abs()
+                    print(f"{regime} round {rnd} k5_pp={opt}: {med:7.3f} ms (min {mn:7.3f}) {flops/med/1e9:7.1f} TF/s | "
+                          f"max|d vs first| {d.max().item():.2e} mean {d.mean().item():.2e} nan={int(torch.isnan(o).sum())}",
+                          flush=True)
+            L.rsa_set_tuning(b"k5_pp", 0)
+            del call
+            torch.cuda.empty_cache()
+        Sd = 16384
+        qd, kd, vd = (torch.randn(1, 24, Sd, D, device=dev).to(torch.bfloat16) for _ in range(3))
+        fld = 4.0 * Sd * Sd * D * 24
+        for opt in opts + opts:
+            assert L.rsa_set_tuning(b"k5_pp", opt) == 0
+            medd, _ = timeit(lambda: _core.dense_attention(qd, kd, vd), n=3, warm=1)
+            print(f"dense16k k5_pp={opt}: {medd:6.3f} ms {fld/medd/1e9:7.1f} TF/s", flush=True)
+        L.rsa_set_tuning(b"k5_pp", 0)
+        return
     if "sparse" in what:
         H = int(os.environ.get("RSA_PERF_H", "24"))
         wl = WORKLOADS["hunyuan_720p_128f"]
