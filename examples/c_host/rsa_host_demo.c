@@ -41,7 +41,7 @@ int main(int argc, char** argv) {
     if (!f || fread(h_in, 1, 3 * bytes, f) != 3 * bytes) { fprintf(stderr, "cannot read %s\n", argv[1]); return 1; }
     fclose(f);
 
-    size_t sizes[14], total = 0, sizes8[4], total8 = 0;
+    size_t sizes[RSA_NUM_BUFFERS], total = 0, sizes8[4], total8 = 0;
     CHECK_RSA(rsa_buffer_bytes(&lay, sizes, &total));
     if (fp8) CHECK_RSA(rsa_fp8_operand_bytes(&lay, sizes8, &total8));
 

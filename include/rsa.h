@@ -80,15 +80,21 @@ typedef struct rsa_buffers {
     uint32_t* bitmask;/* [BH, NBv, ceil(NB_total/32)]  kept blocks, bit j%32 of word j/32 */
     int32_t* cols;    /* [BH, NBv, NB_total] kept block indices ascending (first counts[] entries valid) */
     int32_t* counts;  /* [BH, NBv]                                              */
+    /* query-block PAIRS (q-blocks 2p, 2p+1; NP = ceil(NBv/2)) whose kept lists overlap enough to be walked together by
+     * one 256-row workgroup of K5, each K/V tile staged once for both (K3b, run by rsa_select_mask after K3): */
+    uint16_t* pcols;  /* [BH, NP, NB_total] ascending UNION of the two lists: block | in_first<<14 | in_second<<15 */
+    int32_t* pcounts; /* [BH, NP]           entries of pcols                                                   */
+    int32_t* pair_ok; /* [BH, NP]           1 = K5 serves this pair with the paired workgroup, 0 = two 128-row ones */
 } rsa_buffers;
+#define RSA_NUM_BUFFERS 17
 
 /* Library identification: returns 10000*major + 100*minor + patch. */
 int rsa_version(void);
 
-/* Bytes needed for each rsa_buffers member, written in member order into sizes[14], and their sum
+/* Bytes needed for each rsa_buffers member, written in member order into sizes[RSA_NUM_BUFFERS], and their sum
  * (each rounded up to 256 B) into *total.  Lets a caller carve one workspace.  Replaces the ~25 temporaries
  * the reference allocates per call (hunyuan :189-262, :348-357). */
-int rsa_buffer_bytes(const rsa_layout* lay, size_t sizes[14], size_t* total);
+int rsa_buffer_bytes(const rsa_layout* lay, size_t sizes[RSA_NUM_BUFFERS], size_t* total);
 
 /* Carve `ws` (>= total bytes from rsa_buffer_bytes, 256-B aligned) into an rsa_buffers. */
 int rsa_carve_workspace(const rsa_layout* lay, void* ws, size_t ws_bytes, rsa_buffers* out);
@@ -109,6 +115,9 @@ int rsa_pooled_scores(const rsa_layout* lay, rsa_tensor4 k, const rsa_buffers* b
  * Replaces: hunyuan :208-277 (wan21 :206-271) and the rectification masks :348-355. */
 int rsa_select_mask(const rsa_layout* lay, const uint8_t* neighbor, int top_k, float p_remain,
                     const rsa_buffers* buf, void* stream);
+/* (K3b runs behind K3 only when the paired form of K5 is switched on -- rsa_set_tuning("k5_pair", 1), off by default --
+ * and buf->pcols, pcounts and pair_ok are all non-NULL: a pair is marked ok when the two kept lists share at least 30 %
+ * of the longer one.  The three members may be NULL; K5 then uses 128-row workgroups everywhere.) */
 
 /* K4 -- comp = w @ vbar.  Replaces torch.matmul(attn_pool_novalid, value_pool), hunyuan :357. */
 int rsa_compensation(const rsa_layout* lay, const rsa_buffers* buf, void* stream);

@@ -40,7 +40,8 @@ class RsaOut4(ctypes.Structure):
 
 
 BUFFER_NAMES = ("qbar", "aq", "kbar", "ak", "vbar", "scores", "unrel", "probs", "w", "R", "comp", "bitmask",
-                "cols", "counts")
+                "cols", "counts", "pcols", "pcounts", "pair_ok")
+NUM_BUFFERS = len(BUFFER_NAMES)
 
 
 class RsaBuffers(ctypes.Structure):
@@ -82,7 +83,7 @@ def lib():
     L.rsa_rel_l1.restype = i32
     L.rsa_set_tuning.argtypes = [ctypes.c_char_p, i32]
     L.rsa_set_tuning.restype = i32
-    L.rsa_buffer_bytes.argtypes = [P(RsaLayout), P(sz * 14), P(sz)]
+    L.rsa_buffer_bytes.argtypes = [P(RsaLayout), P(sz * NUM_BUFFERS), P(sz)]
     L.rsa_carve_workspace.argtypes = [P(RsaLayout), vp, sz, P(RsaBuffers)]
     L.rsa_pool_stats.argtypes = [P(RsaLayout), RsaTensor4, RsaTensor4, RsaTensor4, P(RsaBuffers), vp]
     L.rsa_pooled_scores.argtypes = [P(RsaLayout), RsaTensor4, P(RsaBuffers), vp]
@@ -112,10 +113,13 @@ def lib():
                  "rsa_select_mask", "rsa_compensation", "rsa_block_sparse_fwd", "rsa_rectified_attention",
                  "rsa_dense_fwd", "rsa_estimate_pr_gain"):
         getattr(L, name).restype = i32
-    for key in ("k5_pp", "k5_prio"):   # kernel-variant switches for A/B runs and the test suite (debug hooks)
+    # kernel-variant switches for A/B runs and the variant tests; rsa_set_tuning works only under RSA_TUNING=1
+    for key in ("k5_pp", "k5_prio", "k5_maxblocks"):
         val = os.environ.get("RSA_" + key.upper())
         if val is not None:
-            L.rsa_set_tuning(key.encode(), int(val))
+            check_rc = L.rsa_set_tuning(key.encode(), int(val))
+            if check_rc != 0:
+                raise RsaError(f"RSA_{key.upper()} is set but rsa_set_tuning refused it (export RSA_TUNING=1)")
     _lib = L
     return L
 

@@ -54,7 +54,8 @@ def set_dense_fp8(enabled: bool) -> bool:
 
 def run(variant: str, query, key, value, top_k, prob_threshold, block_neighbor_list, shape_xfuse,
         cu_seqlens_q=None, cu_seqlens_kv=None, text_length: int = 256, first_frame_blocks=None,
-        block_size_M: int = 128, block_size_N: int = 128):
+        block_size_M: int = 128, block_size_N: int = 128, qkv_fp8: Optional[bool] = None):
+    """qkv_fp8: per-call choice of the K5 operand precision (None = the process default set_qkv_fp8())."""
     _check_blocks(block_size_M, block_size_N)
     B, H, S, D = query.shape
     if variant == "hunyuan":
@@ -68,7 +69,8 @@ def run(variant: str, query, key, value, top_k, prob_threshold, block_neighbor_l
     else:
         raise ValueError(variant)
     return _core.rectified_attention(query, key, value, spec, int(top_k), float(prob_threshold),
-                                     block_neighbor_list, shape_xfuse=shape_xfuse, qkv_fp8=QKV_FP8 and D == 128)
+                                     block_neighbor_list, shape_xfuse=shape_xfuse,
+                                     qkv_fp8=(QKV_FP8 if qkv_fp8 is None else bool(qkv_fp8)) and D == 128)
 
 
 # ---- small helpers shared by the processors ---------------------------------------------------------

@@ -76,6 +76,10 @@ struct AttnArgs {
     int q_split, kv_split;                    // dense mode
     int n_heavy_pad, NBp, BH;                 // work mapping
     int NPp, list_cap;                        // ping-pong kernel: q-block pairs per head (padded to x8), list capacity
+    const uint16_t* pcols;                    // paired workgroups (K3b): [BH, NP, NB_total] union lists with flag bits
+    const int32_t* pcounts;                   // [BH, NP]
+    const int32_t* pair_ok;                   // [BH, NP]; null = no pairing
+    int NP;
     float qk_scale;
 };
 

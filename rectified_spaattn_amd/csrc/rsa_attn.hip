@@ -1,5 +1,7 @@
 // K5 host side: argument checks and launches of the block-sparse attention kernel (rsa_attn_kernel.hip).
 // rsa_block_sparse_fwd, rsa_dense_fwd and rsa_rectified_attention of include/rsa.h live here.
+#include <stdlib.h>
+
 #include "rsa_attn.h"
 
 // =====================================================================================================
@@ -7,18 +9,31 @@
 // =====================================================================================================
 static int g_k5_prio = 1;  // tuning hook: 1 = raise the wave's issue priority inside the pipelined block
 static int g_dense256 = 0;  // tuning hook: dense mode on 256-row query tiles (8 waves, one workgroup per CU)
+// 1 = serve "ok" query-block pairs (K3b) with the paired 256-row workgroups.  Off by default: measured on the locality
+// regime of bench.py (78 % of a kept list shared with the neighbouring block) it cuts K5's fabric traffic from 73 GB to
+// 48 GB per launch but takes 21.6 instead of 16.1 ms -- the union walk is 1.22 lists long and a tile kept by only one
+// block of the pair still costs a full tile time of the 8-wave workgroup.
+int g_rsa_k5_pair = 0;
+static int g_k5_maxblocks = 0;  // diagnostics: launch only the first N workgroups of K5 (partial result!)
 static int g_k5_pp = 0;     // 1 = the ping-pong kernel (rsa_attn_pp_kernel.hip): two query blocks per 8-wave workgroup
 
 void rsa_set_fp8_variant(int v);
 int rsa_launch_bsfwd(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int dtype, int prio, hipStream_t s);
+int rsa_launch_bsfwd_pair(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int dtype, hipStream_t s);
 int rsa_launch_bsfwd_pp(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int dtype, int opt, hipStream_t s);
 
-// Tuning / diagnostics hook (not part of the data path).
+// Tuning / diagnostics hook (not part of the data path).  The switches are process-global, so the hook only works in a
+// process that opted in with the environment variable RSA_TUNING=1 (the A/B tools and the variant tests); a production
+// host cannot have its kernels changed under it by another library user.
 extern "C" int rsa_set_tuning(const char* key, int value) {
+    static const bool enabled = [] { const char* e = getenv("RSA_TUNING"); return e && e[0] == '1'; }();
     if (!key) return RSA_ERR_BAD_ARG;
+    if (!enabled) return RSA_ERR_UNSUPPORTED;
     if (strcmp(key, "k5_prio") == 0) { g_k5_prio = value; return RSA_OK; }
     if (strcmp(key, "dense256") == 0) { g_dense256 = value != 0; return RSA_OK; }
     if (strcmp(key, "k5_pp") == 0) { g_k5_pp = value; return RSA_OK; }
+    if (strcmp(key, "k5_maxblocks") == 0) { g_k5_maxblocks = value; return RSA_OK; }
+    if (strcmp(key, "k5_pair") == 0) { g_rsa_k5_pair = value; return RSA_OK; }
     if (strcmp(key, "fp8_variant") == 0) { rsa_set_fp8_variant(value); return RSA_OK; }
     return RSA_ERR_BAD_ARG;
 }
@@ -41,7 +56,16 @@ static int launch_attn_pp(AttnArgs& a, int BH, int D, int dtype, hipStream_t s) 
 }
 
 static int launch_attn(AttnArgs& a, int BH, int D, int dtype, hipStream_t s, int variant = -1) {
-    if (g_k5_pp && variant < 0) return launch_attn_pp(a, BH, D, dtype, s);
+    if (g_k5_pp && variant < 0) { a.pair_ok = nullptr; return launch_attn_pp(a, BH, D, dtype, s); }
+    if (a.pair_ok && a.NP > 0) {  // paired workgroups first (they are the longer ones: union lists)
+        a.BH = BH;
+        a.NPp = (a.NP + 7) & ~7;
+        const long npb = (long)BH * a.NPp;
+        if (npb > 0x7FFFFFFF || a.NB_total > 8192) return RSA_ERR_UNSUPPORTED;
+        const size_t lds_p = (size_t)4 * 64 * D * 2 + (((size_t)a.NB_total * 2 + 15) & ~(size_t)15);
+        const int st = rsa_launch_bsfwd_pair(a, dim3((unsigned)npb), lds_p, D, dtype, s);
+        if (st != RSA_OK) return st;
+    }
     const int ntq = a.NQB - a.NBv;
     const int n_heavy = ntq > 0 ? BH * ntq : 0;
     a.BH = BH;
@@ -52,7 +76,8 @@ static int launch_attn(AttnArgs& a, int BH, int D, int dtype, hipStream_t s, int
     if (nblocks > 0x7FFFFFFF) return RSA_ERR_UNSUPPORTED;
     if (a.NB_total > 8192) return RSA_ERR_UNSUPPORTED;  // kept list lives in LDS as u16, 16 KiB max
     const size_t lds_bytes = (size_t)4 * 64 * D * 2 + (((size_t)a.NB_total * 2 + 15) & ~(size_t)15);
-    return rsa_launch_bsfwd(a, dim3((unsigned)nblocks), lds_bytes, D, dtype, variant >= 0 ? variant : g_k5_prio, s);
+    const long launch_blocks = g_k5_maxblocks > 0 && g_k5_maxblocks < nblocks ? g_k5_maxblocks : nblocks;
+    return rsa_launch_bsfwd(a, dim3((unsigned)launch_blocks), lds_bytes, D, dtype, variant >= 0 ? variant : g_k5_prio, s);
 }
 
 static void fill_qkv(AttnArgs& a, const rsa_tensor4& q, const rsa_tensor4& k, const rsa_tensor4& v,
@@ -81,6 +106,9 @@ extern "C" int rsa_block_sparse_fwd(const rsa_layout* l, rsa_tensor4 q, rsa_tens
     AttnArgs a;
     fill_qkv(a, q, k, v, out);
     a.cols = buf->cols; a.counts = buf->counts; a.R = buf->R; a.comp = buf->comp;
+    const bool pairing = g_rsa_k5_pair && buf->pcols && buf->pcounts && buf->pair_ok && l->NBv > 1;
+    a.pcols = pairing ? buf->pcols : nullptr; a.pcounts = pairing ? buf->pcounts : nullptr;
+    a.pair_ok = pairing ? buf->pair_ok : nullptr; a.NP = (l->NBv + 1) / 2;
     a.mode = MODE_SPARSE; a.H = l->H; a.Sq = l->S; a.Sk = l->S;
     a.NBv = l->NBv; a.NQB = l->NB_total; a.NB_total = l->NB_total;
     a.kv_valid = l->kv_valid; a.kv_text_valid = l->kv_text_valid;
@@ -103,6 +131,7 @@ extern "C" int rsa_dense_fwd(int B, int H, int Sq, int Sk, int D, int dtype, rsa
     AttnArgs a;
     fill_qkv(a, q, k, v, out);
     a.cols = nullptr; a.counts = nullptr; a.R = nullptr; a.comp = nullptr;
+    a.pcols = nullptr; a.pcounts = nullptr; a.pair_ok = nullptr; a.NP = 0;
     a.mode = MODE_DENSE; a.H = H; a.Sq = Sq; a.Sk = Sk;
     a.NQB = (Sq + RSA_BLOCK - 1) / RSA_BLOCK; a.NBv = a.NQB; a.NB_total = (Sk + RSA_BLOCK - 1) / RSA_BLOCK;
     a.kv_valid = Sk; a.kv_text_valid = Sk; a.q_text_end = 0;

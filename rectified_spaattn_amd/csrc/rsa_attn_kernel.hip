@@ -39,6 +39,13 @@
 // That form is correct but not built: hipcc (ROCm 7.2) then needs 256 VGPR + 256 AGPR, spills 46 VGPRs, and
 // the scratch reloads' vmcnt(0) drains the hand-issued DMA (32 ms vs 17 ms); it needs MFMA operands pinned by
 // register class, i.e. an asm-level body.
+//
+// PAIRED form (PIPE_OPT bit 1024, NW = 8): one workgroup = 256 rows = the query-block pair (2p, 2p+1) that K3b marked
+// "ok"; waves 0-3 own block 2p, waves 4-7 block 2p+1.  The workgroup walks the UNION of the two kept lists, every K/V
+// tile is staged ONCE by all 8 waves (half the LDS-DMA pieces per wave and per FLOP on shared tiles, and half the L2 /
+// fabric requests), and a wave runs the QK^T / softmax / PV of a tile only if the tile is in ITS block's list (flag
+// bits 14 / 15 of the union entries); results are bit-identical to the 128-row form.  Query blocks of pairs that are
+// not "ok" are served by the 128-row form, which skips the others.
 #include "rsa_attn.h"
 
 // PIPE_OPT bits (tuning experiments): 2 = issue priority 2 for this wave while it is inside the pipelined block;
@@ -49,6 +56,8 @@
 template <int D, typename Tag, int NW, int QT, int PIPE_OPT>
 __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bsfwd_kernel(AttnArgs a) {
     static_assert(NW * QT == 4 || (NW == 8 && QT == 1), "128-row query block, or the 256-row dense tile (8 waves)");
+    constexpr bool PAIR = (PIPE_OPT & 1024) != 0;
+    static_assert(!PAIR || (NW == 8 && QT == 1), "paired form = 8 waves x 32 rows");
     constexpr int QROWS = 32 * NW * QT;          // query rows per workgroup
     constexpr int KS = D / 16;
     constexpr int DT = D / 32;
@@ -64,7 +73,14 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
 
     // ---------------- work mapping: dense text-row blocks first, then the sparse blocks chunked per XCD ----------------
     int bh, qblk;
-    {
+    if constexpr (PAIR) {
+        const int v = blockIdx.x;
+        bh = v / a.NPp;
+        const int j = v % a.NPp;
+        const int chunk = a.NPp >> 3;
+        qblk = (j & 7) * chunk + (j >> 3);          // pair index p: rows p*256 .. p*256+255
+        if (qblk >= a.NP || !a.pair_ok[(long)bh * a.NP + qblk]) return;
+    } else {
         const int bid = blockIdx.x;
         if (bid < a.n_heavy_pad) {
             const int ntq = a.NQB - a.NBv;
@@ -78,12 +94,15 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
             const int chunk = a.NBp >> 3;
             qblk = (j & 7) * chunk + (j >> 3);
             if (qblk >= a.NBv) return;
+            if (a.mode == MODE_SPARSE && a.pair_ok && a.pair_ok[(long)bh * a.NP + (qblk >> 1)]) return;  // paired form's
         }
     }
     const int b = bh / a.H, h = bh % a.H;
     const int t = threadIdx.x, lane = t & 63;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int r = lane & 31, hh = lane >> 5;
+    const int half = PAIR ? (wv >> 2) : 0;            // paired form: which query block of the pair this wave serves
+    const int qb = PAIR ? 2 * qblk + half : qblk;     // its 128-row query block
     int grow[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) grow[qt] = qblk * QROWS + 32 * QT * wv + 32 * qt + r;
@@ -95,8 +114,16 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
     for (int qt = 0; qt < QT; ++qt) { lo_r[qt] = 0; hi_r[qt] = 0; store_r[qt] = false; zero_r[qt] = false; }
     int n_items, first_blk = 0, lo_max, hi_min, hi_max;
     const int32_t* list = nullptr;
+    const uint16_t* plist = nullptr;
     bool rectify = false;
-    if (a.mode == MODE_SPARSE) {
+    if constexpr (PAIR) {
+        const long prow = (long)bh * a.NP + qblk;
+        plist = a.pcols + prow * a.NB_total;
+        n_items = a.pcounts[prow];
+        lo_max = 0; hi_min = hi_max = a.kv_valid;
+        rectify = a.R != nullptr;
+        hi_r[0] = a.kv_valid; store_r[0] = qb < a.NBv && grow[0] < a.Sq;
+    } else if (a.mode == MODE_SPARSE) {
         if (qblk < a.NBv) {
             const long rowi = (long)bh * a.NBv + qblk;
             list = a.cols + rowi * a.NB_total;
@@ -132,12 +159,19 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
         if (hi_max <= lo_min) n_items = 0;
     }
     n_items = __builtin_amdgcn_readfirstlane(n_items);
-    const bool use_list = list != nullptr;
+    const bool use_list = PAIR || list != nullptr;
     if (use_list) {
-        for (int i = t; i < n_items; i += 64 * NW) lds_list[i] = (unsigned short)list[i];
+        if constexpr (PAIR) {
+            for (int i = t; i < n_items; i += 64 * NW) lds_list[i] = plist[i];
+        } else {
+            for (int i = t; i < n_items; i += 64 * NW) lds_list[i] = (unsigned short)list[i];
+        }
         __syncthreads();
     }
-    auto blk_of = [&](int item) -> int { return use_list ? (int)lds_list[item] : first_blk + item; };
+    auto blk_of = [&](int item) -> int {
+        if constexpr (PAIR) return (int)(lds_list[item] & 0x3FFF);
+        else return use_list ? (int)lds_list[item] : first_blk + item;
+    };
     int n_tiles = 2 * n_items;
     if (n_items > 0) {
         const int last_blk = blk_of(n_items - 1);
@@ -149,6 +183,16 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
         const int it = tile >> 1;
         const int blk = __builtin_amdgcn_readfirstlane(blk_of(it < n_items ? it : (n_items > 0 ? n_items - 1 : 0)));
         return blk * RSA_BLOCK + (tile & 1) * 64;
+    };
+    // paired form: does tile `tile` belong to THIS wave's query block?  (false past the end of the union list)
+    auto act_of = [&](int tile) -> bool {
+        if constexpr (PAIR) {
+            const int it = tile >> 1;
+            if (tile >= n_tiles || it >= n_items) return false;
+            return ((__builtin_amdgcn_readfirstlane((int)lds_list[it]) >> (14 + half)) & 1) != 0;
+        } else {
+            return true;
+        }
     };
 
     // ---------------- Q fragments (B operand), two 32-row sub-tiles ----------------
@@ -284,6 +328,7 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
     };
 
     int kq1 = 0, kq2 = 0;  // first keys of tile+1 / tile+2 (fetched from LDS ahead of use)
+    bool act0 = true, act1 = true, act2 = true;  // paired form: this wave's block keeps tile / tile+1 / tile+2
 
     // One pipelined sub-step u = 2*tile + SUB: consumes S_cur (scores of 32 keys, row max in mx_cur), produces
     // S_nxt / mx_nxt for sub-step u+1.  VS = slot parity of `tile` (its K and V slots).
@@ -307,15 +352,18 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
         } else {
             if (tile + 2 < n_tiles) dma(0, kq2, vs);       // K(tile+2) -> slot of K(tile)
         }
+        // paired form: the sub-step just scored (S_cur) / the one scored now (S_nxt) may not be this block's
+        const bool a_cur = PAIR ? act0 : true;
+        const bool a_nxt = PAIR ? (sub == 0 ? act0 : act1) : true;
         // ---- head (rare branches): boundary mask, deferred rescale ----
         const int kfirst = key0 + 32 * sub;
-        if (kfirst < lo_max || kfirst + 32 > hi_min) {
+        if (a_cur && (kfirst < lo_max || kfirst + 32 > hi_min)) {
             apply_mask_sub(S_cur, kfirst);
             rowmax_sub(S_cur, mx_cur);
         }
         bool grow_any = false;
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt) grow_any |= mx_cur[qt] > m_run[qt] + 8.0f;
+        for (int qt = 0; qt < QT; ++qt) grow_any |= a_cur && mx_cur[qt] > m_run[qt] + 8.0f;
         if (__builtin_amdgcn_ballot_w64(grow_any) != 0ull) {
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
@@ -335,6 +383,48 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
         for (int qt = 0; qt < QT; ++qt) m_use[qt] = (m_run[qt] == -INFINITY) ? 0.0f : m_run[qt];
 
         // ---- pipelined block (branch-free on purpose: the scheduler interleaves the MFMA and VALU streams) ----
+        if constexpr (PAIR) {
+            // Common case (both sub-steps belong to this block): the same pipelined block as the 128-row form, below.
+            // Otherwise wave-uniform gates around its three parts.
+            if (!(a_cur && a_nxt)) {
+                if (a_nxt) {
+                    if constexpr (sub == 0) qk_sub(std::integral_constant<int, vs>{}, std::integral_constant<int, 1>{}, S_nxt);
+                    else qk_sub(std::integral_constant<int, vs ^ 1>{}, std::integral_constant<int, 0>{}, S_nxt);
+                    rowmax_sub(S_nxt, mx_nxt);
+                }
+                if (a_cur) {
+                    s16x8 pbp[2];
+                    float ps = 0.0f;
+#pragma unroll
+                    for (int half_ = 0; half_ < 2; ++half_) {
+                        float pv8[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            pv8[i] = __builtin_amdgcn_exp2f(S_cur[0][8 * half_ + i] - m_use[0]);
+                            ps += pv8[i];
+                        }
+                        pbp[half_] = E::cvt8(pv8);
+                    }
+                    l_run[0] += ps;
+                    const unsigned char* vtp = lds + (2 + vs) * TILE_BYTES;
+#pragma unroll
+                    for (int k2 = 0; k2 < 2; ++k2) {
+#pragma unroll
+                        for (int dt = 0; dt < DT; ++dt) {
+                            const int offa = vrd[dt][0] + (2 * sub + k2) * 16 * D * 2;
+                            const int offb = vrd[dt][1] + (2 * sub + k2) * 16 * D * 2;
+                            const s16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                (s16x4 __attribute__((address_space(3)))*)(vtp + offa));
+                            const s16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                (s16x4 __attribute__((address_space(3)))*)(vtp + offb));
+                            const s16x8 av = __builtin_shufflevector(va, vb, 0, 1, 2, 3, 4, 5, 6, 7);
+                            o[dt][0] = E::mfma(av, pbp[k2], o[dt][0]);
+                        }
+                    }
+                }
+                return;
+            }
+        }
         if constexpr (PIPE_OPT & 2) __builtin_amdgcn_s_setprio(2);
         if constexpr (PIPE_OPT & 256) __builtin_amdgcn_iglp_opt(0);  // LLVM's small-GEMM MFMA/DS interleave for this region
         if constexpr (sub == 0) qk_sub(std::integral_constant<int, vs>{}, std::integral_constant<int, 1>{}, S_nxt);
@@ -390,13 +480,17 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
         if (n_tiles > 1) dma(0, kq1, 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        qk_sub(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, SA);
-        rowmax_sub(SA, mxA);
+        act0 = act_of(0); act1 = act_of(1); act2 = act_of(2);
+        if (act0) {
+            qk_sub(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, SA);
+            rowmax_sub(SA, mxA);
+        }
     }
     auto advance = [&](int tile) {  // after finishing `tile`: shift the key queue, fetch tile+3's first key
         key0 = kq1;
         kq1 = kq2;
         kq2 = key0_of(tile + 3);
+        if constexpr (PAIR) { act0 = act1; act1 = act2; act2 = act_of(tile + 3); }
     };
     {
         using I0 = std::integral_constant<int, 0>;
@@ -427,7 +521,7 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
         float Rv = 1.0f;
         const float* cp = nullptr;
         if (rectify) {
-            const long rowi = (long)bh * a.NBv + qblk;
+            const long rowi = (long)bh * a.NBv + qb;
             Rv = a.R[rowi];
             cp = a.comp + rowi * D;
         }
@@ -452,6 +546,18 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
             }
         }
     }
+}
+
+// paired form (sparse mode, after K3b): one workgroup per "ok" query-block pair
+int rsa_launch_bsfwd_pair(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int dtype, hipStream_t s) {
+    if (D == 128) {
+        if (dtype == RSA_BF16) bsfwd_kernel<128, bf16_tag, 8, 1, 2 + 256 + 1024><<<grid, 512, lds_bytes, s>>>(a);
+        else bsfwd_kernel<128, fp16_tag, 8, 1, 2 + 256 + 1024><<<grid, 512, lds_bytes, s>>>(a);
+    } else {
+        if (dtype == RSA_BF16) bsfwd_kernel<64, bf16_tag, 8, 1, 2 + 256 + 1024><<<grid, 512, lds_bytes, s>>>(a);
+        else bsfwd_kernel<64, fp16_tag, 8, 1, 2 + 256 + 1024><<<grid, 512, lds_bytes, s>>>(a);
+    }
+    return rsa_launch_status();
 }
 
 // launch hook used by rsa_attn.hip::launch_attn

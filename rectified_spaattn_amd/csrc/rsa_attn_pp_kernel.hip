@@ -34,6 +34,7 @@ __global__ __launch_bounds__(512, 2) void bsfwd_pp_kernel(AttnArgs a) {
     constexpr int DMA_M = (OPT & 32) ? 4 : ((OPT & 16) ? 2 : 0);   // pieces (of NPC = 4) deferred to the matrix segment
     constexpr bool T_NODMA = (OPT & 64) != 0;    // TIMING-ONLY builds (wrong results): no staging in the loop
     constexpr bool T_NOSM = (OPT & 128) != 0;    //                                      no softmax arithmetic
+    constexpr bool T_NOWAIT = (OPT & 512) != 0;  //                                      no vmcnt wait for the staged tiles
     constexpr int KS = D / 16;
     constexpr int DT = D / 32;
     constexpr int CHR = D / 8;
@@ -365,7 +366,8 @@ __global__ __launch_bounds__(512, 2) void bsfwd_pp_kernel(AttnArgs a) {
                                           // matrix segment and adds them in the next vector segment)
         // the two newest DMA groups may stay in flight; everything older must have landed before the next matrix
         // segments read it (the barrier that follows publishes it to the other waves of the group)
-        if (tile + 2 < n_tiles) {
+        if constexpr (T_NOWAIT) {
+        } else if (tile + 2 < n_tiles) {
             static_assert(NPC == 4 || DMA_M == 0, "piece deferral is written for D = 128 (4 pieces per wave)");
             if constexpr (NPC == 4 && DMA_M == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else if constexpr (NPC == 4 && DMA_M == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -465,24 +467,34 @@ __global__ __launch_bounds__(512, 2) void bsfwd_pp_kernel(AttnArgs a) {
     }
 }
 
-// launch hook used by rsa_attn.hip::launch_attn
-int rsa_launch_bsfwd_pp(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int dtype, int opt, hipStream_t s) {
-#define RSA_K5PP(DD, TT) \
-    do { \
-        constexpr int dm = DD == 128 ? 1 : 0; \
-        if (opt & 64) bsfwd_pp_kernel<DD, TT, 64 + 2 + 256><<<grid, 512, lds_bytes, s>>>(a); \
-        else if (opt & 128) bsfwd_pp_kernel<DD, TT, 128 + 2 + 256><<<grid, 512, lds_bytes, s>>>(a); \
-        else if (opt & 4) bsfwd_pp_kernel<DD, TT, 4 + 2 + 256><<<grid, 512, lds_bytes, s>>>(a); \
-        else if (opt & 32) bsfwd_pp_kernel<DD, TT, 32 * dm + 2 + 256><<<grid, 512, lds_bytes, s>>>(a); \
-        else if (opt & 16) bsfwd_pp_kernel<DD, TT, 16 * dm + 2 + 256><<<grid, 512, lds_bytes, s>>>(a); \
-        else if (opt & 2) bsfwd_pp_kernel<DD, TT, 2 + 256><<<grid, 512, lds_bytes, s>>>(a); \
-        else bsfwd_pp_kernel<DD, TT, 256><<<grid, 512, lds_bytes, s>>>(a); \
-    } while (0)
-    if (D == 128) {
-        if (dtype == RSA_BF16) RSA_K5PP(128, bf16_tag); else RSA_K5PP(128, fp16_tag);
-    } else {
-        if (dtype == RSA_BF16) RSA_K5PP(64, bf16_tag); else RSA_K5PP(64, fp16_tag);
+// launch hook used by rsa_attn.hip::launch_attn_pp.  `opt` = tuning value of "k5_pp": 1 = plain, 2 = with issue priority
+// (product form); the other values select experiment builds (see the OPT bits above; 64 / 128 / 512 give wrong results).
+template <int DD, typename TT>
+static void launch_pp(const AttnArgs& a, dim3 grid, size_t lds_bytes, int opt, hipStream_t s) {
+    constexpr int dm = DD == 128 ? 1 : 0;
+    switch (opt) {
+#define RSA_PP_CASE(V, O) case V: bsfwd_pp_kernel<DD, TT, (O)><<<grid, 512, lds_bytes, s>>>(a); break;
+        RSA_PP_CASE(1, 256)
+        RSA_PP_CASE(6, 4 + 2 + 256)
+        RSA_PP_CASE(18, 16 * dm + 2 + 256)
+        RSA_PP_CASE(34, 32 * dm + 2 + 256)
+        RSA_PP_CASE(66, 64 + 2 + 256)
+        RSA_PP_CASE(130, 128 + 2 + 256)
+        RSA_PP_CASE(194, 64 + 128 + 2 + 256)
+        RSA_PP_CASE(514, 512 + 2 + 256)
+        RSA_PP_CASE(642, 512 + 128 + 2 + 256)
+#undef RSA_PP_CASE
+        default: bsfwd_pp_kernel<DD, TT, 2 + 256><<<grid, 512, lds_bytes, s>>>(a); break;
     }
-#undef RSA_K5PP
+}
+
+int rsa_launch_bsfwd_pp(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int dtype, int opt, hipStream_t s) {
+    if (D == 128) {
+        if (dtype == RSA_BF16) launch_pp<128, bf16_tag>(a, grid, lds_bytes, opt, s);
+        else launch_pp<128, fp16_tag>(a, grid, lds_bytes, opt, s);
+    } else {
+        if (dtype == RSA_BF16) launch_pp<64, bf16_tag>(a, grid, lds_bytes, opt, s);
+        else launch_pp<64, fp16_tag>(a, grid, lds_bytes, opt, s);
+    }
     return rsa_launch_status();
 }

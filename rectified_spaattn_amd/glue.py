@@ -64,7 +64,14 @@ def norm_params(norm) -> Optional[Tuple[Optional[torch.Tensor], float]]:
         return None
     if getattr(norm, "bias", None) is not None:
         return None
-    return getattr(norm, "weight", None), float(norm.eps)
+    if norm.eps is None:   # torch.nn.RMSNorm(eps=None) resolves eps per input dtype: keep the module call
+        return None
+    w = getattr(norm, "weight", None)
+    if w is not None and w.dtype == torch.float32:
+        # diffusers multiplies by an fp32 weight WITHOUT first rounding the normalised value to the activation dtype;
+        # the fused kernel reproduces the 2-byte-weight order of operations only
+        return None
+    return w, float(norm.eps)
 
 
 def qk_norm_rope(x: torch.Tensor, heads: int, norm=None, rotary=None, rope_tokens: Optional[int] = None,

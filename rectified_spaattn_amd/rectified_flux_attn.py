@@ -12,22 +12,22 @@ from .gapr_mask import estimate_pr_gain  # noqa: F401
 def block_sparse_attention_combined(query, key, value, attn_mask, top_k, block_size_M=128, block_size_N=128,
                                     cu_seqlens_q=None, cu_seqlens_kv=None, max_seqlen_q=None, max_seqlen_kv=None,
                                     prob_threshold=0.5, block_neighbor_list=None, text_length=256,
-                                    shape_xfuse=False):
+                                    shape_xfuse=False, qkv_fp8=None):
     """[B,H,S,D] x3 -> [B,S,H*D]; the last `text_length` tokens are text: kept by every visual row, scored
     token-wise for IPAR, and their own rows get exact attention (reference :282-376)."""
     return op.run("flux", query, key, value, top_k, prob_threshold, block_neighbor_list, shape_xfuse,
                   cu_seqlens_q=cu_seqlens_q, cu_seqlens_kv=cu_seqlens_kv, text_length=text_length,
-                  block_size_M=block_size_M, block_size_N=block_size_N)
+                  block_size_M=block_size_M, block_size_N=block_size_N, qkv_fp8=qkv_fp8)
 
 
 def rectified_block_sparse_attention(query, key, value, attn_mask, top_k, block_size_M=128, block_size_N=128,
                                      cu_seqlens_q=None, cu_seqlens_kv=None, max_seqlen_q=None, max_seqlen_kv=None,
                                      block_neighbor_list=None, shape_xfuse=False, p_remain_rates=0.5,
-                                     text_length=256):
+                                     text_length=256, qkv_fp8=None):
     return block_sparse_attention_combined(query, key, value, attn_mask, top_k, block_size_M, block_size_N,
                                            cu_seqlens_q, cu_seqlens_kv, max_seqlen_q, max_seqlen_kv,
                                            prob_threshold=p_remain_rates, block_neighbor_list=block_neighbor_list,
-                                           text_length=text_length, shape_xfuse=shape_xfuse)
+                                           text_length=text_length, shape_xfuse=shape_xfuse, qkv_fp8=qkv_fp8)
 
 
 class RectifiedFluxSpaAttnProcessor2_0:

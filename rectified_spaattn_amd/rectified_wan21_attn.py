@@ -13,21 +13,21 @@ from .gapr_mask import estimate_pr_gain  # noqa: F401
 def block_sparse_attention_combined(query, key, value, attn_mask, top_k, block_size_M=128, block_size_N=128,
                                     cu_seqlens_q=None, cu_seqlens_kv=None, max_seqlen_q=None, max_seqlen_kv=None,
                                     prob_threshold=0.5, block_neighbor_list=None, shape_xfuse=False,
-                                    first_frame_blocks=None):
+                                    first_frame_blocks=None, qkv_fp8=None):
     """[B,H,S,D] x3 -> [B,S,H*D] (reference :276-357).  S need not be a multiple of 128: the tail block is
     treated as zero-padded (its pooled statistics include the zeros, as in the reference :299-302)."""
     return op.run("wan", query, key, value, top_k, prob_threshold, block_neighbor_list, shape_xfuse,
-                  first_frame_blocks=first_frame_blocks, block_size_M=block_size_M, block_size_N=block_size_N)
+                  first_frame_blocks=first_frame_blocks, block_size_M=block_size_M, block_size_N=block_size_N, qkv_fp8=qkv_fp8)
 
 
 def rectified_block_sparse_attention(query, key, value, attn_mask, top_k, block_size_M=128, block_size_N=128,
                                      cu_seqlens_q=None, cu_seqlens_kv=None, max_seqlen_q=None, max_seqlen_kv=None,
                                      block_neighbor_list=None, shape_xfuse=False, p_remain_rates=0.5,
-                                     first_frame_blocks=None):
+                                     first_frame_blocks=None, qkv_fp8=None):
     return block_sparse_attention_combined(query, key, value, attn_mask, top_k, block_size_M, block_size_N,
                                            cu_seqlens_q, cu_seqlens_kv, max_seqlen_q, max_seqlen_kv,
                                            prob_threshold=p_remain_rates, block_neighbor_list=block_neighbor_list,
-                                           shape_xfuse=shape_xfuse, first_frame_blocks=first_frame_blocks)
+                                           shape_xfuse=shape_xfuse, first_frame_blocks=first_frame_blocks, qkv_fp8=qkv_fp8)
 
 
 def _complex_rope(x: torch.Tensor, freqs: torch.Tensor) -> torch.Tensor:

@@ -5,6 +5,7 @@ import sys
 import numpy as np
 import pytest
 
+os.environ.setdefault("RSA_TUNING", "1")  # the variant tests flip kernel forms through rsa_set_tuning (debug hook)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -6,6 +6,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("RSA_TUNING", "1")  # this tool flips kernel variants through rsa_set_tuning
+
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -65,6 +67,33 @@ def main():
                   f"{cnt.mean().item():.1f}/{cnt.max().item():.0f} | select {msel:.3f} ms | adjacent-list overlap "
                   f"(head 0) inter/union {(inter/uni).mean().item():.3f}, inter/own {(inter/bm[:-1].sum(1).float()).mean().item():.3f}",
                   flush=True)
+            del call
+            torch.cuda.empty_cache()
+        return
+    if "pair" in what:  # A/B of the paired 256-row workgroups (tuning key k5_pair) per regime, one process
+        from rectified_spaattn_amd import _lib
+        L = _lib.lib()
+        H = int(os.environ.get("RSA_PERF_H", "24"))
+        for regime in os.environ.get("RSA_PERF_REGIMES", "locality,r1,r2").split(","):
+            call, spec = regime_call(regime, H, dev)
+            assert L.rsa_set_tuning(b"k5_pair", 1) == 0
+            call.select()
+            torch.cuda.synchronize()
+            flops, pairs = call_flops(call, spec, H)
+            ok = call.bufs["pair_ok"].float().mean().item()
+            ref = None
+            for rnd in range(2):
+                for opt in (0, 1):
+                    assert L.rsa_set_tuning(b"k5_pair", opt) == 0
+                    med, mn = timeit(call.attend, n=5, warm=2)
+                    o = call.out.float()
+                    if ref is None:
+                        ref = o.clone()
+                    print(f"{regime} round {rnd} k5_pair={opt}: {med:7.3f} ms (min {mn:7.3f}) {flops/med/1e9:7.1f} TF/s | "
+                          f"pairs ok {ok:.3f} | max|d vs first| {(o - ref).abs().max().item():.2e}", flush=True)
+            L.rsa_set_tuning(b"k5_pair", 0)
+            msel, _ = timeit(call.select, n=5, warm=1)
+            print(f"{regime}: select pass {msel:.3f} ms", flush=True)
             del call
             torch.cuda.empty_cache()
         return
