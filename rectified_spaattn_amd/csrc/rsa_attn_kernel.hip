@@ -432,18 +432,32 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
         s16x8 pb[QT][2];
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
-            float ps = 0.0f;
+            if constexpr (PIPE_OPT & 4) {   // row sum as four short chains, formed inside this block (not in the next head)
+                float ps0 = 0.0f, ps1 = 0.0f, ps2 = 0.0f, ps3 = 0.0f;
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                float pv8[8];
+                for (int hf = 0; hf < 2; ++hf) {
+                    float pv8[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    pv8[i] = __builtin_amdgcn_exp2f(S_cur[qt][8 * half + i] - m_use[qt]);
-                    ps += pv8[i];
+                    for (int i = 0; i < 8; ++i) pv8[i] = __builtin_amdgcn_exp2f(S_cur[qt][8 * hf + i] - m_use[qt]);
+                    ps0 += pv8[0] + pv8[4]; ps1 += pv8[1] + pv8[5]; ps2 += pv8[2] + pv8[6]; ps3 += pv8[3] + pv8[7];
+                    pb[qt][hf] = E::cvt8(pv8);
                 }
-                pb[qt][half] = E::cvt8(pv8);
+                l_run[qt] += (ps0 + ps1) + (ps2 + ps3);
+                asm volatile("" : "+v"(l_run[qt]));
+            } else {
+                float ps = 0.0f;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    float pv8[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        pv8[i] = __builtin_amdgcn_exp2f(S_cur[qt][8 * hf + i] - m_use[qt]);
+                        ps += pv8[i];
+                    }
+                    pb[qt][hf] = E::cvt8(pv8);
+                }
+                l_run[qt] += ps;
             }
-            l_run[qt] += ps;
         }
         const unsigned char* vt_ = lds + (2 + vs) * TILE_BYTES;
 #pragma unroll
@@ -565,6 +579,7 @@ int rsa_launch_bsfwd(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int 
 #define RSA_K5(DD, TT) \
     do { \
         if (prio == 8) bsfwd_kernel<DD, TT, 8, 1, 2 + 256><<<grid, 512, lds_bytes, s>>>(a); \
+        else if (prio == 4) bsfwd_kernel<DD, TT, 4, 1, 2 + 4 + 256><<<grid, 256, lds_bytes, s>>>(a); \
         else if (prio) bsfwd_kernel<DD, TT, 4, 1, 2 + 256><<<grid, 256, lds_bytes, s>>>(a); \
         else bsfwd_kernel<DD, TT, 4, 1, 0><<<grid, 256, lds_bytes, s>>>(a); \
     } while (0)

@@ -284,8 +284,10 @@ struct SelectArgs {
     uint32_t* bitmask;
     int32_t *cols, *counts;
     int NBv, n_txt, NS, L, N2, NB_total, NW, text_end_block, ffb, top_k, rows_total, lds_per_wave;
+    int use_prefix;   // 1 = try the sorted-head path first (same result; tuning key "k3_prefix" for the A/B tests)
     float thr, scale;
 };
+int g_rsa_k3_prefix = 1;
 
 __device__ __forceinline__ float wave_tree4(const float (&part)[4]) {
     float u[4];
@@ -304,6 +306,81 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
     const unsigned hi = __shfl_xor((unsigned)(v >> 32), m, 64);
     return ((unsigned long long)hi << 32) | lo;
 }
+
+
+// bitonic network, descending, N = 64*K keys: lane l holds elements l*K .. l*K+K-1; partner distances below K are
+// in-lane compare-swaps, larger ones go through lane shuffles.
+template <int K>
+__device__ __forceinline__ void bitonic_sort_desc(unsigned long long (&key)[K], int lane) {
+    for (int k = 2; k <= 64 * K; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= K) {  // partner in another lane
+                const int lm = j / K;
+                const bool upper = (lane & lm) != 0;
+#pragma unroll
+                for (int s_ = 0; s_ < K; ++s_) {
+                    const int idx = lane * K + s_;
+                    const bool desc = (idx & k) == 0;
+                    const unsigned long long mine = key[s_], other = shfl_xor_u64(mine, lm);
+                    const bool take_max = (desc != upper);  // lower element of a descending pair keeps the max
+                    const bool other_gt = other > mine;
+                    key[s_] = (other_gt == take_max) ? other : mine;
+                }
+            } else {  // partner in this lane: static slot pairs
+#pragma unroll
+                for (int jj = 1; jj < K; jj <<= 1) {
+                    if (jj == j) {
+#pragma unroll
+                        for (int s_ = 0; s_ < K; ++s_) {
+                            if ((s_ & jj) == 0) {
+                                const int idx = lane * K + s_;
+                                const bool desc = (idx & k) == 0;
+                                const unsigned long long ka = key[s_], kb = key[s_ | jj];
+                                const bool sw = (ka < kb) == desc;
+                                key[s_] = sw ? kb : ka;
+                                key[s_ | jj] = sw ? ka : kb;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Contract C8 on a sorted key array (K per lane): sequential fp32 sum c_i = c_{i-1} + p_i over positions < len, lane after
+// lane; returns #{c_i <= thr} before the first c_i > thr; passed = such an element was met before position len.
+template <int K>
+__device__ __forceinline__ int cumsum_count(const unsigned long long (&key)[K], int lane, int len, float thr,
+                                            bool& passed) {
+    int count = 0;
+    float c = 0.0f;
+    bool done = false, over = false;
+    for (int ln = 0; ln < 64 && !done; ++ln) {
+        float cl = c;
+        int cnt = 0;
+        bool dl = false, ol = false;
+#pragma unroll
+        for (int s_ = 0; s_ < K; ++s_) {
+            const int pos = ln * K + s_;
+            if (!dl && pos < len) {
+                cl = cl + __uint_as_float((unsigned)(key[s_] >> 32));
+                if (cl <= thr) ++cnt; else { dl = true; ol = true; }
+            } else if (pos >= len) {
+                dl = true;
+            }
+        }
+        // take lane ln's result
+        c = __shfl(cl, ln, 64);
+        count += __shfl(cnt, ln, 64);
+        done = __shfl((int)dl, ln, 64) != 0;
+        over = __shfl((int)ol, ln, 64) != 0;
+    }
+    passed = over;
+    return count;
+}
+
+#define RSA_SEL_CAP 256   // keys in the sorted head of the prefix path (4 per lane)
 
 template <int KPL>
 __global__ __launch_bounds__(256) void select_mask_kernel(SelectArgs a) {
@@ -371,75 +448,87 @@ __global__ __launch_bounds__(256) void select_mask_kernel(SelectArgs a) {
             kk = ((unsigned long long)__float_as_uint(pr[idx]) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)idx);
         key[s_] = kk;
     }
-    // bitonic sort, descending
-    for (int k = 2; k <= 64 * KPL; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            if (j >= KPL) {  // partner in another lane
-                const int lm = j / KPL;
-                const bool upper = (lane & lm) != 0;
+    int n = -1;
+    bool marked = false;
+    if constexpr (KPL > RSA_SEL_CAP / 64) {
+        // ---- prefix path (C7/C8 unchanged): the decision needs only the sorted HEAD of the row -- the sequential sum
+        // stops at the first element that exceeds thr, and the kept set is the first n = max(count+1, top_k) elements.
+        // Find a probability threshold t with need <= #{p >= t} <= RSA_SEL_CAP by bisection on the fp32 bit patterns
+        // (positive floats order like their bits), compact those keys (they are exactly the top-C of the total order),
+        // sort them (256 keys = 4 per lane instead of 64*KPL), run the same sequential sum.  If no such t exists (a
+        // plateau of equal probabilities across the window) or the sum does not pass thr inside the head, fall through
+        // to the full sort below -- same result either way.
+        const int need = a.top_k > RSA_SEL_CAP / 2 ? a.top_k : RSA_SEL_CAP / 2;
+        if (a.use_prefix && need <= RSA_SEL_CAP && a.L > RSA_SEL_CAP) {
+            unsigned pmax = 0;
+#pragma unroll
+            for (int s_ = 0; s_ < KPL; ++s_) pmax = max(pmax, (unsigned)(key[s_] >> 32));
+            for (int m = 1; m < 64; m <<= 1) pmax = max(pmax, (unsigned)__shfl_xor((int)pmax, m, 64));
+            unsigned lo = 0u, hi = pmax + 1u, t = 0u;   // #{p >= lo} > CAP (all L > CAP keys), #{p >= hi} = 0 < need
+            int C = 0;
+            bool found = false;
+            for (int it = 0; it < 34 && hi - lo > 1u; ++it) {
+                const unsigned mid = lo + ((hi - lo) >> 1);
+                int c = 0;
+#pragma unroll
+                for (int s_ = 0; s_ < KPL; ++s_) c += __popcll(__ballot((unsigned)(key[s_] >> 32) >= mid));
+                if (c > RSA_SEL_CAP) lo = mid;
+                else if (c < need) hi = mid;
+                else { t = mid; C = c; found = true; break; }
+            }
+            if (found) {
+                unsigned long long* cand = reinterpret_cast<unsigned long long*>(kept + ((a.NB_total + 7) & ~7));
+                for (int j = lane; j < RSA_SEL_CAP; j += 64) cand[j] = 0ull;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                int basep = 0;
 #pragma unroll
                 for (int s_ = 0; s_ < KPL; ++s_) {
-                    const int idx = lane * KPL + s_;
-                    const bool desc = (idx & k) == 0;
-                    const unsigned long long mine = key[s_], other = shfl_xor_u64(mine, lm);
-                    const bool take_max = (desc != upper);  // lower element of a descending pair keeps the max
-                    const bool other_gt = other > mine;
-                    key[s_] = (other_gt == take_max) ? other : mine;
+                    const bool f = (unsigned)(key[s_] >> 32) >= t;
+                    const unsigned long long mk = __ballot(f);
+                    if (f) cand[basep + __popcll(mk & ((1ull << lane) - 1ull))] = key[s_];
+                    basep += __popcll(mk);
                 }
-            } else {  // partner in this lane: static slot pairs
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                constexpr int CK = RSA_SEL_CAP / 64;
+                unsigned long long ck[CK];
 #pragma unroll
-                for (int jj = 1; jj < KPL; jj <<= 1) {
-                    if (jj == j) {
+                for (int s_ = 0; s_ < CK; ++s_) ck[s_] = cand[lane * CK + s_];
+                bitonic_sort_desc<CK>(ck, lane);
+                bool passed = false;
+                const int count = cumsum_count<CK>(ck, lane, C, a.thr, passed);
+                if (passed || C >= a.L) {
+                    n = count + 1;
+                    if (n < a.top_k) n = a.top_k;
+                    if (n > a.L) n = a.L;
+                    if (n <= C) {
+                        for (int j = lane; j < a.NB_total; j += 64) kept[j] = 0;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #pragma unroll
-                        for (int s_ = 0; s_ < KPL; ++s_) {
-                            if ((s_ & jj) == 0) {
-                                const int idx = lane * KPL + s_;
-                                const bool desc = (idx & k) == 0;
-                                const unsigned long long ka = key[s_], kb = key[s_ | jj];
-                                const bool sw = (ka < kb) == desc;
-                                key[s_] = sw ? kb : ka;
-                                key[s_ | jj] = sw ? ka : kb;
-                            }
+                        for (int s_ = 0; s_ < CK; ++s_) {
+                            const int pos = lane * CK + s_;
+                            if (pos < n) kept[0xFFFFFFFFu - (unsigned)(ck[s_] & 0xFFFFFFFFull)] = 1;
                         }
+                        marked = true;
                     }
                 }
             }
         }
     }
-    // sequential cumulative sum over the sorted order (C8), lane after lane, stop once it exceeds thr
-    int count = 0;
-    {
-        float c = 0.0f;
-        bool done = false;
-        for (int ln = 0; ln < 64 && !done; ++ln) {
-            float cl = c;
-            int cnt = 0;
-            bool dl = false;
+    if (!marked) {
+        bitonic_sort_desc<KPL>(key, lane);
+        // sequential cumulative sum over the sorted order (C8), lane after lane, stop once it exceeds thr
+        bool passed = false;
+        const int count = cumsum_count<KPL>(key, lane, a.L, a.thr, passed);
+        n = count + 1;
+        if (n < a.top_k) n = a.top_k;
+        if (n > a.L) n = a.L;
+        for (int j = lane; j < a.NB_total; j += 64) kept[j] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #pragma unroll
-            for (int s_ = 0; s_ < KPL; ++s_) {
-                const int pos = ln * KPL + s_;
-                if (!dl && pos < a.L) {
-                    cl = cl + __uint_as_float((unsigned)(key[s_] >> 32));
-                    if (cl <= a.thr) ++cnt; else dl = true;
-                } else if (pos >= a.L) {
-                    dl = true;
-                }
-            }
-            // take lane ln's result
-            c = __shfl(cl, ln, 64);
-            count += __shfl(cnt, ln, 64);
-            done = __shfl((int)dl, ln, 64) != 0;
+        for (int s_ = 0; s_ < KPL; ++s_) {
+            const int pos = lane * KPL + s_;
+            if (pos < n) kept[0xFFFFFFFFu - (unsigned)(key[s_] & 0xFFFFFFFFull)] = 1;
         }
-    }
-    int n = count + 1;
-    if (n < a.top_k) n = a.top_k;
-    if (n > a.L) n = a.L;
-    for (int j = lane; j < a.NB_total; j += 64) kept[j] = 0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-#pragma unroll
-    for (int s_ = 0; s_ < KPL; ++s_) {
-        const int pos = lane * KPL + s_;
-        if (pos < n) kept[0xFFFFFFFFu - (unsigned)(key[s_] & 0xFFFFFFFFull)] = 1;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     for (int j = lane; j < a.NB_total; j += 64) {
@@ -733,8 +822,9 @@ extern "C" int rsa_select_mask(const rsa_layout* l, const uint8_t* neighbor, int
     a.thr = p_remain;
     a.scale = (float)(1.0 / sqrt((double)l->D));  // head_dim ** -0.5 rounded to fp32 (hunyuan :208)
     a.rows_total = l->B * l->H * l->NBv;
+    a.use_prefix = g_rsa_k3_prefix;
     const size_t per_wave = (((size_t)((a.NS + 3) & ~3) * 4 + (size_t)((a.L + 3) & ~3) * 4 +
-                              (size_t)a.NB_total) + 15) & ~(size_t)15;
+                              (size_t)((a.NB_total + 7) & ~7) + (size_t)RSA_SEL_CAP * 8) + 15) & ~(size_t)15;
     a.lds_per_wave = (int)per_wave;
     const size_t lds = per_wave * 4;
     if (lds > 64 * 1024 || n2 > 4096) return RSA_ERR_UNSUPPORTED;

@@ -1,0 +1,64 @@
+"""K3's sorted-head ("prefix") path against its full-sort path on whole full-size calls: every row of the bitmask, kept
+lists, counts, R and compensation weights must be identical (the oracle pins sampled rows in test_gpu_fullsize.py; this
+test covers all 21 600 rows per head configuration, including inputs that force the fall-back: plateaus of equal
+probabilities and thresholds the head cannot reach)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _select(q, k, v, spec, top_k, p, nbr, prefix):
+    from rectified_spaattn_amd import _core, _lib
+    assert _lib.lib().rsa_set_tuning(b"k3_prefix", prefix) == 0
+    try:
+        call = _core.StagedCall(q, k, v, spec, top_k, p, nbr)
+        call.select()
+        torch.cuda.synchronize()
+    finally:
+        _lib.lib().rsa_set_tuning(b"k3_prefix", 1)
+    cnt = call.bufs["counts"]
+    cols = call.bufs["cols"]
+    valid = torch.arange(cols.shape[-1], device=cols.device)[None, None, :] < cnt[..., None]
+    return dict(bitmask=call.bufs["bitmask"].clone(), counts=cnt.clone(), cols=torch.where(valid, cols, -1),
+                R=call.bufs["R"].clone(), w=call.bufs["w"].clone(), probs=call.bufs["probs"].clone())
+
+
+@pytest.mark.parametrize("cfg", [
+    # (layout, H, S, top_k, p, data)
+    ("hunyuan", 2, 115456, 90, 0.05, "structured"),
+    ("hunyuan", 2, 115456, 180, 0.3, "structured"),
+    ("hunyuan", 1, 115456, 90, 0.9, "iid"),          # flat rows: the sum passes 0.9 far beyond the head -> fall-back
+    ("hunyuan", 1, 115456, 90, 0.3, "zeros"),        # every probability equal: no threshold isolates a head
+    ("wan", 2, 75600, 147, 0.3, "structured"),
+    ("flux", 2, 66048, 51, 0.3, "iid"),
+    ("wan", 2, 40000, 250, 0.2, "structured"),       # top_k close to the head capacity
+    ("wan", 2, 40000, 300, 0.2, "structured"),       # top_k beyond it: prefix path not applicable
+])
+def test_prefix_path_equals_full_sort(cfg):
+    from bench import gen_qkv
+    from rectified_spaattn_amd import _core
+    layout, H, S, top_k, p, data = cfg
+    D = 128
+    dev = torch.device(DEV)
+    if data == "structured":
+        q, k, v = gen_qkv(H, 0, S, S, D, dev, seed=5)
+    elif data == "iid":
+        g = torch.Generator(device=dev).manual_seed(3)
+        q, k, v = (torch.randn(1, H, S, D, generator=g, device=dev).to(torch.bfloat16) for _ in range(3))
+    else:
+        q = torch.zeros(1, H, S, D, device=dev, dtype=torch.bfloat16)
+        k = torch.ones_like(q)
+        v = torch.ones_like(q)
+    if layout == "hunyuan":
+        spec = _core.LayoutSpec.hunyuan(S, S - 56)
+    elif layout == "flux":
+        spec = _core.LayoutSpec.flux(S, 512)
+    else:
+        spec = _core.LayoutSpec.wan(S, 6)
+    a = _select(q, k, v, spec, top_k, p, None, 1)
+    b = _select(q, k, v, spec, top_k, p, None, 0)
+    for name in a:
+        assert torch.equal(a[name], b[name]), f"{cfg}: {name} differs between the two K3 paths"
+    assert int(a["counts"].min()) >= min(top_k, spec.L)
