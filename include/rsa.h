@@ -85,8 +85,12 @@ typedef struct rsa_buffers {
     uint16_t* pcols;  /* [BH, NP, NB_total] ascending UNION of the two lists: block | in_first<<14 | in_second<<15 */
     int32_t* pcounts; /* [BH, NP]           entries of pcols                                                   */
     int32_t* pair_ok; /* [BH, NP]           1 = K5 serves this pair with the paired workgroup, 0 = two 128-row ones */
+    /* split-KV partials of the dense TEXT query blocks (K5 splits each text block's key range over up to RSA_TEXT_SPLIT
+     * workgroups and a small combine kernel merges them; may be NULL: then one workgroup walks all keys of a text block): */
+    float* tpart;     /* [BH, NB_total - NBv, RSA_TEXT_SPLIT, 128, D + 2]  unnormalised O, then (m, l) per query row  */
 } rsa_buffers;
-#define RSA_NUM_BUFFERS 17
+#define RSA_NUM_BUFFERS 18
+#define RSA_TEXT_SPLIT 16
 
 /* Library identification: returns 10000*major + 100*minor + patch. */
 int rsa_version(void);

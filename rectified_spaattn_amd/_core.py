@@ -123,7 +123,7 @@ def _stream() -> ctypes.c_void_p:
 _BUF_DTYPES = dict(qbar=torch.float32, aq=torch.float32, kbar=torch.float32, ak=torch.float32, vbar=torch.float32,
                    scores=torch.float32, unrel=torch.uint8, probs=torch.float32, w=torch.float32, R=torch.float32,
                    comp=torch.float32, bitmask=torch.int32, cols=torch.int32, counts=torch.int32,
-                   pcols=torch.int16, pcounts=torch.int32, pair_ok=torch.int32)
+                   pcols=torch.int16, pcounts=torch.int32, pair_ok=torch.int32, tpart=torch.float32)
 
 
 def buffer_shapes(spec: LayoutSpec, B: int, H: int, D: int) -> Dict[str, tuple]:
@@ -132,7 +132,8 @@ def buffer_shapes(spec: LayoutSpec, B: int, H: int, D: int) -> Dict[str, tuple]:
     return dict(qbar=(BH, NBv, D), aq=(BH, NBv, D), kbar=(BH, NBv, D), ak=(BH, NBv, D), vbar=(BH, NB, D),
                 scores=(BH, NBv, NS), unrel=(BH, NBv, NBv), probs=(BH, NBv, L), w=(BH, NBv, L), R=(BH, NBv),
                 comp=(BH, NBv, D), bitmask=(BH, NBv, NW), cols=(BH, NBv, NB), counts=(BH, NBv),
-                pcols=(BH, NP, NB), pcounts=(BH, NP), pair_ok=(BH, NP))
+                pcols=(BH, NP, NB), pcounts=(BH, NP), pair_ok=(BH, NP),
+                tpart=(BH, NB - NBv, _lib.TEXT_SPLIT, BLOCK, D + 2))
 
 
 def alloc_buffers(spec: LayoutSpec, B: int, H: int, D: int, device) -> Dict[str, torch.Tensor]:

@@ -80,6 +80,8 @@ struct AttnArgs {
     const int32_t* pcounts;                   // [BH, NP]
     const int32_t* pair_ok;                   // [BH, NP]; null = no pairing
     int NP;
+    float* tpart;                             // split-KV partials of the text query blocks, or null
+    int tsplit, tper;                         // workgroups per text block, key blocks per workgroup
     float qk_scale;
 };
 

@@ -15,6 +15,7 @@ static int g_dense256 = 0;  // tuning hook: dense mode on 256-row query tiles (8
 // block of the pair still costs a full tile time of the 8-wave workgroup.
 int g_rsa_k5_pair = 0;
 extern int g_rsa_k3_prefix;  // rsa_stats.hip
+static int g_k5_tsplit = 1;     // 1 = split-KV for the text query blocks when the partial buffer is given
 static int g_k5_maxblocks = 0;  // diagnostics: launch only the first N workgroups of K5 (partial result!)
 static int g_k5_pp = 0;     // 1 = the ping-pong kernel (rsa_attn_pp_kernel.hip): two query blocks per 8-wave workgroup
 
@@ -36,6 +37,7 @@ extern "C" int rsa_set_tuning(const char* key, int value) {
     if (strcmp(key, "k5_maxblocks") == 0) { g_k5_maxblocks = value; return RSA_OK; }
     if (strcmp(key, "k5_pair") == 0) { g_rsa_k5_pair = value; return RSA_OK; }
     if (strcmp(key, "k3_prefix") == 0) { g_rsa_k3_prefix = value; return RSA_OK; }
+    if (strcmp(key, "k5_tsplit") == 0) { g_k5_tsplit = value; return RSA_OK; }
     if (strcmp(key, "fp8_variant") == 0) { rsa_set_fp8_variant(value); return RSA_OK; }
     return RSA_ERR_BAD_ARG;
 }
@@ -57,8 +59,63 @@ static int launch_attn_pp(AttnArgs& a, int BH, int D, int dtype, hipStream_t s) 
     return rsa_launch_bsfwd_pp(a, dim3((unsigned)nblocks), lds_bytes, D, dtype, g_k5_pp, s);
 }
 
+// Merge of the split-KV partials of the text query blocks (K5 wrote, per part, unnormalised O, the running maximum m in
+// the log2 domain and the row sum l): one wave per query row, lanes over the head dim.  Rows beyond the valid text rows
+// are written as zeros (as the 1-workgroup form does).
+template <typename Tag>
+__global__ __launch_bounds__(256) void text_combine_kernel(const float* __restrict__ tpart, unsigned short* out,
+                                                           long osb, long osh, long oss, int D, int H, int NBv, int ntq,
+                                                           int tsplit, int q_text_end, int Sq, long rows_total) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows_total) return;
+    const long bhq = row / RSA_BLOCK;
+    const int r = (int)(row % RSA_BLOCK);
+    const long bh = bhq / ntq;
+    const int tq = (int)(bhq % ntq);
+    const int grow = (NBv + tq) * RSA_BLOCK + r;
+    if (grow >= Sq) return;
+    const float* base = tpart + (bhq * tsplit * RSA_BLOCK + r) * (long)(D + 2);
+    const long pstride = (long)RSA_BLOCK * (D + 2);
+    float M = -INFINITY;
+    for (int s = 0; s < tsplit; ++s) M = fmaxf(M, base[s * pstride + D]);
+    float L = 0.0f;
+    float acc[2] = {0.0f, 0.0f};
+    for (int s = 0; s < tsplit; ++s) {
+        const float m = base[s * pstride + D], l = base[s * pstride + D + 1];
+        const float wgt = (m == -INFINITY) ? 0.0f : __builtin_amdgcn_exp2f(m - M);
+        L += l * wgt;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int d = lane + 64 * e;
+            if (d < D) acc[e] += base[s * pstride + d] * wgt;
+        }
+    }
+    const float inv = (grow < q_text_end && L > 0.0f) ? 1.0f / L : 0.0f;
+    unsigned short* op = out + (bh / H) * osb + (bh % H) * osh + (long)grow * oss;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int d = lane + 64 * e;
+        if (d < D) op[d] = Elem<Tag>::from_f32(acc[e] * inv);
+    }
+}
+
+static int launch_text_combine(const AttnArgs& a, int BH, int D, int dtype, hipStream_t s) {
+    const int ntq = a.NQB - a.NBv;
+    const long rows = (long)BH * ntq * RSA_BLOCK;
+    if (rows <= 0) return RSA_OK;
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    if (dtype == RSA_BF16)
+        text_combine_kernel<bf16_tag><<<grid, 256, 0, s>>>(a.tpart, a.out, a.osb, a.osh, a.oss, D, a.H, a.NBv, ntq,
+                                                         a.tsplit, a.q_text_end, a.Sq, rows);
+    else
+        text_combine_kernel<fp16_tag><<<grid, 256, 0, s>>>(a.tpart, a.out, a.osb, a.osh, a.oss, D, a.H, a.NBv, ntq,
+                                                         a.tsplit, a.q_text_end, a.Sq, rows);
+    return rsa_launch_status();
+}
+
 static int launch_attn(AttnArgs& a, int BH, int D, int dtype, hipStream_t s, int variant = -1) {
-    if (g_k5_pp && variant < 0) { a.pair_ok = nullptr; return launch_attn_pp(a, BH, D, dtype, s); }
+    if (g_k5_pp && variant < 0) { a.pair_ok = nullptr; a.tsplit = 1; return launch_attn_pp(a, BH, D, dtype, s); }
     if (a.pair_ok && a.NP > 0) {  // paired workgroups first (they are the longer ones: union lists)
         a.BH = BH;
         a.NPp = (a.NP + 7) & ~7;
@@ -69,7 +126,17 @@ static int launch_attn(AttnArgs& a, int BH, int D, int dtype, hipStream_t s, int
         if (st != RSA_OK) return st;
     }
     const int ntq = a.NQB - a.NBv;
-    const int n_heavy = ntq > 0 ? BH * ntq : 0;
+    // split-KV for the dense text rows: without it one workgroup walks every key block of a text query block (902 at the
+    // HunyuanVideo shape = 10 kept lists) -- hidden among 21 600 sparse blocks on one GPU, the critical path when the
+    // heads are sharded over 8
+    const int n_txt_items = (a.kv_text_valid + RSA_BLOCK - 1) / RSA_BLOCK;
+    a.tsplit = 1; a.tper = n_txt_items;
+    if (a.mode == MODE_SPARSE && ntq > 0 && a.tpart && g_k5_tsplit && n_txt_items >= 32) {
+        int sp = n_txt_items / 16;
+        a.tsplit = sp > RSA_TEXT_SPLIT ? RSA_TEXT_SPLIT : sp;
+        a.tper = (n_txt_items + a.tsplit - 1) / a.tsplit;
+    }
+    const int n_heavy = ntq > 0 ? BH * ntq * a.tsplit : 0;
     a.BH = BH;
     a.n_heavy_pad = (n_heavy + 7) & ~7;
     a.NBp = (a.NBv + 7) & ~7;
@@ -79,7 +146,10 @@ static int launch_attn(AttnArgs& a, int BH, int D, int dtype, hipStream_t s, int
     if (a.NB_total > 8192) return RSA_ERR_UNSUPPORTED;  // kept list lives in LDS as u16, 16 KiB max
     const size_t lds_bytes = (size_t)4 * 64 * D * 2 + (((size_t)a.NB_total * 2 + 15) & ~(size_t)15);
     const long launch_blocks = g_k5_maxblocks > 0 && g_k5_maxblocks < nblocks ? g_k5_maxblocks : nblocks;
-    return rsa_launch_bsfwd(a, dim3((unsigned)launch_blocks), lds_bytes, D, dtype, variant >= 0 ? variant : g_k5_prio, s);
+    const int st = rsa_launch_bsfwd(a, dim3((unsigned)launch_blocks), lds_bytes, D, dtype,
+                                    variant >= 0 ? variant : g_k5_prio, s);
+    if (st != RSA_OK || a.tsplit <= 1) return st;
+    return launch_text_combine(a, BH, D, dtype, s);
 }
 
 static void fill_qkv(AttnArgs& a, const rsa_tensor4& q, const rsa_tensor4& k, const rsa_tensor4& v,
@@ -111,6 +181,7 @@ extern "C" int rsa_block_sparse_fwd(const rsa_layout* l, rsa_tensor4 q, rsa_tens
     const bool pairing = g_rsa_k5_pair && buf->pcols && buf->pcounts && buf->pair_ok && l->NBv > 1;
     a.pcols = pairing ? buf->pcols : nullptr; a.pcounts = pairing ? buf->pcounts : nullptr;
     a.pair_ok = pairing ? buf->pair_ok : nullptr; a.NP = (l->NBv + 1) / 2;
+    a.tpart = buf->tpart;
     a.mode = MODE_SPARSE; a.H = l->H; a.Sq = l->S; a.Sk = l->S;
     a.NBv = l->NBv; a.NQB = l->NB_total; a.NB_total = l->NB_total;
     a.kv_valid = l->kv_valid; a.kv_text_valid = l->kv_text_valid;
@@ -133,7 +204,8 @@ extern "C" int rsa_dense_fwd(int B, int H, int Sq, int Sk, int D, int dtype, rsa
     AttnArgs a;
     fill_qkv(a, q, k, v, out);
     a.cols = nullptr; a.counts = nullptr; a.R = nullptr; a.comp = nullptr;
-    a.pcols = nullptr; a.pcounts = nullptr; a.pair_ok = nullptr; a.NP = 0;
+    a.pcols = nullptr; a.pcounts = nullptr; a.pair_ok = nullptr; a.NP = 0; a.tpart = nullptr;
+    a.tsplit = 1; a.tper = 0;
     a.mode = MODE_DENSE; a.H = H; a.Sq = Sq; a.Sk = Sk;
     a.NQB = (Sq + RSA_BLOCK - 1) / RSA_BLOCK; a.NBv = a.NQB; a.NB_total = (Sk + RSA_BLOCK - 1) / RSA_BLOCK;
     a.kv_valid = Sk; a.kv_text_valid = Sk; a.q_text_end = 0;

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
     unsigned short* lds_list = reinterpret_cast<unsigned short*>(lds + 4 * TILE_BYTES);
 
     // ---------------- work mapping: dense text-row blocks first, then the sparse blocks chunked per XCD ----------------
-    int bh, qblk;
+    int bh, qblk, tsp = 0;   // tsp: which part of a text block's key range this workgroup walks
     if constexpr (PAIR) {
         const int v = blockIdx.x;
         bh = v / a.NPp;
@@ -84,9 +84,12 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
         const int bid = blockIdx.x;
         if (bid < a.n_heavy_pad) {
             const int ntq = a.NQB - a.NBv;
-            if (ntq <= 0 || bid >= a.BH * ntq) return;
-            bh = bid / ntq;
-            qblk = a.NBv + bid % ntq;
+            const int per_bh = ntq * a.tsplit;      // text blocks x key-range splits (tsplit = 1: no split)
+            if (ntq <= 0 || bid >= a.BH * per_bh) return;
+            bh = bid / per_bh;
+            const int rem = bid % per_bh;
+            qblk = a.NBv + rem / a.tsplit;
+            tsp = rem % a.tsplit;
         } else {
             const int v = bid - a.n_heavy_pad;
             bh = v / a.NBp;
@@ -134,6 +137,11 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
             for (int qt = 0; qt < QT; ++qt) { hi_r[qt] = a.kv_valid; store_r[qt] = grow[qt] < a.Sq; }
         } else {
             n_items = (a.kv_text_valid + RSA_BLOCK - 1) / RSA_BLOCK;
+            if (a.tsplit > 1) {   // split-KV: this workgroup's slice of the key blocks
+                first_blk = tsp * a.tper;
+                n_items = n_items - first_blk < a.tper ? n_items - first_blk : a.tper;
+                if (n_items < 0) n_items = 0;
+            }
             lo_max = 0; hi_min = hi_max = a.kv_text_valid;
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
@@ -530,6 +538,25 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run[qt]), __float_as_uint(l_run[qt]),
                                                          false, false);
         const float l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        if constexpr (!PAIR) {
+            if (a.mode == MODE_SPARSE && a.tsplit > 1 && qblk >= a.NBv) {
+                // split-KV partial of a text block: unnormalised O (fp32), m (log2 domain) and l per row; the combine
+                // kernel (rsa_attn.hip) merges the tsplit parts
+                const int ntq = a.NQB - a.NBv;
+                const int rowb = 32 * QT * wv + 32 * qt + r;
+                float* pp = a.tpart + ((((long)bh * ntq + (qblk - a.NBv)) * a.tsplit + tsp) * RSA_BLOCK + rowb) * (D + 2);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int d0 = 32 * dt + 8 * g + 4 * hh;
+                        *reinterpret_cast<float2*>(pp + d0) = make_float2(o[dt][qt][4 * g + 0], o[dt][qt][4 * g + 1]);
+                        *reinterpret_cast<float2*>(pp + d0 + 2) = make_float2(o[dt][qt][4 * g + 2], o[dt][qt][4 * g + 3]);
+                    }
+                if (hh == 0) *reinterpret_cast<float2*>(pp + D) = make_float2(m_run[qt], l_tot);
+                continue;
+            }
+        }
         if (!(store_r[qt] || zero_r[qt])) continue;
         float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
         float Rv = 1.0f;

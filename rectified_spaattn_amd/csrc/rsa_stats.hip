@@ -708,7 +708,8 @@ extern "C" int rsa_buffer_bytes(const rsa_layout* l, size_t sizes[RSA_NUM_BUFFER
         BH * NBv * D * 4, BH * NBv * D * 4, BH * NBv * D * 4, BH * NBv * D * 4, BH * NB * D * 4,
         BH * NBv * NS * 4, BH * NBv * NBv,  BH * NBv * L * 4, BH * NBv * L * 4, BH * NBv * 4,
         BH * NBv * D * 4,  BH * NBv * NW * 4, BH * NBv * NB * 4, BH * NBv * 4,
-        BH * NP * NB * 2,  BH * NP * 4, BH * NP * 4};
+        BH * NP * NB * 2,  BH * NP * 4, BH * NP * 4,
+        BH * (NB - NBv) * RSA_TEXT_SPLIT * 128 * (D + 2) * 4};
     size_t tot = 0;
     for (int i = 0; i < RSA_NUM_BUFFERS; ++i) {
         sizes[i] = s[i];
@@ -735,6 +736,7 @@ extern "C" int rsa_carve_workspace(const rsa_layout* l, void* ws, size_t ws_byte
     out->probs = (float*)ptrs[7]; out->w = (float*)ptrs[8]; out->R = (float*)ptrs[9]; out->comp = (float*)ptrs[10];
     out->bitmask = (uint32_t*)ptrs[11]; out->cols = (int32_t*)ptrs[12]; out->counts = (int32_t*)ptrs[13];
     out->pcols = (uint16_t*)ptrs[14]; out->pcounts = (int32_t*)ptrs[15]; out->pair_ok = (int32_t*)ptrs[16];
+    out->tpart = (l->NB_total > l->NBv) ? (float*)ptrs[17] : nullptr;
     return RSA_OK;
 }
 

@@ -62,3 +62,27 @@ def test_prefix_path_equals_full_sort(cfg):
     for name in a:
         assert torch.equal(a[name], b[name]), f"{cfg}: {name} differs between the two K3 paths"
     assert int(a["counts"].min()) >= min(top_k, spec.L)
+
+
+def test_text_rows_split_kv_matches_single_workgroup_form():
+    """K5 splits the key range of the dense text query blocks over up to 16 workgroups (+ a combine kernel); the visual
+    rows must not change by a bit, the text rows only by the rounding of a different summation order."""
+    from bench import gen_qkv
+    from rectified_spaattn_amd import _core, _lib
+    S, H, D = 115456, 2, 128
+    q, k, v = gen_qkv(H, 0, S, S, D, torch.device(DEV), seed=9)
+    spec = _core.LayoutSpec.hunyuan(S, S - 56)
+    outs = []
+    for flag in (1, 0):
+        assert _lib.lib().rsa_set_tuning(b"k5_tsplit", flag) == 0
+        try:
+            outs.append(_core.rectified_attention(q, k, v, spec, 90, 0.05, None).clone())
+            torch.cuda.synchronize()
+        finally:
+            _lib.lib().rsa_set_tuning(b"k5_tsplit", 1)
+    a, b = outs
+    nv = spec.NBv * 128
+    assert torch.equal(a[:, :nv], b[:, :nv])
+    d = (a[:, nv:].float() - b[:, nv:].float()).abs()
+    assert float(d.max()) <= 4e-3, float(d.max())
+    assert float(a[:, nv + spec.q_text_valid:].abs().max()) == 0.0 and float(a[:, nv:nv + spec.q_text_valid].abs().max()) > 0
