@@ -401,6 +401,9 @@ def main():
     ap.add_argument("--gather-output", action="store_true",
                     help="N > 1: report only the variant with the all-gather of O along heads inside the timed region "
                          "(default: both variants are measured and reported)")
+    ap.add_argument("--gather-transports", default="",
+                    help="N > 1: also time the exchange through the library's own transports: comma list of rccl (rsa_"
+                         "allgather_heads) and p2p (rsa_allgather_heads_p2p); each is reported beside the torch.distributed one")
     ap.add_argument("--dry", action="store_true", help="host logic only (gloo, CPU): for the multi-process tests")
     args = ap.parse_args()
 
@@ -446,6 +449,24 @@ def main():
                       value=round(rec["flops"] / (elg / args.steps) / 1e12, 3),
                       bytes_per_rank=int(call.out.numel() * call.out.element_size()),
                       transport="torch.distributed all_gather (RCCL)")
+        for tr in [t for t in args.gather_transports.split(",") if t]:
+            try:   # the library's own transports (C-ABI); a failure is reported, it does not take the run down
+                B_, S_, Hl_, D_ = call.out.shape
+                hg = parallel.HeadGather(B_, S_, Hl_, D_, call.out.dtype, dev, transport=tr)
+
+                def hstep(_):
+                    call.select()
+                    if args.qkv_fp8:
+                        call.quantize()
+                    call.attend()
+                    hg.gather(call.out)
+                elh = timed_steps(comm, hstep, args.steps, max(1, args.warmup))
+                elh, _, _, _, _ = parallel.reduce_step_stats(elh, 0.0, 0.0, 0.0, dev)
+                gather[tr] = dict(ms_per_step=round(elh / args.steps * 1e3, 4),
+                                  value=round(rec["flops"] / (elh / args.steps) / 1e12, 3))
+                hg.close()
+            except Exception as e:  # noqa: BLE001
+                gather[tr] = {"error": repr(e)[:300]}
     if world == 1 and not args.no_extras:
         # sustained: >= 2 s of back-to-back steps of the headline regime (what a power / utilisation sampler can see)
         n_sus = max(args.steps, int(2.2 / max(rec["ms_per_step"] * 1e-3, 1e-4)))

@@ -237,9 +237,38 @@ int rsa_dense_fp8_bytes(int B, int H, int Sq, int Sk, int D, size_t* total);
 int rsa_dense_fwd_fp8(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
                       int q_split, int kv_split, void* workspace, size_t workspace_bytes, rsa_out4 out, void* stream);
 
+/* ---- multi-GPU: the exchange step at the layer boundary.  The path itself shards by (batch, head) with
+ * NO collective (reference: no cross-head dependency anywhere, rectified_hunyuan_attn.py:211-277, gapr_mask.py:15-42);
+ * only a consumer that is not head-sharded (the to_out GEMM of an unsharded model) needs every rank's O.  The
+ * reference's only multi-GPU code is prompt-level replication (eval/video/experiments/multigpu_hunyuan.py:290-299). ---- */
+
+/* RCCL communicator over the ranks of one node (librccl is bound at run time).  rsa_comm_unique_id: rank 0 fills
+ * id128 (HOST, 128 bytes) and distributes it by any host channel; every rank then calls rsa_comm_create. */
+int rsa_comm_unique_id(void* id128);
+int rsa_comm_create(int world, int rank, const void* id128, void** comm);
+int rsa_comm_destroy(void* comm);
+
+/* All-gather of O along the head axis: local [rows][local_row_bytes] on every rank -> full [rows][world*local_row_bytes]
+ * on every rank (rank r's bytes at column offset r*local_row_bytes) = ncclAllGather into `staging`
+ * ([world][rows][local_row_bytes]) + one unpack kernel.  DEVICE pointers, 16-byte aligned, local_row_bytes % 16 == 0. */
+int rsa_allgather_heads(void* comm, int world, const void* local, void* staging, void* full, int64_t rows,
+                        int64_t local_row_bytes, void* stream);
+
+/* The same exchange as `world` 2-D peer copies over the point-to-point xGMI links, no staging: this rank writes its
+ * slab into column range [rank*local_row_bytes, +local_row_bytes) of every rank's full buffer.  full_of_rank: HOST
+ * array of `world` device pointers (own buffer at index rank; the others opened with rsa_ipc_open).  Completion on the
+ * peers is the caller's to order (a barrier after the stream has drained). */
+int rsa_allgather_heads_p2p(int world, int rank, const void* local, void* const* full_of_rank, int64_t rows,
+                            int64_t local_row_bytes, void* stream);
+int rsa_ipc_export(const void* dev_ptr, void* handle64);                    /* 64-byte handle of a device allocation */
+int rsa_ipc_open(const void* handle64, int peer_device, void** dev_ptr);    /* map a peer's allocation here */
+int rsa_ipc_close(void* dev_ptr);
+
 /* Tuning / diagnostics hook, not part of the data path.  Keys: "k5_prio" (0/1: issue-priority raise inside K5's
  * pipelined block + LLVM's iglp_opt(0) interleave), "dense256" (0/1: rsa_dense_fwd on 256-row query tiles, 8 waves
- * per workgroup; same results), "fp8_variant" (0..4: iglp_opt strategy of the fp8 kernel's block; 0 = none). */
+ * per workgroup; same results), "fp8_variant" (0..4: iglp_opt strategy of the fp8 kernel's block; 0 = none), "k5_pair" (paired 256-row workgroups),
+ * "k5_pp" (ping-pong kernel), "k5_tsplit" (split-KV of the text blocks), "k3_prefix" (sorted-head path of K3).  The hook
+ * is inert (RSA_ERR_UNSUPPORTED) unless the process was started with the environment variable RSA_TUNING=1. */
 int rsa_set_tuning(const char* key, int value);
 
 const char* rsa_status_string(int status);

@@ -106,6 +106,17 @@ def lib():
     L.rsa_block_sparse_fwd_fp8.argtypes = [P(RsaLayout), P(RsaFp8Operands), P(RsaBuffers), RsaOut4, vp]
     L.rsa_rectified_attention_fp8.argtypes = [P(RsaLayout), RsaTensor4, RsaTensor4, RsaTensor4, vp, i32, f32, vp, sz,
                                               vp, sz, RsaOut4, vp]
+    L.rsa_comm_unique_id.argtypes = [vp]
+    L.rsa_comm_create.argtypes = [i32, i32, vp, P(vp)]
+    L.rsa_comm_destroy.argtypes = [vp]
+    L.rsa_allgather_heads.argtypes = [vp, i32, vp, vp, vp, i64, i64, vp]
+    L.rsa_allgather_heads_p2p.argtypes = [i32, i32, vp, P(vp), i64, i64, vp]
+    L.rsa_ipc_export.argtypes = [vp, vp]
+    L.rsa_ipc_open.argtypes = [vp, i32, P(vp)]
+    L.rsa_ipc_close.argtypes = [vp]
+    for name in ("rsa_comm_unique_id", "rsa_comm_create", "rsa_comm_destroy", "rsa_allgather_heads",
+                 "rsa_allgather_heads_p2p", "rsa_ipc_export", "rsa_ipc_open", "rsa_ipc_close"):
+        getattr(L, name).restype = i32
     for name in ("rsa_fp8_operand_bytes", "rsa_carve_fp8_operands", "rsa_quantize_fp8", "rsa_block_sparse_fwd_fp8",
                  "rsa_rectified_attention_fp8", "rsa_pool_stats_fp8", "rsa_fp8_images", "rsa_dense_fp8_bytes",
                  "rsa_dense_fwd_fp8"):
@@ -130,7 +141,9 @@ EXPORTED = ("rsa_version", "rsa_buffer_bytes", "rsa_carve_workspace", "rsa_pool_
             "rsa_dense_fwd", "rsa_estimate_pr_gain", "rsa_status_string", "rsa_last_hip_error", "rsa_set_tuning", "rsa_gilbert_mapping",
             "rsa_gilbert_block_neighbors", "rsa_permute_tokens", "rsa_qk_norm_rope", "rsa_fp8_operand_bytes",
             "rsa_carve_fp8_operands", "rsa_quantize_fp8", "rsa_block_sparse_fwd_fp8", "rsa_rectified_attention_fp8",
-            "rsa_pool_stats_fp8", "rsa_fp8_images", "rsa_dense_fp8_bytes", "rsa_dense_fwd_fp8", "rsa_rel_l1")
+            "rsa_pool_stats_fp8", "rsa_fp8_images", "rsa_dense_fp8_bytes", "rsa_dense_fwd_fp8", "rsa_rel_l1",
+            "rsa_comm_unique_id", "rsa_comm_create", "rsa_comm_destroy", "rsa_allgather_heads",
+            "rsa_allgather_heads_p2p", "rsa_ipc_export", "rsa_ipc_open", "rsa_ipc_close")
 
 
 def check(status: int, what: str):

@@ -1,0 +1,168 @@
+// Layer-boundary exchange of the head-sharded attention output (include/rsa.h "multi-GPU"):
+// every rank holds O for its heads as [rows = B*S][Hl*D]; the consumer (to_out GEMM) of an unsharded model wants
+// [rows][H*D] on every rank.  Two transports behind the C-ABI:
+//   * rsa_allgather_heads      RCCL ncclAllGather (rank-major staging) + one unpack kernel into the head-major rows;
+//   * rsa_allgather_heads_p2p  every rank copies its [rows][Hl*D] slab straight into its column range of every peer's
+//                              full buffer: world 2-D peer copies (hipMemcpy2DAsync) over the point-to-point xGMI links,
+//                              no staging, no unpack; peers' buffers are opened through HIP IPC handles.
+// RCCL is bound at run time (dlopen): a process that already carries an RCCL (PyTorch bundles one) keeps using that
+// copy, and single-GPU hosts do not need the library at all.  Nothing here is on the attention path itself: the path
+// shards by head with no collective.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "rsa.h"
+
+extern int g_rsa_last_hip_error;
+
+namespace {
+
+typedef struct { char internal[128]; } rsa_nccl_id;   // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128)
+typedef int (*fn_get_id)(rsa_nccl_id*);
+typedef int (*fn_init_rank)(void**, int, rsa_nccl_id, int);
+typedef int (*fn_destroy)(void*);
+typedef int (*fn_allgather)(const void*, void*, size_t, int, void*, hipStream_t);
+
+struct Rccl {
+    void* h = nullptr;
+    fn_get_id get_id = nullptr;
+    fn_init_rank init_rank = nullptr;
+    fn_destroy destroy = nullptr;
+    fn_allgather allgather = nullptr;
+    bool tried = false;
+};
+Rccl g_rccl;
+
+bool load_rccl() {
+    if (g_rccl.tried) return g_rccl.allgather != nullptr;
+    g_rccl.tried = true;
+    const char* names[] = {"librccl.so", "librccl.so.1"};
+    for (const char* n : names) {   // a copy the process already loaded (PyTorch's) first
+        g_rccl.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+        if (g_rccl.h) break;
+    }
+    for (int i = 0; !g_rccl.h && i < 2; ++i) g_rccl.h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+    if (!g_rccl.h) return false;
+    g_rccl.get_id = (fn_get_id)dlsym(g_rccl.h, "ncclGetUniqueId");
+    g_rccl.init_rank = (fn_init_rank)dlsym(g_rccl.h, "ncclCommInitRank");
+    g_rccl.destroy = (fn_destroy)dlsym(g_rccl.h, "ncclCommDestroy");
+    g_rccl.allgather = (fn_allgather)dlsym(g_rccl.h, "ncclAllGather");
+    if (!g_rccl.get_id || !g_rccl.init_rank || !g_rccl.destroy || !g_rccl.allgather) g_rccl.allgather = nullptr;
+    return g_rccl.allgather != nullptr;
+}
+
+int hip_status(hipError_t e) {
+    if (e == hipSuccess) return RSA_OK;
+    g_rsa_last_hip_error = (int)e;
+    return RSA_ERR_LAUNCH;
+}
+
+// staging [world][rows][w16] (16-byte units) -> full [rows][world * w16]
+__global__ __launch_bounds__(256) void unpack_heads_kernel(const uint4* __restrict__ staging, uint4* __restrict__ full,
+                                                           long rows, int w16, int world) {
+    const long n = rows * (long)w16 * world;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long row = i / ((long)w16 * world);
+        const int col = (int)(i % ((long)w16 * world));
+        const int rk = col / w16, c = col % w16;
+        full[i] = staging[((long)rk * rows + row) * w16 + c];
+    }
+}
+
+}  // namespace
+
+extern "C" int rsa_comm_unique_id(void* id128) {
+    if (!id128) return RSA_ERR_BAD_ARG;
+    if (!load_rccl()) return RSA_ERR_UNSUPPORTED;
+    rsa_nccl_id id;
+    if (g_rccl.get_id(&id) != 0) return RSA_ERR_LAUNCH;
+    memcpy(id128, &id, sizeof(id));
+    return RSA_OK;
+}
+
+extern "C" int rsa_comm_create(int world, int rank, const void* id128, void** comm) {
+    if (!id128 || !comm || world <= 0 || rank < 0 || rank >= world) return RSA_ERR_BAD_ARG;
+    if (!load_rccl()) return RSA_ERR_UNSUPPORTED;
+    rsa_nccl_id id;
+    memcpy(&id, id128, sizeof(id));
+    void* c = nullptr;
+    if (g_rccl.init_rank(&c, world, id, rank) != 0) return RSA_ERR_LAUNCH;
+    *comm = c;
+    return RSA_OK;
+}
+
+extern "C" int rsa_comm_destroy(void* comm) {
+    if (!comm) return RSA_ERR_BAD_ARG;
+    if (!load_rccl()) return RSA_ERR_UNSUPPORTED;
+    return g_rccl.destroy(comm) == 0 ? RSA_OK : RSA_ERR_LAUNCH;
+}
+
+extern "C" int rsa_allgather_heads(void* comm, int world, const void* local, void* staging, void* full, int64_t rows,
+                                   int64_t local_row_bytes, void* stream) {
+    if (!comm || !local || !staging || !full || world <= 0 || rows <= 0 || local_row_bytes <= 0) return RSA_ERR_BAD_ARG;
+    if ((local_row_bytes & 15) || ((uintptr_t)local & 15) || ((uintptr_t)staging & 15) || ((uintptr_t)full & 15))
+        return RSA_ERR_BAD_ARG;
+    if (!load_rccl()) return RSA_ERR_UNSUPPORTED;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t count = (size_t)rows * (size_t)local_row_bytes;
+    if (g_rccl.allgather(local, staging, count, /*ncclInt8*/ 0, comm, s) != 0) return RSA_ERR_LAUNCH;
+    const int w16 = (int)(local_row_bytes / 16);
+    const long n = rows * (long)w16 * world;
+    long blocks = (n + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    unpack_heads_kernel<<<dim3((unsigned)blocks), 256, 0, s>>>(static_cast<const uint4*>(staging),
+                                                               static_cast<uint4*>(full), rows, w16, world);
+    return hip_status(hipGetLastError());
+}
+
+extern "C" int rsa_ipc_export(const void* dev_ptr, void* handle64) {
+    if (!dev_ptr || !handle64) return RSA_ERR_BAD_ARG;
+    static_assert(sizeof(hipIpcMemHandle_t) <= 64, "IPC handle does not fit the 64-byte slot of the C-ABI");
+    hipIpcMemHandle_t h;
+    const int st = hip_status(hipIpcGetMemHandle(&h, const_cast<void*>(dev_ptr)));
+    if (st != RSA_OK) return st;
+    memset(handle64, 0, 64);
+    memcpy(handle64, &h, sizeof(h));
+    return RSA_OK;
+}
+
+extern "C" int rsa_ipc_open(const void* handle64, int peer_device, void** dev_ptr) {
+    if (!handle64 || !dev_ptr) return RSA_ERR_BAD_ARG;
+    if (peer_device >= 0) {   // let this device address the peer's memory (idempotent)
+        int cur = 0;
+        int st = hip_status(hipGetDevice(&cur));
+        if (st != RSA_OK) return st;
+        if (peer_device != cur) {
+            const hipError_t e = hipDeviceEnablePeerAccess(peer_device, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return hip_status(e);
+            (void)hipGetLastError();
+        }
+    }
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle64, sizeof(h));
+    return hip_status(hipIpcOpenMemHandle(dev_ptr, h, hipIpcMemLazyEnablePeerAccess));
+}
+
+extern "C" int rsa_ipc_close(void* dev_ptr) {
+    if (!dev_ptr) return RSA_ERR_BAD_ARG;
+    return hip_status(hipIpcCloseMemHandle(dev_ptr));
+}
+
+extern "C" int rsa_allgather_heads_p2p(int world, int rank, const void* local, void* const* full_of_rank, int64_t rows,
+                                       int64_t local_row_bytes, void* stream) {
+    if (!local || !full_of_rank || world <= 0 || rank < 0 || rank >= world || rows <= 0 || local_row_bytes <= 0)
+        return RSA_ERR_BAD_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t pitch = (size_t)local_row_bytes * (size_t)world;
+    for (int step = 0; step < world; ++step) {
+        const int peer = (rank + step) % world;   // own copy first, then a different peer (link) per step on every rank
+        if (!full_of_rank[peer]) return RSA_ERR_BAD_ARG;
+        unsigned char* dst = static_cast<unsigned char*>(full_of_rank[peer]) + (size_t)rank * (size_t)local_row_bytes;
+        const int st = hip_status(hipMemcpy2DAsync(dst, pitch, local, (size_t)local_row_bytes, (size_t)local_row_bytes,
+                                                   (size_t)rows, hipMemcpyDeviceToDevice, s));
+        if (st != RSA_OK) return st;
+    }
+    return RSA_OK;
+}

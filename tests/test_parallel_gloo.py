@@ -69,3 +69,20 @@ def test_bench_starts_its_own_ranks_dry():
     assert rec["n_gpus"] == 2 and rec["steps"] == 4 and rec["warmup"] == 1 and rec["heads_per_gpu"] == 12
     assert len(rec["per_rank_ms"]) == 2 and rec["per_rank_ms"][1] > rec["per_rank_ms"][0]  # rank 1 sleeps longer
     assert rec["imbalance"] > 1.05 and rec["ms_per_step"] >= max(rec["per_rank_ms"]) * 0.99
+
+
+def test_comm_entry_points_validate_arguments_on_the_host():
+    """The exchange entry points of the C-ABI reject bad arguments before touching RCCL / HIP (runs without a GPU)."""
+    import ctypes
+    from rectified_spaattn_amd import _lib
+    L = _lib.lib()
+    vp = ctypes.c_void_p
+    assert L.rsa_comm_unique_id(None) == -1
+    assert L.rsa_comm_create(2, 5, vp(1), ctypes.byref(vp())) == -1          # rank outside the world
+    assert L.rsa_comm_destroy(None) == -1
+    assert L.rsa_allgather_heads(None, 2, vp(16), vp(16), vp(16), 4, 32, None) == -1
+    assert L.rsa_allgather_heads(vp(1), 2, vp(16), vp(16), vp(16), 4, 24, None) == -1   # rows not 16-byte multiples
+    peers = (vp * 2)()
+    assert L.rsa_allgather_heads_p2p(2, 0, vp(16), peers, 4, 32, None) == -1            # null peer pointer
+    assert L.rsa_allgather_heads_p2p(2, 3, vp(16), peers, 4, 32, None) == -1
+    assert L.rsa_ipc_export(None, None) == -1 and L.rsa_ipc_open(None, 0, None) == -1 and L.rsa_ipc_close(None) == -1
