@@ -27,21 +27,25 @@ def rectified_sparse_blocks_cpu(q, k, v, cols, counts, R, comp, kv_valid, qblock
     kb, vb = k.view(nbp, BLOCK, D), v.view(nbp, BLOCK, D)
     qblocks = [int(i) for i in qblocks]
     out = q.new_empty(len(qblocks), BLOCK, D)
-    # group query blocks by kept count so that each group is one batched SDPA call
+    # group query blocks by (kept count, valid keys) so that each group is one SDPA call without a mask: lists are
+    # ascending, so only the LAST kept block of a row can cross kv_valid and the valid keys are a prefix of the gather
     by_n = {}
     for pos, i in enumerate(qblocks):
-        by_n.setdefault(int(counts[i]), []).append((pos, i))
-    tok = torch.arange(BLOCK)
-    for n, items in by_n.items():
+        n = int(counts[i])
+        last = int(cols[i, n - 1]) if n > 0 else 0
+        valid = max(0, (n - 1) * BLOCK + min(BLOCK, int(kv_valid) - last * BLOCK)) if n > 0 else 0
+        by_n.setdefault((n, valid), []).append((pos, i))
+    for (n, valid), items in by_n.items():
         pos = torch.tensor([p for p, _ in items])
         ids = torch.tensor([i for _, i in items])
+        if valid <= 0:
+            out[pos] = comp[ids].float()[:, None, :].expand(-1, BLOCK, -1).to(q.dtype)
+            continue
         blk = cols[ids, :n].long()                                    # [g, n]
-        kg = kb[blk].reshape(len(items), n * BLOCK, D)
-        vg = vb[blk].reshape(len(items), n * BLOCK, D)
+        kg = kb[blk].reshape(len(items), n * BLOCK, D)[:, :valid]
+        vg = vb[blk].reshape(len(items), n * BLOCK, D)[:, :valid]
         qg = q.view(nbp, BLOCK, D)[ids]
-        col_tok = (blk[:, :, None] * BLOCK + tok[None, None, :]).reshape(len(items), 1, n * BLOCK)
-        mask = col_tok < kv_valid                                      # [g, 1, n*128] key-validity mask
-        o = F.scaled_dot_product_attention(qg, kg, vg, attn_mask=mask)
+        o = F.scaled_dot_product_attention(qg[None], kg[None], vg[None])[0]   # [1, g, 128, D]: groups as "heads"
         o = o.float() * R[ids].float()[:, None, None] + comp[ids].float()[:, None, :]
         out[pos] = o.to(q.dtype)
     return out

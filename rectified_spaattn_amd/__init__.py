@@ -12,7 +12,7 @@ Module names mirror the reference package `rectified_spaattn`:
     teacache                  TeaCache step-skipping controller (scripts' teacache_forward bookkeeping), rel_l1_distance
 Device work goes through librsa_hip.so (C-ABI in include/rsa.h); nothing here falls back to PyTorch kernels.
 """
-__version__ = "0.1.0"
+__version__ = "0.2.0"
 
 
 def set_qkv_fp8(enabled: bool) -> bool:

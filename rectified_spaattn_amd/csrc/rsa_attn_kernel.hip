@@ -254,10 +254,17 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
 #pragma unroll
             for (int j = 0; j < NPC; ++j) {
                 const unsigned vo = is_v ? voffv[j % PG] : voffk[j % PG];
-                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                             :: "v"(vo), "s"(tb + (TEAMS * (j / PG) + team) * step),
-                                "s"(ld0 + (TEAMS * (j / PG) + team) * 4096 + (j % PG) * 1024)
-                             : "memory");
+                if constexpr (PIPE_OPT & 2048) {   // experiment: non-temporal policy for the K/V stream
+                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt"
+                                 :: "v"(vo), "s"(tb + (TEAMS * (j / PG) + team) * step),
+                                    "s"(ld0 + (TEAMS * (j / PG) + team) * 4096 + (j % PG) * 1024)
+                                 : "memory");
+                } else {
+                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                                 :: "v"(vo), "s"(tb + (TEAMS * (j / PG) + team) * step),
+                                    "s"(ld0 + (TEAMS * (j / PG) + team) * 4096 + (j % PG) * 1024)
+                                 : "memory");
+                }
             }
         } else {
 #pragma unroll
@@ -607,6 +614,7 @@ int rsa_launch_bsfwd(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int 
     do { \
         if (prio == 8) bsfwd_kernel<DD, TT, 8, 1, 2 + 256><<<grid, 512, lds_bytes, s>>>(a); \
         else if (prio == 4) bsfwd_kernel<DD, TT, 4, 1, 2 + 4 + 256><<<grid, 256, lds_bytes, s>>>(a); \
+        else if (prio == 16) bsfwd_kernel<DD, TT, 4, 1, 2 + 256 + 2048><<<grid, 256, lds_bytes, s>>>(a); \
         else if (prio) bsfwd_kernel<DD, TT, 4, 1, 2 + 256><<<grid, 256, lds_bytes, s>>>(a); \
         else bsfwd_kernel<DD, TT, 4, 1, 0><<<grid, 256, lds_bytes, s>>>(a); \
     } while (0)

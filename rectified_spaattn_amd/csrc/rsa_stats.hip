@@ -921,4 +921,4 @@ extern "C" const char* rsa_status_string(int status) {
 int g_rsa_last_hip_error = 0;
 extern "C" const char* rsa_last_hip_error(void) { return hipGetErrorString((hipError_t)g_rsa_last_hip_error); }
 
-extern "C" int rsa_version(void) { return 100; }
+extern "C" int rsa_version(void) { return 200; }  // 0.2.0: rsa_buffers has 18 members (pair lists, text partials)

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Round-2 measurement set: GPU tests, smoke, the bench line (all sub-records), per-workload lines, rocprofv3 kernel stats,
+# PMC summary of K5 and memory-side traffic of K5 in the three regimes.  Everything lands in gpurun_out/r2z_*.
+set -x
+python -m pytest tests -x -q -m gpu 2>&1 | tail -5 > gpurun_out/r2z_tests.txt
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r2z_smoke.txt 2>&1
+for RG in r2 r1 locality; do
+  bash tools/pmc_traffic.sh r2z_pmc_$RG $RG > gpurun_out/r2z_pmc_$RG.txt 2>&1
+  cp gpurun_out/r2z_pmc_$RG/traffic.json gpurun_out/r02_k5_traffic_$RG.json
+  rm -rf gpurun_out/r2z_pmc_$RG
+done
+python bench.py --steps 20 --warmup 5 --via-api > gpurun_out/r2z_bench.json 2> gpurun_out/r2z_bench.err
+python bench.py --steps 20 --warmup 5 --qkv-fp8 --no-cpu-baseline > gpurun_out/r2z_bench_fp8.json 2>> gpurun_out/r2z_bench.err
+python bench.py --steps 20 --warmup 3 --workload flux_4096 --no-cpu-baseline --no-extras > gpurun_out/r2z_bench_flux.json 2>> gpurun_out/r2z_bench.err
+python bench.py --steps 20 --warmup 3 --workload wan21_720p_81f --no-cpu-baseline --no-extras > gpurun_out/r2z_bench_wan21.json 2>> gpurun_out/r2z_bench.err
+python bench.py --steps 20 --warmup 3 --workload wan22_ti2v_720p_121f --no-cpu-baseline --no-extras > gpurun_out/r2z_bench_wan22.json 2>> gpurun_out/r2z_bench.err
+python bench.py --steps 20 --warmup 3 --workload wan22_ti2v_720p_121f --qkv-fp8 --no-cpu-baseline --no-extras > gpurun_out/r2z_bench_wan22_fp8.json 2>> gpurun_out/r2z_bench.err
+R=$PWD; cd /tmp; export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r2z_prof -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $R/gpurun_out/r2z_prof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r2z_prof_fp8 -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --qkv-fp8 > $R/gpurun_out/r2z_prof_fp8.log 2>&1
+cd $R
+python3 tools/summarize_prof.py $(find gpurun_out/r2z_prof -name "*kernel_stats.csv" | head -1) > gpurun_out/r2z_kernel_stats.md
+python3 tools/summarize_prof.py $(find gpurun_out/r2z_prof_fp8 -name "*kernel_stats.csv" | head -1) > gpurun_out/r2z_kernel_stats_fp8.md
+bash tools/pmc_passes.sh r2z_pmc_all > gpurun_out/r2z_pmc_all.txt 2>&1
+cp gpurun_out/r2z_pmc_all/summary.txt gpurun_out/r2z_pmc_summary.txt; rm -rf gpurun_out/r2z_pmc_all
+for d in r2z_prof r2z_prof_fp8; do find gpurun_out/$d -name "*kernel_trace.csv" -delete; done
+du -sh gpurun_out
+tail -3 gpurun_out/r2z_tests.txt; cat gpurun_out/r2z_smoke.txt | tail -2; tail -c 600 gpurun_out/r2z_bench.json
