@@ -10,7 +10,11 @@ Module names mirror the reference package `rectified_spaattn`:
     rectified_cogvideo_attn   rectified_block_sparse_attention, RectifiedCogVideoXVideoSpaAttnProcessor2_0
     attn_processor            get_attn_processors, set_attn_processor
     teacache                  TeaCache step-skipping controller (scripts' teacache_forward bookkeeping), rel_l1_distance
-Device work goes through librsa_hip.so (C-ABI in include/rsa.h); nothing here falls back to PyTorch kernels.
+Device work goes through librsa_hip.so (C-ABI in include/rsa.h): the attention operators and fullattn never fall back to
+PyTorch kernels for device tensors (they raise).  Two deliberate uses of plain PyTorch expressions remain and are the
+reference's own code paths: fullattn(mode="torch" | "vanilla") on CPU tensors (BASELINE config 1) and
+teacache.rel_l1_distance for CPU tensors / small fp32 inputs such as timestep embeddings (bf16 / fp16 device tensors take
+the one-pass HIP reduction rsa_rel_l1).
 """
 __version__ = "0.2.0"
 

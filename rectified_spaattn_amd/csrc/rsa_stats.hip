@@ -288,6 +288,7 @@ struct SelectArgs {
     float thr, scale;
 };
 int g_rsa_k3_prefix = 1;
+int g_rsa_k4_rows = 32;   // query-block rows per workgroup of K4 (16 or 32; tuning key "k4_rows": measured equal)
 
 __device__ __forceinline__ float wave_tree4(const float (&part)[4]) {
     float u[4];
@@ -569,12 +570,13 @@ __global__ __launch_bounds__(256) void select_mask_kernel(SelectArgs a) {
 // =====================================================================================================
 // K4: comp[i, :] = sum_j w[i, j] * vbar[j, :]   (tolerance-only quantity; fp32 FMA, j ascending)
 // =====================================================================================================
-template <int D>
+template <int D, int TI>
 __global__ __launch_bounds__(256) void compensation_kernel(const float* w, const float* vbar, float* comp, int NBv,
                                                            int L, int NB_total) {
     // out tile 32 (i) x D (d); thread = RI rows x 4 d; j staged through LDS in chunks of 32 (W transposed so a
     // thread's rows are one vector read)
-    constexpr int TI = 32, TJ = 32, TD = D / 4, TG = 256 / TD, RI = TI / TG;
+    constexpr int TJ = 32, TD = D / 4, TG = 256 / TD, RI = TI / TG;
+    static_assert(RI >= 1 && TI * TJ % 256 == 0, "tile shape");
     __shared__ __attribute__((aligned(16))) float Ws[TJ][TI + 4];
     __shared__ __attribute__((aligned(16))) float Vs[TJ][D];
     const int bh = blockIdx.y, i0 = blockIdx.x * TI, t = threadIdx.x;
@@ -860,10 +862,17 @@ extern "C" int rsa_compensation(const rsa_layout* l, const rsa_buffers* buf, voi
     if (!buf || !buf->w || !buf->vbar || !buf->comp) return RSA_ERR_BAD_ARG;
     if (l->NBv == 0) return RSA_OK;
     const int L = l->NBv + (l->n_txt > 0 ? 1 : 0);
-    dim3 grid((l->NBv + 31) / 32, l->B * l->H);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (l->D == 128) compensation_kernel<128><<<grid, 256, 0, s>>>(buf->w, buf->vbar, buf->comp, l->NBv, L, l->NB_total);
-    else compensation_kernel<64><<<grid, 256, 0, s>>>(buf->w, buf->vbar, buf->comp, l->NBv, L, l->NB_total);
+    // 32-row tiles; 16-row tiles (twice the workgroups) measured the same (tools/ab_k4.py)
+    const int ti = g_rsa_k4_rows;
+    dim3 grid((l->NBv + ti - 1) / ti, l->B * l->H);
+    if (l->D == 128) {
+        if (ti == 16) compensation_kernel<128, 16><<<grid, 256, 0, s>>>(buf->w, buf->vbar, buf->comp, l->NBv, L, l->NB_total);
+        else compensation_kernel<128, 32><<<grid, 256, 0, s>>>(buf->w, buf->vbar, buf->comp, l->NBv, L, l->NB_total);
+    } else {
+        if (ti == 16) compensation_kernel<64, 16><<<grid, 256, 0, s>>>(buf->w, buf->vbar, buf->comp, l->NBv, L, l->NB_total);
+        else compensation_kernel<64, 32><<<grid, 256, 0, s>>>(buf->w, buf->vbar, buf->comp, l->NBv, L, l->NB_total);
+    }
     return rsa_launch_status();
 }
 

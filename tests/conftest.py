@@ -36,6 +36,10 @@ OP_CASES = ["wan_640", "wan_pad_1450", "wan_d64_1100", "wan_nonbr_1024", "hunyua
 B2_CASES = ["b2_hunyuan_1280", "b2_flux_1280", "b2_cogvideo_994"]
 
 
+# a row longer than 256 columns through the reference (exercises K3's sorted-head path); output stored as fp16
+BIG_CASES = ["big_wan_33280"]
+
+
 def reference_rows(meta, lay):
     """bool [B, S]: rows of a golden `out` that the reference computes for that batch item.  B = 1: all.  B = 2: the
     visual rows of both items, the text rows of item 0 only -- the reference's text-row flash call gets the 3-entry

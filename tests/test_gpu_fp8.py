@@ -4,7 +4,7 @@
 * the kept lists, R and comp are the 2-byte path's (the mask-selection pass does not see the fp8 images)
 * the kernel's output is within max|d| <= 4e-2, mean|d| <= 4e-3 of the fp8-aware oracle (same dequantised e4m3
   operands, P kept exact) for N(0,1)-scale V -- measured 2.3e-2 / 2.5e-3, which is the e4m3 rounding of P
-* against the bf16 oracle (un-quantised inputs) the stated tolerance is max|d| <= 2e-1, mean|d| <= 2e-2: here the
+* against the bf16 oracle (un-quantised inputs) the stated tolerance is max|d| <= 1.6e-1, mean|d| <= 1.5e-2: here the
   e4m3 rounding of Q, K, V themselves dominates (the fp8-aware oracle alone is 5e-2..1.4e-1 / 1e-2 away from the bf16
   oracle on this data, so SURVEY 8(d)'s provisional 8e-2 is not reachable by any per-head-scaled e4m3 operand set)
 """
@@ -17,7 +17,7 @@ from oracle import oracle as orc
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
-FP8_MAX_VS_BF16, FP8_MEAN_VS_BF16 = 2e-1, 2e-2
+FP8_MAX_VS_BF16, FP8_MEAN_VS_BF16 = 1.6e-1, 1.5e-2   # measured 1.4e-1 / 1.3e-2; see tests/diag_fp8_scale_granularity.py
 FP8_MAX_VS_FP8, FP8_MEAN_VS_FP8 = 4e-2, 4e-3
 
 

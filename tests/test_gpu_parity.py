@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import B2_CASES, OP_CASES, case_inputs, load_op_case, reference_rows
+from conftest import B2_CASES, BIG_CASES, OP_CASES, case_inputs, load_op_case, reference_rows
 from oracle import oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -69,6 +69,22 @@ def test_operator_vs_oracle_and_golden(name, dt):
     if dt == torch.bfloat16:
         e2 = np.abs(out - gold["out"])[reference_rows(meta, lay)]
         assert e2.max() <= mx and e2.mean() <= mean
+
+
+@pytest.mark.parametrize("name", BIG_CASES)
+def test_long_row_case_vs_reference_vectors(name):
+    """Rows of 260 columns (K3's sorted-head path, 20 kept + neighbours per row): every mask bit, GAPR bit and
+    probability against the reference's own run, O against its output (stored as fp16)."""
+    from rectified_spaattn_amd import _core
+    meta, gold = load_op_case(name)
+    q, k, v, lay, nbr = case_inputs(meta)
+    out, g, _ = _run(q, k, v, lay, meta["top_k"], meta["p"], nbr, torch.bfloat16)
+    kept = orc.unpack_bits(g["bitmask"][0].view(np.uint32), lay.NB_total)
+    assert np.array_equal(kept, gold["one_hot"][0, 0]), f"{name}: block mask differs from the reference"
+    assert np.array_equal(g["unrel"][0], gold["nogapr"][0, 0])
+    np.testing.assert_allclose(g["probs"][0], gold["probs"][0, 0], rtol=2e-5, atol=1e-6)
+    err = np.abs(out - gold["out"].astype(np.float32))
+    assert err.max() <= 2e-2 and err.mean() <= 2e-3, f"{name}: max {err.max():.3e} mean {err.mean():.3e}"
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])

@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import B2_CASES, GOLDEN, OP_CASES, case_inputs, load_op_case, reference_rows
+from conftest import B2_CASES, BIG_CASES, GOLDEN, OP_CASES, case_inputs, load_op_case, reference_rows
 from oracle import oracle as orc
 
 
@@ -26,6 +26,23 @@ def test_operator_matches_reference(name):
     err = np.abs(out - gold["out"])[reference_rows(meta, lay)]
     assert err.max() < 2e-3, f"{name}: max|dO| = {err.max()}"
     assert err.mean() < 2e-4
+
+
+@pytest.mark.parametrize("name", BIG_CASES)
+def test_long_row_case_matches_reference(name):
+    """260 blocks per row: masks / GAPR / probabilities of every row, the output on sampled query blocks (the fp64
+    dense-masked restatement of all 33 280 rows would take minutes on CPU; the GPU test compares every row)."""
+    meta, gold = load_op_case(name)
+    q, k, v, lay, nbr = case_inputs(meta)
+    sel = orc.select_head(q[0, 0], k[0, 0], v[0, 0], lay, meta["top_k"], meta["p"], nbr)
+    assert np.array_equal(sel["kept"], gold["one_hot"][0, 0]) and np.array_equal(sel["unrel"], gold["nogapr"][0, 0])
+    np.testing.assert_allclose(sel["probs"], gold["probs"][0, 0], rtol=2e-5, atol=1e-6)
+    rows = [0, 1, 97, 130, 258, 259]
+    o = orc.sparse_attention_head(q[0, 0], k[0, 0], v[0, 0], lay, sel["kept"][rows], rows)
+    o = o * sel["R"][rows][:, None, None].astype(np.float64) + sel["comp"][rows][:, None, :].astype(np.float64)
+    for a, i in enumerate(rows):
+        err = np.abs(o[a] - gold["out"][0, i * 128:(i + 1) * 128].astype(np.float64))
+        assert err.max() < 2.5e-3, f"{name}: block {i}: {err.max()}"
 
 
 def test_estimate_pr_gain_matches_reference():
