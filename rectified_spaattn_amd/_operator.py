@@ -27,7 +27,8 @@ def _check_blocks(bm: int, bn: int):
                                   "(the only value the reference scripts use)")
 
 
-# K5 operand precision for every operator call that goes through run(): False = the input dtype (bf16/fp16, the
+# PROCESS DEFAULT of the K5 operand precision (a processor / call can override it: processor.qkv_fp8, qkv_fp8=...):
+# False = the input dtype (bf16/fp16, the
 # reference's behaviour), True = e4m3 images of Q, K, V on the fp8 MFMA (head_dim 128 only; other head dims keep the
 # 2-byte kernel).  Set with rectified_spaattn_amd.set_qkv_fp8(); the reference has no such switch (fp8 is its TODO).
 QKV_FP8 = False

@@ -90,10 +90,11 @@ def _splits_from_cu(cq, ck, B, S, S1):
     return splits
 
 
-def _device_dense(q, k, v, splits):
+def _device_dense(q, k, v, splits, dense_fp8=None):
     """q [b,a,s,d], k/v [b,a,s1,d]; splits: per batch item (q_split, kv_split).  Returns [b,a,s,d] view."""
     B = q.shape[0]
-    fp8 = _operator.DENSE_FP8 and q.shape[-1] == 128  # set_dense_fp8(): e4m3 operands on the fp8 MFMA
+    # e4m3 operands on the fp8 MFMA: per call, else the process default of set_dense_fp8()
+    fp8 = (_operator.DENSE_FP8 if dense_fp8 is None else bool(dense_fp8)) and q.shape[-1] == 128
     if len(set(splits)) == 1:
         return _core.dense_attention(q, k, v, splits[0][0], splits[0][1], qkv_fp8=fp8).transpose(1, 2)
     outs = [_core.dense_attention(q[i:i + 1], k[i:i + 1], v[i:i + 1], *splits[i], qkv_fp8=fp8) for i in range(B)]
@@ -118,8 +119,10 @@ def _key_padding_counts(attn_mask, B, S1):
 
 
 def fullattn(q, k, v, mode="flash", drop_rate=0, attn_mask=None, causal=False, cu_seqlens_q=None,
-             cu_seqlens_kv=None, max_seqlen_q=None, max_seqlen_kv=None, batch_size=1):
-    """QKV attention.  q [b,a,s,d], k/v [b,a,s1,d] -> [b,a,s,d]  (same contract as attn.py:60-154)."""
+             cu_seqlens_kv=None, max_seqlen_q=None, max_seqlen_kv=None, batch_size=1, dense_fp8=None):
+    """QKV attention.  q [b,a,s,d], k/v [b,a,s1,d] -> [b,a,s,d]  (same contract as attn.py:60-154).
+    dense_fp8 (not in the reference): per-call choice of e4m3 operands for the device kernel; None = the process
+    default set by set_dense_fp8()."""
     if mode not in MEMORY_LAYOUT:
         raise NotImplementedError(f"Unsupported attention mode: {mode}")
     B, _, S, D = q.shape
@@ -140,7 +143,7 @@ def fullattn(q, k, v, mode="flash", drop_rate=0, attn_mask=None, causal=False, c
                 splits = [(S, S1)] * B
             else:
                 splits = [(S, c) for c in _key_padding_counts(attn_mask, B, S1)]
-        return _device_dense(q, k, v, splits)
+        return _device_dense(q, k, v, splits, dense_fp8)
     # ---- CPU tensors: the reference's CPU-runnable modes ----
     if mode == "flash":
         raise RsaError("fullattn(mode='flash') needs device tensors (HIP kernel); use mode='torch' on CPU")

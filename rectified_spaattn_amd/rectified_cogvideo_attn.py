@@ -40,6 +40,9 @@ class RectifiedCogVideoXVideoSpaAttnProcessor2_0:
         self.p_remain_rates = p_remain_rates
         self.current_step = 0
         self.processor_id = processor_id
+        # K5 / dense-kernel operand precision of THIS processor (None = process default, see set_qkv_fp8 / set_dense_fp8)
+        self.qkv_fp8 = None
+        self.dense_fp8 = None
 
     def __call__(self, attn, hidden_states, encoder_hidden_states, attention_mask=None, image_rotary_emb=None):
         n_txt = encoder_hidden_states.size(1)
@@ -66,11 +69,11 @@ class RectifiedCogVideoXVideoSpaAttnProcessor2_0:
             out = rectified_block_sparse_attention(q, k, v, attn_mask=attention_mask, top_k=self.select_block_num,
                                                    cu_seqlens_q=cu_q, cu_seqlens_kv=cu_kv, max_seqlen_q=S,
                                                    max_seqlen_kv=S_k, block_neighbor_list=self.block_neighbor_list,
-                                                   p_remain_rates=self.p_remain_rates, text_length=n_txt)
+                                                   p_remain_rates=self.p_remain_rates, text_length=n_txt, qkv_fp8=self.qkv_fp8)
         else:
             dense_mode = self.mode if self.mode in ("torch", "vanilla") else "flash"
             out = fullattn(q, k, v, mode=dense_mode, drop_rate=0.0, attn_mask=attention_mask, causal=False,
-                           cu_seqlens_q=cu_q, cu_seqlens_kv=cu_kv, max_seqlen_q=S, max_seqlen_kv=S_k, batch_size=B)
+                           cu_seqlens_q=cu_q, cu_seqlens_kv=cu_kv, max_seqlen_q=S, max_seqlen_kv=S_k, batch_size=B, dense_fp8=self.dense_fp8)
             out = out.transpose(1, 2).reshape(B, S, -1)
         out = out.to(q.dtype)
         self.current_step = (self.current_step + 1) % 50

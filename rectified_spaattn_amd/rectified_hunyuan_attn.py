@@ -46,6 +46,9 @@ class RectifiedHunyuanVideoSpaAttnProcessor2_0:
         self.p_remain_rates = p_remain_rates
         self.current_step = 0
         self.processor_id = processor_id
+        # K5 / dense-kernel operand precision of THIS processor (None = process default, see set_qkv_fp8 / set_dense_fp8)
+        self.qkv_fp8 = None
+        self.dense_fp8 = None
 
     def __call__(self, attn, hidden_states: torch.Tensor, encoder_hidden_states: Optional[torch.Tensor] = None,
                  attention_mask: Optional[torch.Tensor] = None, image_rotary_emb=None,
@@ -110,10 +113,10 @@ class RectifiedHunyuanVideoSpaAttnProcessor2_0:
             out = rectified_block_sparse_attention(q, k, v, attn_mask=attention_mask, top_k=self.select_block_num,
                                                    cu_seqlens_q=cu, cu_seqlens_kv=cu, max_seqlen_q=S,
                                                    max_seqlen_kv=S, block_neighbor_list=self.block_neighbor_list,
-                                                   p_remain_rates=self.p_remain_rates)
+                                                   p_remain_rates=self.p_remain_rates, qkv_fp8=self.qkv_fp8)
         elif self.mode in ("flash", "torch", "vanilla"):
             out = fullattn(q, k, v, mode=self.mode, drop_rate=0.0, attn_mask=attention_mask, causal=False,
-                           cu_seqlens_q=cu, cu_seqlens_kv=cu, max_seqlen_q=S, max_seqlen_kv=S, batch_size=B)
+                           cu_seqlens_q=cu, cu_seqlens_kv=cu, max_seqlen_q=S, max_seqlen_kv=S, batch_size=B, dense_fp8=self.dense_fp8)
             out = out.transpose(1, 2).reshape(B, S, -1)
         else:
             raise ImportError("Undefined Attention Processor! Just support sparse, flash, torch, vanilla.")

@@ -53,6 +53,9 @@ class _WanProcessorBase:
         self.p_remain_rates = p_remain_rates
         self.current_step = 0
         self.processor_id = processor_id
+        # K5 / dense-kernel operand precision of THIS processor (None = process default, see set_qkv_fp8 / set_dense_fp8)
+        self.qkv_fp8 = None
+        self.dense_fp8 = None
         self.first_frame_blocks = first_frame_blocks
 
     def _use_sparse(self) -> bool:
@@ -101,11 +104,11 @@ class _WanProcessorBase:
                                                    cu_seqlens_q=cu_q, cu_seqlens_kv=cu_kv, max_seqlen_q=S_q,
                                                    max_seqlen_kv=S_k, block_neighbor_list=self.block_neighbor_list,
                                                    p_remain_rates=self.p_remain_rates,
-                                                   first_frame_blocks=self.first_frame_blocks)
+                                                   first_frame_blocks=self.first_frame_blocks, qkv_fp8=self.qkv_fp8)
         elif self.mode in ("sparse", "flash", "torch", "vanilla"):
             dense_mode = "flash" if self.mode == "sparse" else self.mode  # warm-up layers/steps run dense
             out = fullattn(q, k, v, mode=dense_mode, drop_rate=0.0, attn_mask=attention_mask, causal=False,
-                           cu_seqlens_q=cu_q, cu_seqlens_kv=cu_kv, max_seqlen_q=S_q, max_seqlen_kv=S_k, batch_size=B)
+                           cu_seqlens_q=cu_q, cu_seqlens_kv=cu_kv, max_seqlen_q=S_q, max_seqlen_kv=S_k, batch_size=B, dense_fp8=self.dense_fp8)
             out = out.transpose(1, 2).reshape(B, S_q, -1)
         else:
             raise ImportError("Undefined Attention Processor! Just support sparse, flash, torch, vanilla.")
