@@ -147,10 +147,10 @@ def cpu_baseline_sparse(sample, spec, D, budget_s=10.0):
     ncores = os.cpu_count() or 1
     torch.set_num_threads(ncores)
     q, k, v, cols, counts, R, comp = sample
-    nb = 16
+    nb = min(spec.NBv, 96)   # many query blocks per call: they are the parallel axis of the CPU SDPA kernel
     step = max(1, spec.NBv // nb)
     blocks = list(range(0, spec.NBv, step))[:nb]
-    sparse_cpu.rectified_sparse_blocks_cpu(q, k, v, cols, counts, R, comp, spec.kv_valid, blocks[:2])  # warm-up
+    sparse_cpu.rectified_sparse_blocks_cpu(q, k, v, cols, counts, R, comp, spec.kv_valid, blocks[:8])  # warm-up
     t0 = time.perf_counter()
     sparse_cpu.rectified_sparse_blocks_cpu(q, k, v, cols, counts, R, comp, spec.kv_valid, blocks)
     dt = time.perf_counter() - t0
