@@ -102,18 +102,25 @@ __global__ __launch_bounds__(256) void text_combine_kernel(const float* __restri
     }
 }
 
-static int launch_text_combine(const AttnArgs& a, int BH, int D, int dtype, hipStream_t s) {
-    const int ntq = a.NQB - a.NBv;
+// (also used by the fp8 kernel's host side, rsa_attn_fp8_kernel.hip)
+int rsa_launch_text_combine(const float* tpart, unsigned short* out, long osb, long osh, long oss, int D, int H, int NBv,
+                            int ntq, int tsplit, int q_text_end, int Sq, int BH, int dtype, hipStream_t s) {
     const long rows = (long)BH * ntq * RSA_BLOCK;
     if (rows <= 0) return RSA_OK;
     const dim3 grid((unsigned)((rows + 3) / 4));
     if (dtype == RSA_BF16)
-        text_combine_kernel<bf16_tag><<<grid, 256, 0, s>>>(a.tpart, a.out, a.osb, a.osh, a.oss, D, a.H, a.NBv, ntq,
-                                                         a.tsplit, a.q_text_end, a.Sq, rows);
+        text_combine_kernel<bf16_tag><<<grid, 256, 0, s>>>(tpart, out, osb, osh, oss, D, H, NBv, ntq, tsplit, q_text_end,
+                                                         Sq, rows);
     else
-        text_combine_kernel<fp16_tag><<<grid, 256, 0, s>>>(a.tpart, a.out, a.osb, a.osh, a.oss, D, a.H, a.NBv, ntq,
-                                                         a.tsplit, a.q_text_end, a.Sq, rows);
+        text_combine_kernel<fp16_tag><<<grid, 256, 0, s>>>(tpart, out, osb, osh, oss, D, H, NBv, ntq, tsplit, q_text_end,
+                                                         Sq, rows);
     return rsa_launch_status();
+}
+int rsa_text_split_enabled() { return g_k5_tsplit; }
+
+static int launch_text_combine(const AttnArgs& a, int BH, int D, int dtype, hipStream_t s) {
+    return rsa_launch_text_combine(a.tpart, a.out, a.osb, a.osh, a.oss, D, a.H, a.NBv, a.NQB - a.NBv, a.tsplit,
+                                   a.q_text_end, a.Sq, BH, dtype, s);
 }
 
 static int launch_attn(AttnArgs& a, int BH, int D, int dtype, hipStream_t s, int variant = -1) {

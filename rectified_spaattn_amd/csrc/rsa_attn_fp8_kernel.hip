@@ -48,7 +48,14 @@ struct Attn8Args {
     int n_heavy_pad, NBp, BH;
     float sm_scale_log2e;
     int out_fp16;
+    float* tpart;        // split-KV partials of the text query blocks (layout of rsa_attn.hip's combine kernel) or null
+    int tsplit, tper;
 };
+
+// rsa_attn.hip: merge of the split-KV partials of the text blocks, and the switch for the split
+int rsa_launch_text_combine(const float* tpart, unsigned short* out, long osb, long osh, long oss, int D, int H, int NBv,
+                            int ntq, int tsplit, int q_text_end, int Sq, int BH, int dtype, hipStream_t s);
+int rsa_text_split_enabled();
 
 namespace {
 
@@ -72,14 +79,17 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     unsigned short* lds_list = reinterpret_cast<unsigned short*>(lds + 2 * NSLOT * TILE8 + 64);
 
     // ---------------- work mapping (as rsa_attn_kernel.hip) ----------------
-    int bh, qblk;
+    int bh, qblk, tsp = 0;
     {
         const int bid = blockIdx.x;
         if (bid < a.n_heavy_pad) {
             const int ntq = a.NQB - a.NBv;
-            if (ntq <= 0 || bid >= a.BH * ntq) return;
-            bh = bid / ntq;
-            qblk = a.NBv + bid % ntq;
+            const int per_bh = ntq * a.tsplit;
+            if (ntq <= 0 || bid >= a.BH * per_bh) return;
+            bh = bid / per_bh;
+            const int rem = bid % per_bh;
+            qblk = a.NBv + rem / a.tsplit;
+            tsp = rem % a.tsplit;
         } else {
             const int v = bid - a.n_heavy_pad;
             bh = v / a.NBp;
@@ -111,6 +121,11 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
             hi_r = a.kv_valid; store_r = grow < a.Sq;
         } else {
             n_items = (a.kv_text_valid + RSA_BLOCK - 1) / RSA_BLOCK;
+            if (a.tsplit > 1) {   // split-KV: this workgroup's slice of the key blocks
+                first_blk = tsp * a.tper;
+                n_items = n_items - first_blk < a.tper ? n_items - first_blk : a.tper;
+                if (n_items < 0) n_items = 0;
+            }
             lo_max = 0; hi_min = hi_max = a.kv_text_valid;
             hi_r = a.kv_text_valid;
             store_r = grow < a.q_text_end;
@@ -357,6 +372,22 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
 
     // ---------------- epilogue ----------------
     const float l_tot = lacc[0];
+    if (a.mode == MODE_SPARSE && a.tsplit > 1 && qblk >= a.NBv) {
+        // split-KV partial of a text block (merged by rsa_attn.hip's combine kernel): O in V's units, m, l
+        const int ntq = a.NQB - a.NBv;
+        const int rowb = 32 * wv + r;
+        float* pp = a.tpart + ((((long)bh * ntq + (qblk - a.NBv)) * a.tsplit + tsp) * RSA_BLOCK + rowb) * (D8 + 2);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = 32 * dt + 8 * g + 4 * hh;
+                *reinterpret_cast<float2*>(pp + d0) = make_float2(o[dt][4 * g + 0] * s_v, o[dt][4 * g + 1] * s_v);
+                *reinterpret_cast<float2*>(pp + d0 + 2) = make_float2(o[dt][4 * g + 2] * s_v, o[dt][4 * g + 3] * s_v);
+            }
+        if (hh == 0) *reinterpret_cast<float2*>(pp + D8) = make_float2(m_run, l_tot);
+        return;
+    }
     if (!(store_r || zero_r)) return;
     float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
     float Rv = 1.0f;
@@ -396,7 +427,14 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
 int g_fp8_variant = 0;
 int launch_attn8(Attn8Args& a, int BH, hipStream_t s) {
     const int ntq = a.NQB - a.NBv;
-    const int n_heavy = ntq > 0 ? BH * ntq : 0;
+    const int n_txt_items = (a.kv_text_valid + RSA_BLOCK - 1) / RSA_BLOCK;
+    a.tsplit = 1; a.tper = n_txt_items;
+    if (a.mode == MODE_SPARSE && ntq > 0 && a.tpart && rsa_text_split_enabled() && n_txt_items >= 32) {
+        const int sp = n_txt_items / 16;
+        a.tsplit = sp > RSA_TEXT_SPLIT ? RSA_TEXT_SPLIT : sp;
+        a.tper = (n_txt_items + a.tsplit - 1) / a.tsplit;
+    }
+    const int n_heavy = ntq > 0 ? BH * ntq * a.tsplit : 0;
     a.BH = BH;
     a.n_heavy_pad = (n_heavy + 7) & ~7;
     a.NBp = (a.NBv + 7) & ~7;
@@ -412,7 +450,10 @@ int launch_attn8(Attn8Args& a, int BH, hipStream_t s) {
         case 4: bsfwd_fp8_kernel<2 + 1024><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a); break;
         default: bsfwd_fp8_kernel<2><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a); break;
     }
-    return rsa_launch_status();
+    const int st = rsa_launch_status();
+    if (st != RSA_OK || a.tsplit <= 1) return st;
+    return rsa_launch_text_combine(a.tpart, a.out, a.osb, a.osh, a.oss, D8, a.H, a.NBv, ntq, a.tsplit, a.q_text_end, a.Sq,
+                                   BH, a.out_fp16 ? RSA_FP16 : RSA_BF16, s);
 }
 
 int check_out8(const rsa_out4& o) {
@@ -437,7 +478,7 @@ extern "C" int rsa_block_sparse_fwd_fp8(const rsa_layout* l, const rsa_fp8_opera
     Attn8Args a;
     a.q8 = ops->q8; a.k8 = ops->k8; a.v8t = ops->v8t; a.scales = ops->scales;
     a.out = static_cast<unsigned short*>(out.ptr); a.osb = out.stride_b; a.osh = out.stride_h; a.oss = out.stride_s;
-    a.cols = buf->cols; a.counts = buf->counts; a.R = buf->R; a.comp = buf->comp;
+    a.cols = buf->cols; a.counts = buf->counts; a.R = buf->R; a.comp = buf->comp; a.tpart = buf->tpart;
     a.mode = MODE_SPARSE; a.H = l->H; a.Sq = l->S; a.Sk = l->S;
     a.Sq_pad = a.Sk_pad = l->NB_total * RSA_BLOCK;
     a.NBv = l->NBv; a.NQB = l->NB_total; a.NB_total = l->NB_total;
@@ -485,7 +526,7 @@ extern "C" int rsa_dense_fwd_fp8(int B, int H, int Sq, int Sk, int D, int dtype,
     Attn8Args a;
     a.q8 = ops.q8; a.k8 = ops.k8; a.v8t = ops.v8t; a.scales = ops.scales;
     a.out = static_cast<unsigned short*>(out.ptr); a.osb = out.stride_b; a.osh = out.stride_h; a.oss = out.stride_s;
-    a.cols = nullptr; a.counts = nullptr; a.R = nullptr; a.comp = nullptr;
+    a.cols = nullptr; a.counts = nullptr; a.R = nullptr; a.comp = nullptr; a.tpart = nullptr;
     a.mode = MODE_DENSE; a.H = H; a.Sq = Sq; a.Sk = Sk;
     a.NQB = (Sq + RSA_BLOCK - 1) / RSA_BLOCK; a.NBv = a.NQB; a.NB_total = (Sk + RSA_BLOCK - 1) / RSA_BLOCK;
     a.Sq_pad = a.NQB * RSA_BLOCK; a.Sk_pad = a.NB_total * RSA_BLOCK;

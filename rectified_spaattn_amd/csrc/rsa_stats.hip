@@ -285,6 +285,7 @@ struct SelectArgs {
     int32_t *cols, *counts;
     int NBv, n_txt, NS, L, N2, NB_total, NW, text_end_block, ffb, top_k, rows_total, lds_per_wave;
     int use_prefix;   // 1 = try the sorted-head path first (same result; tuning key "k3_prefix" for the A/B tests)
+    int cand_in_e;    // the sorted-head candidates reuse e[] (saves 2 KiB of LDS per wave: 4 instead of 3 workgroups per CU)
     float thr, scale;
 };
 int g_rsa_k3_prefix = 1;
@@ -478,7 +479,10 @@ __global__ __launch_bounds__(256) void select_mask_kernel(SelectArgs a) {
                 else { t = mid; C = c; found = true; break; }
             }
             if (found) {
-                unsigned long long* cand = reinterpret_cast<unsigned long long*>(kept + ((a.NB_total + 7) & ~7));
+                // candidate keys: over e[] when it is large enough (the exponentials are dead once pr[] is written),
+                // else in the slot the host reserved behind kept[]
+                unsigned long long* cand = a.cand_in_e ? reinterpret_cast<unsigned long long*>(e)
+                                                       : reinterpret_cast<unsigned long long*>(kept + ((a.NB_total + 7) & ~7));
                 for (int j = lane; j < RSA_SEL_CAP; j += 64) cand[j] = 0ull;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 int basep = 0;
@@ -827,8 +831,10 @@ extern "C" int rsa_select_mask(const rsa_layout* l, const uint8_t* neighbor, int
     a.scale = (float)(1.0 / sqrt((double)l->D));  // head_dim ** -0.5 rounded to fp32 (hunyuan :208)
     a.rows_total = l->B * l->H * l->NBv;
     a.use_prefix = g_rsa_k3_prefix;
+    a.cand_in_e = (size_t)((a.NS + 3) & ~3) * 4 >= (size_t)RSA_SEL_CAP * 8;
     const size_t per_wave = (((size_t)((a.NS + 3) & ~3) * 4 + (size_t)((a.L + 3) & ~3) * 4 +
-                              (size_t)((a.NB_total + 7) & ~7) + (size_t)RSA_SEL_CAP * 8) + 15) & ~(size_t)15;
+                              (size_t)((a.NB_total + 7) & ~7) + (a.cand_in_e ? 0 : (size_t)RSA_SEL_CAP * 8)) + 15) &
+                            ~(size_t)15;
     a.lds_per_wave = (int)per_wave;
     const size_t lds = per_wave * 4;
     if (lds > 64 * 1024 || n2 > 4096) return RSA_ERR_UNSUPPORTED;
