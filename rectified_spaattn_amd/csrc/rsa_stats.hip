@@ -192,6 +192,8 @@ __global__ __launch_bounds__(256) void pooled_scores_kernel(ScoreArgs a) {
 #pragma unroll
         for (int y = 0; y < 4; ++y) s[x][y] = eq[x][y] = ek[x][y] = 0.0f;
 
+    // (register-staged double buffering of this staging was measured: 241 vs 226 us -- the extra 32 registers cost a
+    // wave per SIMD and the kernel is LDS / VALU-bound, not latency-bound; K4, which is latency-bound, keeps that form)
     for (int d0 = 0; d0 < D; d0 += DK) {
         __syncthreads();
         // stage: 64 rows x 32 d = 512 float4 per operand, 2 per thread; stored transposed [d][row]
@@ -592,23 +594,40 @@ __global__ __launch_bounds__(256) void compensation_kernel(const float* w, const
     for (int r = 0; r < RI; ++r)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[r][e] = 0.0f;
-    for (int j0 = 0; j0 < L; j0 += TJ) {
-        __syncthreads();
+    // register-staged double buffering: chunk j0 + TJ is loaded from global memory while chunk j0 is multiplied
+    constexpr int NWK = TI * TJ / 256, NVK = TJ * D / 4 / 256;
+    float wreg[NWK];
+    float4 vreg[NVK];
+    auto load_chunk = [&](int j0) {
 #pragma unroll
-        for (int k = 0; k < TI * TJ / 256; ++k) {
+        for (int k = 0; k < NWK; ++k) {
             const int idx = t + k * 256;
             const int ii = idx / TJ, jj = idx % TJ;
-            Ws[jj][ii] = (i0 + ii < NBv && j0 + jj < L) ? wp[(long)(i0 + ii) * L + j0 + jj] : 0.0f;
+            wreg[k] = (i0 + ii < NBv && j0 + jj < L) ? wp[(long)(i0 + ii) * L + j0 + jj] : 0.0f;
         }
 #pragma unroll
-        for (int k = 0; k < TJ * D / 4 / 256; ++k) {
+        for (int k = 0; k < NVK; ++k) {
             const int idx = t + k * 256;
             const int jj = idx / TD, dd = (idx % TD) * 4;
-            float4 v4 = make_float4(0, 0, 0, 0);
-            if (j0 + jj < L) v4 = *reinterpret_cast<const float4*>(vp + (long)(j0 + jj) * D + dd);
-            *reinterpret_cast<float4*>(&Vs[jj][dd]) = v4;
+            vreg[k] = make_float4(0, 0, 0, 0);
+            if (j0 + jj < L) vreg[k] = *reinterpret_cast<const float4*>(vp + (long)(j0 + jj) * D + dd);
+        }
+    };
+    load_chunk(0);
+    for (int j0 = 0; j0 < L; j0 += TJ) {
+        __syncthreads();   // the previous chunk's LDS reads are done
+#pragma unroll
+        for (int k = 0; k < NWK; ++k) {
+            const int idx = t + k * 256;
+            Ws[idx % TJ][idx / TJ] = wreg[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NVK; ++k) {
+            const int idx = t + k * 256;
+            *reinterpret_cast<float4*>(&Vs[idx / TD][(idx % TD) * 4]) = vreg[k];
         }
         __syncthreads();
+        if (j0 + TJ < L) load_chunk(j0 + TJ);   // in flight during the multiply below
 #pragma unroll 8
         for (int jj = 0; jj < TJ; ++jj) {
             const float4 v4 = *reinterpret_cast<const float4*>(&Vs[jj][4 * td]);
