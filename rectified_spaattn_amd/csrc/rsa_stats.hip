@@ -386,12 +386,18 @@ __device__ __forceinline__ int cumsum_count(const unsigned long long (&key)[K], 
 
 #define RSA_SEL_CAP 256   // keys in the sorted head of the prefix path (4 per lane)
 
-template <int KPL>
+// PASS 0: sorted-head path only; a row it cannot decide gets counts[row] = -1 and is left to PASS 1 (a second launch: the
+//         full sort needs twice the registers, and keeping it out of this kernel gives it 5 instead of 3 waves per SIMD).
+// PASS 1: full sort, only for the rows PASS 0 marked.      PASS 2: full sort for every row (short rows, or A/B tests).
+template <int KPL, int PASS>
 __global__ __launch_bounds__(256) void select_mask_kernel(SelectArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long row = (long)blockIdx.x * 4 + wv;
     if (row >= a.rows_total) return;
+    if constexpr (PASS == 1) {
+        if (a.counts[row] != -1) return;
+    }
     const int qblk = (int)(row % a.NBv);
     unsigned char* base = smem + (size_t)wv * a.lds_per_wave;
     float* e = reinterpret_cast<float*>(base);
@@ -454,7 +460,7 @@ __global__ __launch_bounds__(256) void select_mask_kernel(SelectArgs a) {
     }
     int n = -1;
     bool marked = false;
-    if constexpr (KPL > RSA_SEL_CAP / 64) {
+    if constexpr (PASS == 0) {
         // ---- prefix path (C7/C8 unchanged): the decision needs only the sorted HEAD of the row -- the sequential sum
         // stops at the first element that exceeds thr, and the kept set is the first n = max(count+1, top_k) elements.
         // Find a probability threshold t with need <= #{p >= t} <= RSA_SEL_CAP by bisection on the fp32 bit patterns
@@ -463,7 +469,7 @@ __global__ __launch_bounds__(256) void select_mask_kernel(SelectArgs a) {
         // plateau of equal probabilities across the window) or the sum does not pass thr inside the head, fall through
         // to the full sort below -- same result either way.
         const int need = a.top_k > RSA_SEL_CAP / 2 ? a.top_k : RSA_SEL_CAP / 2;
-        if (a.use_prefix && need <= RSA_SEL_CAP && a.L > RSA_SEL_CAP) {
+        {
             unsigned pmax = 0;
 #pragma unroll
             for (int s_ = 0; s_ < KPL; ++s_) pmax = max(pmax, (unsigned)(key[s_] >> 32));
@@ -521,7 +527,12 @@ __global__ __launch_bounds__(256) void select_mask_kernel(SelectArgs a) {
             }
         }
     }
-    if (!marked) {
+    if constexpr (PASS == 0) {
+        if (!marked) {   // undecided: PASS 1 redoes this row with the full sort
+            if (lane == 0) a.counts[row] = -1;
+            return;
+        }
+    } else {
         bitonic_sort_desc<KPL>(key, lane);
         // sequential cumulative sum over the sorted order (C8), lane after lane, stop once it exceeds thr
         bool passed = false;
@@ -859,15 +870,28 @@ extern "C" int rsa_select_mask(const rsa_layout* l, const uint8_t* neighbor, int
     if (lds > 64 * 1024 || n2 > 4096) return RSA_ERR_UNSUPPORTED;
     dim3 grid((unsigned)((a.rows_total + 3) / 4));
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // rows longer than the sorted head (256 keys) take the two-pass form when the head can hold top_k
+    const int need = top_k > RSA_SEL_CAP / 2 ? top_k : RSA_SEL_CAP / 2;
+    const bool two_pass = a.use_prefix && n2 / 64 > RSA_SEL_CAP / 64 && need <= RSA_SEL_CAP && a.L > RSA_SEL_CAP;
+#define RSA_K3(K) \
+    do { \
+        if (two_pass) { \
+            select_mask_kernel<K, 0><<<grid, 256, lds, s>>>(a); \
+            select_mask_kernel<K, 1><<<grid, 256, lds, s>>>(a); \
+        } else { \
+            select_mask_kernel<K, 2><<<grid, 256, lds, s>>>(a); \
+        } \
+    } while (0)
     switch (n2 / 64) {
-        case 1: select_mask_kernel<1><<<grid, 256, lds, s>>>(a); break;
-        case 2: select_mask_kernel<2><<<grid, 256, lds, s>>>(a); break;
-        case 4: select_mask_kernel<4><<<grid, 256, lds, s>>>(a); break;
-        case 8: select_mask_kernel<8><<<grid, 256, lds, s>>>(a); break;
-        case 16: select_mask_kernel<16><<<grid, 256, lds, s>>>(a); break;
-        case 32: select_mask_kernel<32><<<grid, 256, lds, s>>>(a); break;
-        default: select_mask_kernel<64><<<grid, 256, lds, s>>>(a); break;
+        case 1: select_mask_kernel<1, 2><<<grid, 256, lds, s>>>(a); break;
+        case 2: select_mask_kernel<2, 2><<<grid, 256, lds, s>>>(a); break;
+        case 4: select_mask_kernel<4, 2><<<grid, 256, lds, s>>>(a); break;
+        case 8: RSA_K3(8); break;
+        case 16: RSA_K3(16); break;
+        case 32: RSA_K3(32); break;
+        default: RSA_K3(64); break;
     }
+#undef RSA_K3
     st = rsa_launch_status();
     if (st != RSA_OK) return st;
     if (g_rsa_k5_pair && buf->pcols && buf->pcounts && buf->pair_ok) {   // K3b: union lists for K5's paired workgroups
