@@ -150,8 +150,14 @@ __global__ __launch_bounds__(D * 2) void pool_stats_kernel(PoolArgs a) {
 }
 
 // =====================================================================================================
-// K2: pooled scores.  out tile 64(i) x 64(j) per workgroup, 4x4 per thread, d staged through LDS in
-// chunks of 32; accumulation is one k-ordered fmaf chain per output (contract C4).
+// K2: pooled scores on the fp32 matrix pipe.  v_mfma_f32_32x32x2_f32 accumulates its two k-steps as sequential fused
+// multiply-adds, k ascending (tools/probes/mfma_f32_order_probe.hip: d == fmaf(a1,b1,fmaf(a0,b0,c)) on every output),
+// so a chain of D/2 MFMAs over k = 0,1 | 2,3 | ... IS the contract's k-ordered fmaf chain (C4), bit for bit, at the
+// matrix pipe's rate and with one operand register per 4 096 FLOP instead of an LDS read per 32.
+// Workgroup = 4 waves = 64(i) x 64(j) outputs, wave = one 32x32 MFMA tile with three accumulators (s, eq, ek).
+// Operands go global -> registers (next chunk in flight during the MFMAs) -> LDS as [row][16 even k | 16 odd k | pad 4]:
+// lane (r = lane & 31, h = lane >> 5) feeds k = 2j + h, so it reads 4 consecutive steps with one ds_read_b128;
+// LD = 36 floats makes those reads conflict-free.  Waves whose 32 rows or 32 columns lie outside the matrix skip the MFMAs.
 //   MODE 0: visual columns: s = qbar.kbar, eq = aq.kbar, ek = qbar.ak -> scores + GAPR byte
 //   MODE 1: text columns:   s = qbar.K_u for every valid text token u
 // =====================================================================================================
@@ -161,20 +167,29 @@ struct ScoreArgs {
     long ksb, ksh, kss;
     float* scores;
     uint8_t* unrel;
-    int NBv, n_txt, NS, D, H;
+    int NBv, n_txt, NS, D, H, BH;
 };
+
+typedef float k2_f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ int ncols_of(const ScoreArgs& a, int mode) { return mode == 0 ? a.NBv : a.n_txt; }
 
 template <int MODE, typename Tag>
 __global__ __launch_bounds__(256) void pooled_scores_kernel(ScoreArgs a) {
-    constexpr int TI = 64, TJ = 64, DK = 32, LD = 68;
-    __shared__ __attribute__((aligned(16))) float Aq[DK][LD];
-    __shared__ __attribute__((aligned(16))) float Aa[MODE == 0 ? DK : 1][LD];
-    __shared__ __attribute__((aligned(16))) float Bk[DK][LD];
-    __shared__ __attribute__((aligned(16))) float Ba[MODE == 0 ? DK : 1][LD];
-    const int bh = blockIdx.z;
-    const int i0 = blockIdx.y * TI, j0 = blockIdx.x * TJ;
-    const int t = threadIdx.x;
-    const int ti = t >> 4, tj = t & 15;
+    constexpr int DK = 32, LD = 36, NOP = MODE == 0 ? 4 : 2;   // operands: q, k (, aq, ak)
+    __shared__ __attribute__((aligned(16))) float tile[NOP][64 * LD];
+    // 1-D grid, XCD-aware: workgroup ids go round-robin over the 8 XCDs, so XCD c takes the c-th contiguous eighth of the
+    // (bh, i-tile, j-tile) space -- whole heads per XCD, whose pooled operands (1.8 MB per head) then stay in that L2
+    const int ntj = (ncols_of(a, MODE) + 63) / 64, nti = (a.NBv + 63) / 64;
+    const int per = (int)(gridDim.x >> 3);          // the grid is a multiple of 8
+    const int wid = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (wid >= a.BH * nti * ntj) return;
+    const int bh = wid / (nti * ntj);
+    const int rem = wid % (nti * ntj);
+    const int i0 = (rem / ntj) * 64, j0 = (rem % ntj) * 64;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wi = wv >> 1, wj = wv & 1;
+    const int r = lane & 31, h = lane >> 5;
     const int ncols = MODE == 0 ? a.NBv : a.n_txt;
     const int D = a.D;
     const float* qb = a.qbar + (long)bh * a.NBv * D;
@@ -183,88 +198,112 @@ __global__ __launch_bounds__(256) void pooled_scores_kernel(ScoreArgs a) {
     const float* akp = a.ak + (long)bh * a.NBv * D;
     const unsigned short* kt = nullptr;
     if (MODE == 1) {
-        const int b = bh / a.H, h = bh % a.H;
-        kt = a.ktxt + (long)b * a.ksb + (long)h * a.ksh + (long)a.NBv * RSA_BLOCK * a.kss;
+        const int b = bh / a.H, hd = bh % a.H;
+        kt = a.ktxt + (long)b * a.ksb + (long)hd * a.ksh + (long)a.NBv * RSA_BLOCK * a.kss;
     }
-    float s[4][4], eq[4][4], ek[4][4];
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 4; ++y) s[x][y] = eq[x][y] = ek[x][y] = 0.0f;
+    const bool live = i0 + 32 * wi < a.NBv && j0 + 32 * wj < ncols;   // wave-uniform
 
-    // (register-staged double buffering of this staging was measured: 241 vs 226 us -- the extra 32 registers cost a
-    // wave per SIMD and the kernel is LDS / VALU-bound, not latency-bound; K4, which is latency-bound, keeps that form)
-    for (int d0 = 0; d0 < D; d0 += DK) {
-        __syncthreads();
-        // stage: 64 rows x 32 d = 512 float4 per operand, 2 per thread; stored transposed [d][row]
+    // staging slots of this thread: rows srow, srow + 32; k = 4 * sc .. 4 * sc + 3 of the chunk
+    const int srow = t >> 3, sc = t & 7;
+    float4 st[NOP][2];
+    // rows / columns past the matrix edge only feed outputs that are never stored: their loads are clamped to the last
+    // valid row instead of zero-filled, so the fetch has no branches and stays in flight during the MFMAs
+    const float *gq[2], *gaq[2], *gk[2], *gak[2];
+    const unsigned short* gkt[2];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int idx = t + r * 256;
-            const int row = idx >> 3, dc = (idx & 7) * 4;
-            float4 vq = make_float4(0, 0, 0, 0), va = vq, vk = vq, vb = vq;
-            if (i0 + row < a.NBv) {
-                vq = *reinterpret_cast<const float4*>(qb + (long)(i0 + row) * D + d0 + dc);
-                if (MODE == 0) va = *reinterpret_cast<const float4*>(aqp + (long)(i0 + row) * D + d0 + dc);
-            }
-            if (j0 + row < ncols) {
-                if (MODE == 0) {
-                    vk = *reinterpret_cast<const float4*>(kb + (long)(j0 + row) * D + d0 + dc);
-                    vb = *reinterpret_cast<const float4*>(akp + (long)(j0 + row) * D + d0 + dc);
-                } else {
-                    const uint2 raw = *reinterpret_cast<const uint2*>(kt + (long)(j0 + row) * a.kss + d0 + dc);
-                    vk.x = rsa_to_f32<Tag>((unsigned short)(raw.x & 0xFFFF));
-                    vk.y = rsa_to_f32<Tag>((unsigned short)(raw.x >> 16));
-                    vk.z = rsa_to_f32<Tag>((unsigned short)(raw.y & 0xFFFF));
-                    vk.w = rsa_to_f32<Tag>((unsigned short)(raw.y >> 16));
-                }
-            }
-            Aq[dc + 0][row] = vq.x; Aq[dc + 1][row] = vq.y; Aq[dc + 2][row] = vq.z; Aq[dc + 3][row] = vq.w;
-            Bk[dc + 0][row] = vk.x; Bk[dc + 1][row] = vk.y; Bk[dc + 2][row] = vk.z; Bk[dc + 3][row] = vk.w;
+    for (int rr = 0; rr < 2; ++rr) {
+        const int ri = min(i0 + srow + 32 * rr, a.NBv - 1), rj = min(j0 + srow + 32 * rr, ncols - 1);
+        gq[rr] = qb + (long)ri * D + 4 * sc;
+        gaq[rr] = aqp + (long)ri * D + 4 * sc;
+        gk[rr] = kb + (long)rj * D + 4 * sc;
+        gak[rr] = akp + (long)rj * D + 4 * sc;
+        gkt[rr] = MODE == 1 ? kt + (long)rj * a.kss + 4 * sc : nullptr;
+    }
+    auto fetch = [&](int d0) {
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            st[0][rr] = *reinterpret_cast<const float4*>(gq[rr] + d0);
             if (MODE == 0) {
-                Aa[dc + 0][row] = va.x; Aa[dc + 1][row] = va.y; Aa[dc + 2][row] = va.z; Aa[dc + 3][row] = va.w;
-                Ba[dc + 0][row] = vb.x; Ba[dc + 1][row] = vb.y; Ba[dc + 2][row] = vb.z; Ba[dc + 3][row] = vb.w;
+                st[1][rr] = *reinterpret_cast<const float4*>(gk[rr] + d0);
+                st[2][rr] = *reinterpret_cast<const float4*>(gaq[rr] + d0);
+                st[3][rr] = *reinterpret_cast<const float4*>(gak[rr] + d0);
+            } else {
+                const uint2 raw = *reinterpret_cast<const uint2*>(gkt[rr] + d0);
+                st[1][rr].x = rsa_to_f32<Tag>((unsigned short)(raw.x & 0xFFFF));
+                st[1][rr].y = rsa_to_f32<Tag>((unsigned short)(raw.x >> 16));
+                st[1][rr].z = rsa_to_f32<Tag>((unsigned short)(raw.y & 0xFFFF));
+                st[1][rr].w = rsa_to_f32<Tag>((unsigned short)(raw.y >> 16));
             }
         }
+    };
+    auto put = [&]() {
+#pragma unroll
+        for (int op = 0; op < NOP; ++op)
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                float* base = &tile[op][(srow + 32 * rr) * LD];
+                *reinterpret_cast<float2*>(base + 2 * sc) = make_float2(st[op][rr].x, st[op][rr].z);        // even k
+                *reinterpret_cast<float2*>(base + 16 + 2 * sc) = make_float2(st[op][rr].y, st[op][rr].w);   // odd k
+            }
+    };
+
+    k2_f32x16 s, eq, ek;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { s[i] = 0.0f; eq[i] = 0.0f; ek[i] = 0.0f; }
+
+    fetch(0);
+    if (!live) {   // this wave's 32 x 32 outputs lie outside the matrix: it only helps staging (same barriers)
+        for (int d0 = 0; d0 < D; d0 += DK) {
+            __syncthreads();
+            put();
+            __syncthreads();
+            if (d0 + DK < D) fetch(d0 + DK);
+        }
+        return;
+    }
+    const float* pa = &tile[0][(32 * wi + r) * LD + 16 * h];
+    const float* pb = &tile[1][(32 * wj + r) * LD + 16 * h];
+    const float* paa = &tile[2 % NOP][(32 * wi + r) * LD + 16 * h];
+    const float* pba = &tile[3 % NOP][(32 * wj + r) * LD + 16 * h];
+    for (int d0 = 0; d0 < D; d0 += DK) {
+        __syncthreads();          // previous chunk's reads are done
+        put();
         __syncthreads();
-#pragma unroll 8
-        for (int dd = 0; dd < DK; ++dd) {
-            const float4 q4 = *reinterpret_cast<const float4*>(&Aq[dd][4 * ti]);
-            const float4 k4 = *reinterpret_cast<const float4*>(&Bk[dd][4 * tj]);
+        if (d0 + DK < D) fetch(d0 + DK);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const float4 q4 = *reinterpret_cast<const float4*>(pa + 4 * m);
+            const float4 k4 = *reinterpret_cast<const float4*>(pb + 4 * m);
             const float qa[4] = {q4.x, q4.y, q4.z, q4.w};
             const float ka[4] = {k4.x, k4.y, k4.z, k4.w};
-#pragma unroll
-            for (int x = 0; x < 4; ++x)
-#pragma unroll
-                for (int y = 0; y < 4; ++y) s[x][y] = __builtin_fmaf(qa[x], ka[y], s[x][y]);
+            float aa[4] = {0, 0, 0, 0}, ba[4] = {0, 0, 0, 0};
             if (MODE == 0) {
-                const float4 a4 = *reinterpret_cast<const float4*>(&Aa[dd][4 * ti]);
-                const float4 b4 = *reinterpret_cast<const float4*>(&Ba[dd][4 * tj]);
-                const float aa[4] = {a4.x, a4.y, a4.z, a4.w};
-                const float ba[4] = {b4.x, b4.y, b4.z, b4.w};
+                const float4 a4 = *reinterpret_cast<const float4*>(paa + 4 * m);
+                const float4 b4 = *reinterpret_cast<const float4*>(pba + 4 * m);
+                aa[0] = a4.x; aa[1] = a4.y; aa[2] = a4.z; aa[3] = a4.w;
+                ba[0] = b4.x; ba[1] = b4.y; ba[2] = b4.z; ba[3] = b4.w;
+            }
 #pragma unroll
-                for (int x = 0; x < 4; ++x)
-#pragma unroll
-                    for (int y = 0; y < 4; ++y) {
-                        eq[x][y] = __builtin_fmaf(aa[x], ka[y], eq[x][y]);
-                        ek[x][y] = __builtin_fmaf(qa[x], ba[y], ek[x][y]);
-                    }
+            for (int x = 0; x < 4; ++x) {   // step j = 4m + x of the chunk: k = d0 + 2j (h = 0), d0 + 2j + 1 (h = 1)
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[x], ka[x], s, 0, 0, 0);
+                if (MODE == 0) {
+                    eq = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[x], ka[x], eq, 0, 0, 0);
+                    ek = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[x], ba[x], ek, 0, 0, 0);
+                }
             }
         }
     }
+    // accumulator element e of lane (r, h): row (e & 3) + 8 (e >> 2) + 4 h, column r of the wave tile
     const int colbase = MODE == 0 ? 0 : a.NBv;
+    const int j = j0 + 32 * wj + r;
+    if (j >= ncols) return;
 #pragma unroll
-    for (int x = 0; x < 4; ++x) {
-        const int i = i0 + 4 * ti + x;
+    for (int e = 0; e < 16; ++e) {
+        const int i = i0 + 32 * wi + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (i >= a.NBv) continue;
-#pragma unroll
-        for (int y = 0; y < 4; ++y) {
-            const int j = j0 + 4 * tj + y;
-            if (j >= ncols) continue;
-            a.scores[((long)bh * a.NBv + i) * a.NS + colbase + j] = s[x][y];
-            if (MODE == 0)
-                a.unrel[((long)bh * a.NBv + i) * a.NBv + j] =
-                    !(fabsf(s[x][y]) > (fabsf(eq[x][y]) + fabsf(ek[x][y])));
-        }
+        a.scores[((long)bh * a.NBv + i) * a.NS + colbase + j] = s[e];
+        if (MODE == 0)
+            a.unrel[((long)bh * a.NBv + i) * a.NBv + j] = !(fabsf(s[e]) > (fabsf(eq[e]) + fabsf(ek[e])));
     }
 }
 
@@ -829,11 +868,13 @@ extern "C" int rsa_pooled_scores(const rsa_layout* l, rsa_tensor4 k, const rsa_b
     a.NBv = l->NBv; a.n_txt = l->n_txt; a.NS = l->NBv + l->n_txt; a.D = l->D; a.H = l->H;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int BH = l->B * l->H;
-    dim3 g0((l->NBv + 63) / 64, (l->NBv + 63) / 64, BH);
+    const unsigned nti = (unsigned)((l->NBv + 63) / 64);
+    a.BH = BH;
+    dim3 g0((nti * nti * BH + 7) / 8 * 8);
     if (l->dtype == RSA_BF16) pooled_scores_kernel<0, bf16_tag><<<g0, 256, 0, s>>>(a);
     else pooled_scores_kernel<0, fp16_tag><<<g0, 256, 0, s>>>(a);
     if (l->n_txt > 0) {
-        dim3 g1((l->n_txt + 63) / 64, (l->NBv + 63) / 64, BH);
+        dim3 g1(((unsigned)((l->n_txt + 63) / 64) * nti * BH + 7) / 8 * 8);
         if (l->dtype == RSA_BF16) pooled_scores_kernel<1, bf16_tag><<<g1, 256, 0, s>>>(a);
         else pooled_scores_kernel<1, fp16_tag><<<g1, 256, 0, s>>>(a);
     }

@@ -147,6 +147,12 @@ def main():
         msel, _ = timeit(call.select)
         print(f"select pass: {msel:.3f} ms")
         del q, k, v, call
+    if "pmcsel" in what:  # mask-selection pass only, for rocprofv3 --pmc passes over K1..K4
+        call, spec = regime_call(os.environ.get("RSA_PERF_REGIME", "r2"), 24, dev)
+        for _ in range(3):
+            call.select()
+        torch.cuda.synchronize()
+        return
     if "pmc" in what:  # few launches, for rocprofv3 --pmc passes (env RSA_PERF_REGIME selects the regime)
         H = 24
         fp8 = os.environ.get("RSA_PERF_FP8", "0") == "1"
