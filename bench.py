@@ -198,15 +198,20 @@ class Comm:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.dry = dry
         self.dist = None
+        # RSA_BENCH_ONE_DEVICE=1 (tests only): every rank computes on cuda:0 and the control plane runs over gloo, so the
+        # N > 1 code path (spawn, head shards, per-rank timing, exchange over IPC) can be exercised on a 1-GPU box.
+        # The numbers of such a run are functional evidence, not a measurement (the ranks time-slice one GPU).
+        self.one_device = (not dry) and os.environ.get("RSA_BENCH_ONE_DEVICE") == "1"
         if dry:
             self.dev = torch.device("cpu")
         else:
-            self.dev = torch.device("cuda", self.local_rank)
+            self.dev = torch.device("cuda", 0 if self.one_device else self.local_rank)
             torch.cuda.set_device(self.dev)
+        self.stat_dev = torch.device("cpu") if (dry or self.one_device) else self.dev
         if self.world > 1:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            if dry:
+            if dry or self.one_device:
                 dist.init_process_group("gloo")
             else:
                 dist.init_process_group("nccl", device_id=self.dev)
@@ -276,7 +281,7 @@ def run_regime(comm, args, wl, regime, q, k, v, spec, steps, warmup, want_call=F
     counts = float(call.bufs["counts"].sum().item())  # kept (q-block, k-block) pairs over local heads
     local_flops = 4.0 * D * 128 * 128 * counts + 4.0 * D * spec.q_text_valid * spec.kv_text_valid * H_local
     el_max, fl_sum, pairs_sum, k5_max, per_rank = parallel.reduce_step_stats(elapsed, local_flops, counts, k5_ms,
-                                                                            comm.dev, busy_s=busy)
+                                                                            comm.stat_dev, busy_s=busy)
     H = wl["H"]
     rec = dict(regime=regime, neighbors=nbr_kind, p_remain=p,
                ms_per_step=el_max / steps * 1e3, value=fl_sum / (el_max / steps) / 1e12,
@@ -375,7 +380,7 @@ def dry_worker(args, comm):
     flops = 4.0 * 128 * 128 * 128 * pairs
     elapsed, busy = timed_steps(comm, lambda ev: time.sleep(0.001 * (1 + comm.rank)), args.steps, args.warmup,
                                 want_busy=True)
-    el_max, fl_sum, _, _, per_rank = parallel.reduce_step_stats(elapsed, flops, pairs, 0.0, comm.dev, busy_s=busy)
+    el_max, fl_sum, _, _, per_rank = parallel.reduce_step_stats(elapsed, flops, pairs, 0.0, comm.stat_dev, busy_s=busy)
     if comm.rank == 0:
         print(json.dumps({"metric": "dry run (host logic only, no GPU work)", "value": fl_sum / (el_max / args.steps) / 1e12,
                           "unit": "TFLOP/s", "n_gpus": comm.world, "steps": args.steps, "warmup": args.warmup,
@@ -445,7 +450,7 @@ def main():
             parallel.gather_heads(call.out)
         try:
             elg = timed_steps(comm, gstep, args.steps, max(1, args.warmup))
-            elg, _, _, _, per_rank_g = parallel.reduce_step_stats(elg, 0.0, 0.0, 0.0, dev)
+            elg, _, _, _, per_rank_g = parallel.reduce_step_stats(elg, 0.0, 0.0, 0.0, comm.stat_dev)
             gather = dict(ms_per_step=round(elg / args.steps * 1e3, 4),
                           value=round(rec["flops"] / (elg / args.steps) / 1e12, 3),
                           bytes_per_rank=int(call.out.numel() * call.out.element_size()),
@@ -464,7 +469,7 @@ def main():
                     call.attend()
                     hg.gather(call.out)
                 elh = timed_steps(comm, hstep, args.steps, max(1, args.warmup))
-                elh, _, _, _, _ = parallel.reduce_step_stats(elh, 0.0, 0.0, 0.0, dev)
+                elh, _, _, _, _ = parallel.reduce_step_stats(elh, 0.0, 0.0, 0.0, comm.stat_dev)
                 gather[tr] = dict(ms_per_step=round(elh / args.steps * 1e3, 4),
                                   value=round(rec["flops"] / (elh / args.steps) / 1e12, 3))
                 hg.close()
@@ -540,6 +545,8 @@ def main():
                      "select_pass_tbps": round(2.0 * H_local * D * (wl["S_vis"] + 2 * S) /
                                                max(rec["select_pass_ms"], 1e-6) / 1e9, 3)},
     }
+    if comm.one_device:
+        res["config"]["one_device_test"] = "all ranks time-slice cuda:0 over gloo: functional evidence, not a measurement"
     if args.gather_output and gather is not None and "value" in gather:  # headline = the gather-inclusive variant
         res["value"], res["ms_per_step"] = gather["value"], gather["ms_per_step"]
     res.update(extras)

@@ -48,3 +48,45 @@ def test_head_gather_transports_single_rank(transport):
         assert full.shape == (B, S, Hl * D) and torch.equal(full, x.reshape(B, S, Hl * D))
     finally:
         g.close()
+
+
+def test_bench_two_ranks_on_one_device():
+    """The N > 1 bench path end to end on hardware: `python bench.py --gpus 2` starts its own two ranks (as the driver
+    runs it), both compute their 12-head shard on cuda:0 (RSA_BENCH_ONE_DEVICE test hook, gloo control plane), rank 0
+    prints the one JSON line; the p2p exchange transport runs across the two processes through HIP IPC."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RSA_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-extras", "--no-cpu-baseline", "--gather-transports", "p2p"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["config"]["heads_per_gpu"] == 12
+    assert len(rec["config"]["per_rank_ms"]) == 2 and all(ms > 0 for ms in rec["config"]["per_rank_ms"])
+    assert rec["value"] > 0 and "one_device_test" in rec["config"]
+    g = rec["config"]["gather_output"]
+    assert g is not None and "p2p" in g and "ms_per_step" in g["p2p"], g
+
+
+def test_p2p_gather_two_processes_one_device():
+    """rsa_allgather_heads_p2p across two PROCESSES (HIP IPC handles exchanged over gloo), both on cuda:0: content check
+    of the gathered rows on every rank, three consecutive gathers (tests/_ipc_gather_worker.py)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29631",
+                        os.path.join(here, "_ipc_gather_worker.py")],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "IPC_GATHER_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
