@@ -14,8 +14,7 @@ static int g_dense256 = 0;  // tuning hook: dense mode on 256-row query tiles (8
 // 48 GB per launch but takes 21.6 instead of 16.1 ms -- the union walk is 1.22 lists long and a tile kept by only one
 // block of the pair still costs a full tile time of the 8-wave workgroup.
 int g_rsa_k5_pair = 0;
-extern int g_rsa_k3_prefix;  // rsa_stats.hip
-extern int g_rsa_k4_rows;
+extern int g_rsa_k3_prefix;
 static int g_k5_tsplit = 1;     // 1 = split-KV for the text query blocks when the partial buffer is given
 static int g_k5_maxblocks = 0;  // diagnostics: launch only the first N workgroups of K5 (partial result!)
 static int g_k5_pp = 0;     // 1 = the ping-pong kernel (rsa_attn_pp_kernel.hip): two query blocks per 8-wave workgroup
@@ -39,7 +38,6 @@ extern "C" int rsa_set_tuning(const char* key, int value) {
     if (strcmp(key, "k5_pair") == 0) { g_rsa_k5_pair = value; return RSA_OK; }
     if (strcmp(key, "k3_prefix") == 0) { g_rsa_k3_prefix = value; return RSA_OK; }
     if (strcmp(key, "k5_tsplit") == 0) { g_k5_tsplit = value; return RSA_OK; }
-    if (strcmp(key, "k4_rows") == 0) { g_rsa_k4_rows = value == 32 ? 32 : 16; return RSA_OK; }
     if (strcmp(key, "fp8_variant") == 0) { rsa_set_fp8_variant(value); return RSA_OK; }
     return RSA_ERR_BAD_ARG;
 }

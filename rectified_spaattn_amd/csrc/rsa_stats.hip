@@ -330,7 +330,6 @@ struct SelectArgs {
     float thr, scale;
 };
 int g_rsa_k3_prefix = 1;
-int g_rsa_k4_rows = 32;   // query-block rows per workgroup of K4 (16 or 32; tuning key "k4_rows": measured equal)
 
 __device__ __forceinline__ float wave_tree4(const float (&part)[4]) {
     float u[4];
@@ -513,6 +512,8 @@ __global__ __launch_bounds__(256) void select_mask_kernel(SelectArgs a) {
 #pragma unroll
             for (int s_ = 0; s_ < KPL; ++s_) pmax = max(pmax, (unsigned)(key[s_] >> 32));
             for (int m = 1; m < 64; m <<= 1) pmax = max(pmax, (unsigned)__shfl_xor((int)pmax, m, 64));
+            // (alternating the bisection with interpolation on the counts was measured: 236.4 vs 236 us -- the search is
+            // not where this kernel's time goes)
             unsigned lo = 0u, hi = pmax + 1u, t = 0u;   // #{p >= lo} > CAP (all L > CAP keys), #{p >= hi} = 0 < need
             int C = 0;
             bool found = false;
@@ -624,81 +625,83 @@ __global__ __launch_bounds__(256) void select_mask_kernel(SelectArgs a) {
 }
 
 // =====================================================================================================
-// K4: comp[i, :] = sum_j w[i, j] * vbar[j, :]   (tolerance-only quantity; fp32 FMA, j ascending)
+// K4: comp[i, :] = sum_j w[i, j] * vbar[j, :]   (tolerance-only quantity; fp32, j ascending) on the fp32 matrix pipe,
+// same chain form as K2: v_mfma_f32_32x32x2_f32 over j = 0,1 | 2,3 | ...
+// Workgroup = D/32 waves = 32 query-block rows x D; wave = one 32 x 32 tile of comp (16 accumulator registers), all waves
+// share the A operand (the w rows).  j staged in chunks of 32 through registers -> LDS:
+//   w  as [row][16 even j | 16 odd j | pad 4]  (lane (r, h) feeds j = 2s + h: 4 steps per ds_read_b128, conflict-free)
+//   vbar as [j][D]                              (lane (r, h) reads element d0 + r of row 2s + h: one ds_read_b32 per MFMA)
+// 32-row tiles keep the grid at 696 workgroups for the Hunyuan shape (2.7 per CU).  Measured 67 us (97 on the VALU) with
+// the matrix pipe 49 % busy.  Tried on top, all within +-5 us: one wave per tile without barriers, 64-wide chunks, two
+// LDS buffers with one or two register stages in flight, all LDS operand reads of a chunk ahead of its MFMAs, an occupancy
+// cap of 3 per CU; a timing-only build that never refills the tiles runs 57 us.  In-kernel stamps: workgroups spread
+// 2-3 per CU, a wave lives 128k cycles of which its own 464 MFMAs are 30k.
 // =====================================================================================================
-template <int D, int TI>
-__global__ __launch_bounds__(256) void compensation_kernel(const float* w, const float* vbar, float* comp, int NBv,
-                                                           int L, int NB_total) {
-    // out tile 32 (i) x D (d); thread = RI rows x 4 d; j staged through LDS in chunks of 32 (W transposed so a
-    // thread's rows are one vector read)
-    constexpr int TJ = 32, TD = D / 4, TG = 256 / TD, RI = TI / TG;
-    static_assert(RI >= 1 && TI * TJ % 256 == 0, "tile shape");
-    __shared__ __attribute__((aligned(16))) float Ws[TJ][TI + 4];
-    __shared__ __attribute__((aligned(16))) float Vs[TJ][D];
-    const int bh = blockIdx.y, i0 = blockIdx.x * TI, t = threadIdx.x;
-    const int td = t % TD, tg = t / TD;
+template <int D>
+__global__ __launch_bounds__(D * 2) void compensation_kernel(const float* w, const float* vbar, float* comp, int NBv,
+                                                             int L, int NB_total) {
+    constexpr int TJ = 32, LDW = TJ + 4, NT = D * 2, NWK = 32 * TJ / NT, NVK = TJ * D / 4 / NT;
+    __shared__ __attribute__((aligned(16))) float Ws[32 * LDW];
+    __shared__ __attribute__((aligned(16))) float Vs[TJ * D];
+    const int bh = blockIdx.y, i0 = blockIdx.x * 32, t = threadIdx.x, lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int r = lane & 31, h = lane >> 5;
     const float* wp = w + (long)bh * NBv * L;
     const float* vp = vbar + (long)bh * NB_total * D;
-    float acc[RI][4];
+    k2_f32x16 acc;
 #pragma unroll
-    for (int r = 0; r < RI; ++r)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[r][e] = 0.0f;
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
     // register-staged double buffering: chunk j0 + TJ is loaded from global memory while chunk j0 is multiplied
-    constexpr int NWK = TI * TJ / 256, NVK = TJ * D / 4 / 256;
     float wreg[NWK];
     float4 vreg[NVK];
     auto load_chunk = [&](int j0) {
 #pragma unroll
         for (int k = 0; k < NWK; ++k) {
-            const int idx = t + k * 256;
-            const int ii = idx / TJ, jj = idx % TJ;
-            wreg[k] = (i0 + ii < NBv && j0 + jj < L) ? wp[(long)(i0 + ii) * L + j0 + jj] : 0.0f;
+            const int idx = t + k * NT;
+            const int ii = idx / TJ, jj = idx % TJ;   // rows past NBv are clamped: they feed outputs that are not stored
+            const int row = min(i0 + ii, NBv - 1);
+            wreg[k] = j0 + jj < L ? wp[(long)row * L + j0 + jj] : 0.0f;
         }
 #pragma unroll
         for (int k = 0; k < NVK; ++k) {
-            const int idx = t + k * 256;
-            const int jj = idx / TD, dd = (idx % TD) * 4;
+            const int idx = t + k * NT;
+            const int jj = idx / (D / 4), dd = (idx % (D / 4)) * 4;
             vreg[k] = make_float4(0, 0, 0, 0);
             if (j0 + jj < L) vreg[k] = *reinterpret_cast<const float4*>(vp + (long)(j0 + jj) * D + dd);
         }
     };
     load_chunk(0);
+    const float* pa = &Ws[r * LDW + (TJ / 2) * h];
+    const float* pb = &Vs[h * D + 32 * wv + r];
     for (int j0 = 0; j0 < L; j0 += TJ) {
         __syncthreads();   // the previous chunk's LDS reads are done
 #pragma unroll
         for (int k = 0; k < NWK; ++k) {
-            const int idx = t + k * 256;
-            Ws[idx % TJ][idx / TJ] = wreg[k];
+            const int idx = t + k * NT;
+            const int ii = idx / TJ, jj = idx % TJ;
+            Ws[ii * LDW + (TJ / 2) * (jj & 1) + (jj >> 1)] = wreg[k];
         }
 #pragma unroll
         for (int k = 0; k < NVK; ++k) {
-            const int idx = t + k * 256;
-            *reinterpret_cast<float4*>(&Vs[idx / TD][(idx % TD) * 4]) = vreg[k];
+            const int idx = t + k * NT;
+            *reinterpret_cast<float4*>(&Vs[(idx / (D / 4)) * D + (idx % (D / 4)) * 4]) = vreg[k];
         }
         __syncthreads();
-        if (j0 + TJ < L) load_chunk(j0 + TJ);   // in flight during the multiply below
-#pragma unroll 8
-        for (int jj = 0; jj < TJ; ++jj) {
-            const float4 v4 = *reinterpret_cast<const float4*>(&Vs[jj][4 * td]);
-            float wr[RI];
+        if (j0 + TJ < L) load_chunk(j0 + TJ);   // in flight during the MFMAs below
 #pragma unroll
-            for (int r = 0; r < RI; ++r) wr[r] = Ws[jj][tg * RI + r];
+        for (int m = 0; m < TJ / 8; ++m) {
+            const float4 a4 = *reinterpret_cast<const float4*>(pa + 4 * m);
+            const float aa[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
-            for (int r = 0; r < RI; ++r) {
-                acc[r][0] = __builtin_fmaf(wr[r], v4.x, acc[r][0]);
-                acc[r][1] = __builtin_fmaf(wr[r], v4.y, acc[r][1]);
-                acc[r][2] = __builtin_fmaf(wr[r], v4.z, acc[r][2]);
-                acc[r][3] = __builtin_fmaf(wr[r], v4.w, acc[r][3]);
-            }
+            for (int x = 0; x < 4; ++x)   // step s = 4m + x of the chunk: j = j0 + 2s (h = 0), j0 + 2s + 1 (h = 1)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[x], pb[(2 * (4 * m + x)) * D], acc, 0, 0, 0);
         }
     }
+    // accumulator element e of lane (r, h): row (e & 3) + 8 (e >> 2) + 4 h, column r of the wave's 32 x 32 tile
 #pragma unroll
-    for (int r = 0; r < RI; ++r) {
-        const int i = i0 + tg * RI + r;
-        if (i < NBv)
-            *reinterpret_cast<float4*>(comp + ((long)bh * NBv + i) * D + 4 * td) =
-                make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+    for (int e = 0; e < 16; ++e) {
+        const int i = i0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (i < NBv) comp[((long)bh * NBv + i) * D + 32 * wv + r] = acc[e];
     }
 }
 
@@ -953,16 +956,9 @@ extern "C" int rsa_compensation(const rsa_layout* l, const rsa_buffers* buf, voi
     if (l->NBv == 0) return RSA_OK;
     const int L = l->NBv + (l->n_txt > 0 ? 1 : 0);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // 32-row tiles; 16-row tiles (twice the workgroups) measured the same (tools/ab_k4.py)
-    const int ti = g_rsa_k4_rows;
-    dim3 grid((l->NBv + ti - 1) / ti, l->B * l->H);
-    if (l->D == 128) {
-        if (ti == 16) compensation_kernel<128, 16><<<grid, 256, 0, s>>>(buf->w, buf->vbar, buf->comp, l->NBv, L, l->NB_total);
-        else compensation_kernel<128, 32><<<grid, 256, 0, s>>>(buf->w, buf->vbar, buf->comp, l->NBv, L, l->NB_total);
-    } else {
-        if (ti == 16) compensation_kernel<64, 16><<<grid, 256, 0, s>>>(buf->w, buf->vbar, buf->comp, l->NBv, L, l->NB_total);
-        else compensation_kernel<64, 32><<<grid, 256, 0, s>>>(buf->w, buf->vbar, buf->comp, l->NBv, L, l->NB_total);
-    }
+    dim3 grid((l->NBv + 31) / 32, l->B * l->H);
+    if (l->D == 128) compensation_kernel<128><<<grid, 256, 0, s>>>(buf->w, buf->vbar, buf->comp, l->NBv, L, l->NB_total);
+    else compensation_kernel<64><<<grid, 128, 0, s>>>(buf->w, buf->vbar, buf->comp, l->NBv, L, l->NB_total);
     return rsa_launch_status();
 }
 
