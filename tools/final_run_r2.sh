@@ -23,6 +23,8 @@ python3 tools/summarize_prof.py $(find gpurun_out/r2z_prof -name "*kernel_stats.
 python3 tools/summarize_prof.py $(find gpurun_out/r2z_prof_fp8 -name "*kernel_stats.csv" | head -1) > gpurun_out/r2z_kernel_stats_fp8.md
 bash tools/pmc_passes.sh r2z_pmc_all > gpurun_out/r2z_pmc_all.txt 2>&1
 cp gpurun_out/r2z_pmc_all/summary.txt gpurun_out/r2z_pmc_summary.txt; rm -rf gpurun_out/r2z_pmc_all
+bash tools/pmc_select.sh r2z_pmcsel > /dev/null 2>&1; cp gpurun_out/r2z_pmcsel/summary.txt gpurun_out/r2z_pmc_select.txt; rm -rf gpurun_out/r2z_pmcsel
+RSA_BENCH_ONE_DEVICE=1 python bench.py --gpus 2 --steps 5 --warmup 2 --no-extras --no-cpu-baseline --gather-transports p2p > gpurun_out/r2z_bench_2ranks_one_device.json 2>> gpurun_out/r2z_bench.err
 for d in r2z_prof r2z_prof_fp8; do find gpurun_out/$d -name "*kernel_trace.csv" -delete; done
 du -sh gpurun_out
 tail -3 gpurun_out/r2z_tests.txt; cat gpurun_out/r2z_smoke.txt | tail -2; tail -c 600 gpurun_out/r2z_bench.json
