@@ -37,6 +37,12 @@ COEFFICIENTS = {
     "wan21_14b_ret": [-3.03318725e+05, 4.90537029e+04, -2.65530556e+03, 5.87365115e+01, -3.15583525e-01],   # :277
     "wan21_1_3b": [2.39676752e+03, -1.31110545e+03, 2.01331979e+02, -8.29855975e+00, 1.37887774e-01],       # :282
     "wan21_14b": [-5784.54975374, 5449.50911966, -1811.16591783, 256.27178429, -13.02252404],               # :284
+    # main_cogvideox.py:20-26, keyed by the model directory name as the script does (:247)
+    "CogVideoX-2b": [-3.10658903e+01, 2.54732368e+01, -5.92380459e+00, 1.75769064e+00, -3.61568434e-03],
+    "CogVideoX-5b": [-1.53880483e+03, 8.43202495e+02, -1.34363087e+02, 7.97131516e+00, -5.23162339e-02],
+    "CogVideoX-5b-I2V": [-1.53880483e+03, 8.43202495e+02, -1.34363087e+02, 7.97131516e+00, -5.23162339e-02],
+    "CogVideoX1.5-5B": [2.50210439e+02, -1.65061612e+02, 3.57804877e+01, -7.81551492e-01, 3.58559703e-02],
+    "CogVideoX1.5-5B-I2V": [1.22842302e+02, -1.04088754e+02, 2.62981677e+01, -3.06009921e-01, 3.71213220e-02],
 }
 
 
@@ -67,7 +73,8 @@ class TeaCache:
     belongs to stream c % streams; a call always computes when cnt < ret_calls or cnt >= cutoff_calls."""
 
     def __init__(self, total_calls: int, thresh: float, coefficients: Sequence[float], streams: int = 1,
-                 ret_calls: int = 1, cutoff_calls: Optional[int] = None):
+                 ret_calls: int = 1, cutoff_calls: Optional[int] = None, start_cnt: int = 0):
+        self.start_cnt = int(start_cnt)
         self.total_calls = int(total_calls)
         self.thresh = float(thresh)
         self.poly = np.poly1d(list(coefficients))
@@ -87,6 +94,32 @@ class TeaCache:
         return cls(num_steps, rel_l1_thresh, COEFFICIENTS["flux"], 1, 1, num_steps - 1)
 
     @classmethod
+    def cogvideox(cls, model: str, num_steps: int = 50, rel_l1_thresh: float = 0.2) -> "TeaCache":
+        """main_cogvideox.py:106-118: the statistic is taken on the time embedding `emb`; always compute on the first and
+        the last step; `model` is the checkpoint directory name ('CogVideoX1.5-5B', ...).  The forward caches TWO
+        residuals (video and text tokens, :133-134): use store_residual / apply_residual with slot=0 and slot=1."""
+        return cls(num_steps, rel_l1_thresh, COEFFICIENTS[model], 1, 1, num_steps - 1)
+
+    @classmethod
+    def wan22_pair(cls, num_steps: int, transformer_steps: int, teacache_thresh: float = 0.2, use_ret_steps: bool = True,
+                   big: bool = True):
+        """Wan2.2 T2V / I2V run two transformers over one schedule (main_wan22t2v.py:82-127, main_wan22i2v.py:90-135):
+        `transformer` serves the first `transformer_steps` denoising steps, `transformer_2` the rest, each with its own
+        controller.  The script starts transformer_2's call counter at 2*transformer_steps and gives it the windows
+        below; its counter wraps to 0 (not to its start value) after 2*num_steps calls, which is kept.  In the
+        use_ret_steps = False branch the script assigns `transformer.ret_steps` twice and `transformer_2.cutoff_steps`
+        twice (:124-127), leaving transformer.cutoff_steps and transformer_2.ret_steps unset -- that branch cannot run
+        upstream, so only use_ret_steps = True is offered here.  (Wan2.2 TI2V has one transformer: TeaCache.wan.)"""
+        if not use_ret_steps:
+            raise NotImplementedError("the reference's use_ret_steps=False branch for two transformers leaves "
+                                      "cutoff_steps / ret_steps unset (main_wan22t2v.py:124-127)")
+        coeff = COEFFICIENTS[("wan21_14b" if big else "wan21_1_3b") + "_ret"]
+        t1 = cls(2 * transformer_steps, teacache_thresh, coeff, 2, 3 * 2, 2 * transformer_steps)
+        t2 = cls(2 * num_steps, teacache_thresh, coeff, 2, 2 * transformer_steps + 1 * 2, 2 * num_steps,
+                 start_cnt=2 * transformer_steps)
+        return t1, t2
+
+    @classmethod
     def wan(cls, num_steps: int, teacache_thresh: float = 0.2, use_ret_steps: bool = True, big: bool = True) -> "TeaCache":
         """main_wan21t2v.py:273-286: two calls per step; ret_steps = 5*2 / 1*2, cutoff = 2*steps / 2*steps - 2."""
         key = ("wan21_14b" if big else "wan21_1_3b") + ("_ret" if use_ret_steps else "")
@@ -96,10 +129,10 @@ class TeaCache:
 
     # -- state ---------------------------------------------------------------------------------------------------
     def reset(self):
-        self.cnt = 0
+        self.cnt = self.start_cnt
         self.accumulated = [0.0] * self.streams
         self.previous_input: List[Optional[torch.Tensor]] = [None] * self.streams
-        self.previous_residual: List[Optional[torch.Tensor]] = [None] * self.streams
+        self.previous_residual: List[dict] = [{} for _ in range(self.streams)]   # per stream: slot -> tensor
         self._stream = 0
 
     @property
@@ -123,13 +156,14 @@ class TeaCache:
         self.cnt += 1
         if self.cnt == self.total_calls:
             self.cnt = 0
-        if not calc and self.previous_residual[s] is None:  # nothing cached yet (fresh controller mid-run)
+        if not calc and not self.previous_residual[s]:  # nothing cached yet (fresh controller mid-run)
             calc = True
         return calc
 
-    def store_residual(self, hidden_out: torch.Tensor, hidden_in: torch.Tensor):
-        self.previous_residual[self._stream] = hidden_out - hidden_in
+    def store_residual(self, hidden_out: torch.Tensor, hidden_in: torch.Tensor, slot: int = 0):
+        """slot: which of the forward's cached residuals (CogVideoX keeps two: 0 = video tokens, 1 = text tokens)"""
+        self.previous_residual[self._stream][slot] = hidden_out - hidden_in
 
-    def apply_residual(self, hidden_states: torch.Tensor) -> torch.Tensor:
-        hidden_states += self.previous_residual[self._stream]
+    def apply_residual(self, hidden_states: torch.Tensor, slot: int = 0) -> torch.Tensor:
+        hidden_states += self.previous_residual[self._stream][slot]
         return hidden_states

@@ -439,13 +439,17 @@ def _load_script(name, extra_stubs=()):
             self.sample = sample
 
     d = sys.modules.get("diffusers") or mod("diffusers")
-    for n in ("HunyuanVideoPipeline", "HunyuanVideoTransformer3DModel", "AutoencoderKLWan", "WanPipeline"):
+    for n in ("HunyuanVideoPipeline", "HunyuanVideoTransformer3DModel", "AutoencoderKLWan", "WanPipeline",
+              "CogVideoXPipeline", "CogVideoXImageToVideoPipeline", "FluxPipeline", "FluxControlNetModel",
+              "WanImageToVideoPipeline"):
         setattr(d, n, _Any)
+    mod("diffusers.pipelines", FluxControlNetPipeline=_Any)
     mod("diffusers.schedulers")
     mod("diffusers.schedulers.scheduling_unipc_multistep", UniPCMultistepScheduler=_Any)
     log = types.SimpleNamespace(get_logger=lambda n: types.SimpleNamespace(warning=lambda *a, **k: None))
     mod("diffusers.utils", USE_PEFT_BACKEND=False, logging=log, scale_lora_layers=lambda *a: None,
-        unscale_lora_layers=lambda *a: None)
+        unscale_lora_layers=lambda *a: None, is_torch_version=lambda *a: True, export_to_video=lambda *a, **k: None,
+        load_image=lambda *a, **k: None)
     mod("diffusers.models.modeling_outputs", Transformer2DModelOutput=_Out)
     mod("utils.seed", set_seed=lambda s: None)
     mod("utils.save_video", save_videos_grid=lambda *a, **k: None)
@@ -565,6 +569,117 @@ def teacache():
                 dec.append(counter[0] > before)
         res[f"wan_{ci}"] = np.array(dec, np.uint8)
         print("teacache wan", ci, size, "ret" if use_ret else "noret", "computed", sum(dec), "of", len(dec))
+    # ---- CogVideoX: statistic on the time embedding, two cached residuals (main_cogvideox.py:45-196) -----------
+    with contextlib.redirect_stdout(io.StringIO()):
+        cog = _load_script("main_cogvideox")
+        flux = _load_script("main_upflux")
+        w22 = _load_script("main_wan22ti2v")   # main_wan22t2v.py:12 imports its teacache_forward from here
+
+    class CogBlock(Block):
+        def forward(self, hidden_states, encoder_hidden_states, temb, image_rotary_emb):
+            self.counter[0] += 1
+            return hidden_states * 1.01 + 0.1, encoder_hidden_states * 0.99 + 0.2
+
+    for ci, (seed, drift, thresh, num_steps, model) in enumerate(helpers.TEACACHE_COG_CASES):
+        C, F, Hh, W, NT = 8, 2, 4, 4, 3
+        N = F * Hh * W
+        counter = [0]
+        order = torch.arange(N)
+        seq = helpers.teacache_sequence(seed, 2 * num_steps + 3, drift, (1, 16))
+        it = iter(seq)
+        me = types.SimpleNamespace(
+            config=types.SimpleNamespace(patch_size=1, patch_size_t=None, use_rotary_positional_embeddings=True),
+            time_proj=lambda t: torch.zeros(1, 4), time_embedding=lambda t_emb, cond, _it=it: next(_it).clone(),
+            ofs_embedding=None,
+            patch_embed=lambda enc, hs: torch.cat([enc, hs.flatten(3).permute(0, 1, 3, 2).reshape(1, N, C)], 1),
+            embedding_dropout=lambda x: x, hilbert_order=order, linear_to_hilbert=order,
+            transformer_blocks=[CogBlock(counter)], attn_processors={},
+            norm_final=lambda h: h, norm_out=lambda h, temb: h, proj_out=lambda h: h,
+            enable_teacache=True, cnt=0, num_steps=num_steps, rel_l1_thresh=thresh,
+            coefficients=cog.coefficients_dict[model], accumulated_rel_l1_distance=0, previous_modulated_input=None,
+            previous_residual=None, previous_residual_encoder=None)
+        dec = []
+        with contextlib.redirect_stdout(io.StringIO()):
+            for _ in range(len(seq)):
+                before = counter[0]
+                cog.teacache_forward(me, torch.zeros(1, F, C, Hh, W), torch.zeros(1, NT, C), torch.zeros(1), None, None,
+                                     (torch.ones(N, 4), torch.zeros(N, 4)), None, True)
+                dec.append(counter[0] > before)
+        res[f"cog_{ci}"] = np.array(dec, np.uint8)
+        print("teacache cogvideox", ci, model, "computed", sum(dec), "of", len(dec))
+
+    # ---- Flux (main_upflux.py:44-262): statistic on norm1's modulated input, controlnet samples required -------
+    class FluxBlock(Block):
+        def __init__(self, counter, it):
+            super().__init__(counter)
+            self.it = it
+
+        def norm1(self, inp, emb=None):
+            return next(self.it).clone(), None, None, None, None
+
+        def forward(self, hidden_states, encoder_hidden_states, temb, image_rotary_emb, joint_attention_kwargs):
+            self.counter[0] += 1
+            return encoder_hidden_states, hidden_states * 1.01 + 0.1
+
+    for ci, (seed, drift, thresh, num_steps) in enumerate(helpers.TEACACHE_FLUX_CASES):
+        C, N, NT = 8, 32, 3
+        counter = [0]
+        order = torch.arange(N)
+        seq = helpers.teacache_sequence(seed, 2 * num_steps + 3, drift, (1, N, C))
+        it = iter(seq)
+        me = types.SimpleNamespace(
+            x_embedder=lambda x: x, time_text_embed=lambda *a: torch.zeros(1, 4), context_embedder=lambda e: e,
+            pos_embed=lambda ids: (torch.ones(NT + N, 4), torch.zeros(NT + N, 4)),
+            hilbert_order=order, linear_to_hilbert=order,
+            transformer_blocks=[FluxBlock(counter, it)], single_transformer_blocks=[],
+            norm_out=lambda h, t: h, proj_out=lambda h: h,
+            enable_teacache=True, cnt=0, num_steps=num_steps, rel_l1_thresh=thresh,
+            accumulated_rel_l1_distance=0, previous_modulated_input=None, previous_residual=None)
+        dec = []
+        with contextlib.redirect_stdout(io.StringIO()):
+            for _ in range(len(seq)):
+                before = counter[0]
+                flux.teacache_forward(me, torch.zeros(1, N, C), torch.zeros(1, NT, C), torch.zeros(1, 4), torch.zeros(1),
+                                      torch.zeros(N, 3), torch.zeros(NT, 3), None, None, [torch.zeros(1, N, C)], None, True)
+                dec.append(counter[0] > before)
+        res[f"flux_{ci}"] = np.array(dec, np.uint8)
+        print("teacache flux", ci, "computed", sum(dec), "of", len(dec))
+
+    # ---- Wan2.2 T2V: two transformers over one schedule (main_wan22t2v.py:82-127, use_ret_steps) ---------------
+    for ci, (seed, drift, thresh, steps, tsteps, size) in enumerate(helpers.TEACACHE_WAN22_CASES):
+        C, T, Hh, W = 8, 2, 4, 4
+        N = T * Hh * W
+        order = torch.arange(N)
+        seq = helpers.teacache_sequence(seed, 2 * (2 * steps) + 6, drift, (1, 6 * 16))
+        it = iter(seq)
+        counters = [[0], [0]]
+
+        def make(counter, cnt0, num, ret, cutoff):
+            def cond(t, enc, enc_img, timestep_seq_len=None, _it=it):
+                tp = next(_it)
+                return tp[:, :C].clone(), tp.clone(), enc, enc_img
+            return types.SimpleNamespace(
+                config=types.SimpleNamespace(patch_size=(1, 1, 1)), rope=lambda x: (torch.ones(1, N, 4), torch.ones(1, N, 4)),
+                patch_embedding=lambda x: x, condition_embedder=cond, hilbert_order=order, linear_to_hilbert=order,
+                blocks=torch.nn.ModuleList([WanBlock(counter)]), scale_shift_table=torch.zeros(1, 2, C),
+                norm_out=lambda h: h, proj_out=lambda h: h, enable_teacache=True, cnt=cnt0, num_steps=num,
+                teacache_thresh=thresh, accumulated_rel_l1_distance_even=0, accumulated_rel_l1_distance_odd=0,
+                previous_e0_even=None, previous_e0_odd=None, previous_residual_even=None, previous_residual_odd=None,
+                use_ref_steps=True, coefficients=coeff[(size, True)], ret_steps=ret, cutoff_steps=cutoff)
+
+        m1 = make(counters[0], 0, 2 * tsteps, 3 * 2, 2 * tsteps)                       # :85-93, :113-114
+        m2 = make(counters[1], 2 * tsteps, 2 * steps, 2 * tsteps + 1 * 2, 2 * steps)   # :96-105, :115-116
+        dec = []
+        with contextlib.redirect_stdout(io.StringIO()):
+            for gen in range(2):               # two generations with the same pipe: the counters wrap (m2 wraps to 0)
+                for call in range(2 * steps):
+                    me, cn = (m1, counters[0]) if call < 2 * tsteps else (m2, counters[1])
+                    before = cn[0]
+                    w22.teacache_forward(me, torch.zeros(1, C, T, Hh, W), torch.zeros(1), torch.zeros(1, 3, 4), None,
+                                         True, None)
+                    dec.append(cn[0] > before)
+        res[f"wan22_{ci}"] = np.array(dec, np.uint8)
+        print("teacache wan2.2 pair", ci, size, "computed", sum(dec), "of", len(dec))
     np.savez_compressed(os.path.join(outdir, "teacache.npz"), **res)
 
 

@@ -111,6 +111,15 @@ TEACACHE_WAN_CASES = [  # (seed, drift, teacache_thresh, steps, model size key o
     (10, 0.02, 0.08, 10, "1.3B", False)]
 
 
+TEACACHE_COG_CASES = [  # (seed, drift, rel_l1_thresh, num_steps, checkpoint name = key of the script's coefficients_dict)
+    (21, 0.03, 0.2, 16, "CogVideoX1.5-5B"), (22, 0.01, 0.1, 16, "CogVideoX-5b"), (23, 0.05, 0.3, 12, "CogVideoX-2b"),
+    (24, 0.03, 0.2, 12, "CogVideoX1.5-5B-I2V")]
+TEACACHE_FLUX_CASES = [  # (seed, drift, rel_l1_thresh, num_steps)
+    (31, 0.02, 0.4, 16), (32, 0.05, 0.8, 16)]
+TEACACHE_WAN22_CASES = [  # (seed, drift, teacache_thresh, num_steps, transformer_steps, model size key): two transformers
+    (41, 0.004, 0.2, 12, 5, "14B"), (42, 0.003, 0.1, 10, 4, "1.3B")]
+
+
 def teacache_sequence(seed, n, drift, shape):
     """Deterministic drifting tensor sequence (counter-based generator): x_i = x_{i-1} + drift*(1+0.5 sin i)*noise_i."""
     x = torch.from_numpy(synth.normal(seed, 0, shape).astype(np.float32))
