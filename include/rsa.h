@@ -265,7 +265,7 @@ int rsa_ipc_open(const void* handle64, int peer_device, void** dev_ptr);    /* m
 int rsa_ipc_close(void* dev_ptr);
 
 /* Tuning / diagnostics hook, not part of the data path.  Keys: "k5_prio" (0/1: issue-priority raise inside K5's
- * pipelined block + LLVM's iglp_opt(0) interleave), "dense256" (0/1: rsa_dense_fwd on 256-row query tiles, 8 waves
+ * pipelined block + LLVM's iglp_opt(0) interleave; 32 = 1 + 16-byte output stores, the default), "dense256" (0/1: rsa_dense_fwd on 256-row query tiles, 8 waves
  * per workgroup; same results), "fp8_variant" (0..4: iglp_opt strategy of the fp8 kernel's block; 0 = none), "k5_pair" (paired 256-row workgroups),
  * "k5_pp" (ping-pong kernel), "k5_tsplit" (split-KV of the text blocks), "k3_prefix" (sorted-head path of K3).  The hook
  * is inert (RSA_ERR_UNSUPPORTED) unless the process was started with the environment variable RSA_TUNING=1. */

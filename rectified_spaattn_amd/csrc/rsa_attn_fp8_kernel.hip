@@ -400,6 +400,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     if (zero_r) inv = 0.0f;
     const float sc = inv * Rv * s_v;
     unsigned short* op = a.out + (long)b * a.osb + (long)h * a.osh + (long)grow * a.oss;
+    // (16-byte stores after a v_permlane32_swap regroup, the 2-byte kernel's default, measured neutral here: 9.60 vs 9.60 ms)
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
 #pragma unroll

@@ -576,6 +576,38 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
         if (zero_r[qt]) inv = 0.0f;
         const float sc = inv * Rv;
         unsigned short* op = a.out + (long)b * a.osb + (long)h * a.osh + (long)grow[qt] * a.oss;
+        if constexpr ((PIPE_OPT & 4096) != 0) {
+            // wide stores: lane (r, 0) holds d = 8g .. 8g+3 and lane (r, 1) d = 8g+4 .. 8g+7 of a 32-wide d tile; one
+            // v_permlane32_swap per packed register pair regroups two g's so that each lane owns 8 consecutive d:
+            // 8 stores of 16 B per lane instead of 16 of 8 B (the store tail of a row-per-lane epilogue is issue-bound)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    uint2 pk[2];
+#pragma unroll
+                    for (int gi = 0; gi < 2; ++gi) {
+                        const int g = 2 * gp + gi;
+                        const int d0 = 32 * dt + 8 * g + 4 * hh;
+                        float4 c4 = make_float4(0, 0, 0, 0);
+                        if (cp && !zero_r[qt]) c4 = *reinterpret_cast<const float4*>(cp + d0);
+                        const float v0 = o[dt][qt][4 * g + 0] * sc + c4.x;
+                        const float v1 = o[dt][qt][4 * g + 1] * sc + c4.y;
+                        const float v2 = o[dt][qt][4 * g + 2] * sc + c4.z;
+                        const float v3 = o[dt][qt][4 * g + 3] * sc + c4.w;
+                        pk[gi].x = (unsigned)E::from_f32(v0) | ((unsigned)E::from_f32(v1) << 16);
+                        pk[gi].y = (unsigned)E::from_f32(v2) | ((unsigned)E::from_f32(v3) << 16);
+                    }
+                    // X' = [X.lower, Y.lower], Y' = [X.upper, Y.upper]  (X = pk[0], Y = pk[1])
+                    const auto sx = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
+                    const auto sy = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
+                    uint4 w4;
+                    w4.x = sx[0]; w4.y = sy[0]; w4.z = sx[1]; w4.w = sy[1];
+                    *reinterpret_cast<uint4*>(op + 32 * dt + 8 * (2 * gp + hh)) = w4;
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
 #pragma unroll
@@ -610,11 +642,14 @@ int rsa_launch_bsfwd_pair(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D,
 
 // launch hook used by rsa_attn.hip::launch_attn
 int rsa_launch_bsfwd(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int dtype, int prio, hipStream_t s) {
+    // the 16-byte output stores of the default form need 16-byte aligned rows; anything else takes the 8-byte form
+    if (prio == 32 && (((uintptr_t)a.out & 15) || ((a.osb | a.osh | a.oss) & 7))) prio = 1;
 #define RSA_K5(DD, TT) \
     do { \
         if (prio == 8) bsfwd_kernel<DD, TT, 8, 1, 2 + 256><<<grid, 512, lds_bytes, s>>>(a); \
         else if (prio == 4) bsfwd_kernel<DD, TT, 4, 1, 2 + 4 + 256><<<grid, 256, lds_bytes, s>>>(a); \
         else if (prio == 16) bsfwd_kernel<DD, TT, 4, 1, 2 + 256 + 2048><<<grid, 256, lds_bytes, s>>>(a); \
+        else if (prio == 32) bsfwd_kernel<DD, TT, 4, 1, 2 + 256 + 4096><<<grid, 256, lds_bytes, s>>>(a); \
         else if (prio) bsfwd_kernel<DD, TT, 4, 1, 2 + 256><<<grid, 256, lds_bytes, s>>>(a); \
         else bsfwd_kernel<DD, TT, 4, 1, 0><<<grid, 256, lds_bytes, s>>>(a); \
     } while (0)
