@@ -67,3 +67,37 @@ def test_random_layout(case):
     mx, mean = (2e-2, 2e-3) if dt == torch.bfloat16 else (2e-3, 2e-4)
     err = np.abs(out.float().cpu().numpy() - ref)
     assert err.max() <= mx and err.mean() <= mean, f"case {i}: max {err.max():.3e} mean {err.mean():.3e}"
+
+
+@pytest.mark.parametrize("shift", [60, 68, 72])
+def test_tiny_magnitudes_keep_the_contract(shift):
+    """K2 and K4 run their fp32 chains on the matrix pipe (v_mfma_f32_32x32x2_f32).  With Q and K scaled by 2^-shift the
+    pooled products fall into the subnormal range (2^-136 ... 2^-144 and below): the GAPR comparison |s| > |e_q| + |e_k|
+    is then decided on subnormal fp32 values, which the MFMA must neither flush nor round differently from the oracle's
+    fmaf chain.  Everything discrete must still equal the oracle bit for bit."""
+    from rectified_spaattn_amd import _core, synth
+    D, H = 128, 2
+    lay = orc.layout_hunyuan(6 * 128 + 256, 6 * 128 + 77)
+    q, k, v = synth.structured_qkv(4242 + shift, 1, H, lay.S, D)
+    sc = np.float32(2.0 ** -shift)
+    tq, tk, tv = (torch.from_numpy(x).to(DEV, torch.bfloat16) for x in (q * sc, k * sc, v))
+    q, k, v = (x.float().cpu().numpy() for x in (tq, tk, tv))
+    assert np.abs(q).max() > 0 and np.abs(q).max() < 2.0 ** (-shift + 4)      # bf16 keeps the scaled values (no flush)
+    spec = _core.LayoutSpec(lay.S, lay.NB_total, lay.NBv, lay.n_txt, lay.kv_valid, lay.pool_valid,
+                            lay.text_end_block, lay.ffb, lay.q_text_valid, lay.kv_text_valid)
+    out, bufs = _core.rectified_attention(tq, tk, tv, spec, 3, 0.3, None, return_parts=True)
+    ref, parts = orc.rectified_attention(q, k, v, lay, 3, 0.3, None, want_parts=True)
+    sub = 0
+    for bh in range(H):
+        sel = parts[bh]
+        s_gpu = bufs["scores"][bh].cpu().numpy()
+        sub += int(((np.abs(s_gpu) > 0) & (np.abs(s_gpu) < np.float32(2.0 ** -126))).sum())
+        kept = orc.unpack_bits(bufs["bitmask"][bh].cpu().numpy().view(np.uint32), lay.NB_total)
+        assert np.array_equal(bufs["unrel"][bh].cpu().numpy(), sel["unrel"])
+        assert np.array_equal(bufs["probs"][bh].cpu().numpy(), sel["probs"])
+        assert np.array_equal(kept, sel["kept"])
+        assert np.array_equal(bufs["R"][bh].cpu().numpy(), sel["R"])
+    if shift >= 68:
+        assert sub > 0, "the case is meant to produce subnormal pooled scores"
+    err = np.abs(out.float().cpu().numpy() - ref)
+    assert err.max() <= 2e-2 and err.mean() <= 2e-3
