@@ -174,18 +174,8 @@ typedef float k2_f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ int ncols_of(const ScoreArgs& a, int mode) { return mode == 0 ? a.NBv : a.n_txt; }
 
 template <int MODE, typename Tag>
-__global__ __launch_bounds__(256) void pooled_scores_kernel(ScoreArgs a) {
+__device__ __forceinline__ void pooled_scores_tile(const ScoreArgs& a, int bh, int i0, int j0, float (*tile)[64 * 36]) {
     constexpr int DK = 32, LD = 36, NOP = MODE == 0 ? 4 : 2;   // operands: q, k (, aq, ak)
-    __shared__ __attribute__((aligned(16))) float tile[NOP][64 * LD];
-    // 1-D grid, XCD-aware: workgroup ids go round-robin over the 8 XCDs, so XCD c takes the c-th contiguous eighth of the
-    // (bh, i-tile, j-tile) space -- whole heads per XCD, whose pooled operands (1.8 MB per head) then stay in that L2
-    const int ntj = (ncols_of(a, MODE) + 63) / 64, nti = (a.NBv + 63) / 64;
-    const int per = (int)(gridDim.x >> 3);          // the grid is a multiple of 8
-    const int wid = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-    if (wid >= a.BH * nti * ntj) return;
-    const int bh = wid / (nti * ntj);
-    const int rem = wid % (nti * ntj);
-    const int i0 = (rem / ntj) * 64, j0 = (rem % ntj) * 64;
     const int t = threadIdx.x, lane = t & 63;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wi = wv >> 1, wj = wv & 1;
@@ -305,6 +295,23 @@ __global__ __launch_bounds__(256) void pooled_scores_kernel(ScoreArgs a) {
         if (MODE == 0)
             a.unrel[((long)bh * a.NBv + i) * a.NBv + j] = !(fabsf(s[e]) > (fabsf(eq[e]) + fabsf(ek[e])));
     }
+}
+
+// One launch for both column kinds.  1-D grid, XCD-aware: workgroup ids go round-robin over the 8 XCDs, so XCD c takes the
+// c-th contiguous eighth of the (bh, i-tile, j-tile) space -- whole heads per XCD, whose pooled operands (1.8 MB per head)
+// then stay in that L2.  Within a head's row of tiles the visual column tiles come first, then the text-token tiles.
+template <typename Tag>
+__global__ __launch_bounds__(256) void pooled_scores_kernel(ScoreArgs a) {
+    __shared__ __attribute__((aligned(16))) float tile[4][64 * 36];
+    const int nti = (a.NBv + 63) / 64, ntj0 = (a.NBv + 63) / 64, ntj1 = (a.n_txt + 63) / 64, ntj = ntj0 + ntj1;
+    const int per = (int)(gridDim.x >> 3);          // the grid is a multiple of 8
+    const int wid = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (wid >= a.BH * nti * ntj) return;
+    const int bh = wid / (nti * ntj);
+    const int rem = wid % (nti * ntj);
+    const int i0 = (rem / ntj) * 64, tj = rem % ntj;
+    if (tj < ntj0) pooled_scores_tile<0, Tag>(a, bh, i0, tj * 64, tile);
+    else pooled_scores_tile<1, Tag>(a, bh, i0, (tj - ntj0) * 64, tile);
 }
 
 // =====================================================================================================
@@ -873,14 +880,9 @@ extern "C" int rsa_pooled_scores(const rsa_layout* l, rsa_tensor4 k, const rsa_b
     const int BH = l->B * l->H;
     const unsigned nti = (unsigned)((l->NBv + 63) / 64);
     a.BH = BH;
-    dim3 g0((nti * nti * BH + 7) / 8 * 8);
-    if (l->dtype == RSA_BF16) pooled_scores_kernel<0, bf16_tag><<<g0, 256, 0, s>>>(a);
-    else pooled_scores_kernel<0, fp16_tag><<<g0, 256, 0, s>>>(a);
-    if (l->n_txt > 0) {
-        dim3 g1(((unsigned)((l->n_txt + 63) / 64) * nti * BH + 7) / 8 * 8);
-        if (l->dtype == RSA_BF16) pooled_scores_kernel<1, bf16_tag><<<g1, 256, 0, s>>>(a);
-        else pooled_scores_kernel<1, fp16_tag><<<g1, 256, 0, s>>>(a);
-    }
+    dim3 g0((nti * (nti + (unsigned)((l->n_txt + 63) / 64)) * BH + 7) / 8 * 8);
+    if (l->dtype == RSA_BF16) pooled_scores_kernel<bf16_tag><<<g0, 256, 0, s>>>(a);
+    else pooled_scores_kernel<fp16_tag><<<g0, 256, 0, s>>>(a);
     return rsa_launch_status();
 }
 
