@@ -83,6 +83,7 @@ struct AttnArgs {
     float* tpart;                             // split-KV partials of the text query blocks, or null
     int tsplit, tper;                         // workgroups per text block, key blocks per workgroup
     float qk_scale;
+    unsigned long long* dbg;                  // diagnostics (PIPE_OPT bit 8192): per-workgroup s_memtime stamps, or null
 };
 
 // byte offset of 16-byte chunk `ch` of row `row` inside a [64][D] 2-byte tile.  The XOR keeps both the

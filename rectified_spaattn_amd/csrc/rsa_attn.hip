@@ -17,6 +17,7 @@ static int g_dense256 = 0;  // tuning hook: dense mode on 256-row query tiles (8
 int g_rsa_k5_pair = 0;
 extern int g_rsa_k3_prefix;
 static int g_k5_tsplit = 1;     // 1 = split-KV for the text query blocks when the partial buffer is given
+static unsigned long long g_dbg_ptr = 0;   // diagnostics: device buffer for K5's in-kernel stamps (keys dbg_lo / dbg_hi, k5_prio 64)
 static int g_k5_maxblocks = 0;  // diagnostics: launch only the first N workgroups of K5 (partial result!)
 static int g_k5_pp = 0;     // 1 = the ping-pong kernel (rsa_attn_pp_kernel.hip): two query blocks per 8-wave workgroup
 
@@ -37,6 +38,8 @@ extern "C" int rsa_set_tuning(const char* key, int value) {
     if (strcmp(key, "k5_pp") == 0) { g_k5_pp = value; return RSA_OK; }
     if (strcmp(key, "k5_maxblocks") == 0) { g_k5_maxblocks = value; return RSA_OK; }
     if (strcmp(key, "k5_pair") == 0) { g_rsa_k5_pair = value; return RSA_OK; }
+    if (strcmp(key, "dbg_lo") == 0) { g_dbg_ptr = (g_dbg_ptr & 0xFFFFFFFF00000000ull) | (unsigned)value; return RSA_OK; }
+    if (strcmp(key, "dbg_hi") == 0) { g_dbg_ptr = (g_dbg_ptr & 0xFFFFFFFFull) | ((unsigned long long)(unsigned)value << 32); return RSA_OK; }
     if (strcmp(key, "k3_prefix") == 0) { g_rsa_k3_prefix = value; return RSA_OK; }
     if (strcmp(key, "k5_tsplit") == 0) { g_k5_tsplit = value; return RSA_OK; }
     if (strcmp(key, "fp8_variant") == 0) { rsa_set_fp8_variant(value); return RSA_OK; }
@@ -196,6 +199,7 @@ extern "C" int rsa_block_sparse_fwd(const rsa_layout* l, rsa_tensor4 q, rsa_tens
     a.q_text_end = l->NBv * RSA_BLOCK + l->q_text_valid;
     a.q_split = 0; a.kv_split = 0;
     a.qk_scale = (float)((1.0 / sqrt((double)l->D)) * 1.44269504);  // sm_scale * 1.44269504 (hunyuan :145)
+    a.dbg = reinterpret_cast<unsigned long long*>(g_dbg_ptr);
     return launch_attn(a, l->B * l->H, l->D, l->dtype, static_cast<hipStream_t>(stream));
 }
 
@@ -219,6 +223,7 @@ extern "C" int rsa_dense_fwd(int B, int H, int Sq, int Sk, int D, int dtype, rsa
     a.kv_valid = Sk; a.kv_text_valid = Sk; a.q_text_end = 0;
     a.q_split = q_split; a.kv_split = kv_split;
     a.qk_scale = (float)((1.0 / sqrt((double)D)) * 1.44269504);
+    a.dbg = nullptr;
     if (g_dense256) {  // 256 query rows per workgroup: K/V tiles staged once per 256 rows
         a.NQB = (Sq + 255) / 256; a.NBv = a.NQB;
         return launch_attn(a, B * H, D, dtype, static_cast<hipStream_t>(stream), 8);

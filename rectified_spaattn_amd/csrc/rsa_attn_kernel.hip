@@ -71,17 +71,21 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned short* lds_list = reinterpret_cast<unsigned short*>(lds + 4 * TILE_BYTES);
 
+    // (Persistent workgroups -- 2 per CU striding over the work items -- were measured: a fresh workgroup costs ~20k cycles of
+    // dispatch, but with two workgroups per CU the partner runs faster meanwhile, and strided workgroups fall into lock step
+    // (all prologues and epilogues at once): 18.1 vs 17.6 ms at 24 heads, 2.26 vs 2.30 ms at 3 heads; not adopted.)
+    const int work = blockIdx.x;
     // ---------------- work mapping: dense text-row blocks first, then the sparse blocks chunked per XCD ----------------
     int bh, qblk, tsp = 0;   // tsp: which part of a text block's key range this workgroup walks
     if constexpr (PAIR) {
-        const int v = blockIdx.x;
+        const int v = work;
         bh = v / a.NPp;
         const int j = v % a.NPp;
         const int chunk = a.NPp >> 3;
         qblk = (j & 7) * chunk + (j >> 3);          // pair index p: rows p*256 .. p*256+255
         if (qblk >= a.NP || !a.pair_ok[(long)bh * a.NP + qblk]) return;
     } else {
-        const int bid = blockIdx.x;
+        const int bid = work;
         if (bid < a.n_heavy_pad) {
             const int ntq = a.NQB - a.NBv;
             const int per_bh = ntq * a.tsplit;      // text blocks x key-range splits (tsplit = 1: no split)
@@ -110,6 +114,15 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) grow[qt] = qblk * QROWS + 32 * QT * wv + 32 * qt + r;
 
+    unsigned long long T0 = 0, T1 = 0, T2 = 0;
+    auto stamp = [&]() -> unsigned long long {
+        unsigned long long tt;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt) :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        return tt;
+    };
+    if constexpr ((PIPE_OPT & 8192) != 0) T0 = stamp();
     // ---------------- per-row plan ----------------
     int lo_r[QT], hi_r[QT];
     bool store_r[QT], zero_r[QT];
@@ -515,6 +528,7 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
             rowmax_sub(SA, mxA);
         }
     }
+    if constexpr ((PIPE_OPT & 8192) != 0) T1 = stamp();
     auto advance = [&](int tile) {  // after finishing `tile`: shift the key queue, fetch tile+3's first key
         key0 = kq1;
         kq1 = kq2;
@@ -539,6 +553,7 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
         }
     }
 
+    if constexpr ((PIPE_OPT & 8192) != 0) T2 = stamp();
     // ---------------- epilogue ----------------
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
@@ -626,6 +641,17 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
             }
         }
     }
+    if constexpr ((PIPE_OPT & 8192) != 0) {   // diagnostics: stamps of this workgroup's wave 0
+        if (a.dbg && t == 0) {
+            const unsigned long long T3 = stamp();
+            unsigned hwid, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned long long* o8 = a.dbg + (long)work * 8;
+            o8[0] = T0; o8[1] = T1; o8[2] = T2; o8[3] = T3; o8[4] = (unsigned long long)n_items;
+            o8[5] = hwid; o8[6] = xcc; o8[7] = (unsigned long long)qblk;
+        }
+    }
 }
 
 // paired form (sparse mode, after K3b): one workgroup per "ok" query-block pair
@@ -643,6 +669,13 @@ int rsa_launch_bsfwd_pair(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D,
 // launch hook used by rsa_attn.hip::launch_attn
 int rsa_launch_bsfwd(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int dtype, int prio, hipStream_t s) {
     // the 16-byte output stores of the default form need 16-byte aligned rows; anything else takes the 8-byte form
+    if (prio == 64) {   // diagnostics: the default form with s_memtime stamps (tools/dbg_k5.py); D = 128, bf16 only
+        if (D == 128 && dtype == RSA_BF16 && a.dbg) {
+            bsfwd_kernel<128, bf16_tag, 4, 1, 2 + 256 + 4096 + 8192><<<grid, 256, lds_bytes, s>>>(a);
+            return rsa_launch_status();
+        }
+        prio = 32;
+    }
     if (prio == 32 && (((uintptr_t)a.out & 15) || ((a.osb | a.osh | a.oss) & 7))) prio = 1;
 #define RSA_K5(DD, TT) \
     do { \
