@@ -322,7 +322,8 @@ __global__ __launch_bounds__(256) void pooled_scores_kernel(ScoreArgs a) {
 // The contract's 256 strided partial sums are kept as four accumulators per lane (partial t = lane + 64 w), reduced
 // per w across the lanes with the xor tree (strides 1..32) and combined as (u0+u1)+(u2+u3): bit-identical to the
 // 256-thread formulation of the oracle.
-// dynamic LDS per wave: float e[NS] | float pr[L] | u8 kept[NB_total]
+// dynamic LDS per wave: float et[max(n_txt, 512)] (text-column exponentials, later the sorted-head candidates) | float pr[L]
+// | u8 kept[NB_total] -- 6.6 KB at the HunyuanVideo shape, six workgroups per CU; the visual columns stay in registers
 // =====================================================================================================
 struct SelectArgs {
     const float* scores;
@@ -333,7 +334,7 @@ struct SelectArgs {
     int32_t *cols, *counts;
     int NBv, n_txt, NS, L, N2, NB_total, NW, text_end_block, ffb, top_k, rows_total, lds_per_wave;
     int use_prefix;   // 1 = try the sorted-head path first (same result; tuning key "k3_prefix" for the A/B tests)
-    int cand_in_e;    // the sorted-head candidates reuse e[] (saves 2 KiB of LDS per wave: 4 instead of 3 workgroups per CU)
+    int et_len;       // floats in the et[] region: >= n_txt and >= 2 * RSA_SEL_CAP (the sorted-head candidates reuse it)
     float thr, scale;
 };
 int g_rsa_k3_prefix = 1;
@@ -445,53 +446,110 @@ __global__ __launch_bounds__(256) void select_mask_kernel(SelectArgs a) {
     }
     const int qblk = (int)(row % a.NBv);
     unsigned char* base = smem + (size_t)wv * a.lds_per_wave;
-    float* e = reinterpret_cast<float*>(base);
-    float* pr = e + ((a.NS + 3) & ~3);
+    float* et = reinterpret_cast<float*>(base);   // et[u] = column NBv + u
+    float* pr = et + a.et_len;
     uint8_t* kept = reinterpret_cast<uint8_t*>(pr + ((a.L + 3) & ~3));
     const float* sc = a.scores + row * a.NS;
     const bool has_txt = a.n_txt > 0;
 
-    // scaled scores, max
+    // Every global read of the row is issued up front, all in flight together: the scores, the row's GAPR bytes and its
+    // neighbour bytes.  (As dynamic-trip loops each load was waited for on its own -- 18 + 15 + 15 serialised L2 / Infinity
+    // Cache latencies per wave, half of the wave's lifetime by the counters.)  L <= 64 KPL, so the visual columns fit
+    // KPL registers; score columns past 64 (KPL + 8) -- more than 512 text tokens -- take the loop below.
+    constexpr int NE = KPL + 8;
+    float xv[NE];
+    uint8_t urv[KPL], nbv[KPL];
+#pragma unroll
+    for (int m = 0; m < NE; ++m) {
+        const int j = lane + 64 * m;
+        xv[m] = j < a.NS ? sc[j] : 0.0f;
+    }
+#pragma unroll
+    for (int m = 0; m < KPL; ++m) {
+        const int j = lane + 64 * m;
+        urv[m] = j < a.NBv ? a.unrel[row * a.NBv + j] : (uint8_t)0;
+        nbv[m] = (j < a.NBv && a.neighbor) ? a.neighbor[(long)qblk * a.NBv + j] : (uint8_t)0;
+    }
+    // The row's first 64 NE columns live in registers (xv) through the softmax; only the text columns go to LDS (et[]),
+    // where the text partial sums index them by token.  Columns past 64 NE keep the LDS form.  Partial sums take the same
+    // elements in the same order as the contract's 256 strided sums: partial (m & 3) of lane `lane`, m ascending.
     float mx = -INFINITY;
-    for (int j = lane; j < a.NS; j += 64) {
+#pragma unroll
+    for (int m = 0; m < NE; ++m) {
+        const int j = lane + 64 * m;
+        if (j < a.NS) {
+            xv[m] = xv[m] * a.scale;
+            mx = fmaxf(mx, xv[m]);
+        }
+    }
+    for (int j = lane + 64 * NE; j < a.NS; j += 64) {
         const float x = sc[j] * a.scale;
-        e[j] = x;
+        et[j - a.NBv] = x;
         mx = fmaxf(mx, x);
     }
     for (int m = 1; m < 64; m <<= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
     // exp and denominator: element j -> partial (j % 256) = lane + 64*((j >> 6) & 3), sequential in j
     float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int j = lane, m = 0; j < a.NS; j += 64, ++m) {
-        const float v = rsa_exp(e[j] - mx);
-        e[j] = v;
+#pragma unroll
+    for (int m = 0; m < NE; ++m) {
+        const int j = lane + 64 * m;
+        if (j < a.NS) {
+            xv[m] = rsa_exp(xv[m] - mx);
+            part[m & 3] = part[m & 3] + xv[m];
+        }
+    }
+    for (int j = lane + 64 * NE, m = NE; j < a.NS; j += 64, ++m) {
+        const float v = rsa_exp(et[j - a.NBv] - mx);
+        et[j - a.NBv] = v;
         if ((m & 3) == 0) part[0] = part[0] + v;
         else if ((m & 3) == 1) part[1] = part[1] + v;
         else if ((m & 3) == 2) part[2] = part[2] + v;
         else part[3] = part[3] + v;
     }
     const float Z = wave_tree4(part);
-    for (int j = lane; j < a.NS; j += 64) e[j] = e[j] / Z;
+#pragma unroll
+    for (int m = 0; m < NE; ++m) {
+        const int j = lane + 64 * m;
+        if (j < a.NS) {
+            xv[m] = xv[m] / Z;
+            if (j >= a.NBv) et[j - a.NBv] = xv[m];
+        }
+    }
+    for (int j = lane + 64 * NE; j < a.NS; j += 64) et[j - a.NBv] = et[j - a.NBv] / Z;
     if (has_txt) {  // IPAR
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         float pn[4] = {0.0f, 0.0f, 0.0f, 0.0f}, pt[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        for (int j = lane, m = 0; j < a.NBv; j += 64, ++m) {
-            const float v = e[j];
-            if ((m & 3) == 0) pn[0] = pn[0] + v; else if ((m & 3) == 1) pn[1] = pn[1] + v;
-            else if ((m & 3) == 2) pn[2] = pn[2] + v; else pn[3] = pn[3] + v;
+#pragma unroll
+        for (int m = 0; m < KPL; ++m) {
+            if (lane + 64 * m < a.NBv) pn[m & 3] = pn[m & 3] + xv[m];
         }
         for (int u = lane, m = 0; u < a.n_txt; u += 64, ++m) {
-            const float v = e[a.NBv + u];
+            const float v = et[u];
             if ((m & 3) == 0) pt[0] = pt[0] + v; else if ((m & 3) == 1) pt[1] = pt[1] + v;
             else if ((m & 3) == 2) pt[2] = pt[2] + v; else pt[3] = pt[3] + v;
         }
         const float normal_sum = wave_tree4(pn);
         const float text_sum = wave_tree4(pt);
         const float denom = normal_sum * 128.0f + text_sum;
-        for (int j = lane; j < a.NBv; j += 64) pr[j] = (e[j] * 128.0f) / denom;
+#pragma unroll
+        for (int m = 0; m < KPL; ++m) {
+            const int j = lane + 64 * m;
+            if (j < a.NBv) pr[j] = (xv[m] * 128.0f) / denom;
+        }
         if (lane == 0) pr[a.NBv] = text_sum / denom;
     } else {
-        for (int j = lane; j < a.NBv; j += 64) pr[j] = e[j];
+#pragma unroll
+        for (int m = 0; m < KPL; ++m) {
+            const int j = lane + 64 * m;
+            if (j < a.NBv) pr[j] = xv[m];
+        }
     }
-    for (int j = lane; j < a.L; j += 64) a.probs[row * a.L + j] = pr[j];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+    for (int m = 0; m < KPL; ++m) {
+        const int j = lane + 64 * m;
+        if (j < a.L) a.probs[row * a.L + j] = pr[j];
+    }
 
     // keys into registers: element idx = lane*KPL + s
     unsigned long long key[KPL];
@@ -534,10 +592,8 @@ __global__ __launch_bounds__(256) void select_mask_kernel(SelectArgs a) {
                 else { t = mid; C = c; found = true; break; }
             }
             if (found) {
-                // candidate keys: over e[] when it is large enough (the exponentials are dead once pr[] is written),
-                // else in the slot the host reserved behind kept[]
-                unsigned long long* cand = a.cand_in_e ? reinterpret_cast<unsigned long long*>(e)
-                                                       : reinterpret_cast<unsigned long long*>(kept + ((a.NB_total + 7) & ~7));
+                // candidate keys: over et[] (the text exponentials are dead once pr[] is written)
+                unsigned long long* cand = reinterpret_cast<unsigned long long*>(et);
                 for (int j = lane; j < RSA_SEL_CAP; j += 64) cand[j] = 0ull;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 int basep = 0;
@@ -596,30 +652,45 @@ __global__ __launch_bounds__(256) void select_mask_kernel(SelectArgs a) {
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    for (int j = lane; j < a.NB_total; j += 64) {
+#pragma unroll
+    for (int m = 0; m < KPL; ++m) {   // visual columns: j < NBv <= 64 KPL
+        const int j = lane + 64 * m;
+        if (j < a.NBv) {
+            uint8_t kj = kept[j];
+            kj |= (nbv[m] != 0);
+            if (qblk < a.ffb && j < a.ffb) kj = 1;
+            kept[j] = kj;
+        }
+    }
+    for (int j = a.NBv + lane; j < a.NB_total; j += 64) {   // text blocks and the padding behind them
         uint8_t kj = kept[j];
-        if (j < a.NBv && a.neighbor) kj |= (a.neighbor[(long)qblk * a.NBv + j] != 0);
-        if (has_txt && j >= a.NBv && j < a.text_end_block) kj = 1;
+        if (has_txt && j < a.text_end_block) kj = 1;
         if (qblk < a.ffb && j < a.ffb) kj = 1;
         kept[j] = kj;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     // rectification factor and compensation weights
     float pR[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int j = lane, m = 0; j < a.L; j += 64, ++m) {
-        bool mm = kept[j] != 0;
-        if (j < a.NBv) mm = mm || (a.unrel[row * a.NBv + j] != 0);
-        const float pj = pr[j];
-        const float v = mm ? pj : 0.0f;
-        if ((m & 3) == 0) pR[0] = pR[0] + v; else if ((m & 3) == 1) pR[1] = pR[1] + v;
-        else if ((m & 3) == 2) pR[2] = pR[2] + v; else pR[3] = pR[3] + v;
-        a.w[row * a.L + j] = mm ? 0.0f : pj;
+#pragma unroll
+    for (int m = 0; m < KPL; ++m) {   // L <= 64 KPL; partial (m & 3) as in the contract's 256 strided sums
+        const int j = lane + 64 * m;
+        if (j < a.L) {
+            bool mm = kept[j] != 0;
+            if (j < a.NBv) mm = mm || (urv[m] != 0);
+            const float pj = pr[j];
+            const float v = mm ? pj : 0.0f;
+            pR[m & 3] = pR[m & 3] + v;
+            a.w[row * a.L + j] = mm ? 0.0f : pj;
+        }
     }
     const float Rv = wave_tree4(pR);
     if (lane == 0) a.R[row] = Rv;
     // bitmask + ascending column list
     int off = 0;
-    for (int b0 = 0; b0 < a.NB_total; b0 += 64) {
+#pragma unroll
+    for (int mb = 0; mb <= KPL; ++mb) {   // NB_total <= 64 KPL + 63 (checked by the host): static trip count, LDS reads in flight together
+        const int b0 = 64 * mb;
+        if (b0 >= a.NB_total) break;
         const int j = b0 + lane;
         const bool f = j < a.NB_total && kept[j] != 0;
         const unsigned long long m = __ballot(f);
@@ -907,13 +978,13 @@ extern "C" int rsa_select_mask(const rsa_layout* l, const uint8_t* neighbor, int
     a.scale = (float)(1.0 / sqrt((double)l->D));  // head_dim ** -0.5 rounded to fp32 (hunyuan :208)
     a.rows_total = l->B * l->H * l->NBv;
     a.use_prefix = g_rsa_k3_prefix;
-    a.cand_in_e = (size_t)((a.NS + 3) & ~3) * 4 >= (size_t)RSA_SEL_CAP * 8;
-    const size_t per_wave = (((size_t)((a.NS + 3) & ~3) * 4 + (size_t)((a.L + 3) & ~3) * 4 +
-                              (size_t)((a.NB_total + 7) & ~7) + (a.cand_in_e ? 0 : (size_t)RSA_SEL_CAP * 8)) + 15) &
+    a.et_len = (a.n_txt + 3) & ~3;
+    if (a.et_len < 2 * RSA_SEL_CAP) a.et_len = 2 * RSA_SEL_CAP;
+    const size_t per_wave = (((size_t)a.et_len * 4 + (size_t)((a.L + 3) & ~3) * 4 + (size_t)((a.NB_total + 7) & ~7)) + 15) &
                             ~(size_t)15;
     a.lds_per_wave = (int)per_wave;
     const size_t lds = per_wave * 4;
-    if (lds > 64 * 1024 || n2 > 4096) return RSA_ERR_UNSUPPORTED;
+    if (lds > 64 * 1024 || n2 > 4096 || a.NB_total > n2 + 63) return RSA_ERR_UNSUPPORTED;
     dim3 grid((unsigned)((a.rows_total + 3) / 4));
     hipStream_t s = static_cast<hipStream_t>(stream);
     // rows longer than the sorted head (256 keys) take the two-pass form when the head can hold top_k
