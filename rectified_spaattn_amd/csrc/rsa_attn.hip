@@ -127,6 +127,7 @@ static int launch_text_combine(const AttnArgs& a, int BH, int D, int dtype, hipS
 
 static int launch_attn(AttnArgs& a, int BH, int D, int dtype, hipStream_t s, int variant = -1) {
     if (g_k5_pp && variant < 0) { a.pair_ok = nullptr; a.tsplit = 1; return launch_attn_pp(a, BH, D, dtype, s); }
+    if (a.pair_ok && (((uintptr_t)a.out & 15) || ((a.osb | a.osh | a.oss) & 7))) a.pair_ok = nullptr;  // 16-byte stores
     if (a.pair_ok && a.NP > 0) {  // paired workgroups first (they are the longer ones: union lists)
         a.BH = BH;
         a.NPp = (a.NP + 7) & ~7;

@@ -591,6 +591,14 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
         if (zero_r[qt]) inv = 0.0f;
         const float sc = inv * Rv;
         unsigned short* op = a.out + (long)b * a.osb + (long)h * a.osh + (long)grow[qt] * a.oss;
+        // O * sc + comp: one fma rounded to fp32, THEN the conversion to the storage type (what the oracle does).  Left alone,
+        // hipcc folds fma + conversion into v_fma_mixlo_f16 (one rounding, straight to fp16) in one store form and not in the
+        // other; the empty asm keeps the fp32 value, so every instantiation (4-wave, 8-wave, paired) writes the same bytes.
+        auto fin = [&](float acc, float c) -> float {
+            float rr = __builtin_fmaf(acc, sc, c);
+            asm volatile("" : "+v"(rr));
+            return rr;
+        };
         if constexpr ((PIPE_OPT & 4096) != 0) {
             // wide stores: lane (r, 0) holds d = 8g .. 8g+3 and lane (r, 1) d = 8g+4 .. 8g+7 of a 32-wide d tile; one
             // v_permlane32_swap per packed register pair regroups two g's so that each lane owns 8 consecutive d:
@@ -606,10 +614,10 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
                         const int d0 = 32 * dt + 8 * g + 4 * hh;
                         float4 c4 = make_float4(0, 0, 0, 0);
                         if (cp && !zero_r[qt]) c4 = *reinterpret_cast<const float4*>(cp + d0);
-                        const float v0 = o[dt][qt][4 * g + 0] * sc + c4.x;
-                        const float v1 = o[dt][qt][4 * g + 1] * sc + c4.y;
-                        const float v2 = o[dt][qt][4 * g + 2] * sc + c4.z;
-                        const float v3 = o[dt][qt][4 * g + 3] * sc + c4.w;
+                        const float v0 = fin(o[dt][qt][4 * g + 0], c4.x);
+                        const float v1 = fin(o[dt][qt][4 * g + 1], c4.y);
+                        const float v2 = fin(o[dt][qt][4 * g + 2], c4.z);
+                        const float v3 = fin(o[dt][qt][4 * g + 3], c4.w);
                         pk[gi].x = (unsigned)E::from_f32(v0) | ((unsigned)E::from_f32(v1) << 16);
                         pk[gi].y = (unsigned)E::from_f32(v2) | ((unsigned)E::from_f32(v3) << 16);
                     }
@@ -630,10 +638,10 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
                 const int d0 = 32 * dt + 8 * g + 4 * hh;
                 float4 c4 = make_float4(0, 0, 0, 0);
                 if (cp && !zero_r[qt]) c4 = *reinterpret_cast<const float4*>(cp + d0);
-                const float v0 = o[dt][qt][4 * g + 0] * sc + c4.x;
-                const float v1 = o[dt][qt][4 * g + 1] * sc + c4.y;
-                const float v2 = o[dt][qt][4 * g + 2] * sc + c4.z;
-                const float v3 = o[dt][qt][4 * g + 3] * sc + c4.w;
+                const float v0 = fin(o[dt][qt][4 * g + 0], c4.x);
+                const float v1 = fin(o[dt][qt][4 * g + 1], c4.y);
+                const float v2 = fin(o[dt][qt][4 * g + 2], c4.z);
+                const float v3 = fin(o[dt][qt][4 * g + 3], c4.w);
                 uint2 pk;
                 pk.x = (unsigned)E::from_f32(v0) | ((unsigned)E::from_f32(v1) << 16);
                 pk.y = (unsigned)E::from_f32(v2) | ((unsigned)E::from_f32(v3) << 16);
@@ -657,11 +665,11 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
 // paired form (sparse mode, after K3b): one workgroup per "ok" query-block pair
 int rsa_launch_bsfwd_pair(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int dtype, hipStream_t s) {
     if (D == 128) {
-        if (dtype == RSA_BF16) bsfwd_kernel<128, bf16_tag, 8, 1, 2 + 256 + 1024><<<grid, 512, lds_bytes, s>>>(a);
-        else bsfwd_kernel<128, fp16_tag, 8, 1, 2 + 256 + 1024><<<grid, 512, lds_bytes, s>>>(a);
+        if (dtype == RSA_BF16) bsfwd_kernel<128, bf16_tag, 8, 1, 2 + 256 + 1024 + 4096><<<grid, 512, lds_bytes, s>>>(a);
+        else bsfwd_kernel<128, fp16_tag, 8, 1, 2 + 256 + 1024 + 4096><<<grid, 512, lds_bytes, s>>>(a);
     } else {
-        if (dtype == RSA_BF16) bsfwd_kernel<64, bf16_tag, 8, 1, 2 + 256 + 1024><<<grid, 512, lds_bytes, s>>>(a);
-        else bsfwd_kernel<64, fp16_tag, 8, 1, 2 + 256 + 1024><<<grid, 512, lds_bytes, s>>>(a);
+        if (dtype == RSA_BF16) bsfwd_kernel<64, bf16_tag, 8, 1, 2 + 256 + 1024 + 4096><<<grid, 512, lds_bytes, s>>>(a);
+        else bsfwd_kernel<64, fp16_tag, 8, 1, 2 + 256 + 1024 + 4096><<<grid, 512, lds_bytes, s>>>(a);
     }
     return rsa_launch_status();
 }

@@ -17,7 +17,16 @@ __global__ __launch_bounds__(256) void permute_tokens_kernel(const uint4* x, lon
     const int src = order[row];
     const uint4* xp = x + ((long)b * xsb + (long)src * xss);
     uint4* op = out + ((long)b * osb + (long)row * oss);
-    for (int c = lane; c < C16; c += 64) op[c] = xp[c];
+    // four 16-byte chunks per lane in flight before the first store (a load -> store loop waits for each load on its own)
+    for (int c0 = lane; c0 < C16; c0 += 256) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (c0 + 64 * u < C16) v[u] = xp[c0 + 64 * u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (c0 + 64 * u < C16) op[c0 + 64 * u] = v[u];
+    }
 }
 
 extern "C" int rsa_permute_tokens(int B, int S, int C, const void* x, int64_t x_stride_b, int64_t x_stride_s,
@@ -84,8 +93,13 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(NormRopeArgs a, int h
     const unsigned short* xp = a.x + (long)b * a.xsb + (long)s * a.xss + c * 8;
     unsigned short* yp = a.y + (long)b * a.ysb + (long)s * a.yss + c * 8;
     const int h1 = min(h0 + heads_per_group, a.H);
+    // the next head's 16 bytes are requested before this head's arithmetic (a dynamic-trip loop otherwise waits for each
+    // load on its own)
+    uint4 nxt = make_uint4(0, 0, 0, 0);
+    if (h0 < h1) nxt = *reinterpret_cast<const uint4*>(xp + (long)h0 * a.xsh);
     for (int h = h0; h < h1; ++h) {
-        const uint4 raw = *reinterpret_cast<const uint4*>(xp + (long)h * a.xsh);
+        const uint4 raw = nxt;
+        if (h + 1 < h1) nxt = *reinterpret_cast<const uint4*>(xp + (long)(h + 1) * a.xsh);
         const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
         float v[8];
 #pragma unroll
@@ -173,8 +187,7 @@ template <typename Tag>
 __global__ __launch_bounds__(256) void rel_l1_partial_kernel(const uint4* a, const uint4* b, long n16, float* part) {
     __shared__ float red[4];
     float sd = 0.0f, sb = 0.0f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) {
-        const uint4 ra = a[i], rb = b[i];
+    auto acc16 = [&](const uint4& ra, const uint4& rb) {
         const unsigned wa[4] = {ra.x, ra.y, ra.z, ra.w}, wb[4] = {rb.x, rb.y, rb.z, rb.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -183,6 +196,17 @@ __global__ __launch_bounds__(256) void rel_l1_partial_kernel(const uint4* a, con
             sd = sd + fabsf(a0 - b0); sd = sd + fabsf(a1 - b1);
             sb = sb + fabsf(b0); sb = sb + fabsf(b1);
         }
+    };
+    // four grid strides' loads in flight before the first add; the adds keep the order of the plain loop (same bits)
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += 4 * stride) {
+        uint4 ra[4], rb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + u * stride < n16) { ra[u] = a[i + u * stride]; rb[u] = b[i + u * stride]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + u * stride < n16) acc16(ra[u], rb[u]);
     }
     const float td = block_tree_sum(sd, red);
     const float tb = block_tree_sum(sb, red);
