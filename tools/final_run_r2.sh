@@ -2,11 +2,12 @@
 # Round-2 measurement set: GPU tests, smoke, the bench line (all sub-records), per-workload lines, rocprofv3 kernel stats,
 # PMC summary of K5 and memory-side traffic of K5 in the three regimes.  Everything lands in gpurun_out/r2z_*.
 set -x
-python -m pytest tests -x -q -m gpu 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm\|^Hostname\|^Librccl" | tail -5 > gpurun_out/r2z_tests.txt
+python -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed|FAILED|Error" | tail -5 > gpurun_out/r2z_tests.txt
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r2z_smoke.txt 2>&1
 for RG in r2 r1 locality; do
   bash tools/pmc_traffic.sh r2z_pmc_$RG $RG > gpurun_out/r2z_pmc_$RG.txt 2>&1
   cp gpurun_out/r2z_pmc_$RG/traffic.json gpurun_out/r02_k5_traffic_$RG.json
+  cp gpurun_out/r2z_pmc_$RG/traffic.json profiles/r02_k5_traffic_$RG.json   # the bench lines below read these (box-local copy)
   rm -rf gpurun_out/r2z_pmc_$RG
 done
 python bench.py --steps 20 --warmup 5 --via-api > gpurun_out/r2z_bench.json 2> gpurun_out/r2z_bench.err
