@@ -184,6 +184,16 @@ int rsa_permute_tokens(int B, int S, int C, const void* x, int64_t x_stride_b, i
 int rsa_qk_norm_rope(int B, int H, int S, int D, int dtype, rsa_tensor4 x, const float* weight, float eps,
                      int apply_norm, const float* cos, const float* sin, int S_rope, rsa_out4 y, void* stream);
 
+/* The Wan producers in one pass: RMSNorm ACROSS heads (one variance per token over all H*D channels; weight [H*D] as an
+ * fp32 copy, or null; skipped when apply_norm = 0) and the rotary embedding per head, x [B, S, H*D] (row stride
+ * x_stride_s elements) -> y strided [B,H,S,D].  rope_kind 0: none; 1: freqs_a = complex128 [S, D/2] (Wan2.1, the rotation
+ * runs in fp64 like the reference); 2: freqs_a = cos fp32 [S, D], freqs_b = sin fp32 [S, D] with per-pair values
+ * duplicated (Wan2.2).  Replaces attn.norm_q / norm_k + unflatten + apply_rotary_emb in
+ * rectified_wan21_attn.py:424-438 and rectified_wan22_attn.py:54-76. */
+int rsa_norm_rope_heads(int B, int H, int S, int D, int dtype, const void* x, int64_t x_stride_b, int64_t x_stride_s,
+                        const float* weight, float eps, int apply_norm, int rope_kind, const void* freqs_a,
+                        const void* freqs_b, rsa_out4 y, void* stream);
+
 /* ---- fp8 operands for K5 (BASELINE config "fp8 Q/K/V on CDNA4 fp8 MFMA"; the reference has no fp8 path, its P/Q
  * rounding rule "operands in the input dtype, fp32 statistics" (rectified_hunyuan_attn.py:61-62, :97) is kept) ---- */
 

@@ -139,3 +139,30 @@ def fused_qk_ok(x: torch.Tensor, heads: int, norms, rotary) -> bool:
         if rotary[0].dim() != 2 or rotary[0].is_complex():
             return False
     return True
+
+
+def fused_heads_ok(x: torch.Tensor, heads: int, norms, rotary) -> bool:
+    """Preconditions of glue.norm_rope_across_heads for the Wan processors: device bf16/fp16 projections, every norm
+    absent or RMSNorm-like over the full inner dim with a 2-byte (or no) weight, rotary absent, one complex128 table
+    (Wan2.1) or a pair of fp32 (cos, sin) tables (Wan2.2) of exactly S tokens."""
+    from . import glue
+    if not (FUSED_PRODUCER and x.is_cuda and x.dim() == 3 and x.dtype in (torch.bfloat16, torch.float16)):
+        return False
+    HD, S = x.shape[-1], x.shape[1]
+    if HD % heads or (HD // heads) % 8 or 512 % (HD // heads) or HD > 8192:
+        return False
+    D = HD // heads
+    for n in norms:
+        if n is None:
+            continue
+        p = glue.norm_params(n)
+        if p is None or (p[0] is not None and p[0].numel() != HD):
+            return False
+    if rotary is None:
+        return True
+    if torch.is_tensor(rotary):
+        return rotary.is_complex() and rotary.dtype == torch.complex128 and rotary.numel() == S * (D // 2) \
+            and rotary.shape[-1] == D // 2
+    if isinstance(rotary, (tuple, list)) and len(rotary) == 2 and all(torch.is_tensor(t) for t in rotary):
+        return all(t.dtype == torch.float32 and t.numel() == S * D and t.shape[-1] == D for t in rotary)
+    return False

@@ -183,6 +183,163 @@ extern "C" int rsa_qk_norm_rope(int B, int H, int S, int D, int dtype, rsa_tenso
 namespace {
 constexpr int RL1_WGS = 1024;
 
+// ---------------------------------------------------------------------------------------------------------
+// rsa_norm_rope_heads: the Wan producers.  RMSNorm ACROSS heads (one variance per token over all H*D channels, diffusers'
+// qk_norm = "rms_norm_across_heads"), then the rotary embedding per head, written straight into a strided [B,H,S,D]
+// destination -- one pass instead of attn.norm_q + unflatten + the fp64 complex multiply of Wan2.1
+// (rectified_wan21_attn.py:430-438) or the cos/sin form of Wan2.2 (rectified_wan22_attn.py:54-66, :70-76).
+// One wave per token: a lane owns the 16-byte chunks lane, lane + 64, ... of the token's row (up to NCH of them).
+//   rope_kind 1: fa = complex128 [S, D/2] (cos, sin as doubles).  The rotation runs in fp64 like the reference, then
+//                double -> float -> storage type, the conversion chain of torch's .type_as.
+//   rope_kind 2: fa = cos fp32 [S, D], fb = sin fp32 [S, D] (per-pair values duplicated, Wan2.2's tables): cos of pair p
+//                is cos[2p], sin is sin[2p + 1]; fp32 products and differences, each rounded, as torch evaluates them.
+struct NormRopeHeadsArgs {
+    const unsigned short* x;
+    long xsb, xss;
+    unsigned short* y;
+    long ysb, ysh, yss;
+    const float* weight;
+    const void *fa, *fb;
+    float eps;
+    int S, C, D, apply_norm, rope_kind;
+};
+
+template <typename Tag, int NCH>
+__global__ __launch_bounds__(256) void norm_rope_heads_kernel(NormRopeHeadsArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    if (tok >= a.S) return;
+    const int C16 = a.C / 8;
+    const uint4* xp = reinterpret_cast<const uint4*>(a.x + (long)b * a.xsb + (long)tok * a.xss);
+    uint4 raw[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
+        raw[i] = c < C16 ? xp[c] : make_uint4(0, 0, 0, 0);
+    }
+    float r = 1.0f;
+    if (a.apply_norm) {
+        float ss = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const unsigned w[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v0 = rsa_to_f32<Tag>((unsigned short)(w[e] & 0xFFFF)), v1 = rsa_to_f32<Tag>((unsigned short)(w[e] >> 16));
+                ss = ss + v0 * v0;
+                ss = ss + v1 * v1;
+            }
+        }
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) ss = ss + __shfl_xor(ss, m, 64);
+        r = rsqrtf(ss / (float)a.C + a.eps);
+    }
+    // a lane's chunks lane, lane + 64, ... are 512 channels apart: when D divides 512 they sit at the SAME offset d inside
+    // their heads, so the lane's four rotation pairs are loaded once per token (checked by the host)
+    const int dl = (lane * 8) % a.D;
+    double2 fc[4];
+    float cs[4], sn[4];
+    if (a.rope_kind == 1) {
+        const double2* fr = reinterpret_cast<const double2*>(a.fa) + (long)tok * (a.D / 2) + dl / 2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) fc[e] = fr[e];
+    } else if (a.rope_kind == 2) {
+        const float* cp = reinterpret_cast<const float*>(a.fa) + (long)tok * a.D + dl;
+        const float* sp = reinterpret_cast<const float*>(a.fb) + (long)tok * a.D + dl;
+        const float4 c0 = *reinterpret_cast<const float4*>(cp), c1 = *reinterpret_cast<const float4*>(cp + 4);
+        const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
+        cs[0] = c0.x; cs[1] = c0.z; cs[2] = c1.x; cs[3] = c1.z;     // cos[2p]
+        sn[0] = s0.y; sn[1] = s0.w; sn[2] = s1.y; sn[3] = s1.w;     // sin[2p + 1]
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
+        if (c >= C16) continue;
+        const int ch = c * 8, head = ch / a.D, d = dl;
+        const unsigned w[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[2 * e] = rsa_to_f32<Tag>((unsigned short)(w[e] & 0xFFFF));
+            v[2 * e + 1] = rsa_to_f32<Tag>((unsigned short)(w[e] >> 16));
+        }
+        if (a.apply_norm) {
+            float wt[8];
+            if (a.weight) {
+                const float4 w0 = *reinterpret_cast<const float4*>(a.weight + ch), w1 = *reinterpret_cast<const float4*>(a.weight + ch + 4);
+                wt[0] = w0.x; wt[1] = w0.y; wt[2] = w0.z; wt[3] = w0.w; wt[4] = w1.x; wt[5] = w1.y; wt[6] = w1.z; wt[7] = w1.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float n = v[e] * r;
+                if (a.weight) {
+                    n = rsa_to_f32<Tag>(rsa_from_f32<Tag>(n));
+                    n = n * wt[e];
+                }
+                v[e] = rsa_to_f32<Tag>(rsa_from_f32<Tag>(n));
+            }
+        }
+        if (a.rope_kind == 1) {
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const double2 f = fc[e / 2];
+                const double x0 = (double)v[e], x1 = (double)v[e + 1];
+                const double o0 = x0 * f.x - x1 * f.y, o1 = x0 * f.y + x1 * f.x;
+                v[e] = (float)o0;
+                v[e + 1] = (float)o1;
+            }
+        } else if (a.rope_kind == 2) {
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const float x0 = v[e], x1 = v[e + 1];
+                v[e] = x0 * cs[e / 2] - x1 * sn[e / 2];
+                v[e + 1] = x0 * sn[e / 2] + x1 * cs[e / 2];
+            }
+        }
+        uint4 pk;
+        pk.x = (unsigned)rsa_from_f32<Tag>(v[0]) | ((unsigned)rsa_from_f32<Tag>(v[1]) << 16);
+        pk.y = (unsigned)rsa_from_f32<Tag>(v[2]) | ((unsigned)rsa_from_f32<Tag>(v[3]) << 16);
+        pk.z = (unsigned)rsa_from_f32<Tag>(v[4]) | ((unsigned)rsa_from_f32<Tag>(v[5]) << 16);
+        pk.w = (unsigned)rsa_from_f32<Tag>(v[6]) | ((unsigned)rsa_from_f32<Tag>(v[7]) << 16);
+        *reinterpret_cast<uint4*>(a.y + (long)b * a.ysb + (long)head * a.ysh + (long)tok * a.yss + d) = pk;
+    }
+}
+
+extern "C" int rsa_norm_rope_heads(int B, int H, int S, int D, int dtype, const void* x, int64_t x_stride_b,
+                                   int64_t x_stride_s, const float* weight, float eps, int apply_norm, int rope_kind,
+                                   const void* freqs_a, const void* freqs_b, rsa_out4 y, void* stream) {
+    if (B <= 0 || H <= 0 || S <= 0 || D <= 0 || !x || !y.ptr) return RSA_ERR_BAD_ARG;
+    if ((D % 8) || (512 % D) || (long)H * D > 64L * 8 * 16) return RSA_ERR_UNSUPPORTED;   // D | 512; a row = at most 16 chunks per lane
+    if (dtype != RSA_BF16 && dtype != RSA_FP16) return RSA_ERR_UNSUPPORTED;
+    if (rope_kind < 0 || rope_kind > 2 || (rope_kind >= 1 && !freqs_a) || (rope_kind == 2 && !freqs_b)) return RSA_ERR_BAD_ARG;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) || (x_stride_b % 8) || (x_stride_s % 8)) return RSA_ERR_BAD_ARG;
+    if ((reinterpret_cast<uintptr_t>(y.ptr) & 15) || (y.stride_b % 8) || (y.stride_h % 8) || (y.stride_s % 8))
+        return RSA_ERR_BAD_ARG;
+    if (rope_kind >= 1 && (reinterpret_cast<uintptr_t>(freqs_a) & 15)) return RSA_ERR_BAD_ARG;
+    if (rope_kind == 2 && (reinterpret_cast<uintptr_t>(freqs_b) & 15)) return RSA_ERR_BAD_ARG;
+    if (weight && (reinterpret_cast<uintptr_t>(weight) & 15)) return RSA_ERR_BAD_ARG;
+    NormRopeHeadsArgs a;
+    a.x = static_cast<const unsigned short*>(x); a.xsb = x_stride_b; a.xss = x_stride_s;
+    a.y = static_cast<unsigned short*>(y.ptr); a.ysb = y.stride_b; a.ysh = y.stride_h; a.yss = y.stride_s;
+    a.weight = weight; a.fa = freqs_a; a.fb = freqs_b; a.eps = eps; a.S = S; a.C = H * D; a.D = D;
+    a.apply_norm = apply_norm; a.rope_kind = rope_kind;
+    const int nch = (a.C / 8 + 63) / 64;
+    dim3 grid((unsigned)((S + 3) / 4), (unsigned)B);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define RSA_NRH(N) \
+    do { \
+        if (dtype == RSA_BF16) norm_rope_heads_kernel<bf16_tag, N><<<grid, 256, 0, s>>>(a); \
+        else norm_rope_heads_kernel<fp16_tag, N><<<grid, 256, 0, s>>>(a); \
+    } while (0)
+    if (nch <= 3) RSA_NRH(3);
+    else if (nch <= 6) RSA_NRH(6);
+    else if (nch <= 10) RSA_NRH(10);
+    else RSA_NRH(16);
+#undef RSA_NRH
+    return rsa_launch_status();
+}
+
 template <typename Tag>
 __global__ __launch_bounds__(256) void rel_l1_partial_kernel(const uint4* a, const uint4* b, long n16, float* part) {
     __shared__ float red[4];

@@ -112,3 +112,45 @@ def qk_norm_rope(x: torch.Tensor, heads: int, norm=None, rotary=None, rope_token
             vp(cos.data_ptr()) if cos is not None else None, vp(sin.data_ptr()) if sin is not None else None,
             int(rope_tokens or 0), o4, _core._stream()), "rsa_qk_norm_rope")
     return out.transpose(1, 2)
+
+
+def norm_rope_across_heads(x: torch.Tensor, heads: int, norm=None, rotary=None) -> torch.Tensor:
+    """The Wan producers in one pass (rsa_norm_rope_heads): x [B, S, H*D] projection -> [B, H, S, D] view of a new
+    [B, S, H, D] buffer holding RMSNorm-across-heads(x) rotated per head.
+
+    norm: (weight [H*D] | None, eps) from norm_params, or None; rotary: None, a complex128 tensor [..., S, D/2] (Wan2.1's
+    `rotary_emb`, any leading singleton dims) or a (cos, sin) pair of fp32 tensors [..., S, ..., D] with per-pair values
+    duplicated (Wan2.2's `rotary_emb`)."""
+    _core._require_device(x)
+    B, S, HD = x.shape
+    D = HD // heads
+    if x.stride(-1) != 1 or x.stride(0) % 8 or x.stride(1) % 8 or x.data_ptr() % 16:
+        x = x.contiguous()
+    out = torch.empty((B, S, heads, D), dtype=x.dtype, device=x.device)
+    w = eps = None
+    if norm is not None:
+        w, eps = norm
+        if w is not None:
+            w = w.detach().to(device=x.device, dtype=torch.float32).contiguous()
+            assert w.numel() == HD
+    kind, fa, fb = 0, None, None
+    if rotary is not None:
+        if torch.is_tensor(rotary):
+            assert rotary.is_complex() and rotary.dtype == torch.complex128 and rotary.numel() == S * (D // 2)
+            fa = torch.view_as_real(rotary.to(x.device).reshape(S, D // 2)).contiguous()   # [S, D/2, 2] doubles
+            kind = 1
+        else:
+            cos, sin = rotary
+            assert cos.numel() == S * D and sin.numel() == S * D
+            fa = cos.to(device=x.device, dtype=torch.float32).reshape(S, D).contiguous()
+            fb = sin.to(device=x.device, dtype=torch.float32).reshape(S, D).contiguous()
+            kind = 2
+    vp = ctypes.c_void_p
+    o4 = RsaOut4(out.data_ptr(), out.stride(0), out.stride(2), out.stride(1))
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().rsa_norm_rope_heads(
+            B, heads, S, D, _core.dtype_code(x.dtype), vp(x.data_ptr()), x.stride(0), x.stride(1),
+            vp(w.data_ptr()) if w is not None else None, ctypes.c_float(eps if eps is not None else 0.0),
+            1 if norm is not None else 0, kind, vp(fa.data_ptr()) if fa is not None else None,
+            vp(fb.data_ptr()) if fb is not None else None, o4, _core._stream()), "rsa_norm_rope_heads")
+    return out.transpose(1, 2)

@@ -66,6 +66,13 @@ class _WanProcessorBase:
         q = attn.to_q(hidden_states)
         k = attn.to_k(encoder_hidden_states)
         v = attn.to_v(encoder_hidden_states)
+        if op.fused_heads_ok(q, attn.heads, (attn.norm_q,), rotary_emb) and \
+                op.fused_heads_ok(k, attn.heads, (attn.norm_k,), rotary_emb):
+            # one pass per tensor: RMSNorm across heads + the fp64 rotation + the head split (glue.norm_rope_across_heads)
+            from . import glue
+            q = glue.norm_rope_across_heads(q, attn.heads, glue.norm_params(attn.norm_q), rotary_emb)
+            k = glue.norm_rope_across_heads(k, attn.heads, glue.norm_params(attn.norm_k), rotary_emb)
+            return q, k, op.split_heads(v, attn.heads)
         if attn.norm_q is not None:
             q = attn.norm_q(q)
         if attn.norm_k is not None:

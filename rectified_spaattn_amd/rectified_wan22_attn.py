@@ -55,6 +55,12 @@ class _Wan22Base(_WanProcessorBase):
 
     def _qkv(self, attn, hidden_states, encoder_hidden_states, rotary_emb):
         q, k, v = _qkv_projections(attn, hidden_states, encoder_hidden_states)
+        if op.fused_heads_ok(q, attn.heads, (attn.norm_q,), rotary_emb) and \
+                op.fused_heads_ok(k, attn.heads, (attn.norm_k,), rotary_emb):
+            from . import glue   # RMSNorm across heads + cos/sin rotation + head split in one pass per tensor
+            q = glue.norm_rope_across_heads(q, attn.heads, glue.norm_params(attn.norm_q), rotary_emb)
+            k = glue.norm_rope_across_heads(k, attn.heads, glue.norm_params(attn.norm_k), rotary_emb)
+            return q, k, op.split_heads(v, attn.heads)
         q, k = attn.norm_q(q), attn.norm_k(k)
         q, k, v = (x.unflatten(2, (attn.heads, -1)) for x in (q, k, v))
         if rotary_emb is not None:

@@ -152,3 +152,73 @@ def test_teacache_on_device_skips_and_restores():
             decisions.append(False)
     assert decisions[0] and decisions[-1] and not all(decisions)
     assert float(hidden.float().mean()) == 10.0     # a skipped step replays the cached residual (+1)
+
+
+def _count_mismatch(a, b):
+    """(fraction of elements that differ, largest difference in units of the 2-byte spacing at the tensor's largest
+    magnitude -- a rotated output near zero inherits the absolute, not the relative, error of its inputs)"""
+    a32, b32 = a.float(), b.float()
+    diff = (a32 - b32).abs()
+    eps = 2.0 ** -8 if a.dtype == torch.bfloat16 else 2.0 ** -11
+    return float((diff > 0).float().mean()), float(diff.max() / (b32.abs().max() * eps))
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("kind", ["wan21_complex", "wan22_cos_sin", "norm_only"])
+@torch.no_grad()
+def test_across_heads_producer_matches_torch_ops(dt, kind):
+    """rsa_norm_rope_heads against the module calls it replaces in the Wan processors: RMSNorm over the full inner dim
+    (diffusers' order of roundings), then Wan2.1's fp64 complex rotation / Wan2.2's cos-sin rotation.  The only freedom is
+    the summation order of the variance (an fp32 ulp of rsqrt): at most a 2-byte ulp on a small fraction of the elements."""
+    from rectified_spaattn_amd import glue, rectified_wan21_attn as w21, rectified_wan22_attn as w22
+    heads, hd, B, S = 5, 128, 2, 333
+    x = (torch.randn(B, S, heads * hd, device=DEV) * 1.3).to(dt)
+    norm = helpers.RMS(heads * hd).to(DEV, dt)
+    want = norm(x)
+    if kind == "wan21_complex":
+        fr = helpers.wan_freqs(S, hd).to(DEV)
+        want = w21._complex_rope(want.unflatten(2, (heads, -1)).transpose(1, 2), fr)
+        got = glue.norm_rope_across_heads(x, heads, glue.norm_params(norm), fr)
+    elif kind == "wan22_cos_sin":
+        cs = tuple(t.to(DEV) for t in helpers.wan22_rope(S, hd))
+        want = w22._cos_sin_rope(want.unflatten(2, (heads, -1)), *cs).transpose(1, 2)
+        got = glue.norm_rope_across_heads(x, heads, glue.norm_params(norm), cs)
+    else:
+        want = want.unflatten(2, (heads, -1)).transpose(1, 2)
+        got = glue.norm_rope_across_heads(x, heads, glue.norm_params(norm), None)
+    assert got.shape == want.shape == (B, heads, S, hd)
+    frac, worst = _count_mismatch(got, want)
+    assert frac < 2e-3 and worst <= 2.0, (frac, worst)
+    # rotation alone (no norm) is exact: same products, same roundings
+    if kind != "norm_only":
+        rot = fr if kind == "wan21_complex" else cs
+        ref = (w21._complex_rope(x.unflatten(2, (heads, -1)).transpose(1, 2), rot) if kind == "wan21_complex"
+               else w22._cos_sin_rope(x.unflatten(2, (heads, -1)), *rot).transpose(1, 2))
+        assert torch.equal(glue.norm_rope_across_heads(x, heads, None, rot), ref)
+
+
+@pytest.mark.parametrize("family", ["wan21", "wan22"])
+@torch.no_grad()
+def test_wan_processors_take_the_fused_producer(family):
+    """The Wan processors route q / k through the one-pass producer when its preconditions hold, and the output of the
+    whole processor stays within a 2-byte ulp-level distance of the unfused module path."""
+    from rectified_spaattn_amd import _operator as op
+    from rectified_spaattn_amd import rectified_wan21_attn as w21, rectified_wan22_attn as w22
+    heads, hd, S = 4, 128, 640
+    a = helpers.attn_to(helpers.fake_attn(5, heads, hd, wan=True), DEV, torch.bfloat16)
+    hs = helpers.hidden(5, 1, 1, S, heads * hd).to(DEV, torch.bfloat16)
+    if family == "wan21":
+        proc, rot = w21.RectifiedWanT2VSpaAttnProcessor2_0("flash", 2, None, 0.3, processor_id=0), helpers.wan_freqs(S, hd).to(DEV)
+    else:
+        a.fused_projections = False
+        proc = w22.RectifiedWanTI2VSpaAttnProcessor2_0("flash", 2, None, 0.3, processor_id=0)
+        rot = tuple(t.to(DEV) for t in helpers.wan22_rope(S, hd))
+    assert op.fused_heads_ok(a.to_q(hs), heads, (a.norm_q,), rot)
+    fused = proc(a, hs, None, None, rot)
+    op.FUSED_PRODUCER = False
+    try:
+        plain = proc(a, hs, None, None, rot)
+    finally:
+        op.FUSED_PRODUCER = True
+    err = (fused.float() - plain.float()).abs()
+    assert float(err.max()) <= 2e-2 * float(plain.float().abs().max()) and float(err.mean()) <= 1e-3 * float(plain.float().abs().mean() + 1e-6) + 1e-4
