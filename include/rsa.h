@@ -184,6 +184,12 @@ int rsa_permute_tokens(int B, int S, int C, const void* x, int64_t x_stride_b, i
 int rsa_qk_norm_rope(int B, int H, int S, int D, int dtype, rsa_tensor4 x, const float* weight, float eps,
                      int apply_norm, const float* cos, const float* sin, int S_rope, rsa_out4 y, void* stream);
 
+/* Same pass with torch.nn.LayerNorm over the head dim instead of RMSNorm (CogVideoX's qk_norm = "layer_norm",
+ * rectified_cogvideo_attn.py:455-466): fp32 mean / biased variance, (x - mean) * rstd * weight + bias, one rounding; weight
+ * and bias [D] fp32 copies or null; tokens [0, S_rope) are rotated (the visual tokens come first). */
+int rsa_qk_layernorm_rope(int B, int H, int S, int D, int dtype, rsa_tensor4 x, const float* weight, const float* bias,
+                          float eps, const float* cos, const float* sin, int S_rope, rsa_out4 y, void* stream);
+
 /* The Wan producers in one pass: RMSNorm ACROSS heads (one variance per token over all H*D channels; weight [H*D] as an
  * fp32 copy, or null; skipped when apply_norm = 0) and the rotary embedding per head, x [B, S, H*D] (row stride
  * x_stride_s elements) -> y strided [B,H,S,D].  rope_kind 0: none; 1: freqs_a = complex128 [S, D/2] (Wan2.1, the rotation

@@ -80,6 +80,8 @@ def lib():
     L.rsa_permute_tokens.restype = i32
     L.rsa_qk_norm_rope.argtypes = [i32, i32, i32, i32, i32, RsaTensor4, vp, f32, i32, vp, vp, i32, RsaOut4, vp]
     L.rsa_qk_norm_rope.restype = i32
+    L.rsa_qk_layernorm_rope.argtypes = [i32, i32, i32, i32, i32, RsaTensor4, vp, vp, f32, vp, vp, i32, RsaOut4, vp]
+    L.rsa_qk_layernorm_rope.restype = i32
     L.rsa_norm_rope_heads.argtypes = [i32, i32, i32, i32, i32, vp, i64, i64, vp, f32, i32, i32, vp, vp, RsaOut4, vp]
     L.rsa_norm_rope_heads.restype = i32
     L.rsa_rel_l1.argtypes = [vp, vp, i64, i32, vp, vp, vp]
@@ -141,7 +143,7 @@ def lib():
 EXPORTED = ("rsa_version", "rsa_buffer_bytes", "rsa_carve_workspace", "rsa_pool_stats", "rsa_pooled_scores",
             "rsa_select_mask", "rsa_compensation", "rsa_block_sparse_fwd", "rsa_rectified_attention",
             "rsa_dense_fwd", "rsa_estimate_pr_gain", "rsa_status_string", "rsa_last_hip_error", "rsa_set_tuning", "rsa_gilbert_mapping",
-            "rsa_gilbert_block_neighbors", "rsa_permute_tokens", "rsa_qk_norm_rope", "rsa_norm_rope_heads", "rsa_fp8_operand_bytes",
+            "rsa_gilbert_block_neighbors", "rsa_permute_tokens", "rsa_qk_norm_rope", "rsa_qk_layernorm_rope", "rsa_norm_rope_heads", "rsa_fp8_operand_bytes",
             "rsa_carve_fp8_operands", "rsa_quantize_fp8", "rsa_block_sparse_fwd_fp8", "rsa_rectified_attention_fp8",
             "rsa_pool_stats_fp8", "rsa_fp8_images", "rsa_dense_fp8_bytes", "rsa_dense_fwd_fp8", "rsa_rel_l1",
             "rsa_comm_unique_id", "rsa_comm_create", "rsa_comm_destroy", "rsa_allgather_heads",

@@ -124,14 +124,14 @@ FUSED_PRODUCER = True  # processors use the fused RMSNorm + RoPE + concat kernel
 
 def fused_qk_ok(x: torch.Tensor, heads: int, norms, rotary) -> bool:
     """Preconditions of glue.qk_norm_rope for a processor: device bf16/fp16 projections, head_dim 64/128, every
-    norm either absent or RMSNorm-like, rotary absent or a (cos, sin) pair of real tables."""
+    norm either absent, RMSNorm-like or a LayerNorm over the head dim, rotary absent or a (cos, sin) pair of real tables."""
     from . import glue
     if not (FUSED_PRODUCER and x.is_cuda and x.dtype in (torch.bfloat16, torch.float16)):
         return False
     if x.shape[-1] % heads or (x.shape[-1] // heads) not in (64, 128):
         return False
     for n in norms:
-        if n is not None and glue.norm_params(n) is None:
+        if n is not None and glue.norm_params(n) is None and glue.layernorm_params(n) is None:
             return False
     if rotary is not None:
         if not (isinstance(rotary, (tuple, list)) and len(rotary) == 2 and all(torch.is_tensor(t) for t in rotary)):
@@ -166,3 +166,12 @@ def fused_heads_ok(x: torch.Tensor, heads: int, norms, rotary) -> bool:
     if isinstance(rotary, (tuple, list)) and len(rotary) == 2 and all(torch.is_tensor(t) for t in rotary):
         return all(t.dtype == torch.float32 and t.numel() == S * D and t.shape[-1] == D for t in rotary)
     return False
+
+
+def norm_args(norm):
+    """The `norm` argument of glue.qk_norm_rope for a processor's norm module (RMSNorm-like or LayerNorm), or None."""
+    from . import glue
+    if norm is None:
+        return None
+    p = glue.norm_params(norm)
+    return p if p is not None else glue.layernorm_params(norm)

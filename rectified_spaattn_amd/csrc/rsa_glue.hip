@@ -59,9 +59,9 @@ struct NormRopeArgs {
     long xsb, xsh, xss;
     unsigned short* y;
     long ysb, ysh, yss;
-    const float *weight, *cos, *sin;
+    const float *weight, *bias, *cos, *sin;
     float eps;
-    int H, S, S_rope, apply_norm;
+    int H, S, S_rope, apply_norm;   // apply_norm: 0 none, 1 RMSNorm, 2 LayerNorm (weight and bias optional)
 };
 
 // D/8 lanes per token row, 8 elements (16 B) per lane; a 256-thread block covers 256/(D/8) tokens and one group of
@@ -85,10 +85,14 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(NormRopeArgs a, int h
         cs[0] = c0.x; cs[1] = c0.y; cs[2] = c0.z; cs[3] = c0.w; cs[4] = c1.x; cs[5] = c1.y; cs[6] = c1.z; cs[7] = c1.w;
         sn[0] = s0.x; sn[1] = s0.y; sn[2] = s0.z; sn[3] = s0.w; sn[4] = s1.x; sn[5] = s1.y; sn[6] = s1.z; sn[7] = s1.w;
     }
-    float wt[8];
+    float wt[8], bs[8];
     if (a.apply_norm && a.weight) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) wt[e] = a.weight[c * 8 + e];
+    }
+    if (a.apply_norm == 2 && a.bias) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bs[e] = a.bias[c * 8 + e];
     }
     const unsigned short* xp = a.x + (long)b * a.xsb + (long)s * a.xss + c * 8;
     unsigned short* yp = a.y + (long)b * a.ysb + (long)s * a.yss + c * 8;
@@ -107,7 +111,29 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(NormRopeArgs a, int h
             v[2 * e] = rsa_to_f32<Tag>((unsigned short)(w[e] & 0xFFFF));
             v[2 * e + 1] = rsa_to_f32<Tag>((unsigned short)(w[e] >> 16));
         }
-        if (a.apply_norm) {
+        if (a.apply_norm == 2) {
+            // torch.nn.LayerNorm over the head dim (CogVideoX's qk_norm): fp32 mean and biased variance, then
+            // (x - mean) * rstd * weight + bias in fp32, ONE rounding to the storage type
+            float sm = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sm = sm + v[e];
+#pragma unroll
+            for (int m = 1; m < LPR; m <<= 1) sm = sm + __shfl_xor(sm, m, 64);
+            const float mean = sm / (float)D;
+            float sq = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sq = sq + (v[e] - mean) * (v[e] - mean);
+#pragma unroll
+            for (int m = 1; m < LPR; m <<= 1) sq = sq + __shfl_xor(sq, m, 64);
+            const float rstd = rsqrtf(sq / (float)D + a.eps);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float n = (v[e] - mean) * rstd;
+                if (a.weight) n = n * wt[e];
+                if (a.bias) n = n + bs[e];
+                v[e] = rsa_to_f32<Tag>(rsa_from_f32<Tag>(n));
+            }
+        } else if (a.apply_norm) {
             // variance = mean(x^2) in fp32; x * rsqrt(var + eps); round to the storage type; * weight; round
             float ss = 0.0f;
 #pragma unroll
@@ -145,9 +171,9 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(NormRopeArgs a, int h
     }
 }
 
-extern "C" int rsa_qk_norm_rope(int B, int H, int S, int D, int dtype, rsa_tensor4 x, const float* weight, float eps,
-                                int apply_norm, const float* cos, const float* sin, int S_rope, rsa_out4 y,
-                                void* stream) {
+static int launch_qk_norm_rope(int B, int H, int S, int D, int dtype, rsa_tensor4 x, const float* weight, const float* bias,
+                               float eps, int apply_norm, const float* cos, const float* sin, int S_rope, rsa_out4 y,
+                               void* stream) {
     if (B <= 0 || H <= 0 || S <= 0 || !y.ptr) return RSA_ERR_BAD_ARG;
     if (D != 64 && D != 128) return RSA_ERR_UNSUPPORTED;
     if (dtype != RSA_BF16 && dtype != RSA_FP16) return RSA_ERR_UNSUPPORTED;
@@ -159,7 +185,7 @@ extern "C" int rsa_qk_norm_rope(int B, int H, int S, int D, int dtype, rsa_tenso
     NormRopeArgs a;
     a.x = static_cast<const unsigned short*>(x.ptr); a.xsb = x.stride_b; a.xsh = x.stride_h; a.xss = x.stride_s;
     a.y = static_cast<unsigned short*>(y.ptr); a.ysb = y.stride_b; a.ysh = y.stride_h; a.yss = y.stride_s;
-    a.weight = weight; a.cos = cos; a.sin = sin; a.eps = eps; a.H = H; a.S = S; a.S_rope = S_rope;
+    a.weight = weight; a.bias = bias; a.cos = cos; a.sin = sin; a.eps = eps; a.H = H; a.S = S; a.S_rope = S_rope;
     a.apply_norm = apply_norm;
     const int tpb = 256 / (D / 8);
     const int hpg = H >= 8 ? 8 : H;  // heads sharing one cos/sin load
@@ -173,6 +199,18 @@ extern "C" int rsa_qk_norm_rope(int B, int H, int S, int D, int dtype, rsa_tenso
         else qk_norm_rope_kernel<64, fp16_tag><<<grid, 256, 0, s>>>(a, hpg);
     }
     return rsa_launch_status();
+}
+
+extern "C" int rsa_qk_norm_rope(int B, int H, int S, int D, int dtype, rsa_tensor4 x, const float* weight, float eps,
+                                int apply_norm, const float* cos, const float* sin, int S_rope, rsa_out4 y,
+                                void* stream) {
+    return launch_qk_norm_rope(B, H, S, D, dtype, x, weight, nullptr, eps, apply_norm ? 1 : 0, cos, sin, S_rope, y, stream);
+}
+
+extern "C" int rsa_qk_layernorm_rope(int B, int H, int S, int D, int dtype, rsa_tensor4 x, const float* weight,
+                                     const float* bias, float eps, const float* cos, const float* sin, int S_rope,
+                                     rsa_out4 y, void* stream) {
+    return launch_qk_norm_rope(B, H, S, D, dtype, x, weight, bias, eps, 2, cos, sin, S_rope, y, stream);
 }
 
 // =====================================================================================================

@@ -1089,4 +1089,4 @@ extern "C" const char* rsa_status_string(int status) {
 int g_rsa_last_hip_error = 0;
 extern "C" const char* rsa_last_hip_error(void) { return hipGetErrorString((hipError_t)g_rsa_last_hip_error); }
 
-extern "C" int rsa_version(void) { return 200; }  // 0.2.0: rsa_buffers has 18 members (pair lists, text partials)
+extern "C" int rsa_version(void) { return 210; }  // 0.2.1: + rsa_norm_rope_heads, rsa_qk_layernorm_rope (0.2.0: rsa_buffers has 18 members)

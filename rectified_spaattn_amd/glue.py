@@ -74,11 +74,25 @@ def norm_params(norm) -> Optional[Tuple[Optional[torch.Tensor], float]]:
     return w, float(norm.eps)
 
 
+def layernorm_params(norm):
+    """(weight | None, bias | None, eps) of a torch.nn.LayerNorm-like module over the last dim, or None."""
+    if norm is None or type(norm).__name__ not in ("LayerNorm", "FP32LayerNorm") or not hasattr(norm, "eps"):
+        return None
+    shape = tuple(getattr(norm, "normalized_shape", ()))
+    if len(shape) != 1:
+        return None
+    w, b = getattr(norm, "weight", None), getattr(norm, "bias", None)
+    if type(norm).__name__ == "FP32LayerNorm":
+        return None   # computes on an fp32 copy and rounds differently: keep the module call
+    return w, b, float(norm.eps)
+
+
 def qk_norm_rope(x: torch.Tensor, heads: int, norm=None, rotary=None, rope_tokens: Optional[int] = None,
                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x [B, S, H*D] projection -> [B, H, S, D] view of a [B, S, H, D] buffer holding RMSNorm(x) rotated.
 
-    norm: (weight [D] | None, eps) or None (no normalisation); rotary: (cos, sin) fp32 [>= rope_tokens, D] or None;
+    norm: (weight [D] | None, eps) for RMSNorm, (weight | None, bias | None, eps) for LayerNorm (layernorm_params), or
+    None (no normalisation); rotary: (cos, sin) fp32 [>= rope_tokens, D] or None;
     rope_tokens: tokens [0, rope_tokens) are rotated (default all); out: optional [B, S, H, D] destination (e.g. a
     slice of the concat buffer), else a new one."""
     _core._require_device(x)
@@ -90,9 +104,15 @@ def qk_norm_rope(x: torch.Tensor, heads: int, norm=None, rotary=None, rope_token
     if out is None:
         out = torch.empty((B, S, heads, D), dtype=x.dtype, device=x.device)
     assert out.shape == (B, S, heads, D) and out.dtype == x.dtype and out.stride(-1) == 1
-    w = eps = None
+    w = bias = eps = None
+    layer_norm = norm is not None and len(norm) == 3      # (weight, bias, eps) from layernorm_params
     if norm is not None:
-        w, eps = norm
+        if layer_norm:
+            w, bias, eps = norm
+            if bias is not None:
+                bias = bias.detach().to(device=x.device, dtype=torch.float32).contiguous()
+        else:
+            w, eps = norm
         if w is not None:
             w = w.detach().to(device=x.device, dtype=torch.float32).contiguous()
     cos = sin = None
@@ -105,6 +125,14 @@ def qk_norm_rope(x: torch.Tensor, heads: int, norm=None, rotary=None, rope_token
         assert cos.shape[-1] == D and cos.shape[0] >= rope_tokens
     vp = ctypes.c_void_p
     o4 = RsaOut4(out.data_ptr(), out.stride(0), out.stride(2), out.stride(1))
+    if layer_norm:
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().rsa_qk_layernorm_rope(
+                B, heads, S, D, _core.dtype_code(x.dtype), _core._t4(xv), vp(w.data_ptr()) if w is not None else None,
+                vp(bias.data_ptr()) if bias is not None else None, ctypes.c_float(eps),
+                vp(cos.data_ptr()) if cos is not None else None, vp(sin.data_ptr()) if sin is not None else None,
+                int(rope_tokens or 0), o4, _core._stream()), "rsa_qk_layernorm_rope")
+        return out.transpose(1, 2)
     with torch.cuda.device(x.device):
         _lib.check(_lib.lib().rsa_qk_norm_rope(
             B, heads, S, D, _core.dtype_code(x.dtype), _core._t4(xv), vp(w.data_ptr()) if w is not None else None,

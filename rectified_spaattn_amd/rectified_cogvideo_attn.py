@@ -51,17 +51,24 @@ class RectifiedCogVideoXVideoSpaAttnProcessor2_0:
         if attention_mask is not None:
             attention_mask = attn.prepare_attention_mask(attention_mask, S, B)
             attention_mask = attention_mask.view(B, attn.heads, -1, attention_mask.shape[-1])
-        q = op.split_heads(attn.to_q(x), attn.heads)
-        k = op.split_heads(attn.to_k(x), attn.heads)
-        v = op.split_heads(attn.to_v(x), attn.heads)
-        if attn.norm_q is not None:
-            q = attn.norm_q(q)
-        if attn.norm_k is not None:
-            k = attn.norm_k(k)
-        if image_rotary_emb is not None:  # RoPE on the visual tokens only
-            q = torch.cat([op.rotary(q[:, :, :-n_txt], image_rotary_emb), q[:, :, -n_txt:]], dim=2)
-            if not attn.is_cross_attention:
-                k = torch.cat([op.rotary(k[:, :, :-n_txt], image_rotary_emb), k[:, :, -n_txt:]], dim=2)
+        q, k, v = attn.to_q(x), attn.to_k(x), attn.to_v(x)
+        if op.fused_qk_ok(q, attn.heads, (attn.norm_q, attn.norm_k), image_rotary_emb):
+            # per-head LayerNorm + RoPE on the visual tokens + head split in one pass per tensor (rsa_qk_layernorm_rope)
+            from . import glue
+            rope_k = image_rotary_emb if not attn.is_cross_attention else None
+            q = glue.qk_norm_rope(q, attn.heads, op.norm_args(attn.norm_q), image_rotary_emb, S - n_txt)
+            k = glue.qk_norm_rope(k, attn.heads, op.norm_args(attn.norm_k), rope_k, S - n_txt)
+            v = op.split_heads(v, attn.heads)
+        else:
+            q, k, v = (op.split_heads(t, attn.heads) for t in (q, k, v))
+            if attn.norm_q is not None:
+                q = attn.norm_q(q)
+            if attn.norm_k is not None:
+                k = attn.norm_k(k)
+            if image_rotary_emb is not None:  # RoPE on the visual tokens only
+                q = torch.cat([op.rotary(q[:, :, :-n_txt], image_rotary_emb), q[:, :, -n_txt:]], dim=2)
+                if not attn.is_cross_attention:
+                    k = torch.cat([op.rotary(k[:, :, :-n_txt], image_rotary_emb), k[:, :, -n_txt:]], dim=2)
         S_k = k.shape[2]
         s_k = op.valid_keys(attention_mask, S_k)
         cu_q, cu_kv = [0, S, S * B], [0, s_k, S_k * B]

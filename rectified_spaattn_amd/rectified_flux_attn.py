@@ -64,16 +64,16 @@ class RectifiedFluxSpaAttnProcessor2_0:
             if image_rotary_emb is not None:  # rows [0, S_v) for the image part, [S_v, S_v + n_enc) for the text part
                 rot_v = (image_rotary_emb[0][:S_v], image_rotary_emb[1][:S_v])
                 rot_t = (image_rotary_emb[0][S_v:], image_rotary_emb[1][S_v:])
-            glue.qk_norm_rope(attn.to_q(hidden_states), attn.heads, glue.norm_params(attn.norm_q), rot_v, S_v,
+            glue.qk_norm_rope(attn.to_q(hidden_states), attn.heads, op.norm_args(attn.norm_q), rot_v, S_v,
                               out=qbuf[:, :S_v])
-            glue.qk_norm_rope(attn.to_k(hidden_states), attn.heads, glue.norm_params(attn.norm_k), rot_v, S_v,
+            glue.qk_norm_rope(attn.to_k(hidden_states), attn.heads, op.norm_args(attn.norm_k), rot_v, S_v,
                               out=kbuf[:, :S_v])
             v_all = attn.to_v(hidden_states)
             if dual:
                 glue.qk_norm_rope(attn.add_q_proj(encoder_hidden_states), attn.heads,
-                                  glue.norm_params(attn.norm_added_q), rot_t, n_enc, out=qbuf[:, S_v:])
+                                  op.norm_args(attn.norm_added_q), rot_t, n_enc, out=qbuf[:, S_v:])
                 glue.qk_norm_rope(attn.add_k_proj(encoder_hidden_states), attn.heads,
-                                  glue.norm_params(attn.norm_added_k), rot_t, n_enc, out=kbuf[:, S_v:])
+                                  op.norm_args(attn.norm_added_k), rot_t, n_enc, out=kbuf[:, S_v:])
                 v_all = torch.cat([v_all, attn.add_v_proj(encoder_hidden_states)], dim=1)
             q, k, v = qbuf.transpose(1, 2), kbuf.transpose(1, 2), op.split_heads(v_all, attn.heads)
         else:

@@ -70,16 +70,16 @@ class RectifiedHunyuanVideoSpaAttnProcessor2_0:
             qbuf = torch.empty((Bq, S_all, attn.heads, hd), dtype=hidden_states.dtype, device=hidden_states.device)
             kbuf = torch.empty_like(qbuf)
             rope_tokens = S_v - n_txt if single_stream else S_v
-            glue.qk_norm_rope(attn.to_q(hidden_states), attn.heads, glue.norm_params(attn.norm_q), image_rotary_emb,
+            glue.qk_norm_rope(attn.to_q(hidden_states), attn.heads, op.norm_args(attn.norm_q), image_rotary_emb,
                               rope_tokens, out=qbuf[:, :S_v])
-            glue.qk_norm_rope(attn.to_k(hidden_states), attn.heads, glue.norm_params(attn.norm_k), image_rotary_emb,
+            glue.qk_norm_rope(attn.to_k(hidden_states), attn.heads, op.norm_args(attn.norm_k), image_rotary_emb,
                               rope_tokens, out=kbuf[:, :S_v])
             v_all = attn.to_v(hidden_states)
             if dual:
                 glue.qk_norm_rope(attn.add_q_proj(encoder_hidden_states), attn.heads,
-                                  glue.norm_params(attn.norm_added_q), None, 0, out=qbuf[:, S_v:])
+                                  op.norm_args(attn.norm_added_q), None, 0, out=qbuf[:, S_v:])
                 glue.qk_norm_rope(attn.add_k_proj(encoder_hidden_states), attn.heads,
-                                  glue.norm_params(attn.norm_added_k), None, 0, out=kbuf[:, S_v:])
+                                  op.norm_args(attn.norm_added_k), None, 0, out=kbuf[:, S_v:])
                 v_all = torch.cat([v_all, attn.add_v_proj(encoder_hidden_states)], dim=1)
             q, k, v = qbuf.transpose(1, 2), kbuf.transpose(1, 2), op.split_heads(v_all, attn.heads)
         else:

@@ -222,3 +222,50 @@ def test_wan_processors_take_the_fused_producer(family):
         op.FUSED_PRODUCER = True
     err = (fused.float() - plain.float()).abs()
     assert float(err.max()) <= 2e-2 * float(plain.float().abs().max()) and float(err.mean()) <= 1e-3 * float(plain.float().abs().mean() + 1e-6) + 1e-4
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("hd", [64, 128])
+@torch.no_grad()
+def test_fused_layernorm_rope_matches_torch_ops(dt, hd):
+    """rsa_qk_layernorm_rope (CogVideoX's qk_norm = LayerNorm over the head dim, RoPE on the visual tokens only) against
+    torch.nn.LayerNorm + the rotary op: the mean / variance summation order is the only freedom."""
+    from rectified_spaattn_amd import glue
+    heads, S, n_txt = 3, 515, 77
+    x = (torch.randn(2, S, heads * hd, device=DEV) * 1.7 + 0.3).to(dt)
+    ln = torch.nn.LayerNorm(hd, eps=1e-6).to(DEV, dt)
+    ln.weight.copy_(torch.linspace(0.7, 1.3, hd).to(dt))
+    ln.bias.copy_(torch.linspace(-0.2, 0.2, hd).to(dt))
+    cos, sin = (t.to(DEV) for t in helpers.rope_tables(S - n_txt, hd))
+    want = _unfused(x, heads, ln, (cos, sin), S - n_txt)
+    got = glue.qk_norm_rope(x, heads, glue.layernorm_params(ln), (cos, sin), S - n_txt)
+    frac, worst = _count_mismatch(got, want)
+    assert got.shape == want.shape and frac < 2e-2 and worst <= 2.0, (frac, worst)
+    # without affine parameters
+    ln2 = torch.nn.LayerNorm(hd, eps=1e-5, elementwise_affine=False).to(DEV, dt)
+    frac, worst = _count_mismatch(glue.qk_norm_rope(x, heads, glue.layernorm_params(ln2), None, 0), _unfused(x, heads, ln2, None, 0))
+    assert frac < 2e-2 and worst <= 2.0, (frac, worst)
+
+
+@torch.no_grad()
+def test_cogvideo_processor_takes_the_fused_producer():
+    from rectified_spaattn_amd import _operator as op
+    from rectified_spaattn_amd import rectified_cogvideo_attn as cog
+    heads, hd, S_v, n_txt = 4, 64, 768, 226
+    a = helpers.attn_to(helpers.fake_attn(9, heads, hd, added=False), DEV, torch.bfloat16)
+    a.norm_q, a.norm_k = (torch.nn.LayerNorm(hd, eps=1e-6).to(DEV, torch.bfloat16) for _ in range(2))
+    a.prepare_attention_mask = lambda m, s, b: m
+    hs = helpers.hidden(9, 1, 1, S_v, heads * hd).to(DEV, torch.bfloat16)
+    enc = helpers.hidden(9, 2, 1, n_txt, heads * hd).to(DEV, torch.bfloat16)
+    rot = tuple(t.to(DEV) for t in helpers.rope_tables(S_v, hd))
+    proc = cog.RectifiedCogVideoXVideoSpaAttnProcessor2_0("flash", 2, None, 0.3, processor_id=0)
+    assert op.fused_qk_ok(a.to_q(torch.cat([hs, enc], 1)), heads, (a.norm_q, a.norm_k), rot)
+    f_v, f_t = proc(a, hs, enc, None, rot)
+    op.FUSED_PRODUCER = False
+    try:
+        p_v, p_t = proc(a, hs, enc, None, rot)
+    finally:
+        op.FUSED_PRODUCER = True
+    for f, p in ((f_v, p_v), (f_t, p_t)):
+        err = (f.float() - p.float()).abs()
+        assert float(err.max()) <= 2e-2 * float(p.float().abs().max()) and float(err.mean()) <= 2e-3 * float(p.float().abs().mean()) + 1e-4
