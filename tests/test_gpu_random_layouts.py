@@ -101,3 +101,29 @@ def test_tiny_magnitudes_keep_the_contract(shift):
         assert sub > 0, "the case is meant to produce subnormal pooled scores"
     err = np.abs(out.float().cpu().numpy() - ref)
     assert err.max() <= 2e-2 and err.mean() <= 2e-3
+
+
+@pytest.mark.parametrize("tl", [640, 768, 1024])
+def test_many_text_tokens_take_the_tail_path_of_k3(tl):
+    """K3 keeps 64 (KPL + 8) score columns of a row in registers; layouts with more individually scored text tokens than
+    that (none of the reference's pipelines: Flux has 512) run the remaining columns through the LDS loop.  Same contract."""
+    from rectified_spaattn_amd import _core, synth
+    D, H, nbv = 128, 2, 3
+    S = nbv * 128 + tl
+    lay = orc.layout_flux(S, tl)
+    q, k, v = synth.structured_qkv(900 + tl, 1, H, lay.S, D)
+    tq, tk, tv = (torch.from_numpy(x).to(DEV, torch.bfloat16) for x in (q, k, v))
+    q, k, v = (x.float().cpu().numpy() for x in (tq, tk, tv))
+    spec = _core.LayoutSpec(lay.S, lay.NB_total, lay.NBv, lay.n_txt, lay.kv_valid, lay.pool_valid,
+                            lay.text_end_block, lay.ffb, lay.q_text_valid, lay.kv_text_valid)
+    assert lay.NBv + lay.n_txt > 64 * (1 + 8)     # KPL = 1 for three visual blocks: columns past 576 exist
+    out, bufs = _core.rectified_attention(tq, tk, tv, spec, 2, 0.3, None, return_parts=True)
+    ref, parts = orc.rectified_attention(q, k, v, lay, 2, 0.3, None, want_parts=True)
+    for bh in range(H):
+        sel = parts[bh]
+        kept = orc.unpack_bits(bufs["bitmask"][bh].cpu().numpy().view(np.uint32), lay.NB_total)
+        assert np.array_equal(kept, sel["kept"])
+        assert np.array_equal(bufs["probs"][bh].cpu().numpy(), sel["probs"])
+        assert np.array_equal(bufs["R"][bh].cpu().numpy(), sel["R"])
+    err = np.abs(out.float().cpu().numpy() - ref)
+    assert err.max() <= 2e-2 and err.mean() <= 2e-3
