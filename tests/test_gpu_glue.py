@@ -163,6 +163,37 @@ def _count_mismatch(a, b):
     return float((diff > 0).float().mean()), float(diff.max() / (b32.abs().max() * eps))
 
 
+@pytest.mark.parametrize("shape", [(3, 64), (24, 128), (40, 128), (64, 128)])
+@torch.no_grad()
+def test_across_heads_producer_row_widths(shape):
+    """Every instantiation of the one-wave-per-token kernel (3 / 6 / 10 / 16 chunks per lane): head counts of the Wan
+    family (24 = TI2V-5B, 40 = 14B) and the extremes, rotation in the fp64 complex form."""
+    from rectified_spaattn_amd import glue, rectified_wan21_attn as w21
+    heads, hd = shape
+    B, S = 1, 37
+    x = (torch.randn(B, S, heads * hd, device=DEV) * 0.9).to(torch.bfloat16)
+    norm = helpers.RMS(heads * hd).to(DEV, torch.bfloat16)
+    fr = helpers.wan_freqs(S, hd).to(DEV)
+    want = w21._complex_rope(norm(x).unflatten(2, (heads, -1)).transpose(1, 2), fr)
+    got = glue.norm_rope_across_heads(x, heads, glue.norm_params(norm), fr)
+    frac, worst = _count_mismatch(got, want)
+    assert frac < 5e-3 and worst <= 2.0, (frac, worst)
+    assert torch.equal(glue.norm_rope_across_heads(x, heads, None, fr),
+                       w21._complex_rope(x.unflatten(2, (heads, -1)).transpose(1, 2), fr))
+
+
+def test_across_heads_preconditions():
+    from rectified_spaattn_amd import _operator as op
+    x = torch.zeros(1, 8, 3 * 96, device=DEV, dtype=torch.bfloat16)
+    assert not op.fused_heads_ok(x, 3, (None,), None)            # head_dim 96 does not divide 512
+    x = torch.zeros(1, 8, 4 * 128, device=DEV, dtype=torch.bfloat16)
+    assert op.fused_heads_ok(x, 4, (None,), None)
+    assert not op.fused_heads_ok(x.float(), 4, (None,), None)
+    assert not op.fused_heads_ok(x, 4, (None,), helpers.wan_freqs(9, 128).to(DEV))      # table of another length
+    assert not op.fused_heads_ok(x, 4, (None,), helpers.wan_freqs(8, 128).to(DEV).to(torch.complex64))
+    assert not op.fused_heads_ok(x, 4, (torch.nn.LayerNorm(512).to(DEV),), None)        # not an RMSNorm
+
+
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("kind", ["wan21_complex", "wan22_cos_sin", "norm_only"])
 @torch.no_grad()
