@@ -80,16 +80,11 @@ typedef struct rsa_buffers {
     uint32_t* bitmask;/* [BH, NBv, ceil(NB_total/32)]  kept blocks, bit j%32 of word j/32 */
     int32_t* cols;    /* [BH, NBv, NB_total] kept block indices ascending (first counts[] entries valid) */
     int32_t* counts;  /* [BH, NBv]                                              */
-    /* query-block PAIRS (q-blocks 2p, 2p+1; NP = ceil(NBv/2)) whose kept lists overlap enough to be walked together by
-     * one 256-row workgroup of K5, each K/V tile staged once for both (K3b, run by rsa_select_mask after K3): */
-    uint16_t* pcols;  /* [BH, NP, NB_total] ascending UNION of the two lists: block | in_first<<14 | in_second<<15 */
-    int32_t* pcounts; /* [BH, NP]           entries of pcols                                                   */
-    int32_t* pair_ok; /* [BH, NP]           1 = K5 serves this pair with the paired workgroup, 0 = two 128-row ones */
     /* split-KV partials of the dense TEXT query blocks (K5 splits each text block's key range over up to RSA_TEXT_SPLIT
      * workgroups and a small combine kernel merges them; may be NULL: then one workgroup walks all keys of a text block): */
     float* tpart;     /* [BH, NB_total - NBv, RSA_TEXT_SPLIT, 128, D + 2]  unnormalised O, then (m, l) per query row  */
 } rsa_buffers;
-#define RSA_NUM_BUFFERS 18
+#define RSA_NUM_BUFFERS 15
 #define RSA_TEXT_SPLIT 16
 
 /* Library identification: returns 10000*major + 100*minor + patch. */
@@ -119,9 +114,6 @@ int rsa_pooled_scores(const rsa_layout* lay, rsa_tensor4 k, const rsa_buffers* b
  * Replaces: hunyuan :208-277 (wan21 :206-271) and the rectification masks :348-355. */
 int rsa_select_mask(const rsa_layout* lay, const uint8_t* neighbor, int top_k, float p_remain,
                     const rsa_buffers* buf, void* stream);
-/* (K3b runs behind K3 only when the paired form of K5 is switched on -- rsa_set_tuning("k5_pair", 1), off by default --
- * and buf->pcols, pcounts and pair_ok are all non-NULL: a pair is marked ok when the two kept lists share at least 30 %
- * of the longer one.  The three members may be NULL; K5 then uses 128-row workgroups everywhere.) */
 
 /* K4 -- comp = w @ vbar.  Replaces torch.matmul(attn_pool_novalid, value_pool), hunyuan :357. */
 int rsa_compensation(const rsa_layout* lay, const rsa_buffers* buf, void* stream);
@@ -280,10 +272,8 @@ int rsa_ipc_export(const void* dev_ptr, void* handle64);                    /* 6
 int rsa_ipc_open(const void* handle64, int peer_device, void** dev_ptr);    /* map a peer's allocation here */
 int rsa_ipc_close(void* dev_ptr);
 
-/* Tuning / diagnostics hook, not part of the data path.  Keys: "k5_prio" (0/1: issue-priority raise inside K5's
- * pipelined block + LLVM's iglp_opt(0) interleave; 32 = 1 + 16-byte output stores, the default), "dense256" (0/1: rsa_dense_fwd on 256-row query tiles, 8 waves
- * per workgroup; same results), "fp8_variant" (0..4: iglp_opt strategy of the fp8 kernel's block; 0 = none), "k5_pair" (paired 256-row workgroups),
- * "k5_pp" (ping-pong kernel), "k5_tsplit" (split-KV of the text blocks), "k3_prefix" (sorted-head path of K3).  The hook
+/* Tuning / diagnostics hook, not part of the data path.  Keys: "k5_tsplit" (0/1: split-KV of the text query blocks),
+ * "k3_prefix" (0/1: sorted-head path of K3), "fp8_variant" (0..4: iglp_opt strategy of the fp8 kernel's block).  The hook
  * is inert (RSA_ERR_UNSUPPORTED) unless the process was started with the environment variable RSA_TUNING=1. */
 int rsa_set_tuning(const char* key, int value);
 

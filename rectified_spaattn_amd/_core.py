@@ -123,16 +123,15 @@ def _stream() -> ctypes.c_void_p:
 _BUF_DTYPES = dict(qbar=torch.float32, aq=torch.float32, kbar=torch.float32, ak=torch.float32, vbar=torch.float32,
                    scores=torch.float32, unrel=torch.uint8, probs=torch.float32, w=torch.float32, R=torch.float32,
                    comp=torch.float32, bitmask=torch.int32, cols=torch.int32, counts=torch.int32,
-                   pcols=torch.int16, pcounts=torch.int32, pair_ok=torch.int32, tpart=torch.float32)
+                   tpart=torch.float32)
 
 
 def buffer_shapes(spec: LayoutSpec, B: int, H: int, D: int) -> Dict[str, tuple]:
     BH, NBv, NB = B * H, spec.NBv, spec.NB_total
-    NS, L, NW, NP = NBv + spec.n_txt, spec.L, (NB + 31) // 32, (NBv + 1) // 2
+    NS, L, NW = NBv + spec.n_txt, spec.L, (NB + 31) // 32
     return dict(qbar=(BH, NBv, D), aq=(BH, NBv, D), kbar=(BH, NBv, D), ak=(BH, NBv, D), vbar=(BH, NB, D),
                 scores=(BH, NBv, NS), unrel=(BH, NBv, NBv), probs=(BH, NBv, L), w=(BH, NBv, L), R=(BH, NBv),
                 comp=(BH, NBv, D), bitmask=(BH, NBv, NW), cols=(BH, NBv, NB), counts=(BH, NBv),
-                pcols=(BH, NP, NB), pcounts=(BH, NP), pair_ok=(BH, NP),
                 tpart=(BH, NB - NBv, _lib.TEXT_SPLIT, BLOCK, D + 2))
 
 

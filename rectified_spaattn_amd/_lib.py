@@ -40,7 +40,7 @@ class RsaOut4(ctypes.Structure):
 
 
 BUFFER_NAMES = ("qbar", "aq", "kbar", "ak", "vbar", "scores", "unrel", "probs", "w", "R", "comp", "bitmask",
-                "cols", "counts", "pcols", "pcounts", "pair_ok", "tpart")
+                "cols", "counts", "tpart")
 TEXT_SPLIT = 16
 NUM_BUFFERS = len(BUFFER_NAMES)
 
@@ -130,7 +130,7 @@ def lib():
                  "rsa_dense_fwd", "rsa_estimate_pr_gain"):
         getattr(L, name).restype = i32
     # kernel-variant switches for A/B runs and the variant tests; rsa_set_tuning works only under RSA_TUNING=1
-    for key in ("k5_pp", "k5_prio", "k5_maxblocks", "k5_tsplit", "k5_pair", "k3_prefix"):
+    for key in ("k5_tsplit", "k3_prefix"):
         val = os.environ.get("RSA_" + key.upper())
         if val is not None:
             check_rc = L.rsa_set_tuning(key.encode(), int(val))

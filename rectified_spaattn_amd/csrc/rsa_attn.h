@@ -75,15 +75,9 @@ struct AttnArgs {
     int kv_valid, kv_text_valid, q_text_end;  // sparse mode (q_text_end = NBv*128 + q_text_valid)
     int q_split, kv_split;                    // dense mode
     int n_heavy_pad, NBp, BH;                 // work mapping
-    int NPp, list_cap;                        // ping-pong kernel: q-block pairs per head (padded to x8), list capacity
-    const uint16_t* pcols;                    // paired workgroups (K3b): [BH, NP, NB_total] union lists with flag bits
-    const int32_t* pcounts;                   // [BH, NP]
-    const int32_t* pair_ok;                   // [BH, NP]; null = no pairing
-    int NP;
     float* tpart;                             // split-KV partials of the text query blocks, or null
     int tsplit, tper;                         // workgroups per text block, key blocks per workgroup
     float qk_scale;
-    unsigned long long* dbg;                  // diagnostics (PIPE_OPT bit 8192): per-workgroup s_memtime stamps, or null
 };
 
 // byte offset of 16-byte chunk `ch` of row `row` inside a [64][D] 2-byte tile.  The XOR keeps both the

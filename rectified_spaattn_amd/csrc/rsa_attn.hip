@@ -7,24 +7,11 @@
 // =====================================================================================================
 // host side
 // =====================================================================================================
-static int g_k5_prio = 32;  // tuning hook: 1 = raise the wave's issue priority inside the pipelined block; 32 = 1 + 16-byte
-                            // output stores (default: 17.47 -> 17.40 ms, bit-identical output)
-static int g_dense256 = 0;  // tuning hook: dense mode on 256-row query tiles (8 waves, one workgroup per CU)
-// 1 = serve "ok" query-block pairs (K3b) with the paired 256-row workgroups.  Off by default: measured on the locality
-// regime of bench.py (78 % of a kept list shared with the neighbouring block) it cuts K5's fabric traffic from 73 GB to
-// 48 GB per launch but takes 21.6 instead of 16.1 ms -- the union walk is 1.22 lists long and a tile kept by only one
-// block of the pair still costs a full tile time of the 8-wave workgroup.
-int g_rsa_k5_pair = 0;
-extern int g_rsa_k3_prefix;
 static int g_k5_tsplit = 1;     // 1 = split-KV for the text query blocks when the partial buffer is given
-static unsigned long long g_dbg_ptr = 0;   // diagnostics: device buffer for K5's in-kernel stamps (keys dbg_lo / dbg_hi, k5_prio 64)
-static int g_k5_maxblocks = 0;  // diagnostics: launch only the first N workgroups of K5 (partial result!)
-static int g_k5_pp = 0;     // 1 = the ping-pong kernel (rsa_attn_pp_kernel.hip): two query blocks per 8-wave workgroup
+extern int g_rsa_k3_prefix;
 
 void rsa_set_fp8_variant(int v);
-int rsa_launch_bsfwd(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int dtype, int prio, hipStream_t s);
-int rsa_launch_bsfwd_pair(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int dtype, hipStream_t s);
-int rsa_launch_bsfwd_pp(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int dtype, int opt, hipStream_t s);
+int rsa_launch_bsfwd(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int dtype, hipStream_t s);
 
 // Tuning / diagnostics hook (not part of the data path).  The switches are process-global, so the hook only works in a
 // process that opted in with the environment variable RSA_TUNING=1 (the A/B tools and the variant tests); a production
@@ -33,34 +20,10 @@ extern "C" int rsa_set_tuning(const char* key, int value) {
     static const bool enabled = [] { const char* e = getenv("RSA_TUNING"); return e && e[0] == '1'; }();
     if (!key) return RSA_ERR_BAD_ARG;
     if (!enabled) return RSA_ERR_UNSUPPORTED;
-    if (strcmp(key, "k5_prio") == 0) { g_k5_prio = value; return RSA_OK; }
-    if (strcmp(key, "dense256") == 0) { g_dense256 = value != 0; return RSA_OK; }
-    if (strcmp(key, "k5_pp") == 0) { g_k5_pp = value; return RSA_OK; }
-    if (strcmp(key, "k5_maxblocks") == 0) { g_k5_maxblocks = value; return RSA_OK; }
-    if (strcmp(key, "k5_pair") == 0) { g_rsa_k5_pair = value; return RSA_OK; }
-    if (strcmp(key, "dbg_lo") == 0) { g_dbg_ptr = (g_dbg_ptr & 0xFFFFFFFF00000000ull) | (unsigned)value; return RSA_OK; }
-    if (strcmp(key, "dbg_hi") == 0) { g_dbg_ptr = (g_dbg_ptr & 0xFFFFFFFFull) | ((unsigned long long)(unsigned)value << 32); return RSA_OK; }
     if (strcmp(key, "k3_prefix") == 0) { g_rsa_k3_prefix = value; return RSA_OK; }
     if (strcmp(key, "k5_tsplit") == 0) { g_k5_tsplit = value; return RSA_OK; }
     if (strcmp(key, "fp8_variant") == 0) { rsa_set_fp8_variant(value); return RSA_OK; }
     return RSA_ERR_BAD_ARG;
-}
-
-// ping-pong kernel: one workgroup per PAIR of query blocks
-static int launch_attn_pp(AttnArgs& a, int BH, int D, int dtype, hipStream_t s) {
-    const int ntq = a.NQB - a.NBv;
-    const int n_heavy = ntq > 0 ? BH * ((ntq + 1) / 2) : 0;
-    a.BH = BH;
-    a.n_heavy_pad = (n_heavy + 7) & ~7;
-    a.NPp = (((a.NBv + 1) / 2) + 7) & ~7;
-    a.NBp = (a.NBv + 7) & ~7;
-    a.list_cap = (a.NB_total + 7) & ~7;
-    const long nblocks = (long)a.n_heavy_pad + (long)BH * a.NPp;
-    if (nblocks <= 0) return RSA_OK;
-    if (nblocks > 0x7FFFFFFF) return RSA_ERR_UNSUPPORTED;
-    if (a.NB_total > 8192) return RSA_ERR_UNSUPPORTED;
-    const size_t lds_bytes = (size_t)8 * 64 * D * 2 + (size_t)4 * a.list_cap + 16;
-    return rsa_launch_bsfwd_pp(a, dim3((unsigned)nblocks), lds_bytes, D, dtype, g_k5_pp, s);
 }
 
 // Merge of the split-KV partials of the text query blocks (K5 wrote, per part, unnormalised O, the running maximum m in
@@ -125,18 +88,7 @@ static int launch_text_combine(const AttnArgs& a, int BH, int D, int dtype, hipS
                                    a.q_text_end, a.Sq, BH, dtype, s);
 }
 
-static int launch_attn(AttnArgs& a, int BH, int D, int dtype, hipStream_t s, int variant = -1) {
-    if (g_k5_pp && variant < 0) { a.pair_ok = nullptr; a.tsplit = 1; return launch_attn_pp(a, BH, D, dtype, s); }
-    if (a.pair_ok && (((uintptr_t)a.out & 15) || ((a.osb | a.osh | a.oss) & 7))) a.pair_ok = nullptr;  // 16-byte stores
-    if (a.pair_ok && a.NP > 0) {  // paired workgroups first (they are the longer ones: union lists)
-        a.BH = BH;
-        a.NPp = (a.NP + 7) & ~7;
-        const long npb = (long)BH * a.NPp;
-        if (npb > 0x7FFFFFFF || a.NB_total > 8192) return RSA_ERR_UNSUPPORTED;
-        const size_t lds_p = (size_t)4 * 64 * D * 2 + (((size_t)a.NB_total * 2 + 15) & ~(size_t)15);
-        const int st = rsa_launch_bsfwd_pair(a, dim3((unsigned)npb), lds_p, D, dtype, s);
-        if (st != RSA_OK) return st;
-    }
+static int launch_attn(AttnArgs& a, int BH, int D, int dtype, hipStream_t s) {
     const int ntq = a.NQB - a.NBv;
     // split-KV for the dense text rows: without it one workgroup walks every key block of a text query block (902 at the
     // HunyuanVideo shape = 10 kept lists) -- hidden among 21 600 sparse blocks on one GPU, the critical path when the
@@ -157,9 +109,7 @@ static int launch_attn(AttnArgs& a, int BH, int D, int dtype, hipStream_t s, int
     if (nblocks > 0x7FFFFFFF) return RSA_ERR_UNSUPPORTED;
     if (a.NB_total > 8192) return RSA_ERR_UNSUPPORTED;  // kept list lives in LDS as u16, 16 KiB max
     const size_t lds_bytes = (size_t)4 * 64 * D * 2 + (((size_t)a.NB_total * 2 + 15) & ~(size_t)15);
-    const long launch_blocks = g_k5_maxblocks > 0 && g_k5_maxblocks < nblocks ? g_k5_maxblocks : nblocks;
-    const int st = rsa_launch_bsfwd(a, dim3((unsigned)launch_blocks), lds_bytes, D, dtype,
-                                    variant >= 0 ? variant : g_k5_prio, s);
+    const int st = rsa_launch_bsfwd(a, dim3((unsigned)nblocks), lds_bytes, D, dtype, s);
     if (st != RSA_OK || a.tsplit <= 1) return st;
     return launch_text_combine(a, BH, D, dtype, s);
 }
@@ -190,9 +140,6 @@ extern "C" int rsa_block_sparse_fwd(const rsa_layout* l, rsa_tensor4 q, rsa_tens
     AttnArgs a;
     fill_qkv(a, q, k, v, out);
     a.cols = buf->cols; a.counts = buf->counts; a.R = buf->R; a.comp = buf->comp;
-    const bool pairing = g_rsa_k5_pair && buf->pcols && buf->pcounts && buf->pair_ok && l->NBv > 1;
-    a.pcols = pairing ? buf->pcols : nullptr; a.pcounts = pairing ? buf->pcounts : nullptr;
-    a.pair_ok = pairing ? buf->pair_ok : nullptr; a.NP = (l->NBv + 1) / 2;
     a.tpart = buf->tpart;
     a.mode = MODE_SPARSE; a.H = l->H; a.Sq = l->S; a.Sk = l->S;
     a.NBv = l->NBv; a.NQB = l->NB_total; a.NB_total = l->NB_total;
@@ -200,7 +147,6 @@ extern "C" int rsa_block_sparse_fwd(const rsa_layout* l, rsa_tensor4 q, rsa_tens
     a.q_text_end = l->NBv * RSA_BLOCK + l->q_text_valid;
     a.q_split = 0; a.kv_split = 0;
     a.qk_scale = (float)((1.0 / sqrt((double)l->D)) * 1.44269504);  // sm_scale * 1.44269504 (hunyuan :145)
-    a.dbg = reinterpret_cast<unsigned long long*>(g_dbg_ptr);
     return launch_attn(a, l->B * l->H, l->D, l->dtype, static_cast<hipStream_t>(stream));
 }
 
@@ -217,18 +163,13 @@ extern "C" int rsa_dense_fwd(int B, int H, int Sq, int Sk, int D, int dtype, rsa
     AttnArgs a;
     fill_qkv(a, q, k, v, out);
     a.cols = nullptr; a.counts = nullptr; a.R = nullptr; a.comp = nullptr;
-    a.pcols = nullptr; a.pcounts = nullptr; a.pair_ok = nullptr; a.NP = 0; a.tpart = nullptr;
+    a.tpart = nullptr;
     a.tsplit = 1; a.tper = 0;
     a.mode = MODE_DENSE; a.H = H; a.Sq = Sq; a.Sk = Sk;
     a.NQB = (Sq + RSA_BLOCK - 1) / RSA_BLOCK; a.NBv = a.NQB; a.NB_total = (Sk + RSA_BLOCK - 1) / RSA_BLOCK;
     a.kv_valid = Sk; a.kv_text_valid = Sk; a.q_text_end = 0;
     a.q_split = q_split; a.kv_split = kv_split;
     a.qk_scale = (float)((1.0 / sqrt((double)D)) * 1.44269504);
-    a.dbg = nullptr;
-    if (g_dense256) {  // 256 query rows per workgroup: K/V tiles staged once per 256 rows
-        a.NQB = (Sq + 255) / 256; a.NBv = a.NQB;
-        return launch_attn(a, B * H, D, dtype, static_cast<hipStream_t>(stream), 8);
-    }
     return launch_attn(a, B * H, D, dtype, static_cast<hipStream_t>(stream));
 }
 

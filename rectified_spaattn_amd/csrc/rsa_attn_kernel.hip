@@ -35,29 +35,17 @@
 // the flash call, attn.py:107-120), a NaN-free fully-masked path, the fused O*R+comp epilogue (hunyuan :365)
 // and a strided [B,S,H,D] store (hunyuan :383-387).
 //
-// The template also instantiates as NW = 2 waves x QT = 2 sub-tiles (64 rows per wave, one wave per SIMD).
-// That form is correct but not built: hipcc (ROCm 7.2) then needs 256 VGPR + 256 AGPR, spills 46 VGPRs, and
-// the scratch reloads' vmcnt(0) drains the hand-issued DMA (32 ms vs 17 ms); it needs MFMA operands pinned by
-// register class, i.e. an asm-level body.
-//
-// PAIRED form (PIPE_OPT bit 1024, NW = 8): one workgroup = 256 rows = the query-block pair (2p, 2p+1) that K3b marked
-// "ok"; waves 0-3 own block 2p, waves 4-7 block 2p+1.  The workgroup walks the UNION of the two kept lists, every K/V
-// tile is staged ONCE by all 8 waves (half the LDS-DMA pieces per wave and per FLOP on shared tiles, and half the L2 /
-// fabric requests), and a wave runs the QK^T / softmax / PV of a tile only if the tile is in ITS block's list (flag
-// bits 14 / 15 of the union entries); results are bit-identical to the 128-row form.  Query blocks of pairs that are
-// not "ok" are served by the 128-row form, which skips the others.
+// (Forms measured and NOT kept in this library -- a ping-pong 8-wave kernel, paired 256-row workgroups over union lists,
+// persistent workgroups, a 256-row dense tile, non-temporal K/V loads, in-kernel stamps: commit c37b5bb holds their code,
+// profiles/r02_experiments.md their numbers.)
 #include "rsa_attn.h"
 
-// PIPE_OPT bits (tuning experiments): 2 = issue priority 2 for this wave while it is inside the pipelined block;
-// 256 = __builtin_amdgcn_iglp_opt(0) on the pipelined block (+1.7 % sparse, +2.7 % dense 16k; strategies 1, 2 (the
-// "exp interleave" meant for attention) and 3 measured -0.5 ... -3 %).
-// (Pinning a per-MFMA interleave {2 LDS reads, 1 MFMA, 1 exp, 4 VALU} with sched_group_barrier measured -3.5 %: the
-// compiler's own order -- softmax VALU first, then the MFMA cluster -- lets the two co-resident waves alternate.)
-template <int D, typename Tag, int NW, int QT, int PIPE_OPT>
-__global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bsfwd_kernel(AttnArgs a) {
-    static_assert(NW * QT == 4 || (NW == 8 && QT == 1), "128-row query block, or the 256-row dense tile (8 waves)");
-    constexpr bool PAIR = (PIPE_OPT & 1024) != 0;
-    static_assert(!PAIR || (NW == 8 && QT == 1), "paired form = 8 waves x 32 rows");
+// The pipelined block runs with issue priority 2 and LLVM's small-GEMM MFMA/DS interleave (iglp_opt(0): +1.7 % sparse,
+// +2.7 % dense 16k; strategies 1-3 measured -0.5 ... -3 %; a per-MFMA interleave pinned with sched_group_barrier -3.5 %).
+// WIDE: 16-byte output stores after a permlane32_swap regroup (needs 16-byte aligned output rows), else 8-byte stores.
+template <int D, typename Tag, bool WIDE>
+__global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
+    constexpr int NW = 4, QT = 1;                // 4 waves x 32 query rows
     constexpr int QROWS = 32 * NW * QT;          // query rows per workgroup
     constexpr int KS = D / 16;
     constexpr int DT = D / 32;
@@ -77,14 +65,7 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
     const int work = blockIdx.x;
     // ---------------- work mapping: dense text-row blocks first, then the sparse blocks chunked per XCD ----------------
     int bh, qblk, tsp = 0;   // tsp: which part of a text block's key range this workgroup walks
-    if constexpr (PAIR) {
-        const int v = work;
-        bh = v / a.NPp;
-        const int j = v % a.NPp;
-        const int chunk = a.NPp >> 3;
-        qblk = (j & 7) * chunk + (j >> 3);          // pair index p: rows p*256 .. p*256+255
-        if (qblk >= a.NP || !a.pair_ok[(long)bh * a.NP + qblk]) return;
-    } else {
+    {
         const int bid = work;
         if (bid < a.n_heavy_pad) {
             const int ntq = a.NQB - a.NBv;
@@ -101,28 +82,17 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
             const int chunk = a.NBp >> 3;
             qblk = (j & 7) * chunk + (j >> 3);
             if (qblk >= a.NBv) return;
-            if (a.mode == MODE_SPARSE && a.pair_ok && a.pair_ok[(long)bh * a.NP + (qblk >> 1)]) return;  // paired form's
         }
     }
     const int b = bh / a.H, h = bh % a.H;
     const int t = threadIdx.x, lane = t & 63;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int r = lane & 31, hh = lane >> 5;
-    const int half = PAIR ? (wv >> 2) : 0;            // paired form: which query block of the pair this wave serves
-    const int qb = PAIR ? 2 * qblk + half : qblk;     // its 128-row query block
+    const int qb = qblk;
     int grow[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) grow[qt] = qblk * QROWS + 32 * QT * wv + 32 * qt + r;
 
-    unsigned long long T0 = 0, T1 = 0, T2 = 0;
-    auto stamp = [&]() -> unsigned long long {
-        unsigned long long tt;
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt) :: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        return tt;
-    };
-    if constexpr ((PIPE_OPT & 8192) != 0) T0 = stamp();
     // ---------------- per-row plan ----------------
     int lo_r[QT], hi_r[QT];
     bool store_r[QT], zero_r[QT];
@@ -130,16 +100,8 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
     for (int qt = 0; qt < QT; ++qt) { lo_r[qt] = 0; hi_r[qt] = 0; store_r[qt] = false; zero_r[qt] = false; }
     int n_items, first_blk = 0, lo_max, hi_min, hi_max;
     const int32_t* list = nullptr;
-    const uint16_t* plist = nullptr;
     bool rectify = false;
-    if constexpr (PAIR) {
-        const long prow = (long)bh * a.NP + qblk;
-        plist = a.pcols + prow * a.NB_total;
-        n_items = a.pcounts[prow];
-        lo_max = 0; hi_min = hi_max = a.kv_valid;
-        rectify = a.R != nullptr;
-        hi_r[0] = a.kv_valid; store_r[0] = qb < a.NBv && grow[0] < a.Sq;
-    } else if (a.mode == MODE_SPARSE) {
+    if (a.mode == MODE_SPARSE) {
         if (qblk < a.NBv) {
             const long rowi = (long)bh * a.NBv + qblk;
             list = a.cols + rowi * a.NB_total;
@@ -180,18 +142,13 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
         if (hi_max <= lo_min) n_items = 0;
     }
     n_items = __builtin_amdgcn_readfirstlane(n_items);
-    const bool use_list = PAIR || list != nullptr;
+    const bool use_list = list != nullptr;
     if (use_list) {
-        if constexpr (PAIR) {
-            for (int i = t; i < n_items; i += 64 * NW) lds_list[i] = plist[i];
-        } else {
-            for (int i = t; i < n_items; i += 64 * NW) lds_list[i] = (unsigned short)list[i];
-        }
+        for (int i = t; i < n_items; i += 64 * NW) lds_list[i] = (unsigned short)list[i];
         __syncthreads();
     }
     auto blk_of = [&](int item) -> int {
-        if constexpr (PAIR) return (int)(lds_list[item] & 0x3FFF);
-        else return use_list ? (int)lds_list[item] : first_blk + item;
+        return use_list ? (int)lds_list[item] : first_blk + item;
     };
     int n_tiles = 2 * n_items;
     if (n_items > 0) {
@@ -205,17 +162,6 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
         const int blk = __builtin_amdgcn_readfirstlane(blk_of(it < n_items ? it : (n_items > 0 ? n_items - 1 : 0)));
         return blk * RSA_BLOCK + (tile & 1) * 64;
     };
-    // paired form: does tile `tile` belong to THIS wave's query block?  (false past the end of the union list)
-    auto act_of = [&](int tile) -> bool {
-        if constexpr (PAIR) {
-            const int it = tile >> 1;
-            if (tile >= n_tiles || it >= n_items) return false;
-            return ((__builtin_amdgcn_readfirstlane((int)lds_list[it]) >> (14 + half)) & 1) != 0;
-        } else {
-            return true;
-        }
-    };
-
     // ---------------- Q fragments (B operand), two 32-row sub-tiles ----------------
     s16x8 qf[QT][KS];
 #pragma unroll
@@ -267,17 +213,10 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
 #pragma unroll
             for (int j = 0; j < NPC; ++j) {
                 const unsigned vo = is_v ? voffv[j % PG] : voffk[j % PG];
-                if constexpr (PIPE_OPT & 2048) {   // experiment: non-temporal policy for the K/V stream
-                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt"
-                                 :: "v"(vo), "s"(tb + (TEAMS * (j / PG) + team) * step),
-                                    "s"(ld0 + (TEAMS * (j / PG) + team) * 4096 + (j % PG) * 1024)
-                                 : "memory");
-                } else {
-                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                                 :: "v"(vo), "s"(tb + (TEAMS * (j / PG) + team) * step),
-                                    "s"(ld0 + (TEAMS * (j / PG) + team) * 4096 + (j % PG) * 1024)
-                                 : "memory");
-                }
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                             :: "v"(vo), "s"(tb + (TEAMS * (j / PG) + team) * step),
+                                "s"(ld0 + (TEAMS * (j / PG) + team) * 4096 + (j % PG) * 1024)
+                             : "memory");
             }
         } else {
 #pragma unroll
@@ -356,7 +295,6 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
     };
 
     int kq1 = 0, kq2 = 0;  // first keys of tile+1 / tile+2 (fetched from LDS ahead of use)
-    bool act0 = true, act1 = true, act2 = true;  // paired form: this wave's block keeps tile / tile+1 / tile+2
 
     // One pipelined sub-step u = 2*tile + SUB: consumes S_cur (scores of 32 keys, row max in mx_cur), produces
     // S_nxt / mx_nxt for sub-step u+1.  VS = slot parity of `tile` (its K and V slots).
@@ -380,18 +318,15 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
         } else {
             if (tile + 2 < n_tiles) dma(0, kq2, vs);       // K(tile+2) -> slot of K(tile)
         }
-        // paired form: the sub-step just scored (S_cur) / the one scored now (S_nxt) may not be this block's
-        const bool a_cur = PAIR ? act0 : true;
-        const bool a_nxt = PAIR ? (sub == 0 ? act0 : act1) : true;
         // ---- head (rare branches): boundary mask, deferred rescale ----
         const int kfirst = key0 + 32 * sub;
-        if (a_cur && (kfirst < lo_max || kfirst + 32 > hi_min)) {
+        if ((kfirst < lo_max || kfirst + 32 > hi_min)) {
             apply_mask_sub(S_cur, kfirst);
             rowmax_sub(S_cur, mx_cur);
         }
         bool grow_any = false;
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt) grow_any |= a_cur && mx_cur[qt] > m_run[qt] + 8.0f;
+        for (int qt = 0; qt < QT; ++qt) grow_any |= mx_cur[qt] > m_run[qt] + 8.0f;
         if (__builtin_amdgcn_ballot_w64(grow_any) != 0ull) {
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
@@ -411,81 +346,25 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
         for (int qt = 0; qt < QT; ++qt) m_use[qt] = (m_run[qt] == -INFINITY) ? 0.0f : m_run[qt];
 
         // ---- pipelined block (branch-free on purpose: the scheduler interleaves the MFMA and VALU streams) ----
-        if constexpr (PAIR) {
-            // Common case (both sub-steps belong to this block): the same pipelined block as the 128-row form, below.
-            // Otherwise wave-uniform gates around its three parts.
-            if (!(a_cur && a_nxt)) {
-                if (a_nxt) {
-                    if constexpr (sub == 0) qk_sub(std::integral_constant<int, vs>{}, std::integral_constant<int, 1>{}, S_nxt);
-                    else qk_sub(std::integral_constant<int, vs ^ 1>{}, std::integral_constant<int, 0>{}, S_nxt);
-                    rowmax_sub(S_nxt, mx_nxt);
-                }
-                if (a_cur) {
-                    s16x8 pbp[2];
-                    float ps = 0.0f;
-#pragma unroll
-                    for (int half_ = 0; half_ < 2; ++half_) {
-                        float pv8[8];
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            pv8[i] = __builtin_amdgcn_exp2f(S_cur[0][8 * half_ + i] - m_use[0]);
-                            ps += pv8[i];
-                        }
-                        pbp[half_] = E::cvt8(pv8);
-                    }
-                    l_run[0] += ps;
-                    const unsigned char* vtp = lds + (2 + vs) * TILE_BYTES;
-#pragma unroll
-                    for (int k2 = 0; k2 < 2; ++k2) {
-#pragma unroll
-                        for (int dt = 0; dt < DT; ++dt) {
-                            const int offa = vrd[dt][0] + (2 * sub + k2) * 16 * D * 2;
-                            const int offb = vrd[dt][1] + (2 * sub + k2) * 16 * D * 2;
-                            const s16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                                (s16x4 __attribute__((address_space(3)))*)(vtp + offa));
-                            const s16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                                (s16x4 __attribute__((address_space(3)))*)(vtp + offb));
-                            const s16x8 av = __builtin_shufflevector(va, vb, 0, 1, 2, 3, 4, 5, 6, 7);
-                            o[dt][0] = E::mfma(av, pbp[k2], o[dt][0]);
-                        }
-                    }
-                }
-                return;
-            }
-        }
-        if constexpr (PIPE_OPT & 2) __builtin_amdgcn_s_setprio(2);
-        if constexpr (PIPE_OPT & 256) __builtin_amdgcn_iglp_opt(0);  // LLVM's small-GEMM MFMA/DS interleave for this region
+        __builtin_amdgcn_s_setprio(2);
+        __builtin_amdgcn_iglp_opt(0);  // LLVM's small-GEMM MFMA/DS interleave for this region
         if constexpr (sub == 0) qk_sub(std::integral_constant<int, vs>{}, std::integral_constant<int, 1>{}, S_nxt);
         else qk_sub(std::integral_constant<int, vs ^ 1>{}, std::integral_constant<int, 0>{}, S_nxt);
         s16x8 pb[QT][2];
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
-            if constexpr (PIPE_OPT & 4) {   // row sum as four short chains, formed inside this block (not in the next head)
-                float ps0 = 0.0f, ps1 = 0.0f, ps2 = 0.0f, ps3 = 0.0f;
+            float ps = 0.0f;
 #pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    float pv8[8];
+            for (int hf = 0; hf < 2; ++hf) {
+                float pv8[8];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) pv8[i] = __builtin_amdgcn_exp2f(S_cur[qt][8 * hf + i] - m_use[qt]);
-                    ps0 += pv8[0] + pv8[4]; ps1 += pv8[1] + pv8[5]; ps2 += pv8[2] + pv8[6]; ps3 += pv8[3] + pv8[7];
-                    pb[qt][hf] = E::cvt8(pv8);
+                for (int i = 0; i < 8; ++i) {
+                    pv8[i] = __builtin_amdgcn_exp2f(S_cur[qt][8 * hf + i] - m_use[qt]);
+                    ps += pv8[i];
                 }
-                l_run[qt] += (ps0 + ps1) + (ps2 + ps3);
-                asm volatile("" : "+v"(l_run[qt]));
-            } else {
-                float ps = 0.0f;
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    float pv8[8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        pv8[i] = __builtin_amdgcn_exp2f(S_cur[qt][8 * hf + i] - m_use[qt]);
-                        ps += pv8[i];
-                    }
-                    pb[qt][hf] = E::cvt8(pv8);
-                }
-                l_run[qt] += ps;
+                pb[qt][hf] = E::cvt8(pv8);
             }
+            l_run[qt] += ps;
         }
         const unsigned char* vt_ = lds + (2 + vs) * TILE_BYTES;
 #pragma unroll
@@ -504,7 +383,7 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
             }
         }
         rowmax_sub(S_nxt, mx_nxt);
-        if constexpr (PIPE_OPT & 2) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(0);
     };
 
     // ---------------- prologue + main loop ----------------
@@ -522,18 +401,13 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
         if (n_tiles > 1) dma(0, kq1, 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        act0 = act_of(0); act1 = act_of(1); act2 = act_of(2);
-        if (act0) {
-            qk_sub(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, SA);
-            rowmax_sub(SA, mxA);
-        }
+        qk_sub(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, SA);
+        rowmax_sub(SA, mxA);
     }
-    if constexpr ((PIPE_OPT & 8192) != 0) T1 = stamp();
     auto advance = [&](int tile) {  // after finishing `tile`: shift the key queue, fetch tile+3's first key
         key0 = kq1;
         kq1 = kq2;
         kq2 = key0_of(tile + 3);
-        if constexpr (PAIR) { act0 = act1; act1 = act2; act2 = act_of(tile + 3); }
     };
     {
         using I0 = std::integral_constant<int, 0>;
@@ -553,14 +427,13 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
         }
     }
 
-    if constexpr ((PIPE_OPT & 8192) != 0) T2 = stamp();
     // ---------------- epilogue ----------------
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run[qt]), __float_as_uint(l_run[qt]),
                                                          false, false);
         const float l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-        if constexpr (!PAIR) {
+        {
             if (a.mode == MODE_SPARSE && a.tsplit > 1 && qblk >= a.NBv) {
                 // split-KV partial of a text block: unnormalised O (fp32), m (log2 domain) and l per row; the combine
                 // kernel (rsa_attn.hip) merges the tsplit parts
@@ -599,7 +472,7 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
             asm volatile("" : "+v"(rr));
             return rr;
         };
-        if constexpr ((PIPE_OPT & 4096) != 0) {
+        if constexpr (WIDE) {
             // wide stores: lane (r, 0) holds d = 8g .. 8g+3 and lane (r, 1) d = 8g+4 .. 8g+7 of a 32-wide d tile; one
             // v_permlane32_swap per packed register pair regroups two g's so that each lane owns 8 consecutive d:
             // 8 stores of 16 B per lane instead of 16 of 8 B (the store tail of a row-per-lane epilogue is issue-bound)
@@ -649,50 +522,16 @@ __global__ __launch_bounds__(64 * NW, (NW * QT == 4 && QT == 1) ? 2 : 1) void bs
             }
         }
     }
-    if constexpr ((PIPE_OPT & 8192) != 0) {   // diagnostics: stamps of this workgroup's wave 0
-        if (a.dbg && t == 0) {
-            const unsigned long long T3 = stamp();
-            unsigned hwid, xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            unsigned long long* o8 = a.dbg + (long)work * 8;
-            o8[0] = T0; o8[1] = T1; o8[2] = T2; o8[3] = T3; o8[4] = (unsigned long long)n_items;
-            o8[5] = hwid; o8[6] = xcc; o8[7] = (unsigned long long)qblk;
-        }
-    }
-}
-
-// paired form (sparse mode, after K3b): one workgroup per "ok" query-block pair
-int rsa_launch_bsfwd_pair(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int dtype, hipStream_t s) {
-    if (D == 128) {
-        if (dtype == RSA_BF16) bsfwd_kernel<128, bf16_tag, 8, 1, 2 + 256 + 1024 + 4096><<<grid, 512, lds_bytes, s>>>(a);
-        else bsfwd_kernel<128, fp16_tag, 8, 1, 2 + 256 + 1024 + 4096><<<grid, 512, lds_bytes, s>>>(a);
-    } else {
-        if (dtype == RSA_BF16) bsfwd_kernel<64, bf16_tag, 8, 1, 2 + 256 + 1024 + 4096><<<grid, 512, lds_bytes, s>>>(a);
-        else bsfwd_kernel<64, fp16_tag, 8, 1, 2 + 256 + 1024 + 4096><<<grid, 512, lds_bytes, s>>>(a);
-    }
-    return rsa_launch_status();
 }
 
 // launch hook used by rsa_attn.hip::launch_attn
-int rsa_launch_bsfwd(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int dtype, int prio, hipStream_t s) {
-    // the 16-byte output stores of the default form need 16-byte aligned rows; anything else takes the 8-byte form
-    if (prio == 64) {   // diagnostics: the default form with s_memtime stamps (tools/dbg_k5.py); D = 128, bf16 only
-        if (D == 128 && dtype == RSA_BF16 && a.dbg) {
-            bsfwd_kernel<128, bf16_tag, 4, 1, 2 + 256 + 4096 + 8192><<<grid, 256, lds_bytes, s>>>(a);
-            return rsa_launch_status();
-        }
-        prio = 32;
-    }
-    if (prio == 32 && (((uintptr_t)a.out & 15) || ((a.osb | a.osh | a.oss) & 7))) prio = 1;
+int rsa_launch_bsfwd(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int dtype, hipStream_t s) {
+    // the 16-byte output stores need 16-byte aligned rows; anything else takes the 8-byte form
+    const bool wide = !(((uintptr_t)a.out & 15) || ((a.osb | a.osh | a.oss) & 7));
 #define RSA_K5(DD, TT) \
     do { \
-        if (prio == 8) bsfwd_kernel<DD, TT, 8, 1, 2 + 256><<<grid, 512, lds_bytes, s>>>(a); \
-        else if (prio == 4) bsfwd_kernel<DD, TT, 4, 1, 2 + 4 + 256><<<grid, 256, lds_bytes, s>>>(a); \
-        else if (prio == 16) bsfwd_kernel<DD, TT, 4, 1, 2 + 256 + 2048><<<grid, 256, lds_bytes, s>>>(a); \
-        else if (prio == 32) bsfwd_kernel<DD, TT, 4, 1, 2 + 256 + 4096><<<grid, 256, lds_bytes, s>>>(a); \
-        else if (prio) bsfwd_kernel<DD, TT, 4, 1, 2 + 256><<<grid, 256, lds_bytes, s>>>(a); \
-        else bsfwd_kernel<DD, TT, 4, 1, 0><<<grid, 256, lds_bytes, s>>>(a); \
+        if (wide) bsfwd_kernel<DD, TT, true><<<grid, 256, lds_bytes, s>>>(a); \
+        else bsfwd_kernel<DD, TT, false><<<grid, 256, lds_bytes, s>>>(a); \
     } while (0)
     if (D == 128) {
         if (dtype == RSA_BF16) RSA_K5(128, bf16_tag); else RSA_K5(128, fp16_tag);

@@ -805,50 +805,6 @@ __global__ void gapr_compare_kernel(const float* qbar, const float* aq, const fl
 }
 
 // =====================================================================================================
-// K3b: union lists of query-block pairs (2p, 2p+1) for K5's paired workgroups.  One wave per pair: the two rows of
-// the kept bitmask are OR-ed 64 columns at a time; entry = block | in_first << 14 | in_second << 15, ascending.
-// A pair is "ok" when the lists share at least PAIR_MIN_SHARE of the longer one (otherwise the union walk would
-// stage mostly single-use tiles and make each half wait for the other's).
-// =====================================================================================================
-extern int g_rsa_k5_pair;   // rsa_attn.hip: the paired form is opt-in (tuning key "k5_pair")
-#define RSA_PAIR_MIN_SHARE_NUM 3
-#define RSA_PAIR_MIN_SHARE_DEN 10
-__global__ __launch_bounds__(256) void pair_lists_kernel(const uint32_t* __restrict__ bitmask, int NBv, int NB_total,
-                                                         int NW, int NP, long rows_total, uint16_t* __restrict__ pcols,
-                                                         int32_t* __restrict__ pcounts, int32_t* __restrict__ pair_ok) {
-    const int lane = threadIdx.x & 63;
-    const long pr = (long)blockIdx.x * 4 + (threadIdx.x >> 6);   // pair row = bh * NP + p
-    if (pr >= rows_total) return;
-    const long bh = pr / NP;
-    const int p = (int)(pr % NP);
-    const int qa = 2 * p, qb = 2 * p + 1;
-    const uint32_t* ra = bitmask + ((long)bh * NBv + qa) * NW;
-    const uint32_t* rb = qb < NBv ? bitmask + ((long)bh * NBv + qb) * NW : nullptr;
-    uint16_t* out = pcols + pr * NB_total;
-    int off = 0, na = 0, nb = 0, nab = 0;
-    for (int b0 = 0; b0 < NB_total; b0 += 64) {
-        const int j = b0 + lane;
-        bool fa = false, fb = false;
-        if (j < NB_total) {
-            fa = (ra[j >> 5] >> (j & 31)) & 1u;
-            if (rb) fb = (rb[j >> 5] >> (j & 31)) & 1u;
-        }
-        const unsigned long long ma = __ballot(fa), mb = __ballot(fb), mu = ma | mb;
-        if (fa || fb) {
-            const int pos = off + __popcll(mu & ((1ull << lane) - 1ull));
-            out[pos] = (uint16_t)(j | (fa ? 0x4000 : 0) | (fb ? 0x8000 : 0));
-        }
-        off += __popcll(mu);
-        na += __popcll(ma); nb += __popcll(mb); nab += __popcll(ma & mb);
-    }
-    if (lane == 0) {
-        pcounts[pr] = off;
-        const int longer = na > nb ? na : nb;
-        pair_ok[pr] = (rb != nullptr && nab * RSA_PAIR_MIN_SHARE_DEN >= longer * RSA_PAIR_MIN_SHARE_NUM) ? 1 : 0;
-    }
-}
-
-// =====================================================================================================
 // host entry points
 // =====================================================================================================
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -859,12 +815,10 @@ extern "C" int rsa_buffer_bytes(const rsa_layout* l, size_t sizes[RSA_NUM_BUFFER
     if (!sizes || !total) return RSA_ERR_BAD_ARG;
     const size_t BH = (size_t)l->B * l->H, NBv = l->NBv, NB = l->NB_total, D = l->D;
     const size_t NS = NBv + l->n_txt, L = NBv + (l->n_txt > 0 ? 1 : 0), NW = (NB + 31) / 32;
-    const size_t NP = (NBv + 1) / 2;
     const size_t s[RSA_NUM_BUFFERS] = {
         BH * NBv * D * 4, BH * NBv * D * 4, BH * NBv * D * 4, BH * NBv * D * 4, BH * NB * D * 4,
         BH * NBv * NS * 4, BH * NBv * NBv,  BH * NBv * L * 4, BH * NBv * L * 4, BH * NBv * 4,
         BH * NBv * D * 4,  BH * NBv * NW * 4, BH * NBv * NB * 4, BH * NBv * 4,
-        BH * NP * NB * 2,  BH * NP * 4, BH * NP * 4,
         BH * (NB - NBv) * RSA_TEXT_SPLIT * 128 * (D + 2) * 4};
     size_t tot = 0;
     for (int i = 0; i < RSA_NUM_BUFFERS; ++i) {
@@ -891,8 +845,7 @@ extern "C" int rsa_carve_workspace(const rsa_layout* l, void* ws, size_t ws_byte
     out->vbar = (float*)ptrs[4]; out->scores = (float*)ptrs[5]; out->unrel = (uint8_t*)ptrs[6];
     out->probs = (float*)ptrs[7]; out->w = (float*)ptrs[8]; out->R = (float*)ptrs[9]; out->comp = (float*)ptrs[10];
     out->bitmask = (uint32_t*)ptrs[11]; out->cols = (int32_t*)ptrs[12]; out->counts = (int32_t*)ptrs[13];
-    out->pcols = (uint16_t*)ptrs[14]; out->pcounts = (int32_t*)ptrs[15]; out->pair_ok = (int32_t*)ptrs[16];
-    out->tpart = (l->NB_total > l->NBv) ? (float*)ptrs[17] : nullptr;
+    out->tpart = (l->NB_total > l->NBv) ? (float*)ptrs[14] : nullptr;
     return RSA_OK;
 }
 
@@ -1011,14 +964,6 @@ extern "C" int rsa_select_mask(const rsa_layout* l, const uint8_t* neighbor, int
 #undef RSA_K3
     st = rsa_launch_status();
     if (st != RSA_OK) return st;
-    if (g_rsa_k5_pair && buf->pcols && buf->pcounts && buf->pair_ok) {   // K3b: union lists for K5's paired workgroups
-        if (l->NB_total > 0x3FFF) return RSA_ERR_UNSUPPORTED;
-        const int NP = (l->NBv + 1) / 2;
-        const long rows = (long)l->B * l->H * NP;
-        pair_lists_kernel<<<dim3((unsigned)((rows + 3) / 4)), 256, 0, s>>>(buf->bitmask, l->NBv, l->NB_total, a.NW, NP,
-                                                                           rows, buf->pcols, buf->pcounts, buf->pair_ok);
-        st = rsa_launch_status();
-    }
     return st;
 }
 
