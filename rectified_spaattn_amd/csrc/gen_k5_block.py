@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Generator of K5's hand-placed pipelined block (rsa_attn_block.h).
+
+The block is one sub-step of the block-sparse attention main loop of rsa_attn_kernel.hip for ONE wave (32 query rows):
+
+    S_nxt^T = K(sub-tile u+1) . Q^T - m    KS = D/16 MFMAs  (A = K rows from LDS by ds_read_b128, B = Q fragments, registers;
+                                                             the chain starts from a 16-register block holding -m)
+    P       = exp2(S_cur)                  in place, fp32; row sum into l; packed to the 2-byte type
+    O^T    += V(sub-tile u)^T . P^T        2 * D/32 MFMAs   (A = V^T by ds_read_b64_tr_b16, B = packed P)
+    mx      = row max of S_nxt             (two v_max3 chains + one v_permlane32_swap)
+
+hipcc schedules that as it pleases (round 2: every operand read followed by lgkmcnt(0), profiles/r03_k5_r1_vs_head.md), so
+the instruction stream is written here, once, with every register named: LDS operand reads run AHEAD MFMAs ahead of their
+MFMA behind counted lgkmcnt waits, and the softmax's vector instructions are dealt into the MFMA shadows by issue cost
+(cdna_hip_programming.md: 4 cycles per plain VALU, 8 per v_exp_f32, an MFMA leaves about 24 issue cycles of its 32).
+Registers are pinned through physical-register constraints ("{v[96:111]}"); the operand lists are generated with the
+streams (RSA_K5_OPS*), so the C++ side cannot drift from the register map.
+
+Two forms are generated per (D, dtype, K/V slot parity, sub-step parity):
+  * RSA_K5_BLOCKN_*: the product.  The kernel runs at the board's power cap (1.39 kW, 1.72 GHz under this loop,
+    tools/clock_probe.py), so what it saves is instructions, not stalls: starting the score chain from -m removes the 16
+    subtractions of a sub-step (-3.7 % time), the row maximum as two chains placed as soon as S_nxt is complete another
+    0.7 % (profiles/r03_k5_block.md).  Nothing pads the statement behind its last MFMA: the only vector code that touches O
+    outside the blocks (the rare rescale, the epilogue) carries the 12 wait states itself.
+  * RSA_K5_BLOCK_*: the compiled block's arithmetic operation for operation (S, then S - m by v_sub), for the A/B build:
+    bit-identical to the block as hipcc schedules it (tools/check_blk.py).
+
+Measured and dropped: the sub-step's LDS-DMA pieces spread over the MFMA shadows (16.96 vs 16.42 ms: a piece stalls its wave
+~70 cycles wherever it is issued, and inside the block that stall stops the wave's MFMA stream), 16x16x32 MFMAs (timing
+probe: +-0 sparse, +3 % dense), packed f32 adds for the row sum (+0.8 % time).
+
+usage: python3 gen_k5_block.py > rsa_attn_block.h
+"""
+
+AHEAD = 4          # LDS operand buffers per operand kind (K fragments, V^T fragments)
+COST = dict(sub=4, exp=8, cvt=4, add=4, max=4, mov=4, nop=8, swap=4)
+
+
+class Map:
+    def __init__(self, D, negm):
+        self.D, self.KS, self.DT = D, D // 16, D // 32
+        r = 0
+        self.O = r; r += 16 * self.DT
+        self.Q = r; r += 4 * self.KS
+        self.SA = r; r += 16
+        self.SB = r; r += 16
+        self.NM = r
+        if negm: r += 16         # the reference maximum, negated, in all 16 registers: C operand of the first QK^T MFMA
+        self.tmp0 = r
+        self.P = r; r += 8
+        self.KF = r; r += 4 * AHEAD
+        self.VF = r; r += 4 * AHEAD
+        self.PS = r; r += 1
+        self.T0 = r; r += 1
+        self.T1 = r; r += 1
+        self.tmp1 = r            # clobbered temporaries: [tmp0, tmp1)
+        r = (r + 3) & ~3
+        self.KA = r; r += self.KS
+        self.VA = r; r += 2 * self.DT
+        self.end = r
+
+
+def vr(a, n=1):
+    return f"v{a}" if n == 1 else f"v[{a}:{a + n - 1}]"
+
+
+def gen_block(D, dt, VS, SUB, negm):
+    """The asm lines of one block variant."""
+    m = Map(D, negm)
+    KS, DT = m.KS, m.DT
+    mf = "v_mfma_f32_32x32x16_bf16" if dt == "bf16" else "v_mfma_f32_32x32x16_f16"
+    cv = "v_cvt_pk_bf16_f32" if dt == "bf16" else "v_cvt_pk_f16_f32"
+    TILE = 64 * D * 2
+    SC, SN = (m.SA, m.SB) if SUB == 0 else (m.SB, m.SA)
+    kslot, ksub = (VS, 1) if SUB == 0 else (VS ^ 1, 0)
+    koff = kslot * TILE + ksub * 32 * D * 2
+    vbase = (2 + VS) * TILE
+    lines = []
+    lds_seq = []          # issue order of LDS ops: (tag, count)
+
+    def k_read(ks):
+        lines.append(f"ds_read_b128 {vr(m.KF + 4 * (ks % AHEAD), 4)}, {vr(m.KA + ks)} offset:{koff}")
+        lds_seq.append((("K", ks), 1))
+
+    def v_read(p):
+        k2, d = divmod(p, DT)
+        off = vbase + (2 * SUB + k2) * 16 * D * 2
+        b = m.VF + 4 * (p % AHEAD)
+        lines.append(f"ds_read_b64_tr_b16 {vr(b, 2)}, {vr(m.VA + 2 * d)} offset:{off}")
+        lines.append(f"ds_read_b64_tr_b16 {vr(b + 2, 2)}, {vr(m.VA + 2 * d + 1)} offset:{off}")
+        lds_seq.append((("V", p), 2))
+
+    def wait_for(tag):
+        idx = [i for i, (t, _) in enumerate(lds_seq) if t == tag][-1]
+        after = sum(c for _, c in lds_seq[idx + 1:])
+        lines.append(f"s_waitcnt lgkmcnt({after})")
+
+    # ---- the vector work, in issue order ----
+    def pair(i):   # two scores interleaved so that no instruction reads its predecessor's result
+        sub = [("sub", f"v_sub_f32 {vr(SC + j)}, {vr(SC + j)}, %[m]") for j in (i, i + 1)]
+        exp = [("exp", f"v_exp_f32 {vr(SC + j)}, {vr(SC + j)}") for j in (i, i + 1)]
+        return exp if negm else sub + exp
+
+    def C(j):
+        return [("cvt", f"{cv} {vr(m.P + j)}, {vr(SC + 2 * j)}, {vr(SC + 2 * j + 1)}")]
+
+    work = []
+    for i in range(0, 8, 2): work += pair(i)
+    work += pair(8)
+    for j in range(0, 4): work += C(j)
+    for i in range(10, 16, 2): work += pair(i)
+    work += [("add", f"v_add_f32 {vr(m.PS)}, {vr(SC)}, {vr(SC + 1)}")]
+    for i in range(2, 8): work += [("add", f"v_add_f32 {vr(m.PS)}, {vr(m.PS)}, {vr(SC + i)}")]
+    for j in range(4, 8): work += C(j)
+    for i in range(8, 16): work += [("add", f"v_add_f32 {vr(m.PS)}, {vr(m.PS)}, {vr(SC + i)}")]
+    work += [("add", f"v_add_f32 %[l], %[l], {vr(m.PS)}")]
+    if negm:   # two chains, merged by a v_max
+        maxw = [("max", f"v_max_f32 {vr(m.T0)}, {vr(SN)}, {vr(SN + 1)}"), ("max", f"v_max_f32 {vr(m.T1)}, {vr(SN + 2)}, {vr(SN + 3)}")]
+        for i in range(2, 8):
+            t = m.T0 if i % 2 == 0 else m.T1
+            maxw += [("max", f"v_max3_f32 {vr(t)}, {vr(t)}, {vr(SN + 2 * i)}, {vr(SN + 2 * i + 1)}")]
+        maxw += [("max", f"v_max_f32 {vr(m.T0)}, {vr(m.T0)}, {vr(m.T1)}")]
+    else:
+        maxw = [("max", f"v_max_f32 {vr(m.T0)}, {vr(SN)}, {vr(SN + 1)}")]
+        for i in range(1, 8): maxw += [("max", f"v_max3_f32 {vr(m.T0)}, {vr(m.T0)}, {vr(SN + 2 * i)}, {vr(SN + 2 * i + 1)}")]
+    maxw += [("mov", f"v_mov_b32 {vr(m.T1)}, {vr(m.T0)}"), ("nop", "s_nop 1"),
+             ("swap", f"v_permlane32_swap_b32 {vr(m.T0)}, {vr(m.T1)}"), ("nop", "s_nop 1"),
+             ("max", f"v_max_f32 %[mx], {vr(m.T0)}, {vr(m.T1)}")]
+
+    nm = KS + 2 * DT                      # MFMAs of the block
+    total = sum(COST[k] for k, _ in work + maxw)
+    pre = 72 if D == 128 else 48          # vector work issued while the first K fragments are in flight
+    budget = max(24, -(-(total - pre) // nm) + 2)
+    wi, mi = 0, 0
+
+    def emit_work(cycles, allow_max):
+        nonlocal wi, mi
+        used = 0
+        while used < cycles:
+            if wi < len(work):
+                k, t = work[wi]; wi += 1
+            elif allow_max and mi < len(maxw):
+                k, t = maxw[mi]; mi += 1
+            else:
+                break
+            lines.append(t)
+            used += COST[k]
+
+    lines.append("s_setprio 2")
+    for ks in range(min(AHEAD, KS)): k_read(ks)
+    emit_work(pre, False)
+    for i in range(nm):
+        if i < KS:
+            wait_for(("K", i))
+            c = (vr(m.NM, 16) if negm else "0") if i == 0 else vr(SN, 16)
+            lines.append(f"{mf} {vr(SN, 16)}, {vr(m.KF + 4 * (i % AHEAD), 4)}, {vr(m.Q + 4 * i, 4)}, {c}")
+            if i + AHEAD < KS: k_read(i + AHEAD)
+            p = i - (KS - min(AHEAD, KS))          # V^T fragments of the first PV MFMAs ride the last QK shadows
+            if 0 <= p < min(AHEAD, 2 * DT) and KS >= AHEAD: v_read(p)
+            if KS < AHEAD and i == KS - 1:
+                for pp in range(min(AHEAD, 2 * DT)): v_read(pp)
+        else:
+            p = i - KS
+            k2, d = divmod(p, DT)
+            text = "\n".join(lines)
+            for jj in range(4):   # sanity: the half of P this MFMA reads has been packed
+                assert f"{cv} {vr(m.P + 4 * k2 + jj)}," in text, (D, dt, VS, SUB, "P not packed before PV", p)
+            wait_for(("V", p))
+            lines.append(f"{mf} {vr(m.O + 16 * d, 16)}, {vr(m.VF + 4 * (p % AHEAD), 4)}, {vr(m.P + 4 * k2, 4)}, {vr(m.O + 16 * d, 16)}")
+            if p + AHEAD < 2 * DT: v_read(p + AHEAD)
+        last = i == nm - 1
+        # The row max reads S_nxt: two or more MFMAs behind the last QK MFMA (its 8 passes are over).  Classic form: it fills
+        # the last two shadows and the tail, padded to the 12 wait states between the last PV MFMA and any VALU touching O.
+        n0 = len(lines)
+        emit_work(10 ** 6 if last else budget, i >= (KS + 1 if negm else max(KS + 1, nm - 2)))
+        if last and not negm:
+            tail = sum(int(l.split()[1]) + 1 if l.startswith("s_nop") else 1 for l in lines[n0:])
+            if tail < 12: lines.append(f"s_nop {11 - tail}")
+    assert wi == len(work) and mi == len(maxw)
+    lines.append("s_setprio 0")
+    return lines, m
+
+
+def c_string(lines):
+    return "\n".join(f'    "{l}\\n\\t"' for l in lines)
+
+
+def main():
+    out = ["// GENERATED by gen_k5_block.py -- do not edit; edit the generator (its docstring says what this is).", "#pragma once", ""]
+    for D in (128, 64):
+        for dt in ("bf16", "f16"):
+            for negm in (False, True):
+                for VS in (0, 1):
+                    for SUB in (0, 1):
+                        lines, m = gen_block(D, dt, VS, SUB, negm)
+                        out.append(f"#define RSA_K5_BLOCK{'N' if negm else ''}_{D}_{dt.upper()}_V{VS}_S{SUB} \\")
+                        out.append(" \\\n".join(c_string(lines).split("\n")))
+                        out.append("")
+    # operand lists (the constraint strings carry the register map) and the clobbered temporaries
+    for D in (128, 64):
+        for negm in (False, True):
+            m = Map(D, negm)
+            outs = [f'"+{{{vr(m.O + 16 * d, 16)}}}"(o[{d}])' for d in range(m.DT)]
+            outs += [f'"+{{{vr(m.SA, 16)}}}"(SA)', f'"+{{{vr(m.SB, 16)}}}"(SB)', '[l] "+v"(l)', '[mx] "=&v"(mx)']
+            ins = [f'"{{{vr(m.Q + 4 * k, 4)}}}"(q[{k}])' for k in range(m.KS)]
+            ins += [f'"{{{vr(m.NM, 16)}}}"(nm)'] if negm else ['[m] "v"(m)']
+            ins += [f'"{{{vr(m.KA, m.KS)}}}"(ka)', f'"{{{vr(m.VA, 2 * m.DT)}}}"(va)']
+            tag = f"{'N' if negm else ''}_{D}"
+            out.append(f"#define RSA_K5_OPS{tag} : {', '.join(outs)} : {', '.join(ins)}")
+            out.append(f"#define RSA_K5_CLOBBER{tag} " + ", ".join(f'"v{r}"' for r in range(m.tmp0, m.tmp1)))
+            out.append(f"// D = {D}{' (-m form)' if negm else ''}: O v[{m.O}:{m.Q - 1}], Q v[{m.Q}:{m.SA - 1}], SA v[{m.SA}:{m.SA + 15}], "
+                       f"SB v[{m.SB}:{m.SB + 15}], " + (f"-m v[{m.NM}:{m.NM + 15}], " if negm else "")
+                       + f"temporaries v[{m.tmp0}:{m.tmp1 - 1}], K addresses v[{m.KA}:{m.KA + m.KS - 1}], V addresses v[{m.VA}:{m.end - 1}]")
+    print("\n".join(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -78,6 +78,9 @@ struct AttnArgs {
     float* tpart;                             // split-KV partials of the text query blocks, or null
     int tsplit, tper;                         // workgroups per text block, key blocks per workgroup
     float qk_scale;
+#ifdef RSA_K5_DIAG
+    unsigned long long* dbg;                  // diagnostics build only (make diag): per-wave s_memtime sums, see tools/diag_k5.py
+#endif
 };
 
 // byte offset of 16-byte chunk `ch` of row `row` inside a [64][D] 2-byte tile.  The XOR keeps both the

@@ -9,6 +9,12 @@
 // =====================================================================================================
 static int g_k5_tsplit = 1;     // 1 = split-KV for the text query blocks when the partial buffer is given
 extern int g_rsa_k3_prefix;
+#ifdef RSA_K5_FORMS
+extern int g_rsa_k5_form;
+#endif
+#ifdef RSA_K5_DIAG
+static unsigned long long g_dbg_ptr = 0;   // diagnostics build: device buffer for K5's in-kernel time sums
+#endif
 
 void rsa_set_fp8_variant(int v);
 int rsa_launch_bsfwd(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int dtype, hipStream_t s);
@@ -21,6 +27,13 @@ extern "C" int rsa_set_tuning(const char* key, int value) {
     if (!key) return RSA_ERR_BAD_ARG;
     if (!enabled) return RSA_ERR_UNSUPPORTED;
     if (strcmp(key, "k3_prefix") == 0) { g_rsa_k3_prefix = value; return RSA_OK; }
+#ifdef RSA_K5_FORMS
+    if (strcmp(key, "k5_form") == 0) { g_rsa_k5_form = value; return RSA_OK; }
+#endif
+#ifdef RSA_K5_DIAG
+    if (strcmp(key, "dbg_lo") == 0) { g_dbg_ptr = (g_dbg_ptr & 0xFFFFFFFF00000000ull) | (unsigned)value; return RSA_OK; }
+    if (strcmp(key, "dbg_hi") == 0) { g_dbg_ptr = (g_dbg_ptr & 0xFFFFFFFFull) | ((unsigned long long)(unsigned)value << 32); return RSA_OK; }
+#endif
     if (strcmp(key, "k5_tsplit") == 0) { g_k5_tsplit = value; return RSA_OK; }
     if (strcmp(key, "fp8_variant") == 0) { rsa_set_fp8_variant(value); return RSA_OK; }
     return RSA_ERR_BAD_ARG;
@@ -147,6 +160,9 @@ extern "C" int rsa_block_sparse_fwd(const rsa_layout* l, rsa_tensor4 q, rsa_tens
     a.q_text_end = l->NBv * RSA_BLOCK + l->q_text_valid;
     a.q_split = 0; a.kv_split = 0;
     a.qk_scale = (float)((1.0 / sqrt((double)l->D)) * 1.44269504);  // sm_scale * 1.44269504 (hunyuan :145)
+#ifdef RSA_K5_DIAG
+    a.dbg = reinterpret_cast<unsigned long long*>(g_dbg_ptr);
+#endif
     return launch_attn(a, l->B * l->H, l->D, l->dtype, static_cast<hipStream_t>(stream));
 }
 
@@ -170,6 +186,9 @@ extern "C" int rsa_dense_fwd(int B, int H, int Sq, int Sk, int D, int dtype, rsa
     a.kv_valid = Sk; a.kv_text_valid = Sk; a.q_text_end = 0;
     a.q_split = q_split; a.kv_split = kv_split;
     a.qk_scale = (float)((1.0 / sqrt((double)D)) * 1.44269504);
+#ifdef RSA_K5_DIAG
+    a.dbg = nullptr;
+#endif
     return launch_attn(a, B * H, D, dtype, static_cast<hipStream_t>(stream));
 }
 

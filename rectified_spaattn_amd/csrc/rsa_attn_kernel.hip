@@ -13,20 +13,25 @@
 // 64-key tiles so every LDS address is a loop-invariant VGPR plus an immediate):
 //      MFMA stream:  S(u+1)^T = K(u+1) . Q^T      then   O^T += V(u)^T . P(u)^T
 //      VALU stream:  P(u) = exp2(S(u) - m) (+ row sums, 2-byte packing)   then   row max of S(u+1)
-// The block is branch-free; hipcc emits the VALU part first and the MFMA cluster after it, and the two
-// co-resident waves of a SIMD (one per workgroup) alternate between the two (measured: pinning a fine
-// per-MFMA interleave with sched_group_barrier is 3.5 % slower).  The running max is deferred: the reference
-// max only moves when some row's max grew by more than 2^8 since it was set (P <= 2^8: same relative precision
-// in bf16/fp16 P, fp32 accumulators); that rare rescale and the boundary-tile mask sit in branches at the head
-// of the sub-step, outside the pipelined block.
+// That block is ONE hand-placed instruction stream (gen_k5_block.py -> rsa_attn_block.h: inline asm, every register
+// pinned): round 2 showed that leaving it to hipcc makes the kernel's speed a matter of which schedule the compiler
+// happens to emit (profiles/r03_k5_r1_vs_head.md: the same source went from read-ahead operand reads to one
+// lgkmcnt(0) per MFMA between two rounds, -8 %).  The running max is deferred: the reference max only moves when some
+// row's max grew by more than 2^8 since it was set (P <= 2^8: same relative precision in bf16/fp16 P, fp32
+// accumulators); that rare rescale and the boundary-tile mask sit in branches in front of the block.
 //
 // Staging: K/V tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction) issued
-// from inline asm so that hipcc neither counts nor drains them; LDS = [K0 K1 V0 V1 | kept list (u16)].  At the
-// head of sub-step (t,0) V(t+1) is issued into V(t-1)'s slot, at the head of (t,1) K(t+2) into K(t)'s slot,
-// each behind a counted vmcnt (the group issued half a tile ago stays in flight) + barrier; every tile has a
-// full tile time to land.  The LDS image is lane-linear, so the XOR swizzle is applied to the per-lane SOURCE
-// chunk (same involution as tile_off on the read side); per-lane source offsets are tile-invariant 32-bit
-// values and the tile only moves a scalar base.
+// from inline asm so that hipcc neither counts nor drains them; LDS = [K0 K1 V0 V1 | kept list (u16)], 64-key tiles.  At the
+// head of sub-step (t,0) V(t+1) is issued into V(t-1)'s slot, at the head of (t,1) K(t+2) into K(t)'s slot, each behind a
+// counted vmcnt (the group issued half a tile ago stays in flight) + barrier; every tile has a full tile time to land.
+// (One wait + barrier + issue point per 64-key TILE -- half the barriers, 8 pieces per issue point -- measured the same:
+// 16.33 vs 16.23 ms, profiles/r03_k5_block.md; not kept.)  The LDS image is lane-linear, so the XOR swizzle is applied to
+// the per-lane SOURCE chunk (same involution as tile_off on the read side); per-lane source offsets are tile-invariant
+// 32-bit values and the tile only moves a scalar base.
+//
+// The chip runs this loop at its board power cap (1.39 kW at 1.72 GHz, tools/clock_probe.py), so cycles saved from stalls
+// come back as a lower clock; what pays is fewer instructions per MFMA: the score chain starts from -m (a 16-register
+// block, C operand of the first QK^T MFMA), so the accumulator is S - m and the softmax needs no subtraction.
 //
 // Semantics kept from the reference kernel (rectified_hunyuan_attn.py:15-105): Q is pre-multiplied by
 // sm_scale*log2(e) and rounded to the input dtype (:61-62), P is rounded to the input dtype before PV (:97),
@@ -36,68 +41,103 @@
 // and a strided [B,S,H,D] store (hunyuan :383-387).
 //
 // (Forms measured and NOT kept in this library -- a ping-pong 8-wave kernel, paired 256-row workgroups over union lists,
-// persistent workgroups, a 256-row dense tile, non-temporal K/V loads, in-kernel stamps: commit c37b5bb holds their code,
-// profiles/r02_experiments.md their numbers.)
+// persistent workgroups, a 256-row dense tile, non-temporal K/V loads, the LDS-DMA pieces spread over the block's MFMA
+// shadows, 16x16x32 MFMAs, one staging point per tile: commit c37b5bb / profiles/r02_experiments.md, profiles/r03_k5_block.md.)
 #include "rsa_attn.h"
+#include "rsa_attn_block.h"
 
-// The pipelined block runs with issue priority 2 and LLVM's small-GEMM MFMA/DS interleave (iglp_opt(0): +1.7 % sparse,
-// +2.7 % dense 16k; strategies 1-3 measured -0.5 ... -3 %; a per-MFMA interleave pinned with sched_group_barrier -3.5 %).
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// The hand-placed pipelined block (gen_k5_block.py): one asm statement per sub-step with every register pinned (register
+// map and operand lists: rsa_attn_block.h, RSA_K5_OPS*; e.g. D = 128: O v[0:63], Q v[64:95], SA v[96:111], SB v[112:127],
+// -m v[128:143]).  S_cur = SA on even sub-steps, SB on odd ones.
+#define RSA_K5_PICK(NAME, DD, TT, OPS, CLOB) \
+    do { \
+        if constexpr (VS == 0 && SUB == 0) asm volatile(NAME##_##DD##_##TT##_V0_S0 OPS : CLOB, "memory"); \
+        else if constexpr (VS == 0 && SUB == 1) asm volatile(NAME##_##DD##_##TT##_V0_S1 OPS : CLOB, "memory"); \
+        else if constexpr (VS == 1 && SUB == 0) asm volatile(NAME##_##DD##_##TT##_V1_S0 OPS : CLOB, "memory"); \
+        else asm volatile(NAME##_##DD##_##TT##_V1_S1 OPS : CLOB, "memory"); \
+    } while (0)
+
+// the product's block: S_cur / S_nxt hold S - m (nm = -m in 16 registers), no subtraction in the softmax
+template <int D, typename Tag, int VS, int SUB, typename KA, typename VA>
+__device__ __forceinline__ void k5_block_nm(f32x16 (&o)[D / 32], const s16x8 (&q)[D / 16], f32x16& S_cur, f32x16& S_nxt,
+                                            const f32x16& nm, float& l, float& mx, const KA& ka, const VA& va) {
+    f32x16& SA = SUB == 0 ? S_cur : S_nxt;
+    f32x16& SB = SUB == 0 ? S_nxt : S_cur;
+    constexpr bool BF = std::is_same<Tag, bf16_tag>::value;
+    if constexpr (D == 128) {
+        if constexpr (BF) RSA_K5_PICK(RSA_K5_BLOCKN, 128, BF16, RSA_K5_OPSN_128, RSA_K5_CLOBBERN_128);
+        else RSA_K5_PICK(RSA_K5_BLOCKN, 128, F16, RSA_K5_OPSN_128, RSA_K5_CLOBBERN_128);
+    } else {
+        if constexpr (BF) RSA_K5_PICK(RSA_K5_BLOCKN, 64, BF16, RSA_K5_OPSN_64, RSA_K5_CLOBBERN_64);
+        else RSA_K5_PICK(RSA_K5_BLOCKN, 64, F16, RSA_K5_OPSN_64, RSA_K5_CLOBBERN_64);
+    }
+}
+#ifdef RSA_K5_FORMS
+// A/B build: the compiled block's arithmetic, hand-placed (S, then S - m by v_sub): bit-identical to the block as hipcc emits it
+template <int D, typename Tag, int VS, int SUB, typename KA, typename VA>
+__device__ __forceinline__ void k5_block(f32x16 (&o)[D / 32], const s16x8 (&q)[D / 16], f32x16& S_cur, f32x16& S_nxt, float m,
+                                         float& l, float& mx, const KA& ka, const VA& va) {
+    f32x16& SA = SUB == 0 ? S_cur : S_nxt;
+    f32x16& SB = SUB == 0 ? S_nxt : S_cur;
+    constexpr bool BF = std::is_same<Tag, bf16_tag>::value;
+    if constexpr (D == 128) {
+        if constexpr (BF) RSA_K5_PICK(RSA_K5_BLOCK, 128, BF16, RSA_K5_OPS_128, RSA_K5_CLOBBER_128);
+        else RSA_K5_PICK(RSA_K5_BLOCK, 128, F16, RSA_K5_OPS_128, RSA_K5_CLOBBER_128);
+    } else {
+        if constexpr (BF) RSA_K5_PICK(RSA_K5_BLOCK, 64, BF16, RSA_K5_OPS_64, RSA_K5_CLOBBER_64);
+        else RSA_K5_PICK(RSA_K5_BLOCK, 64, F16, RSA_K5_OPS_64, RSA_K5_CLOBBER_64);
+    }
+}
+#endif
+
 // WIDE: 16-byte output stores after a permlane32_swap regroup (needs 16-byte aligned output rows), else 8-byte stores.
-template <int D, typename Tag, bool WIDE>
+// FORM: 2 = the product (hand-placed block, score chain started from -m).  The A/B and diagnostics builds (make ab / make
+// diag, -DRSA_K5_FORMS) also carry 1 = the hand-placed block with the compiled block's arithmetic and 0 = the block as hipcc
+// schedules it (round 2's kernel); 0 and 1 are bit-identical to each other, 2 differs from them by the rounding order of S - m.
+template <int D, typename Tag, bool WIDE, int FORM>
 __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
-    constexpr int NW = 4, QT = 1;                // 4 waves x 32 query rows
-    constexpr int QROWS = 32 * NW * QT;          // query rows per workgroup
+    constexpr int NW = 4;                   // 4 waves x 32 query rows
     constexpr int KS = D / 16;
     constexpr int DT = D / 32;
     constexpr int CHR = D / 8;
     constexpr int RPI = 1024 / (D * 2);     // rows per 1-KiB piece
     constexpr int TILE_BYTES = 64 * D * 2;
-    constexpr int NPC = TILE_BYTES / 1024 / NW;  // 1-KiB pieces per wave per tile operand
-    constexpr int PG = NW >= 4 ? 1 : 4 / NW;    // pieces of each group of 4 that this wave moves (1 or 2)
-    constexpr int TEAMS = NW >= 4 ? NW / 4 : 1; // wave teams that alternate over the groups of 4 pieces
+    constexpr int NPC = TILE_BYTES / 1024 / NW;  // 1-KiB pieces per wave per tile operand (4 at head dim 128, 2 at 64)
     using E = Elem<Tag>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned short* lds_list = reinterpret_cast<unsigned short*>(lds + 4 * TILE_BYTES);
 
-    // (Persistent workgroups -- 2 per CU striding over the work items -- were measured: a fresh workgroup costs ~20k cycles of
-    // dispatch, but with two workgroups per CU the partner runs faster meanwhile, and strided workgroups fall into lock step
-    // (all prologues and epilogues at once): 18.1 vs 17.6 ms at 24 heads, 2.26 vs 2.30 ms at 3 heads; not adopted.)
     const int work = blockIdx.x;
     // ---------------- work mapping: dense text-row blocks first, then the sparse blocks chunked per XCD ----------------
     int bh, qblk, tsp = 0;   // tsp: which part of a text block's key range this workgroup walks
-    {
-        const int bid = work;
-        if (bid < a.n_heavy_pad) {
-            const int ntq = a.NQB - a.NBv;
-            const int per_bh = ntq * a.tsplit;      // text blocks x key-range splits (tsplit = 1: no split)
-            if (ntq <= 0 || bid >= a.BH * per_bh) return;
-            bh = bid / per_bh;
-            const int rem = bid % per_bh;
-            qblk = a.NBv + rem / a.tsplit;
-            tsp = rem % a.tsplit;
-        } else {
-            const int v = bid - a.n_heavy_pad;
-            bh = v / a.NBp;
-            const int j = v % a.NBp;
-            const int chunk = a.NBp >> 3;
-            qblk = (j & 7) * chunk + (j >> 3);
-            if (qblk >= a.NBv) return;
-        }
+    if (work < a.n_heavy_pad) {
+        const int ntq = a.NQB - a.NBv;
+        const int per_bh = ntq * a.tsplit;      // text blocks x key-range splits (tsplit = 1: no split)
+        if (ntq <= 0 || work >= a.BH * per_bh) return;
+        bh = work / per_bh;
+        const int rem = work % per_bh;
+        qblk = a.NBv + rem / a.tsplit;
+        tsp = rem % a.tsplit;
+    } else {
+        const int v = work - a.n_heavy_pad;
+        bh = v / a.NBp;
+        const int j = v % a.NBp;
+        const int chunk = a.NBp >> 3;
+        qblk = (j & 7) * chunk + (j >> 3);
+        if (qblk >= a.NBv) return;
     }
     const int b = bh / a.H, h = bh % a.H;
     const int t = threadIdx.x, lane = t & 63;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int r = lane & 31, hh = lane >> 5;
-    const int qb = qblk;
-    int grow[QT];
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) grow[qt] = qblk * QROWS + 32 * QT * wv + 32 * qt + r;
+    const int grow = qblk * 128 + 32 * wv + r;
 
     // ---------------- per-row plan ----------------
-    int lo_r[QT], hi_r[QT];
-    bool store_r[QT], zero_r[QT];
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) { lo_r[qt] = 0; hi_r[qt] = 0; store_r[qt] = false; zero_r[qt] = false; }
+    int lo_r = 0, hi_r = 0;
+    bool store_r = false, zero_r = false;
     int n_items, first_blk = 0, lo_max, hi_min, hi_max;
     const int32_t* list = nullptr;
     bool rectify = false;
@@ -108,8 +148,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
             n_items = a.counts[rowi];
             lo_max = 0; hi_min = hi_max = a.kv_valid;
             rectify = a.R != nullptr;
-#pragma unroll
-            for (int qt = 0; qt < QT; ++qt) { hi_r[qt] = a.kv_valid; store_r[qt] = grow[qt] < a.Sq; }
+            hi_r = a.kv_valid; store_r = grow < a.Sq;
         } else {
             n_items = (a.kv_text_valid + RSA_BLOCK - 1) / RSA_BLOCK;
             if (a.tsplit > 1) {   // split-KV: this workgroup's slice of the key blocks
@@ -118,21 +157,15 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
                 if (n_items < 0) n_items = 0;
             }
             lo_max = 0; hi_min = hi_max = a.kv_text_valid;
-#pragma unroll
-            for (int qt = 0; qt < QT; ++qt) {
-                hi_r[qt] = a.kv_text_valid;
-                store_r[qt] = grow[qt] < a.q_text_end;
-                zero_r[qt] = !store_r[qt] && grow[qt] < a.Sq;
-            }
+            hi_r = a.kv_text_valid;
+            store_r = grow < a.q_text_end;
+            zero_r = !store_r && grow < a.Sq;
         }
     } else {
-        const int row0 = qblk * QROWS, row1 = row0 + QROWS;
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            if (grow[qt] < a.q_split) { lo_r[qt] = 0; hi_r[qt] = a.kv_split; }
-            else { lo_r[qt] = a.kv_split; hi_r[qt] = a.Sk; }
-            store_r[qt] = grow[qt] < a.Sq;
-        }
+        const int row0 = qblk * 128, row1 = row0 + 128;
+        if (grow < a.q_split) { lo_r = 0; hi_r = a.kv_split; }
+        else { lo_r = a.kv_split; hi_r = a.Sk; }
+        store_r = grow < a.Sq;
         int lo_min;
         if (row1 <= a.q_split) { lo_min = 0; lo_max = 0; hi_min = hi_max = a.kv_split; }
         else if (row0 >= a.q_split) { lo_min = lo_max = a.kv_split; hi_min = hi_max = a.Sk; }
@@ -147,9 +180,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
         for (int i = t; i < n_items; i += 64 * NW) lds_list[i] = (unsigned short)list[i];
         __syncthreads();
     }
-    auto blk_of = [&](int item) -> int {
-        return use_list ? (int)lds_list[item] : first_blk + item;
-    };
+    auto blk_of = [&](int item) -> int { return use_list ? (int)lds_list[item] : first_blk + item; };
     int n_tiles = 2 * n_items;
     if (n_items > 0) {
         const int last_blk = blk_of(n_items - 1);
@@ -162,12 +193,12 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
         const int blk = __builtin_amdgcn_readfirstlane(blk_of(it < n_items ? it : (n_items > 0 ? n_items - 1 : 0)));
         return blk * RSA_BLOCK + (tile & 1) * 64;
     };
-    // ---------------- Q fragments (B operand), two 32-row sub-tiles ----------------
-    s16x8 qf[QT][KS];
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        const unsigned short* qp = a.q + (long)b * a.qsb + (long)h * a.qsh + (long)grow[qt] * a.qss + 8 * hh;
-        const bool qok = grow[qt] < a.Sq;
+
+    // ---------------- Q fragments (B operand) ----------------
+    s16x8 qf[KS];
+    {
+        const unsigned short* qp = a.q + (long)b * a.qsb + (long)h * a.qsh + (long)grow * a.qss + 8 * hh;
+        const bool qok = grow < a.Sq;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             uint4 raw = make_uint4(0, 0, 0, 0);
@@ -179,70 +210,62 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
                 f[2 * e] = rsa_to_f32<Tag>((unsigned short)(w4[e] & 0xFFFF)) * a.qk_scale;
                 f[2 * e + 1] = rsa_to_f32<Tag>((unsigned short)(w4[e] >> 16)) * a.qk_scale;
             }
-            qf[qt][ks] = E::cvt8(f);
+            qf[ks] = E::cvt8(f);
         }
     }
 
     // ---------------- LDS-DMA staging ----------------
     const unsigned char* kbase = reinterpret_cast<const unsigned char*>(a.k + (long)b * a.ksb + (long)h * a.ksh);
     const unsigned char* vbase = reinterpret_cast<const unsigned char*>(a.v + (long)b * a.vsb + (long)h * a.vsh);
-    // piece pc = 4*grp + PG*wslot + (j%PG), grp = TEAMS*(j/PG) + team, j = 0..NPC-1: tile rows pc*RPI .. +RPI-1.  The
-    // source-chunk swizzle depends on pc & 3 = PG*wslot + (j%PG): PG per-lane offsets per operand.
-    const int wslot = NW >= 4 ? (wv & 3) : wv, team = NW >= 4 ? (wv >> 2) : 0;
+    // A region of keys is staged in groups of 4 pieces (4 KiB = 4*RPI rows); in every group wave w moves piece w: rows
+    // w*RPI .. +RPI-1 of the group.  The source-chunk swizzle depends on the row inside the group only.
     const int rsub = lane / CHR, cl = lane % CHR;
-    unsigned voffk[PG], voffv[PG];
-    int gsw[PG];
-#pragma unroll
-    for (int par = 0; par < PG; ++par) {
-        const int rowl = (PG * wslot + par) * RPI + rsub;  // row inside the first group of 4 pieces
-        if constexpr (D == 128) gsw[par] = cl ^ (((rowl & 3) << 2) | ((rowl >> 2) & 3));
-        else gsw[par] = cl ^ ((rowl >> 1) & 7);
-        voffk[par] = (unsigned)(((long)rowl * a.kss + gsw[par] * 8) * 2);
-        voffv[par] = (unsigned)(((long)rowl * a.vss + gsw[par] * 8) * 2);
-    }
+    const int rowl = wv * RPI + rsub;  // row inside a group
+    const int gsw = D == 128 ? (cl ^ (((rowl & 3) << 2) | ((rowl >> 2) & 3))) : (cl ^ ((rowl >> 1) & 7));
+    const unsigned voffk = (unsigned)(((long)rowl * a.kss + gsw * 8) * 2);
+    const unsigned voffv = (unsigned)(((long)rowl * a.vss + gsw * 8) * 2);
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
-    const long kstep = (long)(4 * RPI) * a.kss * 2, vstep = (long)(4 * RPI) * a.vss * 2;  // bytes per 4 pieces
-    // is_v: 0 = K tile into K slot `slot`, 1 = V tile into V slot `slot`
-    auto dma = [&](int is_v, int key0, int slot) {
-        const unsigned ld0 = lds_base + (is_v ? 2 : 0) * TILE_BYTES + slot * TILE_BYTES + (PG * wslot) * 1024;
+    const long kstep = (long)(4 * RPI) * a.kss * 2, vstep = (long)(4 * RPI) * a.vss * 2;  // bytes per group
+    // the 64-key tile starting at key `key_first` -> LDS byte offset `lds_off` (tile slots: K0 K1 V0 V1)
+    auto dma = [&](int is_v, int key_first, unsigned lds_off) {
+        const unsigned ld0 = lds_base + lds_off + wv * 1024;
         const unsigned char* base = is_v ? vbase : kbase;
         const long ss = is_v ? a.vss : a.kss;
-        if (key0 + 64 <= kv_limit) {
-            const unsigned char* tb = base + (long)key0 * ss * 2;
+        if (key_first + 64 <= kv_limit) {
+            const unsigned char* tb = base + (long)key_first * ss * 2;
             const long step = is_v ? vstep : kstep;
+            const unsigned vo = is_v ? voffv : voffk;
 #pragma unroll
-            for (int j = 0; j < NPC; ++j) {
-                const unsigned vo = is_v ? voffv[j % PG] : voffk[j % PG];
+            for (int j = 0; j < NPC; ++j)
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                             :: "v"(vo), "s"(tb + (TEAMS * (j / PG) + team) * step),
-                                "s"(ld0 + (TEAMS * (j / PG) + team) * 4096 + (j % PG) * 1024)
-                             : "memory");
-            }
-        } else {
+                             :: "v"(vo), "s"(tb + j * step), "s"(ld0 + j * 4096) : "memory");
+        } else {   // the tile runs past the last valid key: rows clamped (their scores are masked)
 #pragma unroll
             for (int j = 0; j < NPC; ++j) {
-                const int rowl = (PG * wslot + (j % PG)) * RPI + rsub;
-                int krow = key0 + (TEAMS * (j / PG) + team) * 4 * RPI + rowl;
+                int krow = key_first + j * 4 * RPI + rowl;
                 krow = krow < kv_limit ? krow : kv_limit - 1;
-                const unsigned vo = (unsigned)(((long)krow * ss + gsw[j % PG] * 8) * 2);
+                const unsigned vo = (unsigned)(((long)krow * ss + gsw * 8) * 2);
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                             :: "v"(vo), "s"(base), "s"(ld0 + (TEAMS * (j / PG) + team) * 4096 + (j % PG) * 1024)
-                             : "memory");
+                             :: "v"(vo), "s"(base), "s"(ld0 + j * 4096) : "memory");
             }
         }
     };
 
     // ---------------- state ----------------
-    f32x16 o[DT][QT];
+    f32x16 o[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt)
+        for (int i = 0; i < 16; ++i) o[dt][i] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;
+    // m_ref = the finite reference the scores are taken against (S_cur, S_nxt hold S - m_ref), nm = its negation in 16
+    // registers (C operand of the first QK^T MFMA), thr = how far a new row maximum may exceed it before the rescale (-inf
+    // until the row has seen a finite score: the first finite maximum always becomes the reference).  m_run is the running
+    // maximum itself (-inf = nothing seen): what the split-KV partials carry, and the A/B forms' reference.
+    float m_ref = 0.0f, thr = -INFINITY;
+    f32x16 nm;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) o[dt][qt][i] = 0.0f;
-    float m_run[QT], l_run[QT];
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) { m_run[qt] = -INFINITY; l_run[qt] = 0.0f; }
+    for (int i = 0; i < 16; ++i) nm[i] = 0.0f;
 
     // per-lane read addressing
     const int kswz = ((r & 3) << 2) | ((r >> 2) & 3);
@@ -258,147 +281,185 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
         if constexpr (D == 128) return (32 * sub + r) * 256 + (((2 * ks + hh) ^ kswz) << 4);
         else return tile_off<D>(32 * sub + r, 2 * ks + hh);
     };
+    // read addresses of the hand-placed block: LDS byte addresses of sub-tile 0 / slot 0; slot, sub-tile and k-step are immediates
+    using KAv = typename std::conditional<D == 128, i32x8, i32x4>::type;
+    using VAv = typename std::conditional<D == 128, i32x8, i32x4>::type;
+    KAv ka;
+    VAv va;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) ka[ks] = (int)lds_base + k_off(ks, 0);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) { va[2 * dt] = (int)lds_base + vrd[dt][0]; va[2 * dt + 1] = (int)lds_base + vrd[dt][1]; }
 
-    // S^T[qt] (32 keys x 32 rows per qt) = K[sub-tile SUB of K slot] . Q^T ; one K fragment feeds both query sub-tiles
-    auto qk_sub = [&](auto KSLOT, auto SUB, f32x16 (&S)[QT]) {
+    // S^T (32 keys x 32 rows) = K[sub-tile SUB of K slot] . Q^T
+    auto qk_sub = [&](auto KSLOT, auto SUB, f32x16& S) {
         constexpr int slot = decltype(KSLOT)::value, sub = decltype(SUB)::value;
         const unsigned char* kt_ = lds + slot * TILE_BYTES;
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) S[qt][i] = 0.0f;
+        for (int i = 0; i < 16; ++i) S[i] = 0.0f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const s16x8 a0 = *reinterpret_cast<const s16x8*>(kt_ + k_off(ks, sub));
-#pragma unroll
-            for (int qt = 0; qt < QT; ++qt) S[qt] = E::mfma(a0, qf[qt][ks], S[qt]);
+            S = E::mfma(a0, qf[ks], S);
         }
     };
-    auto rowmax_sub = [&](const f32x16 (&S)[QT], float (&mx)[QT]) {
+    auto rowmax_sub = [&](const f32x16& S, float& mx) {
+        float m = S[0];
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            float m = S[qt][0];
-#pragma unroll
-            for (int i = 1; i < 16; ++i) m = fmaxf(m, S[qt][i]);
-            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
-            mx[qt] = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-        }
+        for (int i = 1; i < 16; ++i) m = fmaxf(m, S[i]);
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+        mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
     };
-    auto apply_mask_sub = [&](f32x16 (&S)[QT], int key_first) {
+    auto apply_mask_sub = [&](f32x16& S, int key_first) {
+        int kbase = key_first + 4 * hh;
+        asm volatile("" : "+v"(kbase));   // rare branch: keep its 16 key indices out of the loop's live registers
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int kk = key_first + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                if (kk < lo_r[qt] || kk >= hi_r[qt]) S[qt][i] = -INFINITY;
-            }
+        for (int i = 0; i < 16; ++i) {
+            const int kk = kbase + (i & 3) + 8 * (i >> 2);
+            if (kk < lo_r || kk >= hi_r) S[i] = -INFINITY;
+        }
     };
 
     int kq1 = 0, kq2 = 0;  // first keys of tile+1 / tile+2 (fetched from LDS ahead of use)
+#ifdef RSA_K5_DIAG
+    // diagnostics build: s_memtime at four points of every sub-step, differences summed per wave (scalar registers)
+    unsigned long long tstamp[4] = {0, 0, 0, 0}, tsum[4] = {0, 0, 0, 0}, tkern0;
+    auto stamp_now = [&]() -> unsigned long long {
+        unsigned long long tt;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt) :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        return tt;
+    };
+    tkern0 = stamp_now();
+#define RSA_STAMP(i) do { tstamp[i] = stamp_now(); if ((i) > 0) tsum[i] += tstamp[i] - tstamp[(i) > 0 ? (i) - 1 : 0]; } while (0)
+#else
+#define RSA_STAMP(i) do { } while (0)
+#endif
 
-    // One pipelined sub-step u = 2*tile + SUB: consumes S_cur (scores of 32 keys, row max in mx_cur), produces
-    // S_nxt / mx_nxt for sub-step u+1.  VS = slot parity of `tile` (its K and V slots).
-    //   SUB = 0: head issues V(tile+1);  next scores = K(tile) sub-tile 1
-    //   SUB = 1: head issues K(tile+2);  next scores = K(tile+1) sub-tile 0
-    auto step = [&](auto VS, auto SUB, int tile, int key0, f32x16 (&S_cur)[QT], float (&mx_cur)[QT],
-                    f32x16 (&S_nxt)[QT], float (&mx_nxt)[QT]) {
+    // The part of a sub-step u = 2*tile + SUB behind its staging: rare branches (boundary mask, deferred rescale), then the
+    // pipelined block: consumes S_cur (scores of 32 keys, row max in mx_cur), produces S_nxt / mx_nxt for sub-step u+1.
+    // VS = slot parity of `tile` (its K and V slots); next scores = K(tile) sub-tile 1 (SUB 0) / K(tile+1) sub-tile 0 (SUB 1).
+    auto half = [&](auto VS, auto SUB, int key0, f32x16& S_cur, float& mx_cur, f32x16& S_nxt, float& mx_nxt) {
         constexpr int vs = decltype(VS)::value, sub = decltype(SUB)::value;
-        // the newest DMA group (issued half a tile ago) may stay in flight; the one issued a tile ago must land
+        const int kfirst = key0 + 32 * sub;
+        if (kfirst < lo_max || kfirst + 32 > hi_min) {
+            apply_mask_sub(S_cur, kfirst);
+            rowmax_sub(S_cur, mx_cur);
+        }
+        if constexpr (FORM == 2) {
+            // S_cur, mx_cur are relative to m_ref as it was when they were computed, and that is still m_ref
+            if (__builtin_amdgcn_ballot_w64(mx_cur > thr) != 0ull) {
+                asm volatile("s_nop 11" ::: "memory");   // the block's last MFMA wrote O: 12 wait states before a VALU touches it
+                const bool first = thr == -INFINITY;
+                float delta = first ? mx_cur : fmaxf(mx_cur, 0.0f);
+                if (delta == -INFINITY) delta = 0.0f;      // nothing but masked keys so far
+                else thr = 8.0f;
+                const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);   // (first: O and l are still zero)
+                m_ref += delta;
+                l_run *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { S_cur[i] -= delta; nm[i] = -m_ref; }
+            }
+            RSA_STAMP(2);
+            k5_block_nm<D, Tag, vs, sub>(o, qf, S_cur, S_nxt, nm, l_run, mx_nxt, ka, va);
+            RSA_STAMP(3);
+        }
+#ifdef RSA_K5_FORMS
+        else {   // A/B build: round 2's arithmetic (scores S, reference m_run subtracted in the softmax)
+            if (__builtin_amdgcn_ballot_w64(mx_cur > m_run + 8.0f) != 0ull) {
+                asm volatile("s_nop 11" ::: "memory");
+                const float m_new = fmaxf(m_run, mx_cur);
+                const float mu = (m_new == -INFINITY) ? 0.0f : m_new;
+                const float alpha = __builtin_amdgcn_exp2f(m_run - mu);
+                m_run = m_new;
+                l_run *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+            }
+            const float m_use = (m_run == -INFINITY) ? 0.0f : m_run;
+            RSA_STAMP(2);
+            if constexpr (FORM == 1) {
+                k5_block<D, Tag, vs, sub>(o, qf, S_cur, S_nxt, m_use, l_run, mx_nxt, ka, va);
+            } else {   // the block left to hipcc; iglp_opt(0) = LLVM's small-GEMM MFMA/DS interleave
+                __builtin_amdgcn_s_setprio(2);
+                __builtin_amdgcn_iglp_opt(0);
+                if constexpr (sub == 0) qk_sub(std::integral_constant<int, vs>{}, std::integral_constant<int, 1>{}, S_nxt);
+                else qk_sub(std::integral_constant<int, vs ^ 1>{}, std::integral_constant<int, 0>{}, S_nxt);
+                s16x8 pb[2];
+                float ps = 0.0f;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    float pv8[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        pv8[i] = __builtin_amdgcn_exp2f(S_cur[8 * hf + i] - m_use);
+                        ps += pv8[i];
+                    }
+                    pb[hf] = E::cvt8(pv8);
+                }
+                l_run += ps;
+                const unsigned char* vt_ = lds + (2 + vs) * TILE_BYTES;
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) {
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) {
+                        const int offa = vrd[dt][0] + (2 * sub + k2) * 16 * D * 2;
+                        const int offb = vrd[dt][1] + (2 * sub + k2) * 16 * D * 2;
+                        const s16x4 va_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (s16x4 __attribute__((address_space(3)))*)(vt_ + offa));
+                        const s16x4 vb_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (s16x4 __attribute__((address_space(3)))*)(vt_ + offb));
+                        const s16x8 av = __builtin_shufflevector(va_, vb_, 0, 1, 2, 3, 4, 5, 6, 7);
+                        o[dt] = E::mfma(av, pb[k2], o[dt]);
+                    }
+                }
+                rowmax_sub(S_nxt, mx_nxt);
+                __builtin_amdgcn_s_setprio(0);
+            }
+            RSA_STAMP(3);
+        }
+#endif
+    };
+
+    // staging: a wait + barrier + issue point in front of every sub-step.  SUB 0 issues V(tile+1) into V(tile-1)'s slot,
+    // SUB 1 K(tile+2) into K(tile)'s slot; the newest group (issued half a tile ago) may stay in flight, the one issued a
+    // tile ago must land.
+    auto stage = [&](auto VS, auto SUB, int tile) {
+        constexpr int vs = decltype(VS)::value, sub = decltype(SUB)::value;
+        RSA_STAMP(0);
         if (tile + 1 < n_tiles) {
-            if constexpr (NPC == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if constexpr (NPC == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if constexpr (NPC == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            if constexpr (NPC == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
+        RSA_STAMP(1);
         if constexpr (sub == 0) {
-            if (tile + 1 < n_tiles) dma(1, kq1, vs ^ 1);   // V(tile+1) -> slot of V(tile-1)
+            if (tile + 1 < n_tiles) dma(1, kq1, (2 + (vs ^ 1)) * TILE_BYTES);
         } else {
-            if (tile + 2 < n_tiles) dma(0, kq2, vs);       // K(tile+2) -> slot of K(tile)
+            if (tile + 2 < n_tiles) dma(0, kq2, vs * TILE_BYTES);
         }
-        // ---- head (rare branches): boundary mask, deferred rescale ----
-        const int kfirst = key0 + 32 * sub;
-        if ((kfirst < lo_max || kfirst + 32 > hi_min)) {
-            apply_mask_sub(S_cur, kfirst);
-            rowmax_sub(S_cur, mx_cur);
-        }
-        bool grow_any = false;
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) grow_any |= mx_cur[qt] > m_run[qt] + 8.0f;
-        if (__builtin_amdgcn_ballot_w64(grow_any) != 0ull) {
-#pragma unroll
-            for (int qt = 0; qt < QT; ++qt) {
-                const float m_new = fmaxf(m_run[qt], mx_cur[qt]);
-                const float mu = (m_new == -INFINITY) ? 0.0f : m_new;
-                const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - mu);
-                m_run[qt] = m_new;
-                l_run[qt] *= alpha;
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) o[dt][qt][i] *= alpha;
-            }
-        }
-        float m_use[QT];
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) m_use[qt] = (m_run[qt] == -INFINITY) ? 0.0f : m_run[qt];
-
-        // ---- pipelined block (branch-free on purpose: the scheduler interleaves the MFMA and VALU streams) ----
-        __builtin_amdgcn_s_setprio(2);
-        __builtin_amdgcn_iglp_opt(0);  // LLVM's small-GEMM MFMA/DS interleave for this region
-        if constexpr (sub == 0) qk_sub(std::integral_constant<int, vs>{}, std::integral_constant<int, 1>{}, S_nxt);
-        else qk_sub(std::integral_constant<int, vs ^ 1>{}, std::integral_constant<int, 0>{}, S_nxt);
-        s16x8 pb[QT][2];
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            float ps = 0.0f;
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                float pv8[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    pv8[i] = __builtin_amdgcn_exp2f(S_cur[qt][8 * hf + i] - m_use[qt]);
-                    ps += pv8[i];
-                }
-                pb[qt][hf] = E::cvt8(pv8);
-            }
-            l_run[qt] += ps;
-        }
-        const unsigned char* vt_ = lds + (2 + vs) * TILE_BYTES;
-#pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) {
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                const int offa = vrd[dt][0] + (2 * sub + k2) * 16 * D * 2;
-                const int offb = vrd[dt][1] + (2 * sub + k2) * 16 * D * 2;
-                const s16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (s16x4 __attribute__((address_space(3)))*)(vt_ + offa));
-                const s16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (s16x4 __attribute__((address_space(3)))*)(vt_ + offb));
-                const s16x8 av = __builtin_shufflevector(va, vb, 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-                for (int qt = 0; qt < QT; ++qt) o[dt][qt] = E::mfma(av, pb[qt][k2], o[dt][qt]);
-            }
-        }
-        rowmax_sub(S_nxt, mx_nxt);
-        __builtin_amdgcn_s_setprio(0);
     };
 
     // ---------------- prologue + main loop ----------------
-    f32x16 SA[QT], SB[QT];
-    float mxA[QT], mxB[QT];
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) { mxA[qt] = -INFINITY; mxB[qt] = -INFINITY; }
+    f32x16 SA, SB;
+    float mxA = -INFINITY, mxB = -INFINITY;
     int key0 = 0;
     if (n_tiles > 0) {
         key0 = key0_of(0);
         kq1 = key0_of(1);
         kq2 = key0_of(2);
         dma(0, key0, 0);
-        dma(1, key0, 0);
-        if (n_tiles > 1) dma(0, kq1, 1);
+        dma(1, key0, 2 * TILE_BYTES);
+        if (n_tiles > 1) dma(0, kq1, TILE_BYTES);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         qk_sub(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, SA);
@@ -412,61 +473,60 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
     {
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
+        auto tile_step = [&](auto VS, int tile) {
+            stage(VS, I0{}, tile);
+            half(VS, I0{}, key0, SA, mxA, SB, mxB);
+            stage(VS, I1{}, tile);
+            half(VS, I1{}, key0, SB, mxB, SA, mxA);
+        };
         int tile = 0;
         for (; tile + 1 < n_tiles; tile += 2) {
-            step(I0{}, I0{}, tile, key0, SA, mxA, SB, mxB);
-            step(I0{}, I1{}, tile, key0, SB, mxB, SA, mxA);
+            tile_step(I0{}, tile);
             advance(tile);
-            step(I1{}, I0{}, tile + 1, key0, SA, mxA, SB, mxB);
-            step(I1{}, I1{}, tile + 1, key0, SB, mxB, SA, mxA);
+            tile_step(I1{}, tile + 1);
             advance(tile + 1);
         }
-        if (tile < n_tiles) {
-            step(I0{}, I0{}, tile, key0, SA, mxA, SB, mxB);
-            step(I0{}, I1{}, tile, key0, SB, mxB, SA, mxA);
-        }
+        if (tile < n_tiles) tile_step(I0{}, tile);
     }
 
     // ---------------- epilogue ----------------
+    asm volatile("s_nop 11" ::: "memory");   // (the last block's last MFMA -> the reads of O below)
+    if constexpr (FORM == 2) m_run = thr == -INFINITY ? -INFINITY : m_ref;
+    const auto swl = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+    const float l_tot = __uint_as_float(swl[0]) + __uint_as_float(swl[1]);
+    bool done = false;
+    if (a.mode == MODE_SPARSE && a.tsplit > 1 && qblk >= a.NBv) {
+        // split-KV partial of a text block: unnormalised O (fp32), m (log2 domain) and l per row; the combine
+        // kernel (rsa_attn.hip) merges the tsplit parts
+        const int ntq = a.NQB - a.NBv;
+        const int rowb = 32 * wv + r;
+        float* pp = a.tpart + ((((long)bh * ntq + (qblk - a.NBv)) * a.tsplit + tsp) * RSA_BLOCK + rowb) * (D + 2);
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run[qt]), __float_as_uint(l_run[qt]),
-                                                         false, false);
-        const float l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-        {
-            if (a.mode == MODE_SPARSE && a.tsplit > 1 && qblk >= a.NBv) {
-                // split-KV partial of a text block: unnormalised O (fp32), m (log2 domain) and l per row; the combine
-                // kernel (rsa_attn.hip) merges the tsplit parts
-                const int ntq = a.NQB - a.NBv;
-                const int rowb = 32 * QT * wv + 32 * qt + r;
-                float* pp = a.tpart + ((((long)bh * ntq + (qblk - a.NBv)) * a.tsplit + tsp) * RSA_BLOCK + rowb) * (D + 2);
+        for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int d0 = 32 * dt + 8 * g + 4 * hh;
-                        *reinterpret_cast<float2*>(pp + d0) = make_float2(o[dt][qt][4 * g + 0], o[dt][qt][4 * g + 1]);
-                        *reinterpret_cast<float2*>(pp + d0 + 2) = make_float2(o[dt][qt][4 * g + 2], o[dt][qt][4 * g + 3]);
-                    }
-                if (hh == 0) *reinterpret_cast<float2*>(pp + D) = make_float2(m_run[qt], l_tot);
-                continue;
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = 32 * dt + 8 * g + 4 * hh;
+                *reinterpret_cast<float2*>(pp + d0) = make_float2(o[dt][4 * g + 0], o[dt][4 * g + 1]);
+                *reinterpret_cast<float2*>(pp + d0 + 2) = make_float2(o[dt][4 * g + 2], o[dt][4 * g + 3]);
             }
-        }
-        if (!(store_r[qt] || zero_r[qt])) continue;
+        if (hh == 0) *reinterpret_cast<float2*>(pp + D) = make_float2(m_run, l_tot);
+        done = true;
+    }
+    if (!done && (store_r || zero_r)) {
         float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
         float Rv = 1.0f;
         const float* cp = nullptr;
         if (rectify) {
-            const long rowi = (long)bh * a.NBv + qb;
+            const long rowi = (long)bh * a.NBv + qblk;
             Rv = a.R[rowi];
             cp = a.comp + rowi * D;
         }
-        if (zero_r[qt]) inv = 0.0f;
+        if (zero_r) inv = 0.0f;
         const float sc = inv * Rv;
-        unsigned short* op = a.out + (long)b * a.osb + (long)h * a.osh + (long)grow[qt] * a.oss;
+        unsigned short* op = a.out + (long)b * a.osb + (long)h * a.osh + (long)grow * a.oss;
         // O * sc + comp: one fma rounded to fp32, THEN the conversion to the storage type (what the oracle does).  Left alone,
         // hipcc folds fma + conversion into v_fma_mixlo_f16 (one rounding, straight to fp16) in one store form and not in the
-        // other; the empty asm keeps the fp32 value, so every instantiation (4-wave, 8-wave, paired) writes the same bytes.
+        // other; the empty asm keeps the fp32 value, so both store forms write the same bytes.
         auto fin = [&](float acc, float c) -> float {
             float rr = __builtin_fmaf(acc, sc, c);
             asm volatile("" : "+v"(rr));
@@ -486,11 +546,11 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
                         const int g = 2 * gp + gi;
                         const int d0 = 32 * dt + 8 * g + 4 * hh;
                         float4 c4 = make_float4(0, 0, 0, 0);
-                        if (cp && !zero_r[qt]) c4 = *reinterpret_cast<const float4*>(cp + d0);
-                        const float v0 = fin(o[dt][qt][4 * g + 0], c4.x);
-                        const float v1 = fin(o[dt][qt][4 * g + 1], c4.y);
-                        const float v2 = fin(o[dt][qt][4 * g + 2], c4.z);
-                        const float v3 = fin(o[dt][qt][4 * g + 3], c4.w);
+                        if (cp && !zero_r) c4 = *reinterpret_cast<const float4*>(cp + d0);
+                        const float v0 = fin(o[dt][4 * g + 0], c4.x);
+                        const float v1 = fin(o[dt][4 * g + 1], c4.y);
+                        const float v2 = fin(o[dt][4 * g + 2], c4.z);
+                        const float v3 = fin(o[dt][4 * g + 3], c4.w);
                         pk[gi].x = (unsigned)E::from_f32(v0) | ((unsigned)E::from_f32(v1) << 16);
                         pk[gi].y = (unsigned)E::from_f32(v2) | ((unsigned)E::from_f32(v3) << 16);
                     }
@@ -502,37 +562,58 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
                     *reinterpret_cast<uint4*>(op + 32 * dt + 8 * (2 * gp + hh)) = w4;
                 }
             }
-            continue;
-        }
+        } else {
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
+            for (int dt = 0; dt < DT; ++dt) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d0 = 32 * dt + 8 * g + 4 * hh;
-                float4 c4 = make_float4(0, 0, 0, 0);
-                if (cp && !zero_r[qt]) c4 = *reinterpret_cast<const float4*>(cp + d0);
-                const float v0 = fin(o[dt][qt][4 * g + 0], c4.x);
-                const float v1 = fin(o[dt][qt][4 * g + 1], c4.y);
-                const float v2 = fin(o[dt][qt][4 * g + 2], c4.z);
-                const float v3 = fin(o[dt][qt][4 * g + 3], c4.w);
-                uint2 pk;
-                pk.x = (unsigned)E::from_f32(v0) | ((unsigned)E::from_f32(v1) << 16);
-                pk.y = (unsigned)E::from_f32(v2) | ((unsigned)E::from_f32(v3) << 16);
-                *reinterpret_cast<uint2*>(op + d0) = pk;
+                for (int g = 0; g < 4; ++g) {
+                    const int d0 = 32 * dt + 8 * g + 4 * hh;
+                    float4 c4 = make_float4(0, 0, 0, 0);
+                    if (cp && !zero_r) c4 = *reinterpret_cast<const float4*>(cp + d0);
+                    const float v0 = fin(o[dt][4 * g + 0], c4.x);
+                    const float v1 = fin(o[dt][4 * g + 1], c4.y);
+                    const float v2 = fin(o[dt][4 * g + 2], c4.z);
+                    const float v3 = fin(o[dt][4 * g + 3], c4.w);
+                    uint2 pk;
+                    pk.x = (unsigned)E::from_f32(v0) | ((unsigned)E::from_f32(v1) << 16);
+                    pk.y = (unsigned)E::from_f32(v2) | ((unsigned)E::from_f32(v3) << 16);
+                    *reinterpret_cast<uint2*>(op + d0) = pk;
+                }
             }
         }
     }
+#ifdef RSA_K5_DIAG
+    if (a.dbg && lane == 0) {
+        const unsigned long long tend = stamp_now();
+        unsigned long long* o8 = a.dbg + ((long)work * 4 + wv) * 8;
+        o8[0] = tsum[1]; o8[1] = tsum[2]; o8[2] = tsum[3]; o8[3] = tend - tkern0; o8[4] = (unsigned long long)n_tiles;
+        o8[5] = (unsigned long long)qblk; o8[6] = tkern0; o8[7] = tend;
+    }
+#endif
 }
 
 // launch hook used by rsa_attn.hip::launch_attn
+#ifdef RSA_K5_FORMS
+int g_rsa_k5_form = 2;   // A/B and diagnostics builds: tuning key "k5_form" (see the FORM template parameter)
+#endif
 int rsa_launch_bsfwd(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int dtype, hipStream_t s) {
     // the 16-byte output stores need 16-byte aligned rows; anything else takes the 8-byte form
     const bool wide = !(((uintptr_t)a.out & 15) || ((a.osb | a.osh | a.oss) & 7));
+#ifdef RSA_K5_FORMS
 #define RSA_K5(DD, TT) \
     do { \
-        if (wide) bsfwd_kernel<DD, TT, true><<<grid, 256, lds_bytes, s>>>(a); \
-        else bsfwd_kernel<DD, TT, false><<<grid, 256, lds_bytes, s>>>(a); \
+        if (!wide) bsfwd_kernel<DD, TT, false, 2><<<grid, 256, lds_bytes, s>>>(a); \
+        else if (g_rsa_k5_form == 0) bsfwd_kernel<DD, TT, true, 0><<<grid, 256, lds_bytes, s>>>(a); \
+        else if (g_rsa_k5_form == 1) bsfwd_kernel<DD, TT, true, 1><<<grid, 256, lds_bytes, s>>>(a); \
+        else bsfwd_kernel<DD, TT, true, 2><<<grid, 256, lds_bytes, s>>>(a); \
     } while (0)
+#else
+#define RSA_K5(DD, TT) \
+    do { \
+        if (wide) bsfwd_kernel<DD, TT, true, 2><<<grid, 256, lds_bytes, s>>>(a); \
+        else bsfwd_kernel<DD, TT, false, 2><<<grid, 256, lds_bytes, s>>>(a); \
+    } while (0)
+#endif
     if (D == 128) {
         if (dtype == RSA_BF16) RSA_K5(128, bf16_tag); else RSA_K5(128, fp16_tag);
     } else {

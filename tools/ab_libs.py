@@ -63,7 +63,7 @@ def main():
         name, rest = a.split("=", 1)
         parts = rest.split(":")
         path, nbuf = parts[0], int(parts[1]) if len(parts) > 1 and parts[1] else 15
-        flags = parts[2].split(",") if len(parts) > 2 else []   # o8: output rows 8-byte aligned only; nots: no split-KV
+        flags = parts[2].split(",") if len(parts) > 2 else []   # o8: output rows 8-byte aligned only; nots: no split-KV; key=value: rsa_set_tuning before every call
         L, Buf = load(path, nbuf)
         ptrs = [call.bufs[n].data_ptr() for n in FIRST14]
         extra = [None] * (nbuf - 14)
@@ -76,9 +76,17 @@ def main():
         else:
             out = torch.empty_like(call.out)
         o4 = RsaOut4(out.data_ptr(), out.stride(0), out.stride(2), out.stride(1))
-        libs.append(dict(name=name, L=L, cb=cb, out=out, o4=o4, ts=[], td=[]))
+        tune = [(f.split("=")[0].encode(), int(f.split("=")[1])) for f in flags if "=" in f]   # e.g. k5_blk=2
+        if tune:
+            L.rsa_set_tuning.argtypes = [ctypes.c_char_p, ctypes.c_int]
+        libs.append(dict(name=name, L=L, cb=cb, out=out, o4=o4, ts=[], td=[], tune=tune))
+
+    def apply_tuning(lib):
+        for key, val in lib["tune"]:
+            assert lib["L"].rsa_set_tuning(key, val) == 0, (lib["name"], key)
 
     def run(lib):
+        apply_tuning(lib)
         rc = lib["L"].rsa_block_sparse_fwd(ctypes.byref(call.lay), *call.t, ctypes.byref(lib["cb"]), lib["o4"], st)
         assert rc == 0, (lib["name"], rc)
 
@@ -89,6 +97,7 @@ def main():
     fld = 4.0 * Sd * Sd * 128 * H
 
     def run_dense(lib):
+        apply_tuning(lib)
         rc = lib["L"].rsa_dense_fwd(1, H, Sd, Sd, 128, 0, _core._t4(qd), _core._t4(kd), _core._t4(vd), Sd, Sd, od4, st)
         assert rc == 0, (lib["name"], rc)
 
