@@ -228,9 +228,70 @@ class Comm:
             self.dist.barrier()
         self.local_sync()
 
+    def all_ok(self, ok: bool) -> bool:
+        """True only if EVERY rank says ok (a rank that failed inside a guarded stage must not leave its peers inside
+        that stage's collectives: all ranks agree here first, then skip the stage together)."""
+        if self.dist is None:
+            return ok
+        import torch
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.stat_dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return bool(t.item())
+
     def close(self):
         if self.dist is not None:
             self.dist.destroy_process_group()
+
+
+class SmiSampler:
+    """Clock / power telemetry over a timed window: `rocm-smi --showclocks --showpower --json` polled from a thread (about
+    4 samples per second).  The kernels run at the board's power cap, so the clock the chip holds is part of the result."""
+
+    def __init__(self, period=0.25):
+        import threading
+        self.period, self.rows, self._stop = period, [], False
+        self._t = threading.Thread(target=self._run, daemon=True)
+
+    @staticmethod
+    def _num(x):
+        import re
+        m = re.search(r"[-+]?\d+(\.\d+)?", str(x))
+        return float(m.group(0)) if m else None
+
+    def _run(self):
+        while not self._stop:
+            try:
+                r = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True,
+                                   timeout=5)
+                c = json.loads(r.stdout).get("card0", {})
+                row = {}
+                for k_, v_ in c.items():
+                    kl = k_.lower()
+                    if "sclk clock speed" in kl: row["sclk_mhz"] = self._num(v_)
+                    elif "mclk clock speed" in kl: row["mclk_mhz"] = self._num(v_)
+                    elif "power" in kl and "(w)" in kl: row["power_w"] = self._num(v_)
+                if row:
+                    self.rows.append(row)
+            except Exception:  # noqa: BLE001  (telemetry is best effort)
+                pass
+            time.sleep(self.period)
+
+    def __enter__(self):
+        self._t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        self._t.join(timeout=6)
+
+    def summary(self):
+        rows = self.rows[2:] if len(self.rows) > 4 else self.rows   # the first samples still see the ramp
+        out = {"samples": len(rows)}
+        for key in ("sclk_mhz", "mclk_mhz", "power_w"):
+            vals = [r_[key] for r_ in rows if r_.get(key) is not None]
+            if vals:
+                out[key] = {"min": min(vals), "max": max(vals), "mean": round(sum(vals) / len(vals), 1)}
+        return out
 
 
 def timed_steps(comm, step, steps, warmup, events=None, want_busy=False):
@@ -448,45 +509,71 @@ def main():
                 call.quantize()
             call.attend()
             parallel.gather_heads(call.out)
-        try:
-            elg = timed_steps(comm, gstep, args.steps, max(1, args.warmup))
-            elg, _, _, _, per_rank_g = parallel.reduce_step_stats(elg, 0.0, 0.0, 0.0, comm.stat_dev)
-            gather = dict(ms_per_step=round(elg / args.steps * 1e3, 4),
-                          value=round(rec["flops"] / (elg / args.steps) / 1e12, 3),
-                          bytes_per_rank=int(call.out.numel() * call.out.element_size()),
-                          transport="torch.distributed all_gather (RCCL)")
-        except Exception as e:  # noqa: BLE001  (the headline value above does not depend on the exchange step)
-            gather = {"error": repr(e)[:300]}
+        # (a failure inside a collective cannot be caught rank by rank -- the peers would hang in it --, so these timed
+        # stages run unguarded: an exception takes the job down through torch.distributed.run.  What CAN fail on one rank
+        # alone, the set-up of the library's own transports below, is agreed on across ranks before anyone enters it.)
+        elg = timed_steps(comm, gstep, args.steps, max(1, args.warmup))
+        elg, _, _, _, per_rank_g = parallel.reduce_step_stats(elg, 0.0, 0.0, 0.0, comm.stat_dev)
+        gather = dict(ms_per_step=round(elg / args.steps * 1e3, 4),
+                      value=round(rec["flops"] / (elg / args.steps) / 1e12, 3),
+                      bytes_per_rank=int(call.out.numel() * call.out.element_size()),
+                      transport="torch.distributed all_gather (RCCL)")
         for tr in [t for t in args.gather_transports.split(",") if t]:
-            try:   # the library's own transports (C-ABI); a failure is reported, it does not take the run down
-                B_, S_, Hl_, D_ = call.out.shape
+            B_, S_, Hl_, D_ = call.out.shape
+            hg, err = None, None
+            try:   # the library's own transports (C-ABI): the set-up may fail on one rank (librccl missing, IPC refused)
                 hg = parallel.HeadGather(B_, S_, Hl_, D_, call.out.dtype, dev, transport=tr)
-
-                def hstep(_):
-                    call.select()
-                    if args.qkv_fp8:
-                        call.quantize()
-                    call.attend()
-                    hg.gather(call.out)
-                elh = timed_steps(comm, hstep, args.steps, max(1, args.warmup))
-                elh, _, _, _, _ = parallel.reduce_step_stats(elh, 0.0, 0.0, 0.0, comm.stat_dev)
-                gather[tr] = dict(ms_per_step=round(elh / args.steps * 1e3, 4),
-                                  value=round(rec["flops"] / (elh / args.steps) / 1e12, 3))
-                hg.close()
             except Exception as e:  # noqa: BLE001
-                gather[tr] = {"error": repr(e)[:300]}
+                err = repr(e)[:300]
+            if not comm.all_ok(hg is not None):   # all ranks skip the stage together
+                if hg is not None:
+                    hg.close()
+                gather[tr] = {"error": err or "set-up failed on another rank"}
+                continue
+
+            def hstep(_):
+                call.select()
+                if args.qkv_fp8:
+                    call.quantize()
+                call.attend()
+                hg.gather(call.out)
+            elh = timed_steps(comm, hstep, args.steps, max(1, args.warmup))
+            elh, _, _, _, _ = parallel.reduce_step_stats(elh, 0.0, 0.0, 0.0, comm.stat_dev)
+            gather[tr] = dict(ms_per_step=round(elh / args.steps * 1e3, 4),
+                              value=round(rec["flops"] / (elh / args.steps) / 1e12, 3))
+            hg.close()
     if world == 1 and not args.no_extras:
-        # sustained: >= 2 s of back-to-back steps of the headline regime (what a power / utilisation sampler can see)
-        n_sus = max(args.steps, int(2.2 / max(rec["ms_per_step"] * 1e-3, 1e-4)))
+        # sustained: >= 6 s of back-to-back steps of the headline regime, with the clock / power the chip holds meanwhile
+        n_sus = max(args.steps, int(6.5 / max(rec["ms_per_step"] * 1e-3, 1e-4)))
 
         def sstep(_):
             call.select()
             if args.qkv_fp8:
                 call.quantize()
             call.attend()
-        els = timed_steps(comm, sstep, n_sus, 0)
+        with SmiSampler() as smi:
+            els = timed_steps(comm, sstep, n_sus, 0)
         extras["sustained"] = dict(steps=n_sus, seconds=round(els, 3), ms_per_step=round(els / n_sus * 1e3, 4),
-                                   value=round(rec["flops"] / (els / n_sus) / 1e12, 3))
+                                   value=round(rec["flops"] / (els / n_sus) / 1e12, 3), smi=smi.summary())
+        # box calibration: the SAME kernel in dense mode on a fixed 16k x 16k x 24-head problem (L2-resident K/V): devices
+        # differ by several percent on this loop, so every line carries its own reference point
+        try:
+            from rectified_spaattn_amd import _core as _c
+            gq = torch.Generator(device=dev).manual_seed(11)
+            qd = torch.randn(1, 24, 16384, D, device=dev, generator=gq).to(torch.bfloat16)
+            for _ in range(2):
+                _c.dense_attention(qd, qd, qd, qkv_fp8=args.qkv_fp8)
+            evd = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(8)]
+            for a_, b_ in evd:
+                a_.record(); _c.dense_attention(qd, qd, qd, qkv_fp8=args.qkv_fp8); b_.record()
+            torch.cuda.synchronize()
+            msd = sorted(a_.elapsed_time(b_) for a_, b_ in evd)[len(evd) // 2]
+            extras["box_ref"] = dict(what="dense attention 1 x 24 x 16384 x 128 bf16 inputs through the same K5 kernel "
+                                          "(fp8 line: incl. its quantisation pass), median of 8",
+                                     ms=round(msd, 4), tflops=round(4.0 * 16384 * 16384 * D * 24 / (msd * 1e-3) / 1e12, 1))
+            del qd
+        except Exception as e:  # noqa: BLE001
+            extras["box_ref"] = {"error": repr(e)[:200]}
         if not args.qkv_fp8 and wl["variant"] == "hunyuan" and main_regime == "r2":
             extras["api"] = api_record(comm, wl, spec, q, k, v, args.steps, args.warmup, rec["ms_per_step"],
                                        args.via_api)
@@ -508,7 +595,7 @@ def main():
                             ms_per_step=round(r2["ms_per_step"], 4), value=round(r2["value"], 3),
                             k5_ms=round(r2["k5_ms"], 4), k5_tflops=round(r2["k5_tflops"], 2),
                             k5_frac=round(r2["k5_tflops"] / peak_, 4), select_pass_ms=round(r2["select_pass_ms"], 4))
-            tb, _ = load_traffic(f"r02_k5_traffic_{rg}.json")
+            tb, _ = load_traffic(f"r03_k5_traffic_{rg}.json")
             regs[rg]["traffic"] = tb
         extras["regimes"] = regs
 
@@ -517,7 +604,7 @@ def main():
         return
 
     peak = MFMA_FP8_PEAK_TFLOPS if args.qkv_fp8 else MFMA_BF16_PEAK_TFLOPS
-    tname = f"r02_k5_traffic_{main_regime}{'_fp8' if args.qkv_fp8 else ''}.json"
+    tname = f"r03_k5_traffic_{main_regime}{'_fp8' if args.qkv_fp8 else ''}.json"
     traffic, tnote = (None, "N > 1: traffic is collected at N = 1")
     if world == 1 and args.workload == "hunyuan_720p_128f":
         traffic, tnote = load_traffic(tname)
@@ -550,6 +637,10 @@ def main():
     if args.gather_output and gather is not None and "value" in gather:  # headline = the gather-inclusive variant
         res["value"], res["ms_per_step"] = gather["value"], gather["ms_per_step"]
     res.update(extras)
+    if "sustained" in extras:
+        res["roofline"]["clock"] = extras["sustained"].get("smi")
+    if "box_ref" in extras:
+        res["roofline"]["box_ref"] = extras["box_ref"]
     if world == 1:
         if args.no_cpu_baseline:
             res["cpu_baseline"] = None

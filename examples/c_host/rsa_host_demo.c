@@ -28,6 +28,10 @@ int main(int argc, char** argv) {
     const size_t n = (size_t)B * H * S * D, bytes = n * 2;
 
     rsa_layout lay;
+    if (rsa_version() < 300) {   /* this host was built against the 0.3 header (rsa_buffers: 15 members) */
+        fprintf(stderr, "librsa_hip %d is older than the header this demo was built with\n", rsa_version());
+        return 1;
+    }
     memset(&lay, 0, sizeof lay);
     lay.B = B; lay.H = H; lay.D = D; lay.S = S;
     lay.NB_total = (S + RSA_BLOCK - 1) / RSA_BLOCK;

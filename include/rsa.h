@@ -64,7 +64,9 @@ typedef struct rsa_out4 {
     int64_t stride_b, stride_h, stride_s;
 } rsa_out4;
 
-/* Sizes (in elements) of the intermediate buffers for a layout; all are per call. */
+/* Sizes (in elements) of the intermediate buffers for a layout; all are per call.  Fill the struct with
+ * rsa_carve_workspace, or zero it first (memset) and set the members by hand: a member this header adds in a later
+ * version is then NULL = "feature not used" (check rsa_version() >= 300 for this layout: 15 members). */
 typedef struct rsa_buffers {
     float* qbar;      /* [BH, NBv, D]       block means of visual Q            */
     float* aq;        /* [BH, NBv, D]       mean |Q - qbar|                    */
@@ -262,15 +264,22 @@ int rsa_comm_destroy(void* comm);
 int rsa_allgather_heads(void* comm, int world, const void* local, void* staging, void* full, int64_t rows,
                         int64_t local_row_bytes, void* stream);
 
-/* The same exchange as `world` 2-D peer copies over the point-to-point xGMI links, no staging: this rank writes its
- * slab into column range [rank*local_row_bytes, +local_row_bytes) of every rank's full buffer.  full_of_rank: HOST
- * array of `world` device pointers (own buffer at index rank; the others opened with rsa_ipc_open).  Completion on the
- * peers is the caller's to order (a barrier after the stream has drained). */
-int rsa_allgather_heads_p2p(int world, int rank, const void* local, void* const* full_of_rank, int64_t rows,
-                            int64_t local_row_bytes, void* stream);
+/* The same exchange written straight into the peers: ONE copy kernel whose workgroups are dealt over the peers (all xGMI
+ * links carry their slab at once; 16-byte stores into column range [rank*local_row_bytes, +local_row_bytes) of every
+ * rank's full buffer), arrival signalled through IPC-shared device flags and awaited by a one-workgroup kernel on the same
+ * stream: stream-ordered end to end, no host barrier, no host synchronisation.
+ *   full_of_rank / state_of_rank: HOST arrays of `world` device pointers (own buffers at index rank; the others opened with
+ *   rsa_ipc_open + rsa_ipc_offset).  state = rsa_p2p_state_bytes() bytes per rank, zeroed ONCE by its owner before the
+ *   first exchange; its word 1 turns nonzero (missing rank + 1) if a wait gave up after 4 s.
+ * Every rank must call this the same number of times.  A rank may overwrite a peer's full buffer as soon as that peer has
+ * issued its NEXT exchange, so alternate between two full buffers and consume each on the stream that issued the exchange. */
+int rsa_p2p_state_bytes(void);
+int rsa_allgather_heads_p2p(int world, int rank, const void* local, void* const* full_of_rank, void* const* state_of_rank,
+                            int64_t rows, int64_t local_row_bytes, void* stream);
 int rsa_ipc_export(const void* dev_ptr, void* handle64);                    /* 64-byte handle of a device allocation */
 int rsa_ipc_open(const void* handle64, int peer_device, void** dev_ptr);    /* map a peer's allocation here */
 int rsa_ipc_close(void* dev_ptr);
+int rsa_ipc_offset(const void* dev_ptr, int64_t* offset);                   /* dev_ptr - base of its allocation (a handle names the allocation) */
 
 /* Tuning / diagnostics hook, not part of the data path.  Keys: "k5_tsplit" (0/1: split-KV of the text query blocks),
  * "k3_prefix" (0/1: sorted-head path of K3), "fp8_variant" (0..4: iglp_opt strategy of the fp8 kernel's block).  The hook

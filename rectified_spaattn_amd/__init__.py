@@ -16,7 +16,7 @@ reference's own code paths: fullattn(mode="torch" | "vanilla") on CPU tensors (B
 teacache.rel_l1_distance for CPU tensors / small fp32 inputs such as timestep embeddings (bf16 / fp16 device tensors take
 the one-pass HIP reduction rsa_rel_l1).
 """
-__version__ = "0.2.0"
+__version__ = "0.3.0"
 
 
 def set_qkv_fp8(enabled: bool) -> bool:
@@ -31,3 +31,11 @@ def set_dense_fp8(enabled: bool) -> bool:
     setting.  Default off."""
     from . import _operator
     return _operator.set_dense_fp8(enabled)
+
+
+def clear_buffer_cache() -> None:
+    """Drops the intermediate buffers the operators keep per (geometry, device, stream) between calls (about 0.45 GB per
+    set at the HunyuanVideo shape; `_core.BUFFER_CACHE_MAX_BYTES` bounds the total, `_core.BUFFER_CACHE = False` turns the
+    cache off).  Calls inside a HIP-graph capture never use the cache."""
+    from . import _core
+    _core.clear_buffer_cache()

@@ -144,26 +144,35 @@ def alloc_buffers(spec: LayoutSpec, B: int, H: int, D: int, device) -> Dict[str,
 # intermediates are cached -- the output tensor is always fresh, as in the reference.  Stream-ordered reuse is safe;
 # a different stream gets its own set.  A few entries at most (0.4 GB each at the HunyuanVideo shape).
 _BUF_CACHE: "Dict[tuple, Dict[str, torch.Tensor]]" = {}
-_BUF_CACHE_MAX = 4
-BUFFER_CACHE = True
+BUFFER_CACHE = True                    # set False to allocate per call (e.g. while debugging memory)
+BUFFER_CACHE_MAX_BYTES = 2 << 30       # least recently used sets are dropped beyond this (0.45 GB per set at the Hunyuan shape)
+
+
+def _set_bytes(bufs: Dict[str, torch.Tensor]) -> int:
+    return sum(t.numel() * t.element_size() for t in bufs.values())
 
 
 def cached_buffers(spec: LayoutSpec, B: int, H: int, D: int, device) -> Dict[str, torch.Tensor]:
-    if not BUFFER_CACHE:
-        return alloc_buffers(spec, B, H, D, device)
+    """Intermediate buffers reused across calls of one geometry on one stream.  Never during a HIP-graph capture: a
+    captured launch bakes the pointers in, and an entry evicted later would hand that memory to someone else while the
+    graph still writes to it -- captured calls get their own buffers (owned by the capture's allocator pool)."""
     dev = torch.device(device)
+    if not BUFFER_CACHE or (dev.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+        return alloc_buffers(spec, B, H, D, device)
     stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
     key = (dev.type, dev.index, stream, B, H, D, spec.S, spec.NB_total, spec.NBv, spec.n_txt)
     hit = _BUF_CACHE.pop(key, None)
     if hit is None:
-        while len(_BUF_CACHE) >= _BUF_CACHE_MAX:
-            _BUF_CACHE.pop(next(iter(_BUF_CACHE)))
         hit = alloc_buffers(spec, B, H, D, device)
+        total = _set_bytes(hit) + sum(_set_bytes(b_) for b_ in _BUF_CACHE.values())
+        while _BUF_CACHE and total > BUFFER_CACHE_MAX_BYTES:
+            total -= _set_bytes(_BUF_CACHE.pop(next(iter(_BUF_CACHE))))
     _BUF_CACHE[key] = hit  # most recently used last
     return hit
 
 
 def clear_buffer_cache() -> None:
+    """Drops every cached buffer set (they return to PyTorch's allocator)."""
     _BUF_CACHE.clear()
 
 

@@ -106,13 +106,19 @@ def valid_keys(attention_mask, default: int, num_true: Optional[int] = None) -> 
         return int(num_true)
     if attention_mask is None:
         return default
+    try:   # (inference-mode tensors have no version counter: reading it raises RuntimeError -- no memo for those)
+        version = None if attention_mask.is_inference() else attention_mask._version
+    except (RuntimeError, AttributeError):
+        version = None
+    if version is None:
+        return int(attention_mask.sum().item())
     ref, ver, cnt = _VALID_KEYS_MEMO
-    if ref is not None and ref() is attention_mask and ver == attention_mask._version:
+    if ref is not None and ref() is attention_mask and ver == version:
         return cnt
     cnt = int(attention_mask.sum().item())
     import weakref
     try:
-        _VALID_KEYS_MEMO[:] = [weakref.ref(attention_mask), attention_mask._version, cnt]
+        _VALID_KEYS_MEMO[:] = [weakref.ref(attention_mask), version, cnt]   # one slot, replaced as a whole (GIL-atomic)
     except TypeError:
         _VALID_KEYS_MEMO[:] = [None, -1, 0]
     return cnt

@@ -2,9 +2,13 @@
 // every rank holds O for its heads as [rows = B*S][Hl*D]; the consumer (to_out GEMM) of an unsharded model wants
 // [rows][H*D] on every rank.  Two transports behind the C-ABI:
 //   * rsa_allgather_heads      RCCL ncclAllGather (rank-major staging) + one unpack kernel into the head-major rows;
-//   * rsa_allgather_heads_p2p  every rank copies its [rows][Hl*D] slab straight into its column range of every peer's
-//                              full buffer: world 2-D peer copies (hipMemcpy2DAsync) over the point-to-point xGMI links,
-//                              no staging, no unpack; peers' buffers are opened through HIP IPC handles.
+//   * rsa_allgather_heads_p2p  every rank writes its [rows][Hl*D] slab straight into its column range of every peer's
+//                              full buffer with ONE copy kernel whose workgroups are dealt over the peers, so all xGMI
+//                              links (point to point, one per peer) carry their slab at the same time: 16-byte peer
+//                              stores, no staging, no unpack.  Arrival is signalled through IPC-shared device flags
+//                              (an epoch per source rank, written behind a system-scope release by the last workgroup of
+//                              a peer's share) and awaited by a one-workgroup kernel on the consumer's stream: the exchange
+//                              is stream-ordered end to end -- no host barrier, no host synchronisation, capturable.
 // RCCL is bound at run time (dlopen): a process that already carries an RCCL (PyTorch bundles one) keeps using that
 // copy, and single-GPU hosts do not need the library at all.  Nothing here is on the attention path itself: the path
 // shards by head with no collective.
@@ -136,8 +140,8 @@ extern "C" int rsa_ipc_open(const void* handle64, int peer_device, void** dev_pt
         if (st != RSA_OK) return st;
         if (peer_device != cur) {
             const hipError_t e = hipDeviceEnablePeerAccess(peer_device, 0);
-            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return hip_status(e);
-            (void)hipGetLastError();
+            if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();   // clear exactly this sticky state
+            else if (e != hipSuccess) return hip_status(e);
         }
     }
     hipIpcMemHandle_t h;
@@ -150,19 +154,96 @@ extern "C" int rsa_ipc_close(void* dev_ptr) {
     return hip_status(hipIpcCloseMemHandle(dev_ptr));
 }
 
-extern "C" int rsa_allgather_heads_p2p(int world, int rank, const void* local, void* const* full_of_rank, int64_t rows,
-                                       int64_t local_row_bytes, void* stream) {
-    if (!local || !full_of_rank || world <= 0 || rank < 0 || rank >= world || rows <= 0 || local_row_bytes <= 0)
-        return RSA_ERR_BAD_ARG;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t pitch = (size_t)local_row_bytes * (size_t)world;
-    for (int step = 0; step < world; ++step) {
-        const int peer = (rank + step) % world;   // own copy first, then a different peer (link) per step on every rank
-        if (!full_of_rank[peer]) return RSA_ERR_BAD_ARG;
-        unsigned char* dst = static_cast<unsigned char*>(full_of_rank[peer]) + (size_t)rank * (size_t)local_row_bytes;
-        const int st = hip_status(hipMemcpy2DAsync(dst, pitch, local, (size_t)local_row_bytes, (size_t)local_row_bytes,
-                                                   (size_t)rows, hipMemcpyDeviceToDevice, s));
-        if (st != RSA_OK) return st;
-    }
+extern "C" int rsa_ipc_offset(const void* dev_ptr, int64_t* offset) {
+    // byte offset of dev_ptr inside its allocation: an IPC handle names the allocation (a framework's caching allocator
+    // hands out interior pointers), so the opener adds this offset to the pointer rsa_ipc_open returns
+    if (!dev_ptr || !offset) return RSA_ERR_BAD_ARG;
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    const int st = hip_status(hipMemGetAddressRange(&base, &size, const_cast<void*>(dev_ptr)));
+    if (st != RSA_OK) return st;
+    *offset = (int64_t)((const unsigned char*)dev_ptr - (const unsigned char*)base);
     return RSA_OK;
+}
+
+namespace {
+
+// exchange state of one rank (device memory, zeroed once by its owner, IPC-shared): 32-bit words
+//   [0] epoch = gathers completed by this rank   [1] time-out word (nonzero: a wait gave up)
+//   [ARRIVE + p] workgroups of this rank's copy kernel done with peer p's share (local counter)
+//   [FLAGS + r]  written BY rank r: the epoch of its slab that has landed in this rank's full buffer
+enum { P2P_EPOCH = 0, P2P_TIMEOUT = 1, P2P_ARRIVE = 16, P2P_FLAGS = 128, P2P_WORDS = 256, P2P_MAX_WORLD = 64 };
+constexpr int P2P_BLOCKS_PER_PEER = 48;
+
+struct P2pPeers {
+    unsigned char* full[P2P_MAX_WORLD];
+    unsigned* state[P2P_MAX_WORLD];
+};
+
+__global__ __launch_bounds__(256) void p2p_copy_kernel(const uint4* __restrict__ local, P2pPeers peers, int world, int rank,
+                                                        long rows, int w16) {
+    const int p = blockIdx.x / P2P_BLOCKS_PER_PEER, part = blockIdx.x % P2P_BLOCKS_PER_PEER;
+    unsigned* my_state = peers.state[rank];
+    const unsigned epoch = my_state[P2P_EPOCH] + 1;   // (bumped by this gather's wait kernel, behind this kernel)
+    uint4* dst = reinterpret_cast<uint4*>(peers.full[p]) + (long)rank * w16;
+    const long n = rows * (long)w16, pitch16 = (long)w16 * world;
+    for (long i = (long)part * 256 + threadIdx.x; i < n; i += (long)P2P_BLOCKS_PER_PEER * 256) {
+        const long row = i / w16;
+        const int c = (int)(i % w16);
+        dst[row * pitch16 + c] = local[i];
+    }
+    __threadfence_system();   // this thread's peer stores before the arrival below
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = atomicAdd(&my_state[P2P_ARRIVE + p], 1u);
+        if (old == P2P_BLOCKS_PER_PEER - 1) {   // the whole share of peer p has been written (every block fenced first)
+            my_state[P2P_ARRIVE + p] = 0;
+            __hip_atomic_store(&peers.state[p][P2P_FLAGS + rank], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+// one workgroup on the consumer's stream: until every source's slab of this epoch has landed here (bounded spin)
+__global__ __launch_bounds__(64) void p2p_wait_kernel(unsigned* state, int world, int rank, long long timeout_ticks) {
+    const unsigned epoch = state[P2P_EPOCH] + 1;
+    const int p = threadIdx.x;
+    if (p < world && p != rank) {
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(&state[P2P_FLAGS + p], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+            __builtin_amdgcn_s_sleep(32);
+            if (wall_clock64() - t0 > timeout_ticks) {
+                __hip_atomic_store(&state[P2P_TIMEOUT], (unsigned)(p + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) state[P2P_EPOCH] = epoch;
+}
+
+}  // namespace
+
+extern "C" int rsa_p2p_state_bytes(void) { return P2P_WORDS * 4; }
+
+extern "C" int rsa_allgather_heads_p2p(int world, int rank, const void* local, void* const* full_of_rank,
+                                       void* const* state_of_rank, int64_t rows, int64_t local_row_bytes, void* stream) {
+    if (!local || !full_of_rank || !state_of_rank || world <= 0 || world > P2P_MAX_WORLD || rank < 0 || rank >= world ||
+        rows <= 0 || local_row_bytes <= 0)
+        return RSA_ERR_BAD_ARG;
+    if ((local_row_bytes & 15) || ((uintptr_t)local & 15)) return RSA_ERR_BAD_ARG;
+    P2pPeers peers;
+    for (int r = 0; r < world; ++r) {
+        if (!full_of_rank[r] || !state_of_rank[r] || ((uintptr_t)full_of_rank[r] & 15)) return RSA_ERR_BAD_ARG;
+        peers.full[r] = static_cast<unsigned char*>(full_of_rank[r]);
+        peers.state[r] = static_cast<unsigned*>(state_of_rank[r]);
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    p2p_copy_kernel<<<dim3((unsigned)(world * P2P_BLOCKS_PER_PEER)), 256, 0, s>>>(
+        static_cast<const uint4*>(local), peers, world, rank, (long)rows, (int)(local_row_bytes / 16));
+    int st = hip_status(hipGetLastError());
+    if (st != RSA_OK) return st;
+    // 100 MHz wall clock: give a peer 4 s before the wait gives up (the time-out word then names the missing rank + 1)
+    p2p_wait_kernel<<<1, 64, 0, s>>>(peers.state[rank], world, rank, 400000000ll);
+    return hip_status(hipGetLastError());
 }

@@ -1034,4 +1034,4 @@ extern "C" const char* rsa_status_string(int status) {
 int g_rsa_last_hip_error = 0;
 extern "C" const char* rsa_last_hip_error(void) { return hipGetErrorString((hipError_t)g_rsa_last_hip_error); }
 
-extern "C" int rsa_version(void) { return 210; }  // 0.2.1: + rsa_norm_rope_heads, rsa_qk_layernorm_rope (0.2.0: rsa_buffers has 18 members)
+extern "C" int rsa_version(void) { return 300; }  // 0.3.0: rsa_buffers has 15 members (K3b's union lists gone), rsa_allgather_heads_p2p is stream-ordered (+ state buffers), rsa_ipc_offset

@@ -53,12 +53,21 @@ class HeadGather:
     """The optional exchange step through the library's own transports (include/rsa.h, "multi-GPU"):
 
         transport="rccl"  rsa_allgather_heads      ncclAllGather into a rank-major staging buffer + one unpack kernel
-        transport="p2p"   rsa_allgather_heads_p2p  world 2-D peer copies straight into every rank's full buffer (xGMI is
-                                                   point to point: one link per peer, no ring, no staging)
+        transport="p2p"   rsa_allgather_heads_p2p  one copy kernel writing this rank's slab into every peer's full buffer
+                                                   over all xGMI links at once + device flags + a wait kernel: stream-
+                                                   ordered, NO host synchronisation or barrier inside gather()
 
     Both need one process per GPU with torch.distributed initialised (any backend): it carries the 128-byte RCCL id /
     the 64-byte IPC handles between the ranks once, at construction.  gather(out_local) -> [B, S, H*D] on every rank.
-    world_size 1 (or no process group) degenerates to a local copy through the same entry points."""
+    world_size 1 (or no process group) degenerates to a local copy through the same entry points.
+
+    Construction is collective.  Every step that can fail on one rank alone (library missing, IPC refused) is local and
+    is followed by an agreement (all ranks learn whether anyone failed) BEFORE the next collective, so a failure raises on
+    every rank instead of leaving the others inside a collective.
+
+    p2p: the result alternates between two buffers (a peer may overwrite buffer A of this rank as soon as this rank has
+    issued the exchange that fills buffer B), so consume a gather's result on the issuing stream before the gather after
+    the next one; `check()` reads the time-out word (synchronises)."""
 
     def __init__(self, B: int, S: int, H_local: int, D: int, dtype: torch.dtype, device, transport: str = "rccl",
                  group=None):
@@ -74,43 +83,91 @@ class HeadGather:
         self.rows, self.row_bytes = B * S, H_local * D * torch.empty((), dtype=dtype).element_size()
         if self.row_bytes % 16:
             raise ValueError("H_local * D * itemsize must be a multiple of 16 bytes")
-        self.full = torch.empty((B, S, self.world * H_local * D), dtype=dtype, device=self.device)
         self.comm = ctypes.c_void_p()
         self.staging: Optional[torch.Tensor] = None
-        self.peers = None
         self._opened: List[ctypes.c_void_p] = []
+        self._calls = 0
         vp = ctypes.c_void_p
-        with torch.cuda.device(self.device):
-            if transport == "rccl":
-                idbuf = (ctypes.c_ubyte * 128)()
-                if self.rank == 0:
-                    self._check(self.L.rsa_comm_unique_id(idbuf), "rsa_comm_unique_id")
-                ids = [bytes(idbuf)]
-                if self.world > 1:
-                    dist.broadcast_object_list(ids, src=0, group=group)
-                idbuf = (ctypes.c_ubyte * 128).from_buffer_copy(ids[0])
-                self._check(self.L.rsa_comm_create(self.world, self.rank, idbuf, ctypes.byref(self.comm)),
-                            "rsa_comm_create")
-                self.staging = torch.empty((self.world, B * S, H_local * D), dtype=dtype, device=self.device)
-            else:
-                h = (ctypes.c_ubyte * 64)()
-                self._check(self.L.rsa_ipc_export(vp(self.full.data_ptr()), h), "rsa_ipc_export")
-                mine = (bytes(h), self.device.index if self.device.index is not None else torch.cuda.current_device())
-                allh = [None] * self.world
-                if self.world > 1:
-                    dist.all_gather_object(allh, mine, group=group)
+        try:
+            with torch.cuda.device(self.device):
+                if transport == "rccl":
+                    self.full = torch.empty((B, S, self.world * H_local * D), dtype=dtype, device=self.device)
+                    idbuf = (ctypes.c_ubyte * 128)()
+                    err = self._local(lambda: self._check(self.L.rsa_comm_unique_id(idbuf), "rsa_comm_unique_id")
+                                      if self.rank == 0 else None)
+                    self._agree(err, "rsa_comm_unique_id")
+                    ids = [bytes(idbuf)]
+                    if self.world > 1:
+                        dist.broadcast_object_list(ids, src=0, group=group)
+                    idbuf = (ctypes.c_ubyte * 128).from_buffer_copy(ids[0])
+                    # (ncclCommInitRank is itself collective: every rank enters it, or none does -- agreed above)
+                    self._check(self.L.rsa_comm_create(self.world, self.rank, idbuf, ctypes.byref(self.comm)),
+                                "rsa_comm_create")
+                    self.staging = torch.empty((self.world, B * S, H_local * D), dtype=dtype, device=self.device)
                 else:
-                    allh = [mine]
-                self.peers = (vp * self.world)()
-                for r, (hb, dev_idx) in enumerate(allh):
-                    if r == self.rank:
-                        self.peers[r] = self.full.data_ptr()
+                    # one allocation: [exchange state | full buffer 0 | full buffer 1]; a single IPC handle + offsets
+                    nstate = (self.L.rsa_p2p_state_bytes() + 255) // 256 * 256
+                    nfull = self.rows * self.world * self.row_bytes
+                    nfull_pad = (nfull + 255) // 256 * 256
+                    self._blob = torch.zeros(nstate + 2 * nfull_pad, dtype=torch.uint8, device=self.device)
+                    torch.cuda.current_stream(self.device).synchronize()   # the zeroed state is in memory before any peer writes
+                    self._fulls = [self._blob[nstate + i * nfull_pad: nstate + i * nfull_pad + nfull].view(dtype)
+                                   .view(B, S, self.world * H_local * D) for i in range(2)]
+                    self.full = self._fulls[0]
+                    h = (ctypes.c_ubyte * 64)()
+                    off = ctypes.c_int64()
+
+                    def export():
+                        self._check(self.L.rsa_ipc_export(vp(self._blob.data_ptr()), h), "rsa_ipc_export")
+                        self._check(self.L.rsa_ipc_offset(vp(self._blob.data_ptr()), ctypes.byref(off)), "rsa_ipc_offset")
+                    self._agree(self._local(export), "rsa_ipc_export")
+                    mine = (bytes(h), int(off.value),
+                            self.device.index if self.device.index is not None else torch.cuda.current_device())
+                    allh = [None] * self.world
+                    if self.world > 1:
+                        dist.all_gather_object(allh, mine, group=group)
                     else:
-                        ptr = vp()
-                        self._check(self.L.rsa_ipc_open((ctypes.c_ubyte * 64).from_buffer_copy(hb), int(dev_idx),
-                                                        ctypes.byref(ptr)), "rsa_ipc_open")
-                        self.peers[r] = ptr.value
-                        self._opened.append(ptr)
+                        allh = [mine]
+                    bases = [0] * self.world
+
+                    def open_peers():
+                        for r, (hb, off_r, dev_idx) in enumerate(allh):
+                            if r == self.rank:
+                                bases[r] = self._blob.data_ptr()
+                                continue
+                            ptr = vp()
+                            self._check(self.L.rsa_ipc_open((ctypes.c_ubyte * 64).from_buffer_copy(hb), int(dev_idx),
+                                                            ctypes.byref(ptr)), "rsa_ipc_open")
+                            self._opened.append(ptr)
+                            bases[r] = ptr.value + off_r
+                    self._agree(self._local(open_peers), "rsa_ipc_open")
+                    self._states = (vp * self.world)(*[b for b in bases])
+                    self._peer_fulls = [(vp * self.world)(*[b + nstate + i * nfull_pad for b in bases]) for i in range(2)]
+        except BaseException:
+            self.close()   # handles already opened / the communicator do not outlive a failed construction
+            raise
+
+    @staticmethod
+    def _local(fn):
+        """Runs a step that may fail on this rank alone; returns the error text or None."""
+        try:
+            fn()
+            return None
+        except Exception as e:  # noqa: BLE001
+            return repr(e)[:300]
+
+    def _agree(self, err, what):
+        """All ranks learn whether the local step failed anywhere; raises on EVERY rank if it did."""
+        bad = 1 if err else 0
+        if self.world > 1:
+            t = torch.tensor([bad], dtype=torch.int32)
+            if dist.get_backend(self.group) == "nccl":
+                t = t.to(self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            bad = int(t.item())
+        if bad:
+            from ._lib import RsaError
+            raise RsaError(f"HeadGather({self.transport}): {what} failed on " + (f"this rank: {err}" if err else "another rank"))
 
     def gather(self, out_local: torch.Tensor) -> torch.Tensor:
         flat = out_local.reshape(self.rows, -1)
@@ -125,20 +182,28 @@ class HeadGather:
                                                        vp(self.staging.data_ptr()), vp(self.full.data_ptr()), self.rows,
                                                        self.row_bytes, st), "rsa_allgather_heads")
             else:
-                if self.world > 1:   # every peer must be done READING its full buffer of the previous step
-                    torch.cuda.current_stream(self.device).synchronize()
-                    dist.barrier(group=self.group)
-                self._check(self.L.rsa_allgather_heads_p2p(self.world, self.rank, vp(flat.data_ptr()), self.peers,
-                                                           self.rows, self.row_bytes, st), "rsa_allgather_heads_p2p")
-                if self.world > 1:   # ... and every peer's slab must have landed here before this rank reads
-                    torch.cuda.current_stream(self.device).synchronize()
-                    dist.barrier(group=self.group)
+                par = self._calls & 1
+                self._calls += 1
+                self._check(self.L.rsa_allgather_heads_p2p(self.world, self.rank, vp(flat.data_ptr()),
+                                                           self._peer_fulls[par], self._states, self.rows, self.row_bytes,
+                                                           st), "rsa_allgather_heads_p2p")
+                self.full = self._fulls[par]
         return self.full
 
+    def check(self) -> None:
+        """p2p: raises if a wait inside an exchange gave up (a peer did not deliver within 4 s).  Synchronises."""
+        if self.transport != "p2p":
+            return
+        torch.cuda.current_stream(self.device).synchronize()
+        word = int(self._blob[:8].view(torch.int32)[1].item())
+        if word:
+            from ._lib import RsaError
+            raise RsaError(f"HeadGather(p2p): rank {self.rank} timed out waiting for rank {word - 1}")
+
     def close(self):
-        for ptr in self._opened:
+        for ptr in getattr(self, "_opened", []):
             self.L.rsa_ipc_close(ptr)
         self._opened = []
-        if self.comm:
+        if getattr(self, "comm", None):
             self.L.rsa_comm_destroy(self.comm)
             self.comm = ctypes.c_void_p()

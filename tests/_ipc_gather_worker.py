@@ -22,9 +22,22 @@ def main():
     full_ref = torch.randn(B, S, world * Hl, D, generator=g).to(torch.bfloat16)
     mine = full_ref[:, :, rank * Hl:(rank + 1) * Hl].contiguous().to(dev)
     hg = parallel.HeadGather(B, S, Hl, D, torch.bfloat16, dev, transport="p2p")
-    for step in range(3):   # repeated gathers reuse the peers' buffers
-        out = hg.gather(mine + step)
-        torch.cuda.synchronize()
+    # six back-to-back gathers with NO host synchronisation between them: the exchange is stream-ordered (device flags),
+    # the results alternate between the two full buffers, each is consumed (copied) on the issuing stream
+    sync_calls = []
+    real_sync, real_barrier = torch.cuda.Stream.synchronize, dist.barrier
+    torch.cuda.Stream.synchronize = lambda self_: (sync_calls.append("stream"), real_sync(self_))[1]
+    dist.barrier = lambda *a, **k: (sync_calls.append("barrier"), real_barrier(*a, **k))[1]
+    outs = []
+    for step in range(6):
+        outs.append(hg.gather(mine + step).clone())
+        if rank == 1 and step == 2:
+            torch.cuda._sleep(200_000_000)   # uneven load: this rank falls ~0.1 s behind; the peer's wait kernel covers it
+    torch.cuda.Stream.synchronize, dist.barrier = real_sync, real_barrier
+    assert not sync_calls, f"gather() synchronised with the host: {sync_calls}"
+    torch.cuda.synchronize()
+    hg.check()
+    for step, out in enumerate(outs):
         want = (full_ref.to(dev) + step).reshape(B, S, world * Hl * D)
         assert torch.equal(out, want), f"rank {rank} step {step}: gathered rows differ"
     hg.close()

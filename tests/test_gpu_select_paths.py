@@ -64,9 +64,11 @@ def test_prefix_path_equals_full_sort(cfg):
     assert int(a["counts"].min()) >= min(top_k, spec.L)
 
 
-def test_text_rows_split_kv_matches_single_workgroup_form():
+@pytest.mark.parametrize("fp8", [False, True])
+def test_text_rows_split_kv_matches_single_workgroup_form(fp8):
     """K5 splits the key range of the dense text query blocks over up to 16 workgroups (+ a combine kernel); the visual
-    rows must not change by a bit, the text rows only by the rounding of a different summation order."""
+    rows must not change by a bit, the text rows only by the rounding of a different summation order.  The e4m3 kernel has
+    its own partial writer (scaled by s_v, offset by P_OFFSET) in front of the shared combine kernel: same check."""
     from bench import gen_qkv
     from rectified_spaattn_amd import _core, _lib
     S, H, D = 115456, 2, 128
@@ -76,7 +78,7 @@ def test_text_rows_split_kv_matches_single_workgroup_form():
     for flag in (1, 0):
         assert _lib.lib().rsa_set_tuning(b"k5_tsplit", flag) == 0
         try:
-            outs.append(_core.rectified_attention(q, k, v, spec, 90, 0.05, None).clone())
+            outs.append(_core.rectified_attention(q, k, v, spec, 90, 0.05, None, qkv_fp8=fp8).clone())
             torch.cuda.synchronize()
         finally:
             _lib.lib().rsa_set_tuning(b"k5_tsplit", 1)
@@ -84,5 +86,5 @@ def test_text_rows_split_kv_matches_single_workgroup_form():
     nv = spec.NBv * 128
     assert torch.equal(a[:, :nv], b[:, :nv])
     d = (a[:, nv:].float() - b[:, nv:].float()).abs()
-    assert float(d.max()) <= 4e-3, float(d.max())
+    assert float(d.max()) <= (8e-3 if fp8 else 4e-3), float(d.max())
     assert float(a[:, nv + spec.q_text_valid:].abs().max()) == 0.0 and float(a[:, nv:nv + spec.q_text_valid].abs().max()) > 0

@@ -83,6 +83,13 @@ def test_comm_entry_points_validate_arguments_on_the_host():
     assert L.rsa_allgather_heads(None, 2, vp(16), vp(16), vp(16), 4, 32, None) == -1
     assert L.rsa_allgather_heads(vp(1), 2, vp(16), vp(16), vp(16), 4, 24, None) == -1   # rows not 16-byte multiples
     peers = (vp * 2)()
-    assert L.rsa_allgather_heads_p2p(2, 0, vp(16), peers, 4, 32, None) == -1            # null peer pointer
-    assert L.rsa_allgather_heads_p2p(2, 3, vp(16), peers, 4, 32, None) == -1
+    states = (vp * 2)()
+    assert L.rsa_allgather_heads_p2p(2, 0, vp(16), peers, states, 4, 32, None) == -1    # null peer pointers
+    assert L.rsa_allgather_heads_p2p(2, 3, vp(16), peers, states, 4, 32, None) == -1    # rank outside the world
+    assert L.rsa_allgather_heads_p2p(2, 0, vp(16), peers, None, 4, 32, None) == -1      # no state buffers
+    assert L.rsa_allgather_heads_p2p(65, 0, vp(16), peers, states, 4, 32, None) == -1   # more ranks than flag slots
+    peers[0], peers[1], states[0], states[1] = 16, 32, 4096, 8192
+    assert L.rsa_allgather_heads_p2p(2, 0, vp(16), peers, states, 4, 24, None) == -1    # rows not 16-byte multiples
+    assert L.rsa_p2p_state_bytes() == 1024
     assert L.rsa_ipc_export(None, None) == -1 and L.rsa_ipc_open(None, 0, None) == -1 and L.rsa_ipc_close(None) == -1
+    assert L.rsa_ipc_offset(None, None) == -1
