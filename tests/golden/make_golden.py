@@ -213,6 +213,10 @@ def main():
         ("b2_cogvideo_994", "cogvideo", 2, 2, 994, 64, 2, 0.3, 1, dict(text_length=226)),
         # round 2: a row longer than 256 columns (K3's sorted-head path) through the reference, 260 blocks
         ("big_wan_33280", "wan", 1, 1, 33280, 64, 20, 0.3, 1, dict(ffb=3)),
+        # round 3: the text-tail layouts with rows longer than 128 visual blocks (IPAR + text columns on K3's sorted-head
+        # path) through the reference: 136 visual blocks + 256 text (200 valid) / 132 visual blocks + 512 text tokens
+        ("big_hunyuan_17664", "hunyuan", 1, 1, 17664, 128, 14, 0.3, 1, dict(num_true=17408 + 200)),
+        ("big_flux_17408", "flux", 1, 1, 17408, 128, 13, 0.3, 1, dict(text_length=512)),
     ]
     only = os.environ.get("RSA_GOLDEN_ONLY")
     if only:
@@ -418,6 +422,79 @@ def processors_round2():
     np.savez_compressed(os.path.join(outdir, "processors_r2.npz"),
                         **{k: (v.astype(np.float16) if v.ndim else v) for k, v in res.items()})
     print("processors_r2.npz:", {k: v.shape for k, v in res.items()})
+
+
+def processors_round3():
+    """Round-3 vectors for the processors' SPARSE branches: besides the processor output (processors_r2.npz) the kept-block
+    mask the reference's builder produced and the operator's own output [B, S, H*D] of the same call, so that the device
+    test can compare mask against mask first and then bound the output on the query blocks whose kept set agrees
+    (the device processor projects in bf16, the reference in fp32: a few rows near a threshold may flip)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers
+    import rectified_spaattn.attn as ref_attn
+    import rectified_spaattn.rectified_wan21_attn as ref_wan
+    import rectified_spaattn.rectified_cogvideo_attn as ref_cog
+    ref_attn.flash_attn_varlen_func = _varlen_sdpa
+    tw = sys.modules["diffusers.models.transformers.transformer_wan"]
+    tw._get_qkv_projections = lambda attn, hs, enc: (attn.to_q(hs), attn.to_k(hs if enc is None else enc),
+                                                     attn.to_v(hs if enc is None else enc))
+    tw._get_added_kv_projections = lambda attn, enc_img: (attn.add_k_proj(enc_img), attn.add_v_proj(enc_img))
+    import rectified_spaattn.rectified_wan22_attn as ref_w22
+    for m in (ref_wan, ref_cog):
+        if not getattr(m, "_rsa_wrapped", False):
+            _wrap_kernel(m)
+            m._rsa_wrapped = True
+    from rectified_spaattn_amd import synth
+    outdir = os.path.dirname(os.path.abspath(__file__))
+    res = {}
+
+    def spied(mod, key, fn):
+        cap = {}
+        ob, oc = mod._build_block_index_with_importance_optimized, mod.block_sparse_attention_combined
+
+        def sb(*a, **k):
+            r = ob(*a, **k)
+            cap["one_hot"] = r[0].clone()
+            return r
+
+        def sc(*a, **k):
+            r = oc(*a, **k)
+            cap["op_out"] = r.clone()
+            return r
+        mod._build_block_index_with_importance_optimized, mod.block_sparse_attention_combined = sb, sc
+        try:
+            fn()
+        finally:
+            mod._build_block_index_with_importance_optimized, mod.block_sparse_attention_combined = ob, oc
+        oh = cap["one_hot"].numpy().astype(np.uint8)
+        res[key + "_mask"] = np.packbits(oh, axis=-1)
+        res[key + "_mask_shape"] = np.array(oh.shape)
+        res[key + "_op_out"] = cap["op_out"].float().numpy().astype(np.float16)
+
+    heads, hd = 2, 128
+    dim = heads * hd
+    with torch.no_grad():
+        S = 900
+        a = helpers.fake_attn(111, heads, hd, wan=True)
+        hs = helpers.hidden(111, 20, 1, S, dim)
+        rope = helpers.wan22_rope(S, hd)
+        nbr = torch.from_numpy(synth.banded_neighbors((S + 127) // 128, 1))
+        p = ref_w22.RectifiedWanTI2VSpaAttnProcessor2_0("sparse", 2, nbr, 0.3, 3, 1)
+        p.current_step = 10
+        spied(ref_wan, "w22_ti2v_sparse", lambda: p(a, hs, None, None, rope))
+        p2 = ref_w22.RectifiedWanT2VSpaAttnProcessor2_0("sparse", 3, nbr, 0.4, 5, 0, warm_steps=2)
+        p2.current_step = 2
+        spied(ref_wan, "w22_t2v_sparse", lambda: p2(a, hs, None, None, rope))
+        p3 = ref_w22.RectifiedWanI2VSpaAttnProcessor2_0("sparse", 2, nbr, 0.3, 7, 2, warm_steps=0)
+        spied(ref_wan, "w22_i2v_sparse", lambda: p3(a, hs, None, None, rope))
+        ac = helpers.fake_attn(106, 4, 64, added=False)
+        nbr_c = torch.from_numpy(synth.banded_neighbors(6, 1))
+        pc = ref_cog.RectifiedCogVideoXVideoSpaAttnProcessor2_0("sparse", 2, nbr_c, 0.3, 0)
+        pc.current_step = 5
+        spied(ref_cog, "cog_sparse", lambda: pc(ac, helpers.hidden(106, 20, 1, 768, 256), helpers.hidden(106, 21, 1, 226, 256),
+                                                None, helpers.rope_tables(768, 64)))
+    np.savez_compressed(os.path.join(outdir, "processors_r3.npz"), **res)
+    print("processors_r3.npz:", {k: v.shape for k, v in res.items()})
 
 
 def _load_script(name, extra_stubs=()):
@@ -724,6 +801,9 @@ if __name__ == "__main__":
     elif len(sys.argv) > 1 and sys.argv[1] == "processors_r2":
         _install_stubs()
         processors_round2()
+    elif len(sys.argv) > 1 and sys.argv[1] == "processors_r3":
+        _install_stubs()
+        processors_round3()
     elif len(sys.argv) > 1 and sys.argv[1] == "teacache":
         _install_stubs()
         teacache()
@@ -736,5 +816,6 @@ if __name__ == "__main__":
         main()
         processors()
         processors_round2()
+        processors_round3()
         teacache()
         gilbert()

@@ -1,7 +1,8 @@
-"""Parity at BASELINE.json's full sizes (GPU).  The oracle cannot run a whole 115k-token layer in seconds, so the
-full-size checks are (i) bit-exact masks / statistics and output tolerance on SAMPLED query blocks (the oracle
-pools the whole head, then evaluates only those rows), and (ii) size-independent properties over the whole
-result: list/bitmask consistency, top-k lower bound, text blocks always kept, R in [0, 1+eps], finite output."""
+"""Parity at BASELINE.json's full sizes (GPU).  The oracle cannot run a whole 115k-token layer's ATTENTION in seconds, so
+the full-size checks are (i) the mask-selection pass of one whole head -- EVERY query-block row: kept bitmask, counts,
+probabilities, GAPR bytes, R, all bit-exact against the C oracle (pool once, loop the rows in C) --, (ii) output tolerance
+on sampled query blocks of the first and last head, and (iii) size-independent properties over the whole result:
+list/bitmask consistency, top-k lower bound, text blocks always kept, R in [0, 1+eps], finite output."""
 import numpy as np
 import pytest
 import torch
@@ -42,6 +43,20 @@ def _check_config(name, spec, lay, H, top_k, p, nbr, sample_rows, seed=77):
     for bh in (0, H - 1):
         for i in (0, lay.NBv // 2, lay.NBv - 1):
             assert np.array_equal(cols[bh, i, : counts[bh, i]], np.nonzero(kept[bh, i])[0])
+    # ---- one whole head: every row of the mask-selection pass against the C oracle, bit for bit ----
+    bh_all = H // 2
+    qh, kh, vh = (x[0, bh_all].float().cpu().numpy() for x in (q, k, v))
+    if lay.pool_valid < lay.S:
+        kh[lay.pool_valid:] = 0
+        vh[lay.pool_valid:] = 0
+    full = orc.select_head(qh, kh, vh, lay, top_k, p, nbr)
+    assert np.array_equal(kept[bh_all], full["kept"].astype(bool)), f"{name}: kept bitmask of head {bh_all}, all rows"
+    assert np.array_equal(counts[bh_all], full["kept"].sum(-1)), f"{name}: counts of head {bh_all}"
+    assert np.array_equal(bufs["probs"][bh_all].cpu().numpy(), full["probs"]), f"{name}: probabilities of head {bh_all}"
+    assert np.array_equal(bufs["unrel"][bh_all].cpu().numpy(), full["unrel"]), f"{name}: GAPR bytes of head {bh_all}"
+    assert np.array_equal(R[bh_all], full["R"]), f"{name}: R of head {bh_all}"
+    err_c = np.abs(bufs["comp"][bh_all].cpu().numpy() - full["comp"]).max()
+    assert err_c <= 1e-5, f"{name}: comp of head {bh_all}: {err_c:.3e}"
     # ---- sampled rows against the oracle (bit-exact statistics, tolerance on O) ----
     o = out.view(1, lay.S, H, D)
     for bh in (0, H - 1):

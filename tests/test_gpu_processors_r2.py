@@ -5,7 +5,9 @@ Checkers: (a) reference vectors (tests/golden/processors_r2.npz, produced by the
 fp32) for everything dense -- tolerance 6e-2 because the device modules run bf16 linear layers; (b) for the sparse
 branches the oracle on the q / k / v the processor itself handed to the operator (captured), tolerance 2e-2 / 2e-3 as
 everywhere, plus the reference's sparse vector as a distance report (bf16 projections can flip near-tied blocks, so that
-one is asserted on the mean only)."""
+one is asserted on the mean only); (c) round 3: the reference's OWN kept mask and operator output of the same processor call
+(tests/golden/processors_r3.npz): masks are compared first, flipped query blocks are counted and reported (bounded), and on
+every (head, query block) whose kept set equals the reference's the operator output is bounded element-wise."""
 import os
 
 import numpy as np
@@ -19,8 +21,45 @@ from oracle import oracle as orc
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 G2 = np.load(os.path.join(GOLDEN, "processors_r2.npz"))
+G3 = np.load(os.path.join(GOLDEN, "processors_r3.npz"))
 heads, hd = 2, 128
 dim = heads * hd
+
+
+def _against_reference_mask(key, kept, op_out, H, D, max_flipped_fraction=0.25, tol=6e-2):
+    """kept [H, NQ, NB] bool and op_out [1, S, H*D] of the device call against the reference's mask / operator output of
+    the same processor call (fp32 projections on CPU).  Returns (flipped, compared) query-block counts."""
+    shape = tuple(int(x) for x in G3[key + "_mask_shape"])
+    ref_kept = np.unpackbits(G3[key + "_mask"], axis=-1)[..., : shape[-1]].astype(bool)[0]     # [H, NQ, NB]
+    ref_out = G3[key + "_op_out"].astype(np.float32)                                          # [1, S, H*D]
+    assert ref_kept.shape == kept.shape, (ref_kept.shape, kept.shape)
+    S = ref_out.shape[1]
+    got = op_out.astype(np.float32).reshape(1, S, H, D)
+    ref = ref_out.reshape(1, S, H, D)
+    flipped, compared, worst = 0, 0, 0.0
+    for h in range(H):
+        for i in range(kept.shape[1]):
+            if not np.array_equal(kept[h, i], ref_kept[h, i]):
+                flipped += 1
+                continue
+            r0, r1 = i * 128, min(S, (i + 1) * 128)
+            err = np.abs(got[0, r0:r1, h] - ref[0, r0:r1, h]).max()
+            worst = max(worst, float(err))
+            compared += 1
+    total = flipped + compared
+    print(f"{key}: {flipped} of {total} (head, query block) rows keep another block set than the reference; "
+          f"max |O - O_ref| on the {compared} agreeing rows {worst:.3e}")
+    assert flipped <= max_flipped_fraction * total, (key, flipped, total)
+    assert compared > 0 and worst <= tol, (key, worst)
+    return flipped, compared
+
+
+def _device_mask(q, k, v, spec, top_k, p, nbr):
+    """Kept-block mask [H, NQ, NB_total] of the device operator on the (captured) q, k, v."""
+    from rectified_spaattn_amd import _core
+    tq, tk, tv = (torch.from_numpy(x).to(DEV, torch.bfloat16) for x in (q, k, v))
+    _, parts = _core.rectified_attention(tq, tk, tv, spec, top_k, p, nbr, return_parts=True)
+    return _core.unpack_bitmask(parts["bitmask"], spec.NB_total).cpu().numpy()
 
 
 def _capture(module, fn_name="rectified_block_sparse_attention"):
@@ -79,6 +118,9 @@ def test_wan22_processors_on_device(which):
     assert torch.allclose(o.float(), want.float(), atol=1e-2)
     dist = np.abs(o.float().cpu().numpy() - G2[vec].astype(np.float32))
     assert dist.mean() <= 2e-2, (which, dist.mean(), dist.max())   # vs the reference's own sparse output (fp32 CPU run)
+    from rectified_spaattn_amd import _core
+    kept = _device_mask(q, k, v, _core.LayoutSpec.wan(S, ffb), top_k, pr, nbr)
+    _against_reference_mask(vec, kept, captured["out"].float().cpu().numpy(), heads, hd)
     # cross attention of the same block type
     pc = w22.RectifiedWanT2VSpaAttnProcessor2_0("flash", 2, None, 0.3, 5, 0)
     oc = pc(a, hs, helpers.hidden(111, 23, 1, 512, dim).to(DEV, torch.bfloat16), None, None)
@@ -110,6 +152,10 @@ def test_cogvideo_sparse_branch_on_device():
     full = torch.cat([o, e], 1).float().cpu().numpy()
     gold = np.concatenate([G2["cog_sparse_out"], G2["cog_sparse_enc"]], 1).astype(np.float32)
     assert np.abs(full - gold).mean() <= 2e-2
+    from rectified_spaattn_amd import _core
+    spec = _core.LayoutSpec.cogvideo(994, 226)
+    kept = _device_mask(q, k, v, spec, 2, 0.3, nbr)
+    _against_reference_mask("cog_sparse", kept[:, : spec.NBv], captured["out"].float().cpu().numpy(), 4, 64)
 
 
 @torch.no_grad()
