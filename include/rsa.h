@@ -141,6 +141,11 @@ int rsa_rectified_attention(const rsa_layout* lay, rsa_tensor4 q, rsa_tensor4 k,
  * softmax attention (fullattn mode "torch"/"vanilla", attn.py:101-106, :121-149, without bias). */
 int rsa_dense_fwd(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
                   int q_split, int kv_split, rsa_out4 out, void* stream);
+/* The same with causal = True (attn.py:60-73 forwards it to flash_attn_varlen_func, :108-116): inside a segment key j
+ * is visible to row i iff j <= i + (keys - rows) -- flash-attn's bottom-right alignment, which is the top-left mask of
+ * the reference's "torch" / "vanilla" modes (attn.py:105, :129-133) whenever a segment has as many keys as rows. */
+int rsa_dense_causal_fwd(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
+                         int q_split, int kv_split, rsa_out4 out, void* stream);
 
 /* Stand-alone GAPR for callers of estimate_pr_gain (gapr_mask.py:4): blocks are [BH, N, 128, D] contiguous
  * 2-byte elements, pools [BH, N, D] fp32, scores [BH, NQ, NK] fp32 -> mask [BH, NQ, NK] uint8 (1 = ~gapr_mask). */

@@ -277,12 +277,23 @@ def sparse_attention_head(q, k, v, lay: Layout, kept_rows: np.ndarray, rows: Seq
     return out
 
 
-def dense_attention(q, k, v, kv_valid: Optional[int] = None):
-    """Exact softmax attention for one head; fullattn(mode='torch'/'vanilla') semantics (attn.py:101-149)."""
+def dense_attention(q, k, v, kv_valid: Optional[int] = None, causal: bool = False):
+    """Exact softmax attention for one head; fullattn(mode='torch'/'vanilla') semantics (attn.py:101-149).  causal: key j
+    visible to row i iff j <= i + (keys - rows) (flash-attn's alignment, attn.py:108-116; == the tril of :105 / :129-133
+    when there are as many keys as rows); rows that see no key give zeros."""
     D = q.shape[1]
     n = k.shape[0] if kv_valid is None else kv_valid
     ok = np.arange(k.shape[0]) < n
-    return _masked_attention_rows(q, k, v, ok, float(D) ** -0.5)
+    if not causal:
+        return _masked_attention_rows(q, k, v, ok, float(D) ** -0.5)
+    off = n - q.shape[0]
+    vis = ok[None, :] & (np.arange(k.shape[0])[None, :] <= np.arange(q.shape[0])[:, None] + off)
+    s = (q.astype(np.float64) @ k.astype(np.float64).T) * float(D) ** -0.5
+    s = np.where(vis, s, -np.inf)
+    m = np.where(vis.any(1, keepdims=True), s.max(axis=1, keepdims=True), 0.0)
+    e = np.where(vis, np.exp(s - m), 0.0)
+    den = e.sum(axis=1, keepdims=True)
+    return np.where(den > 0, (e @ v.astype(np.float64)) / np.where(den > 0, den, 1.0), 0.0)
 
 
 def rectified_attention(q, k, v, lay: Layout, top_k: int, p: float, neighbor=None, want_parts: bool = False):

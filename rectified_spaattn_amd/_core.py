@@ -319,9 +319,10 @@ def rectified_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, spec:
 
 
 def dense_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, q_split: Optional[int] = None,
-                    kv_split: Optional[int] = None, qkv_fp8: bool = False) -> torch.Tensor:
+                    kv_split: Optional[int] = None, qkv_fp8: bool = False, causal: bool = False) -> torch.Tensor:
     """Exact attention on the HIP kernel.  q [B,H,Sq,D], k/v [B,H,Sk,D] -> [B,Sq,H,D].
-    Rows < q_split attend kv [0, kv_split); rows >= q_split attend kv [kv_split, Sk) (attn.py:107-120)."""
+    Rows < q_split attend kv [0, kv_split); rows >= q_split attend kv [kv_split, Sk) (attn.py:107-120); causal: inside a
+    segment key j is visible to row i iff j <= i + (keys - rows) (2-byte kernel only)."""
     _require_device(q, k, v)
     L = _lib.lib()
     B, H, Sq, D = q.shape
@@ -333,6 +334,8 @@ def dense_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, q_split: 
     kv_split = Sk if kv_split is None else int(kv_split)
     out = torch.empty((B, Sq, H, D), dtype=q.dtype, device=q.device)
     o4 = RsaOut4(out.data_ptr(), out.stride(0), out.stride(2), out.stride(1))
+    if qkv_fp8 and causal:
+        raise NotImplementedError("causal attention runs on the 2-byte kernel only (no causal form of the e4m3 dense kernel)")
     if qkv_fp8:  # e4m3 images of q, k, v (per-head scales) + the fp8 MFMA kernel; head_dim 128 only
         total = ctypes.c_size_t()
         _lib.check(L.rsa_dense_fp8_bytes(B, H, Sq, Sk, D, ctypes.byref(total)), "rsa_dense_fp8_bytes")
@@ -341,9 +344,9 @@ def dense_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, q_split: 
             _lib.check(L.rsa_dense_fwd_fp8(B, H, Sq, Sk, D, dtype_code(q.dtype), _t4(q), _t4(k), _t4(v), q_split,
                                            kv_split, ws.data_ptr(), ws.numel(), o4, _stream()), "rsa_dense_fwd_fp8")
         return out
+    fn, name = (L.rsa_dense_causal_fwd, "rsa_dense_causal_fwd") if causal else (L.rsa_dense_fwd, "rsa_dense_fwd")
     with torch.cuda.device(q.device):
-        _lib.check(L.rsa_dense_fwd(B, H, Sq, Sk, D, dtype_code(q.dtype), _t4(q), _t4(k), _t4(v), q_split, kv_split,
-                                   o4, _stream()), "rsa_dense_fwd")
+        _lib.check(fn(B, H, Sq, Sk, D, dtype_code(q.dtype), _t4(q), _t4(k), _t4(v), q_split, kv_split, o4, _stream()), name)
     return out
 
 

@@ -1,6 +1,7 @@
 """Dense attention entry point `fullattn` -- same signature, layouts and modes as the reference's
 rectified_spaattn/attn.py:60-154, served by the HIP dense kernel (rsa_dense_fwd) for device tensors.
 
+causal=True is served too (per-row key limits of the same kernel; flash-attn's bottom-right alignment inside each segment).
 Modes on DEVICE tensors all run the same gfx950 kernel (there is no flash-attn / SDPA dependency):
   "flash"   two-segment varlen semantics from cu_seqlens_q / cu_seqlens_kv (attn.py:107-120)
   "torch"   plain attention, optional boolean key-padding mask [b,1,1,s1] (attn.py:101-106)
@@ -90,14 +91,15 @@ def _splits_from_cu(cq, ck, B, S, S1):
     return splits
 
 
-def _device_dense(q, k, v, splits, dense_fp8=None):
+def _device_dense(q, k, v, splits, dense_fp8=None, causal=False):
     """q [b,a,s,d], k/v [b,a,s1,d]; splits: per batch item (q_split, kv_split).  Returns [b,a,s,d] view."""
     B = q.shape[0]
-    # e4m3 operands on the fp8 MFMA: per call, else the process default of set_dense_fp8()
-    fp8 = (_operator.DENSE_FP8 if dense_fp8 is None else bool(dense_fp8)) and q.shape[-1] == 128
+    # e4m3 operands on the fp8 MFMA: per call, else the process default of set_dense_fp8() (never for causal calls)
+    fp8 = (_operator.DENSE_FP8 if dense_fp8 is None else bool(dense_fp8)) and q.shape[-1] == 128 and not causal
     if len(set(splits)) == 1:
-        return _core.dense_attention(q, k, v, splits[0][0], splits[0][1], qkv_fp8=fp8).transpose(1, 2)
-    outs = [_core.dense_attention(q[i:i + 1], k[i:i + 1], v[i:i + 1], *splits[i], qkv_fp8=fp8) for i in range(B)]
+        return _core.dense_attention(q, k, v, splits[0][0], splits[0][1], qkv_fp8=fp8, causal=causal).transpose(1, 2)
+    outs = [_core.dense_attention(q[i:i + 1], k[i:i + 1], v[i:i + 1], *splits[i], qkv_fp8=fp8, causal=causal)
+            for i in range(B)]
     return torch.cat(outs, 0).transpose(1, 2)
 
 
@@ -130,8 +132,10 @@ def fullattn(q, k, v, mode="flash", drop_rate=0, attn_mask=None, causal=False, c
     if q.is_cuda:
         if drop_rate:
             raise NotImplementedError("dropout is not implemented in the HIP attention path")
-        if causal:
-            raise NotImplementedError("causal attention is not implemented in the HIP attention path")
+        if causal and mode != "flash" and (attn_mask is not None or S != S1):
+            # "torch" / "vanilla" put the causal triangle top-left (attn.py:105, :129-133; vanilla asserts no mask); the
+            # kernel's segments are bottom-right aligned like flash-attn: the two agree only for s == s1 without padding
+            raise NotImplementedError("device fullattn: causal with mode 'torch' / 'vanilla' needs s == s1 and no attn_mask")
         if mode == "flash":
             cq, ck = _to_list(cu_seqlens_q), _to_list(cu_seqlens_kv)
             if cq is None or ck is None:
@@ -143,7 +147,7 @@ def fullattn(q, k, v, mode="flash", drop_rate=0, attn_mask=None, causal=False, c
                 splits = [(S, S1)] * B
             else:
                 splits = [(S, c) for c in _key_padding_counts(attn_mask, B, S1)]
-        return _device_dense(q, k, v, splits, dense_fp8)
+        return _device_dense(q, k, v, splits, dense_fp8, causal=bool(causal))
     # ---- CPU tensors: the reference's CPU-runnable modes ----
     if mode == "flash":
         raise RsaError("fullattn(mode='flash') needs device tensors (HIP kernel); use mode='torch' on CPU")

@@ -74,6 +74,7 @@ struct AttnArgs {
     int NBv, NQB, NB_total;  // sparse: q blocks < NBv use lists; NQB = total q blocks
     int kv_valid, kv_text_valid, q_text_end;  // sparse mode (q_text_end = NBv*128 + q_text_valid)
     int q_split, kv_split;                    // dense mode
+    int causal;                               // dense mode: key j of a segment visible to its row i iff j <= i + (keys - rows)
     int n_heavy_pad, NBp, BH;                 // work mapping
     float* tpart;                             // split-KV partials of the text query blocks, or null
     int tsplit, tper;                         // workgroups per text block, key blocks per workgroup

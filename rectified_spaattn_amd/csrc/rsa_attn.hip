@@ -158,7 +158,7 @@ extern "C" int rsa_block_sparse_fwd(const rsa_layout* l, rsa_tensor4 q, rsa_tens
     a.NBv = l->NBv; a.NQB = l->NB_total; a.NB_total = l->NB_total;
     a.kv_valid = l->kv_valid; a.kv_text_valid = l->kv_text_valid;
     a.q_text_end = l->NBv * RSA_BLOCK + l->q_text_valid;
-    a.q_split = 0; a.kv_split = 0;
+    a.q_split = 0; a.kv_split = 0; a.causal = 0;
     a.qk_scale = (float)((1.0 / sqrt((double)l->D)) * 1.44269504);  // sm_scale * 1.44269504 (hunyuan :145)
 #ifdef RSA_K5_DIAG
     a.dbg = reinterpret_cast<unsigned long long*>(g_dbg_ptr);
@@ -166,8 +166,8 @@ extern "C" int rsa_block_sparse_fwd(const rsa_layout* l, rsa_tensor4 q, rsa_tens
     return launch_attn(a, l->B * l->H, l->D, l->dtype, static_cast<hipStream_t>(stream));
 }
 
-extern "C" int rsa_dense_fwd(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k,
-                             rsa_tensor4 v, int q_split, int kv_split, rsa_out4 out, void* stream) {
+static int dense_fwd(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
+                     int q_split, int kv_split, int causal, rsa_out4 out, void* stream) {
     if (B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0) return RSA_ERR_BAD_ARG;
     if (D != 64 && D != 128) return RSA_ERR_UNSUPPORTED;
     if (dtype != RSA_BF16 && dtype != RSA_FP16) return RSA_ERR_UNSUPPORTED;
@@ -184,12 +184,22 @@ extern "C" int rsa_dense_fwd(int B, int H, int Sq, int Sk, int D, int dtype, rsa
     a.mode = MODE_DENSE; a.H = H; a.Sq = Sq; a.Sk = Sk;
     a.NQB = (Sq + RSA_BLOCK - 1) / RSA_BLOCK; a.NBv = a.NQB; a.NB_total = (Sk + RSA_BLOCK - 1) / RSA_BLOCK;
     a.kv_valid = Sk; a.kv_text_valid = Sk; a.q_text_end = 0;
-    a.q_split = q_split; a.kv_split = kv_split;
+    a.q_split = q_split; a.kv_split = kv_split; a.causal = causal;
     a.qk_scale = (float)((1.0 / sqrt((double)D)) * 1.44269504);
 #ifdef RSA_K5_DIAG
     a.dbg = nullptr;
 #endif
     return launch_attn(a, B * H, D, dtype, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int rsa_dense_fwd(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k,
+                             rsa_tensor4 v, int q_split, int kv_split, rsa_out4 out, void* stream) {
+    return dense_fwd(B, H, Sq, Sk, D, dtype, q, k, v, q_split, kv_split, 0, out, stream);
+}
+
+extern "C" int rsa_dense_causal_fwd(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k,
+                                    rsa_tensor4 v, int q_split, int kv_split, rsa_out4 out, void* stream) {
+    return dense_fwd(B, H, Sq, Sk, D, dtype, q, k, v, q_split, kv_split, 1, out, stream);
 }
 
 extern "C" int rsa_rectified_attention(const rsa_layout* l, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,

@@ -162,14 +162,34 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
             zero_r = !store_r && grow < a.Sq;
         }
     } else {
+        // dense mode: one or two (query rows, key rows) segments (attn.py:107-120); causal = bottom-right aligned inside a
+        // segment (the flash-attn convention the reference's "flash" mode forwards, attn.py:108-116; equal to the top-left
+        // form of its "torch" / "vanilla" modes whenever a segment has as many keys as rows)
         const int row0 = qblk * 128, row1 = row0 + 128;
-        if (grow < a.q_split) { lo_r = 0; hi_r = a.kv_split; }
-        else { lo_r = a.kv_split; hi_r = a.Sk; }
+        auto seg_hi = [&](int row) -> int {   // one past the last key row `row` may see
+            const bool s1 = row >= a.q_split;
+            const int lo = s1 ? a.kv_split : 0, hi = s1 ? a.Sk : a.kv_split;
+            if (!a.causal) return hi;
+            const int rows = s1 ? a.Sq - a.q_split : a.q_split, rin = row - (s1 ? a.q_split : 0);
+            const int lim = lo + rin + 1 + ((hi - lo) - rows);
+            return lim < lo ? lo : (lim < hi ? lim : hi);
+        };
+        lo_r = grow < a.q_split ? 0 : a.kv_split;
+        hi_r = seg_hi(grow < a.Sq ? grow : a.Sq - 1);
         store_r = grow < a.Sq;
         int lo_min;
-        if (row1 <= a.q_split) { lo_min = 0; lo_max = 0; hi_min = hi_max = a.kv_split; }
-        else if (row0 >= a.q_split) { lo_min = lo_max = a.kv_split; hi_min = hi_max = a.Sk; }
-        else { lo_min = 0; lo_max = a.kv_split; hi_min = a.kv_split; hi_max = a.Sk; }
+        const int rlast = (row1 <= a.Sq ? row1 : a.Sq) - 1;   // last real row of the block
+        if (row1 <= a.q_split) { lo_min = 0; lo_max = 0; }
+        else if (row0 >= a.q_split) { lo_min = lo_max = a.kv_split; }
+        else { lo_min = 0; lo_max = a.kv_split; }
+        // seg_hi grows with the row inside a segment: extremes of the block sit at its first / last row of each segment
+        hi_min = seg_hi(row0);
+        hi_max = seg_hi(rlast);
+        if (row0 < a.q_split && rlast >= a.q_split) {   // the block straddles the two segments
+            const int h0 = seg_hi(a.q_split - 1), h1 = seg_hi(a.q_split);
+            hi_min = hi_min < h1 ? hi_min : h1;
+            hi_max = hi_max > h0 ? hi_max : h0;
+        }
         first_blk = lo_min / RSA_BLOCK;
         n_items = (hi_max + RSA_BLOCK - 1) / RSA_BLOCK - first_blk;
         if (hi_max <= lo_min) n_items = 0;

@@ -257,7 +257,16 @@ def main():
                         shape=np.array(g.shape), q_pools=qp.numpy(), k_pools=kp.numpy(), scores=sc.numpy())
     print("gapr_1024: unreliable fraction", float(g.float().mean()))
 
-    # ---- dense fullattn torch / vanilla (attn.py:60-154), config-1 shape reduced to H=1 --------------
+    dense()
+
+
+def dense():
+    """fullattn(mode="torch" | "vanilla" | "flash") of the reference (attn.py:60-154) on the config-1 shape reduced to one
+    head; round 3: also causal=True through "torch" and "vanilla"."""
+    import rectified_spaattn.attn as ref_attn
+    from rectified_spaattn_amd import synth
+    ref_attn.flash_attn_varlen_func = _varlen_sdpa
+    outdir = os.path.dirname(os.path.abspath(__file__))
     q, k, v = synth.structured_qkv(11, 1, 1, 1536, 128)
     tq, tk, tv = (torch.from_numpy(x) for x in (q, k, v))
     am = torch.zeros(1, 1, 1, 1536, dtype=torch.bool)
@@ -269,9 +278,11 @@ def main():
     cu = torch.tensor([0, 1400, 1536], dtype=torch.int32)
     o_f = ref_attn.fullattn(tq, tk, tv, mode="flash", cu_seqlens_q=cu, cu_seqlens_kv=cu, max_seqlen_q=1536,
                             max_seqlen_kv=1536, batch_size=1)
-    assert float((o_tm - o_vm).abs().max()) < 1e-5
+    o_tc = ref_attn.fullattn(tq, tk, tv, mode="torch", causal=True)
+    o_vc = ref_attn.fullattn(tq, tk, tv, mode="vanilla", causal=True)
+    assert float((o_tm - o_vm).abs().max()) < 1e-5 and float((o_tc - o_vc).abs().max()) < 1e-5
     np.savez_compressed(os.path.join(outdir, "dense_1536.npz"), seed=11, torch=o_t.numpy(),
-                        vanilla_masked=o_vm.numpy(), flash_varlen=o_f.numpy(), n_valid=1400)
+                        vanilla_masked=o_vm.numpy(), flash_varlen=o_f.numpy(), n_valid=1400, torch_causal=o_tc.numpy())
     print("dense_1536 done; |torch-vanilla| =", float((o_t - o_v).abs().max()))
 
 
@@ -801,6 +812,9 @@ if __name__ == "__main__":
     elif len(sys.argv) > 1 and sys.argv[1] == "processors_r2":
         _install_stubs()
         processors_round2()
+    elif len(sys.argv) > 1 and sys.argv[1] == "dense":
+        _install_stubs()
+        dense()
     elif len(sys.argv) > 1 and sys.argv[1] == "processors_r3":
         _install_stubs()
         processors_round3()

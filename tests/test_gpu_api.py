@@ -87,8 +87,43 @@ def test_fullattn_device_modes(mode):
         bad[..., 3] = False
         with pytest.raises(NotImplementedError):
             attn.fullattn(q, k, v, mode=mode, attn_mask=bad)
+    # causal=True (attn.py:60-73): the reference's own vector ("torch" == "vanilla" on CPU; s == s1, so flash-attn's
+    # bottom-right alignment of mode "flash" is the same triangle)
+    oc = attn.fullattn(q, k, v, mode=mode, causal=True)
+    assert np.abs(oc.float().cpu().numpy() - z["torch_causal"]).max() <= 2e-2
+    if mode != "flash":   # top-left triangle + padding mask / s != s1 is not what the kernel's segments express
+        am = torch.ones(1, 1, 1, 1536, dtype=torch.bool, device=DEV)
+        with pytest.raises(NotImplementedError):
+            attn.fullattn(q, k, v, mode=mode, attn_mask=am, causal=True)
     with pytest.raises(NotImplementedError):
-        attn.fullattn(q, k, v, mode=mode, causal=True)
+        attn.fullattn(q, k, v, mode=mode, drop_rate=0.1)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(700, 700, 128), (300, 1000, 128), (1000, 300, 64), (129, 129, 64), (5, 640, 128)])
+def test_causal_dense_kernel_vs_oracle(shape, dt):
+    """Causal dense attention on the kernel's per-row key limits: rows == keys, more keys than rows (a decode-style
+    suffix), fewer keys than rows (the first rows see nothing: zeros), a block that ends mid-tile; and two segments."""
+    from rectified_spaattn_amd import _core, synth
+    from oracle import oracle as orc
+    Sq, Sk, D = shape
+    H = 2
+    S = max(Sq, Sk)
+    q, k, v = synth.structured_qkv(23, 1, H, S, D)
+    tq, tk, tv = (torch.from_numpy(x).to(DEV, dt) for x in (q[:, :, :Sq], k[:, :, :Sk], v[:, :, :Sk]))
+    qf, kf, vf = (x.float().cpu().numpy() for x in (tq, tk, tv))
+    out = _core.dense_attention(tq, tk, tv, causal=True).float().cpu().numpy()      # [1, Sq, H, D]
+    mx = 2e-2 if dt == torch.bfloat16 else 2e-3
+    for h in range(H):
+        ref = orc.dense_attention(qf[0, h], kf[0, h], vf[0, h], causal=True)
+        assert np.abs(out[0, :, h] - ref).max() <= mx, (shape, dt, h)
+    if Sq == Sk and Sq >= 300:   # two segments, each causal inside: rows < qs see keys < ks, the rest the rest
+        qs, ks = 200, 260
+        out2 = _core.dense_attention(tq, tk, tv, qs, ks, causal=True).float().cpu().numpy()
+        for h in range(H):
+            r1 = orc.dense_attention(qf[0, h, :qs], kf[0, h, :ks], vf[0, h, :ks], causal=True)
+            r2 = orc.dense_attention(qf[0, h, qs:], kf[0, h, ks:], vf[0, h, ks:], causal=True)
+            assert np.abs(out2[0, :qs, h] - r1).max() <= mx and np.abs(out2[0, qs:, h] - r2).max() <= mx
 
 
 def test_estimate_pr_gain_device():

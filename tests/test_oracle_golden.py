@@ -76,6 +76,9 @@ def test_dense_matches_reference():
     # flash mode also returns [b, a, s, d] (attn.py:153): rows < n attend kv < n ; rows >= n attend kv >= n
     fl = z["flash_varlen"][0, 0]
     np.testing.assert_allclose(om[:n], fl[:n], atol=2e-5)
+    # causal=True of the reference ("torch" == "vanilla", attn.py:105, :129-133)
+    oc = orc.dense_attention(q[0, 0], k[0, 0], v[0, 0], causal=True)
+    np.testing.assert_allclose(oc, z["torch_causal"][0, 0], atol=2e-5)
 
 
 def test_exp_contract_accuracy():

@@ -134,6 +134,8 @@ def test_fullattn_cpu_modes_match_reference_vectors():
                                atol=2e-5)
     np.testing.assert_allclose(attn.fullattn(q, k, v, mode="torch", attn_mask=am).numpy(), z["vanilla_masked"],
                                atol=2e-5)
+    np.testing.assert_allclose(attn.fullattn(q, k, v, mode="torch", causal=True).numpy(), z["torch_causal"], atol=2e-5)
+    np.testing.assert_allclose(attn.fullattn(q, k, v, mode="vanilla", causal=True).numpy(), z["torch_causal"], atol=2e-5)
     with pytest.raises(NotImplementedError):
         attn.fullattn(q, k, v, mode="nope")
     with pytest.raises(RsaError):
