@@ -70,67 +70,6 @@ def main():
             del call
             torch.cuda.empty_cache()
         return
-    if "pair" in what:  # A/B of the paired 256-row workgroups (tuning key k5_pair) per regime, one process
-        from rectified_spaattn_amd import _lib
-        L = _lib.lib()
-        H = int(os.environ.get("RSA_PERF_H", "24"))
-        for regime in os.environ.get("RSA_PERF_REGIMES", "locality,r1,r2").split(","):
-            call, spec = regime_call(regime, H, dev)
-            assert L.rsa_set_tuning(b"k5_pair", 1) == 0
-            call.select()
-            torch.cuda.synchronize()
-            flops, pairs = call_flops(call, spec, H)
-            ok = call.bufs["pair_ok"].float().mean().item()
-            ref = None
-            for rnd in range(2):
-                for opt in (0, 1):
-                    assert L.rsa_set_tuning(b"k5_pair", opt) == 0
-                    med, mn = timeit(call.attend, n=5, warm=2)
-                    o = call.out.float()
-                    if ref is None:
-                        ref = o.clone()
-                    print(f"{regime} round {rnd} k5_pair={opt}: {med:7.3f} ms (min {mn:7.3f}) {flops/med/1e9:7.1f} TF/s | "
-                          f"pairs ok {ok:.3f} | max|d vs first| {(o - ref).abs().max().item():.2e}", flush=True)
-            L.rsa_set_tuning(b"k5_pair", 0)
-            msel, _ = timeit(call.select, n=5, warm=1)
-            print(f"{regime}: select pass {msel:.3f} ms", flush=True)
-            del call
-            torch.cuda.empty_cache()
-        return
-    if "pp" in what:  # A/B of the ping-pong K5 (tuning key k5_pp) against the 4-wave kernel, per regime, one process
-        from rectified_spaattn_amd import _lib
-        L = _lib.lib()
-        H = int(os.environ.get("RSA_PERF_H", "24"))
-        opts = [int(x) for x in os.environ.get("RSA_PERF_OPTS", "0,2").split(",")]
-        for regime in os.environ.get("RSA_PERF_REGIMES", "r2,locality").split(","):
-            call, spec = regime_call(regime, H, dev)
-            call.select()
-            torch.cuda.synchronize()
-            flops, pairs = call_flops(call, spec, H)
-            ref = None
-            for rnd in range(2):
-                for opt in opts:
-                    assert L.rsa_set_tuning(b"k5_pp", opt) == 0
-                    med, mn = timeit(call.attend, n=5, warm=2)
-                    o = call.out.float()
-                    if ref is None:
-                        ref = o.clone()
-                    d = (o - ref).abs()
-                    print(f"{regime} round {rnd} k5_pp={opt}: {med:7.3f} ms (min {mn:7.3f}) {flops/med/1e9:7.1f} TF/s | "
-                          f"max|d vs first| {d.max().item():.2e} mean {d.mean().item():.2e} nan={int(torch.isnan(o).sum())}",
-                          flush=True)
-            L.rsa_set_tuning(b"k5_pp", 0)
-            del call
-            torch.cuda.empty_cache()
-        Sd = 16384
-        qd, kd, vd = (torch.randn(1, 24, Sd, D, device=dev).to(torch.bfloat16) for _ in range(3))
-        fld = 4.0 * Sd * Sd * D * 24
-        for opt in opts + opts:
-            assert L.rsa_set_tuning(b"k5_pp", opt) == 0
-            medd, _ = timeit(lambda: _core.dense_attention(qd, kd, vd), n=3, warm=1)
-            print(f"dense16k k5_pp={opt}: {medd:6.3f} ms {fld/medd/1e9:7.1f} TF/s", flush=True)
-        L.rsa_set_tuning(b"k5_pp", 0)
-        return
     if "sparse" in what:
         H = int(os.environ.get("RSA_PERF_H", "24"))
         wl = WORKLOADS["hunyuan_720p_128f"]
@@ -179,37 +118,6 @@ def main():
             _core.dense_attention(qd, qd, qd)
         torch.cuda.synchronize()
         return
-    if "variants" in what:
-        from rectified_spaattn_amd import _lib
-        L = _lib.lib()
-        H = 24
-        wl = WORKLOADS["hunyuan_720p_128f"]
-        S = wl["S_vis"] + wl["text"]
-        spec = _core.LayoutSpec.hunyuan(S, wl["S_vis"] + wl["text_valid"])
-        q, k, v = gen_qkv(H, 0, S, wl["S_vis"], D, dev)
-        call = _core.StagedCall(q, k, v, spec, wl["top_k"], 0.0, None)
-        call.select()
-        pairs = call.bufs["counts"].sum().item()
-        flops = 4.0 * D * 128 * 128 * pairs + 4.0 * D * spec.q_text_valid * spec.kv_text_valid * H
-        Sd = 16384
-        qd = torch.randn(1, H, Sd, D, device=dev).to(torch.bfloat16)
-        kd = torch.randn(1, H, Sd, D, device=dev).to(torch.bfloat16)
-        vd = torch.randn(1, H, Sd, D, device=dev).to(torch.bfloat16)
-        fld = 4.0 * Sd * Sd * D * H
-        ref = None
-        opts = [int(x) for x in os.environ.get("RSA_PERF_OPTS", "0,1").split(",")]
-        for rnd in range(2):
-            for opt in opts:
-                assert L.rsa_set_tuning(b"k5_prio", opt) == 0
-                med, mn = timeit(call.attend, n=4, warm=1)
-                o = call.out.float()
-                if ref is None:
-                    ref = o.clone()
-                err = (o - ref).abs().max().item()
-                medd, _ = timeit(lambda: _core.dense_attention(qd, kd, vd), n=3, warm=1)
-                print(f"round {rnd} opt {opt:2d}: sparse {med:7.3f} ms {flops/med/1e9:7.1f} TF/s | dense16k {medd:6.3f} ms "
-                      f"{fld/medd/1e9:7.1f} TF/s | max|d vs opt0| {err:.2e}", flush=True)
-        return
     if "fp8variants" in what:
         from rectified_spaattn_amd import _lib
         L = _lib.lib()
@@ -232,26 +140,6 @@ def main():
                     ref = o.clone()
                 print(f"round {rnd} fp8 variant {opt}: {med:7.3f} ms {flops/med/1e9:7.1f} TF/s | max|d| {(o-ref).abs().max().item():.2e}", flush=True)
         L.rsa_set_tuning(b"fp8_variant", 0)
-        return
-    if "dense256" in what:  # A/B of the 256-row dense tile (tuning key "dense256") against the 128-row kernel
-        from rectified_spaattn_amd import _lib
-        L = _lib.lib()
-        for S in (4096, 16384, 65536, 115456):
-            H = 24 if S < 100000 else 8
-            q, k, v = (torch.randn(1, H, S, D, device=dev).to(torch.bfloat16) for _ in range(3))
-            fl = 4.0 * S * S * D * H
-            res = {}
-            for flag in (0, 1, 0, 1):
-                assert L.rsa_set_tuning(b"dense256", flag) == 0
-                med, _ = timeit(lambda: _core.dense_attention(q, k, v), n=3, warm=1)
-                res.setdefault(flag, []).append(med)
-                if flag:
-                    o1 = _core.dense_attention(q, k, v).float()
-                else:
-                    o0 = _core.dense_attention(q, k, v).float()
-            L.rsa_set_tuning(b"dense256", 0)
-            print(f"dense S={S} H={H}: 128-row {min(res[0]):.3f} ms {fl/min(res[0])/1e9:.0f} TF/s | 256-row {min(res[1]):.3f} ms "
-                  f"{fl/min(res[1])/1e9:.0f} TF/s | max|d| {(o0-o1).abs().max().item():.2e}", flush=True)
         return
     if "dense" in what:
         for S in (8192, 16384, 32768, 65536):
