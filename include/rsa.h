@@ -287,7 +287,7 @@ int rsa_ipc_close(void* dev_ptr);
 int rsa_ipc_offset(const void* dev_ptr, int64_t* offset);                   /* dev_ptr - base of its allocation (a handle names the allocation) */
 
 /* Tuning / diagnostics hook, not part of the data path.  Keys: "k5_tsplit" (0/1: split-KV of the text query blocks),
- * "k3_prefix" (0/1: sorted-head path of K3), "fp8_variant" (0..4: iglp_opt strategy of the fp8 kernel's block).  The hook
+ * "k3_prefix" (0/1: sorted-head path of K3), "fp8_variant" (1: the e4m3 kernel with its block as hipcc schedules it, for A/B; 0: hand-placed, the product).  The hook
  * is inert (RSA_ERR_UNSUPPORTED) unless the process was started with the environment variable RSA_TUNING=1. */
 int rsa_set_tuning(const char* key, int value);
 

@@ -211,7 +211,156 @@ def main():
             out.append(f"// D = {D}{' (-m form)' if negm else ''}: O v[{m.O}:{m.Q - 1}], Q v[{m.Q}:{m.SA - 1}], SA v[{m.SA}:{m.SA + 15}], "
                        f"SB v[{m.SB}:{m.SB + 15}], " + (f"-m v[{m.NM}:{m.NM + 15}], " if negm else "")
                        + f"temporaries v[{m.tmp0}:{m.tmp1 - 1}], K addresses v[{m.KA}:{m.KA + m.KS - 1}], V addresses v[{m.VA}:{m.end - 1}]")
+    main8(out)
     print("\n".join(out))
+
+
+
+# =====================================================================================================================
+# e4m3 kernel (rsa_attn_fp8_kernel.hip): one block = one 64-KEY TILE of one wave
+#     S_nxt^T (two 32-key halves) = K8(tile+1) . Q8^T + (4 - m)   4 x v_mfma_scale_f32_32x32x64_f8f6f4 (chains start from MB)
+#     P = exp2(S_cur) -> e4m3, packed in place into S_cur[0][0:7] 32 v_exp_f32 + 16 v_cvt_pk_fp8_f32
+#     l += ones . P (row sum on the matrix pipe)                    1 x v_mfma_f32_16x16x128_f8f6f4
+#     O^T += V8^T(tile) . P                                         4 x v_mfma_f32_32x32x64_f8f6f4
+#     mx = row max of S_nxt
+# Every A operand is 8 registers = 2 x ds_read_b128, read AHEAD8 MFMAs ahead into a ring of RING8 buffers.  K and V live in
+# 4-slot LDS rings: the tile's slot (TS = tile & 3) is a compile-time constant of the block, so every LDS address is a
+# loop-invariant VGPR plus an immediate (the compiled block spent ~16 v_add_u32 per tile on them).
+# =====================================================================================================================
+AHEAD8, RING8 = 3, 4
+
+
+class Map8:
+    def __init__(self):
+        r = 0
+        self.O = r; r += 64
+        self.Q = r; r += 16
+        self.SA = r; r += 32
+        self.SB = r; r += 32
+        self.MB = r; r += 16
+        self.LACC = r; r += 4
+        self.tmp0 = r
+        self.OP = r; r += 8 * RING8
+        self.T0 = r; r += 1
+        self.T1 = r; r += 1
+        self.tmp1 = r
+        r = (r + 1) & ~1
+        self.SC = r; r += 2          # E8M0 scale operands of the QK^T MFMAs
+        self.KA = r; r += 4          # K read addresses [ks][chunk]
+        self.VA = r; r += 2          # V read addresses [chunk]
+        self.ON = r; r += 1          # address of this lane's ones / zeros pattern
+        self.end = r
+
+
+def gen_block8(TS):
+    m = Map8()
+    SC_, SN = (m.SA, m.SB) if TS % 2 == 0 else (m.SB, m.SA)
+    TILE8 = 8192
+    kslot = (TS + 1) & 3
+    lines, lds_seq = [], []
+    # the nine A operands, in MFMA order: (kind, LDS reads as (address register, immediate) pairs)
+    ops = []
+    for sub in range(2):
+        for ks in range(2):
+            off = kslot * TILE8 + sub * 4096
+            ops.append(("qk", sub, ks, [(m.KA + 2 * ks, off), (m.KA + 2 * ks + 1, off)]))
+    ops.append(("rs", 0, 0, [(m.ON, 0), (m.ON, 16)]))
+    for dt in range(4):
+        off = (4 + TS) * TILE8 + dt * 2048
+        ops.append(("pv", dt, 0, [(m.VA, off), (m.VA + 1, off)]))
+
+    def read(i):
+        b = m.OP + 8 * (i % RING8)
+        for c2, (areg, off) in enumerate(ops[i][3]):
+            lines.append(f"ds_read_b128 {vr(b + 4 * c2, 4)}, {vr(areg)}" + (f" offset:{off}" if off else ""))
+        lds_seq.append((i, 2))
+
+    def wait_for(i):
+        idx = [k for k, (t, _) in enumerate(lds_seq) if t == i][-1]
+        lines.append(f"s_waitcnt lgkmcnt({sum(c for _, c in lds_seq[idx + 1:])})")
+
+    # vector work: exponentials in place, the e4m3 words of P built in place in S_cur[0][0:7]
+    work = []
+    def exps(sub, i0):
+        return [("exp", f"v_exp_f32 {vr(SC_ + 16 * sub + i)}, {vr(SC_ + 16 * sub + i)}") for i in range(i0, i0 + 4)]
+    def pack(j):   # P word j = 4 * sub + w4 <- exp values 4 w4 .. 4 w4 + 3 of half `sub`
+        sub, w4 = divmod(j, 4)
+        e = SC_ + 16 * sub + 4 * w4
+        return [("cvt", f"v_cvt_pk_fp8_f32 {vr(SC_ + j)}, {vr(e)}, {vr(e + 1)}"),
+                ("cvt", f"v_cvt_pk_fp8_f32 {vr(SC_ + j)}, {vr(e + 2)}, {vr(e + 3)} op_sel:[0,0,1]")]
+    # order: a group's exponentials, then the PREVIOUS group's packing (a transcendental's result is not read by the next
+    # instruction); word j overwrites register j of S_cur[0], whose value the words before it have consumed
+    groups = [(s_, i0) for s_ in range(2) for i0 in range(0, 16, 4)]
+    for g, (s_, i0) in enumerate(groups):
+        work += exps(s_, i0)
+        if g >= 1: work += pack(g - 1)
+    work += pack(7)
+    maxw = [("max", f"v_max_f32 {vr(m.T0)}, {vr(SN)}, {vr(SN + 1)}"), ("max", f"v_max_f32 {vr(m.T1)}, {vr(SN + 2)}, {vr(SN + 3)}")]
+    for i in range(2, 16):
+        t = m.T0 if i % 2 == 0 else m.T1
+        maxw += [("max", f"v_max3_f32 {vr(t)}, {vr(t)}, {vr(SN + 2 * i)}, {vr(SN + 2 * i + 1)}")]
+    maxw += [("max", f"v_max_f32 {vr(m.T0)}, {vr(m.T0)}, {vr(m.T1)}"), ("mov", f"v_mov_b32 {vr(m.T1)}, {vr(m.T0)}"),
+             ("nop", "s_nop 1"), ("swap", f"v_permlane32_swap_b32 {vr(m.T0)}, {vr(m.T1)}"), ("nop", "s_nop 1"),
+             ("max", f"v_max_f32 %[mx], {vr(m.T0)}, {vr(m.T1)}")]
+    wi, mi = 0, 0
+
+    def emit_work(cycles, allow_max, force_all=False):
+        nonlocal wi, mi
+        used = 0
+        while used < cycles or force_all:
+            if wi < len(work):
+                k, t = work[wi]; wi += 1
+            elif allow_max and mi < len(maxw):
+                k, t = maxw[mi]; mi += 1
+            else:
+                break
+            lines.append(t)
+            used += COST[k]
+
+    lines.append("s_setprio 2")
+    for i in range(AHEAD8): read(i)
+    emit_work(64, False)
+    n = len(ops)
+    for i, (kind, x, y, _) in enumerate(ops):
+        if kind != "qk" and wi < len(work):   # the row sum and PV read the whole packed P
+            emit_work(0, False, force_all=True)
+        wait_for(i)
+        a = vr(m.OP + 8 * (i % RING8), 8)
+        if kind == "qk":
+            c = vr(m.MB, 16) if y == 0 else vr(SN + 16 * x, 16)
+            lines.append(f"v_mfma_scale_f32_32x32x64_f8f6f4 {vr(SN + 16 * x, 16)}, {a}, {vr(m.Q + 8 * y, 8)}, {c}, "
+                         f"{vr(m.SC)}, {vr(m.SC + 1)} op_sel_hi:[0,0,0]")
+        elif kind == "rs":
+            lines.append("s_nop 1")   # the last word of P was packed just above
+            lines.append(f"v_mfma_f32_16x16x128_f8f6f4 {vr(m.LACC, 4)}, {a}, {vr(SC_, 8)}, {vr(m.LACC, 4)}")
+        else:
+            lines.append(f"v_mfma_f32_32x32x64_f8f6f4 {vr(m.O + 16 * x, 16)}, {a}, {vr(SC_, 8)}, {vr(m.O + 16 * x, 16)}")
+        if i + AHEAD8 < n: read(i + AHEAD8)
+        # row max of S_nxt: two MFMAs behind the last QK^T MFMA (index 3): from the shadow of PV 0 (index 5) on
+        emit_work(10 ** 6 if i == n - 1 else 48, i >= 5)
+    assert wi == len(work) and mi == len(maxw)
+    lines.append("s_setprio 0")
+    return lines, m
+
+
+def main8(out):
+    for TS in range(4):
+        lines, m = gen_block8(TS)
+        out.append(f"#define RSA_K5F8_BLOCK_T{TS} \\")
+        out.append(" \\\n".join(c_string(lines).split("\n")))
+        out.append("")
+    m = Map8()
+    outs = [f'"+{{{vr(m.O + 16 * d, 16)}}}"(o[{d}])' for d in range(4)]
+    outs += [f'"+{{{vr(m.SA, 16)}}}"(SA[0])', f'"+{{{vr(m.SA + 16, 16)}}}"(SA[1])', f'"+{{{vr(m.SB, 16)}}}"(SB[0])',
+             f'"+{{{vr(m.SB + 16, 16)}}}"(SB[1])', f'"+{{{vr(m.LACC, 4)}}}"(lacc)', '[mx] "=&v"(mx)']
+    ins = [f'"{{{vr(m.Q, 8)}}}"(q[0])', f'"{{{vr(m.Q + 8, 8)}}}"(q[1])', f'"{{{vr(m.MB, 16)}}}"(mblk)',
+           f'"{{{vr(m.SC)}}}"(sca)', f'"{{{vr(m.SC + 1)}}}"(scb)', f'"{{{vr(m.KA, 4)}}}"(ka)', f'"{{{vr(m.VA, 2)}}}"(va)',
+           f'"{{{vr(m.ON)}}}"(ona)']
+    out.append(f"#define RSA_K5F8_OPS : {', '.join(outs)} : {', '.join(ins)}")
+    out.append("#define RSA_K5F8_CLOBBER " + ", ".join(f'"v{r}"' for r in range(m.tmp0, m.tmp1)))
+    out.append(f"// e4m3 kernel: O v[0:63], Q v[{m.Q}:{m.SA - 1}], SA v[{m.SA}:{m.SB - 1}], SB v[{m.SB}:{m.MB - 1}], 4 - m v[{m.MB}:{m.LACC - 1}], "
+               f"l v[{m.LACC}:{m.LACC + 3}], temporaries v[{m.tmp0}:{m.tmp1 - 1}], scales v[{m.SC}:{m.SC + 1}], "
+               f"K / V / ones addresses v[{m.KA}:{m.end - 1}]")
 
 
 if __name__ == "__main__":

@@ -27,7 +27,9 @@
 // K(t+3) and V(t+2) behind `s_waitcnt vmcnt(4)` + barrier, so every tile has two full steps to land.  (Issuing them
 // before the barrier wait -- legal with four slots -- measured the same: 9.71 vs 9.66 ms.)
 #include "rsa_attn.h"
+#include "rsa_attn_block.h"
 
+typedef int i32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -72,6 +74,18 @@ __device__ __forceinline__ f32x16 mfma8s(i32x8 a, i32x8 b, f32x16 c, int sa, int
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, sa, 0, sb);
 }
 
+// the hand-placed tile block (gen_k5_block.py, RSA_K5F8_*): one asm statement per 64-key tile, registers pinned; TS = tile & 3
+template <int TS>
+__device__ __forceinline__ void k5f8_block(f32x16 (&o)[4], const i32x8 (&q)[2], f32x16 (&SA)[2], f32x16 (&SB)[2],
+                                           const f32x16& mblk, f32x4& lacc, float& mx, int sca, int scb, const i32x4& ka,
+                                           const i32x2& va, int ona) {
+    if constexpr (TS == 0) asm volatile(RSA_K5F8_BLOCK_T0 RSA_K5F8_OPS : RSA_K5F8_CLOBBER, "memory");
+    else if constexpr (TS == 1) asm volatile(RSA_K5F8_BLOCK_T1 RSA_K5F8_OPS : RSA_K5F8_CLOBBER, "memory");
+    else if constexpr (TS == 2) asm volatile(RSA_K5F8_BLOCK_T2 RSA_K5F8_OPS : RSA_K5F8_CLOBBER, "memory");
+    else asm volatile(RSA_K5F8_BLOCK_T3 RSA_K5F8_OPS : RSA_K5F8_CLOBBER, "memory");
+}
+
+// PIPE_OPT bit 1: the hand-placed block (product); 0: the block as hipcc schedules it (tuning key fp8_variant = 1, A/B only)
 template <int PIPE_OPT>
 __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -233,6 +247,17 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
 #pragma unroll
     for (int c2 = 0; c2 < 2; ++c2) voff_rd[c2] = r * 64 + (((2 * hh + c2) ^ ((r >> 2) & 3)) << 4);
 
+    // read addresses of the hand-placed block (LDS byte addresses; ring slot, sub-tile and d-tile are immediates)
+    i32x4 ka;
+    i32x2 va;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) ka[2 * ks + c2] = (int)lds_base + koff[0][ks][c2];
+    va[0] = (int)lds_base + voff_rd[0];
+    va[1] = (int)lds_base + voff_rd[1];
+    const int ona = (int)lds_base + 2 * NSLOT * TILE8 + ones_off;
+
     auto ld32 = [&](const unsigned char* p0, const unsigned char* p1) -> i32x8 {
         const i32x4 lo = *reinterpret_cast<const i32x4*>(p0);
         const i32x4 hi = *reinterpret_cast<const i32x4*>(p1);
@@ -257,11 +282,13 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
         return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));  // = score_max - m_eff + P_OFFSET
     };
     auto apply_mask = [&](f32x16 (&S)[2], int key0) {
+        int kbase = key0 + 4 * hh;
+        asm volatile("" : "+v"(kbase));   // rare branch: keep its 32 key indices out of the loop's live registers
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int kk = key0 + 32 * sub + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                const int kk = kbase + 32 * sub + (i & 3) + 8 * (i >> 2);
                 if (kk < lo_r || kk >= hi_r) S[sub][i] = -INFINITY;
             }
     };
@@ -284,6 +311,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
         // mx_cur and S_cur are relative to the block's reference: score - m_eff + P_OFFSET
         const bool grow = (m_run == -INFINITY) ? (mx_cur > -INFINITY) : (mx_cur > P_THRESH + P_OFFSET);
         if (__builtin_amdgcn_ballot_w64(grow) != 0ull) {
+            asm volatile("s_nop 15\n\ts_nop 5" ::: "memory");   // the block's last (16-pass) MFMA wrote O: wait states before VALU
             const float m_eff_old = (m_run == -INFINITY) ? 0.0f : m_run;
             const float m_new = fmaxf(m_run, mx_cur - P_OFFSET + m_eff_old);
             const float m_eff = (m_new == -INFINITY) ? 0.0f : m_new;
@@ -305,6 +333,13 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
         }
 
         // ---- pipelined block ----
+        if constexpr ((PIPE_OPT & 1) != 0) {
+            constexpr int tsc = decltype(TS)::value;
+            // S_cur is SA on even tiles, SB on odd ones (tile & 1 == TS & 1)
+            if constexpr ((tsc & 1) == 0) k5f8_block<tsc>(o, qf, S_cur, S_nxt, mblk, lacc, mx_nxt, sc_a, sc_b, ka, va, ona);
+            else k5f8_block<tsc>(o, qf, S_nxt, S_cur, mblk, lacc, mx_nxt, sc_a, sc_b, ka, va, ona);
+            return;
+        }
         if constexpr (PIPE_OPT & 2) __builtin_amdgcn_s_setprio(2);
         if constexpr ((PIPE_OPT >> 8) == 1) __builtin_amdgcn_iglp_opt(0);
         if constexpr ((PIPE_OPT >> 8) == 2) __builtin_amdgcn_iglp_opt(1);
@@ -359,7 +394,26 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
         kq2 = kq3;
         kq3 = key0_of(tile + 4);
     };
-    {
+    if constexpr ((PIPE_OPT & 1) != 0) {   // four tiles per trip: the ring slot is a compile-time constant of every block
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        using I3 = std::integral_constant<int, 3>;
+        int tile = 0;
+        for (; tile + 3 < n_tiles; tile += 4) {
+            step(I0{}, tile, key0, SA, mxA, SB, mxB);
+            advance(tile);
+            step(I1{}, tile + 1, key0, SB, mxB, SA, mxA);
+            advance(tile + 1);
+            step(I2{}, tile + 2, key0, SA, mxA, SB, mxB);
+            advance(tile + 2);
+            step(I3{}, tile + 3, key0, SB, mxB, SA, mxA);
+            advance(tile + 3);
+        }
+        if (tile < n_tiles) { step(I0{}, tile, key0, SA, mxA, SB, mxB); advance(tile); }
+        if (tile + 1 < n_tiles) { step(I1{}, tile + 1, key0, SB, mxB, SA, mxA); advance(tile + 1); }
+        if (tile + 2 < n_tiles) step(I2{}, tile + 2, key0, SA, mxA, SB, mxB);
+    } else {
         int tile = 0;
         for (; tile + 1 < n_tiles; tile += 2) {
             step(tile & 3, tile, key0, SA, mxA, SB, mxB);
@@ -371,6 +425,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     }
 
     // ---------------- epilogue ----------------
+    asm volatile("s_nop 15\n\ts_nop 5" ::: "memory");   // (the last block's last MFMA -> the reads of O / l below)
     const float l_tot = lacc[0];
     if (a.mode == MODE_SPARSE && a.tsplit > 1 && qblk >= a.NBv) {
         // split-KV partial of a text block (merged by rsa_attn.hip's combine kernel): O in V's units, m, l
@@ -444,13 +499,8 @@ int launch_attn8(Attn8Args& a, int BH, hipStream_t s) {
     if (nblocks > 0x7FFFFFFF) return RSA_ERR_UNSUPPORTED;
     if (a.NB_total > 8192) return RSA_ERR_UNSUPPORTED;
     const size_t lds_bytes = (size_t)2 * NSLOT * TILE8 + 64 + (((size_t)a.NB_total * 2 + 15) & ~(size_t)15);
-    switch (g_fp8_variant) {
-        case 1: bsfwd_fp8_kernel<2 + 256><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a); break;
-        case 2: bsfwd_fp8_kernel<2 + 512><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a); break;
-        case 3: bsfwd_fp8_kernel<2 + 768><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a); break;
-        case 4: bsfwd_fp8_kernel<2 + 1024><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a); break;
-        default: bsfwd_fp8_kernel<2><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a); break;
-    }
+    if (g_fp8_variant == 1) bsfwd_fp8_kernel<2><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a);   // A/B: hipcc's schedule
+    else bsfwd_fp8_kernel<3><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a);
     const int st = rsa_launch_status();
     if (st != RSA_OK || a.tsplit <= 1) return st;
     return rsa_launch_text_combine(a.tpart, a.out, a.osb, a.osh, a.oss, D8, a.H, a.NBv, ntq, a.tsplit, a.q_text_end, a.Sq,
