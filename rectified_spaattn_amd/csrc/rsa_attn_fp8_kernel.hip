@@ -388,11 +388,19 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
         qk_tile(0, SA);
         mxA = rowmax_tile(SA);
     }
-    auto advance = [&](int tile) {  // after finishing `tile`: shift the key queue, fetch tile+4's first key
+    // The kept-list entry of tile+4 is read from LDS one advance() EARLY into a register (pref_raw) and only made scalar
+    // here: the LDS round trip (~100 cycles, once per tile and wave) is off the wave's critical path.
+    auto raw_item = [&](int tile) -> int {   // block index of `tile`'s list entry, still per lane (index clamped)
+        const int it = tile >> 1;
+        return blk_of(it < n_items ? it : (n_items > 0 ? n_items - 1 : 0));
+    };
+    int pref_raw = n_tiles > 0 ? raw_item(4) : 0;
+    auto advance = [&](int tile) {  // after finishing `tile`: shift the key queue, tile+4's first key from the prefetched entry
         key0 = kq1;
         kq1 = kq2;
         kq2 = kq3;
-        kq3 = key0_of(tile + 4);
+        kq3 = __builtin_amdgcn_readfirstlane(pref_raw) * RSA_BLOCK + ((tile + 4) & 1) * 64;
+        pref_raw = raw_item(tile + 5);
     };
     if constexpr ((PIPE_OPT & 1) != 0) {   // four tiles per trip: the ring slot is a compile-time constant of every block
         using I0 = std::integral_constant<int, 0>;

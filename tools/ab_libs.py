@@ -46,14 +46,17 @@ def main():
         rounds = int(sys.argv[sys.argv.index("--rounds") + 1])
         args = [a for a in args if a != str(rounds)]
     pmc = "--pmc" in sys.argv
+    fp8 = "--fp8" in sys.argv      # K5 on the e4m3 images (rsa_block_sparse_fwd_fp8); builds with the current rsa_fp8_operands only
     dev = torch.device("cuda:0")
     H = int(os.environ.get("RSA_PERF_H", "24"))
     wl = WORKLOADS["hunyuan_720p_128f"]
     spec = make_spec(wl)
     cent, nbr_kind, p = REGIMES[os.environ.get("RSA_PERF_REGIME", "r2")]
     q, k, v = gen_inputs(wl, H, 0, dev, cent)
-    call = _core.StagedCall(q, k, v, spec, wl["top_k"], p, make_neighbors(wl, spec, nbr_kind))
+    call = _core.StagedCall(q, k, v, spec, wl["top_k"], p, make_neighbors(wl, spec, nbr_kind), qkv_fp8=fp8)
     call.select()
+    if fp8:
+        call.quantize()
     torch.cuda.synchronize()
     pairs = call.bufs["counts"].sum().item()
     flops = 4.0 * 128 * 128 * 128 * pairs + 4.0 * 128 * spec.q_text_valid * spec.kv_text_valid * H
@@ -87,6 +90,12 @@ def main():
 
     def run(lib):
         apply_tuning(lib)
+        if fp8:
+            fn = lib["L"].rsa_block_sparse_fwd_fp8
+            fn.restype = ctypes.c_int
+            rc = fn(ctypes.byref(call.lay), ctypes.byref(call.cf), ctypes.byref(lib["cb"]), lib["o4"], st)
+            assert rc == 0, (lib["name"], rc)
+            return
         rc = lib["L"].rsa_block_sparse_fwd(ctypes.byref(call.lay), *call.t, ctypes.byref(lib["cb"]), lib["o4"], st)
         assert rc == 0, (lib["name"], rc)
 
@@ -98,6 +107,8 @@ def main():
 
     def run_dense(lib):
         apply_tuning(lib)
+        if fp8:
+            return
         rc = lib["L"].rsa_dense_fwd(1, H, Sd, Sd, 128, 0, _core._t4(qd), _core._t4(kd), _core._t4(vd), Sd, Sd, od4, st)
         assert rc == 0, (lib["name"], rc)
 
