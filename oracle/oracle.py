@@ -521,11 +521,111 @@ def fp8_dequantized_qkv(q, k, v, lay: Layout, smooth_k: bool = True):
     return res[0], res[1], res[2], ops
 
 
+# The e4m3 kernel's P ("code map", rsa_attn_fp8_kernel.hip PMap<true>): with x = log2(e) sm_scale (q . k) - m + 6.5 the byte
+# stored for P is code = rint(8 x + 56) clamped to [0, 255] (round half to even), i.e. P = 2^e (1 + m3 / 8) for
+# code = 8 (e + 7) + m3 -- the format's own piecewise-linear log2 instead of an exponential followed by a rounding.  m is
+# the row's running reference: the first finite tile maximum, afterwards moved to the current tile maximum whenever SOME
+# row of the same wave (32 consecutive query rows) sees a tile maximum more than 2 above its reference; O and l are
+# rescaled by 2^(m_old - m_new) then.  Tiles are 64 keys, in the order the kernel walks the kept list.
+PCODE_U, PCODE_BIAS, PCODE_OFFSET, PCODE_THRESH = 8.0, 56.0, 6.5, 2.0
+_E4M3_CODE_VALUE = None
+
+
+def e4m3_code_values() -> np.ndarray:
+    global _E4M3_CODE_VALUE
+    if _E4M3_CODE_VALUE is None:
+        _E4M3_CODE_VALUE = dequantize_e4m3(np.arange(128, dtype=np.uint8)).astype(np.float64)
+    return _E4M3_CODE_VALUE
+
+
+def attention_rows_pcode(qr, k, v, tile_keys: Sequence[int], lo, hi, sm_scale, wave: int = 32):
+    """softmax(qr k^T sm_scale) v over the 64-key tiles starting at `tile_keys` (in that order), keys outside
+    [lo[row], hi[row]) masked, P through the code map above with the kernel's deferred reference.  fp64 accumulation.
+    Returns (O, l) un-normalised in V's units plus the final reference m: [rows, D], [rows], [rows]."""
+    n, D = qr.shape
+    val = e4m3_code_values()
+    lo = np.broadcast_to(np.asarray(lo), (n,))
+    hi = np.broadcast_to(np.asarray(hi), (n,))
+    c = float(sm_scale) * math.log2(math.e)
+    q64 = qr.astype(np.float64)
+    O = np.zeros((n, D), np.float64)
+    l = np.zeros(n, np.float64)
+    m = np.full(n, -np.inf)
+    npad = (-n) % wave
+    for key0 in tile_keys:
+        kk = np.arange(key0, key0 + 64)
+        kt = np.zeros((64, D), np.float64)
+        vt = np.zeros((64, D), np.float64)
+        ok = kk < k.shape[0]
+        kt[ok] = k[kk[ok]]
+        vt[ok] = v[kk[ok]]
+        s = (q64 @ kt.T) * c
+        s = np.where((kk[None, :] >= lo[:, None]) & (kk[None, :] < hi[:, None]), s, -np.inf)
+        mx = s.max(axis=1)
+        grow = np.where(np.isneginf(m), mx > -np.inf, mx > m + PCODE_THRESH)
+        g = np.concatenate([grow, np.zeros(npad, bool)]).reshape(-1, wave).any(axis=1)
+        g = np.repeat(g, wave)[:n]
+        m_new = np.where(g, np.maximum(m, mx), m)
+        with np.errstate(invalid="ignore"):
+            alpha = np.where(np.isneginf(m_new) | (m_new == m), 1.0, np.exp2(np.where(np.isneginf(m), -np.inf, m) - np.where(np.isneginf(m_new), 0.0, m_new)))
+        O *= alpha[:, None]
+        l *= alpha
+        m = m_new
+        m_eff = np.where(np.isneginf(m), 0.0, m)
+        with np.errstate(invalid="ignore"):
+            code = np.rint(PCODE_U * (s - m_eff[:, None] + PCODE_OFFSET) + PCODE_BIAS)
+        code = np.clip(np.where(np.isnan(code), 0, code), 0, 127).astype(np.int64)
+        P = val[code]
+        O += P @ vt
+        l += P.sum(axis=1)
+    return O, l, m
+
+
+def sparse_attention_head_pcode(q, k, v, lay: Layout, kept_rows: np.ndarray, rows: Sequence[int]):
+    """sparse_attention_head with the e4m3 kernel's P (same arguments; q, k, v = the dequantised images)."""
+    D = q.shape[1]
+    sm = float(D) ** -0.5
+    out = np.zeros((len(rows), BLOCK, D), np.float64)
+    for a, i in enumerate(rows):
+        r0 = i * BLOCK
+        nrow = max(0, min(BLOCK, lay.S - r0))
+        if nrow == 0:
+            continue
+        qb = np.zeros((BLOCK, D), np.float32)          # the kernel always runs four full waves (rows past S: zero queries)
+        qb[:nrow] = q[r0: r0 + nrow]
+        tiles = [int(b) * BLOCK + t for b in np.nonzero(kept_rows[a])[0] for t in (0, 64)]
+        O, l, _ = attention_rows_pcode(qb, k, v, tiles, 0, lay.kv_valid, sm)
+        out[a, :nrow] = (O / np.where(l > 0, l, 1.0)[:, None])[:nrow]
+    return out
+
+
+def dense_rows_pcode(qr, k, v, kv_valid: int, row0: int):
+    """Dense text rows with the e4m3 kernel's P: query rows `qr` start at row `row0` of their 128-row block grid (the wave
+    grouping follows the block), keys [0, kv_valid), one workgroup per query block (no split-KV: < 32 key blocks)."""
+    D = qr.shape[1]
+    assert (kv_valid + BLOCK - 1) // BLOCK < 32, "split-KV text rows are not modelled here"
+    out = np.zeros((qr.shape[0], D), np.float64)
+    tiles = list(range(0, kv_valid, 64))
+    first = row0
+    while first < row0 + qr.shape[0]:
+        blk0 = (first // BLOCK) * BLOCK
+        n_here = min(blk0 + BLOCK, row0 + qr.shape[0]) - first
+        qb = np.zeros((BLOCK, D), np.float32)
+        qb[first - blk0: first - blk0 + n_here] = qr[first - row0: first - row0 + n_here]
+        O, l, _ = attention_rows_pcode(qb, k, v, tiles, 0, kv_valid, float(D) ** -0.5)
+        res = O / np.where(l > 0, l, 1.0)[:, None]
+        out[first - row0: first - row0 + n_here] = res[first - blk0: first - blk0 + n_here]
+        first += n_here
+    return out
+
+
 def rectified_attention_fp8(q, k, v, lay: Layout, top_k: int, p: float, neighbor=None, want_parts: bool = False,
-                            smooth_k: bool = True):
+                            smooth_k: bool = True, p_form: str = "exact"):
     """Operator with fp8 K5 operands: mask statistics, R and comp from the 2-byte inputs (unchanged contract), the
-    sparse / text-row attention itself on the dequantised e4m3 values (P kept in fp64 here; the kernel rounds P to
-    e4m3 -- covered by the stated fp8 tolerance)."""
+    sparse / text-row attention itself on the dequantised e4m3 values.  p_form = "exact": P kept in fp64 (what the e4m3
+    rounding of P is measured against: the stated fp8 tolerance); "code": P exactly as the kernel forms it (code map and
+    deferred reference above) -- the kernel then differs only by fp32 accumulation and by codes on a rounding boundary."""
+    assert p_form in ("exact", "code")
     B, H, S, D = q.shape
     q8, k8, v8, ops = fp8_dequantized_qkv(q, k, v, lay, smooth_k)
     out = np.zeros((B, S, H, D), np.float32)
@@ -540,13 +640,17 @@ def rectified_attention_fp8(q, k, v, lay: Layout, top_k: int, p: float, neighbor
                 kk[lay.pool_valid:] = 0
                 vv[lay.pool_valid:] = 0
             sel = select_head(qq, kk, vv, lay, top_k, p, neighbor)
-            o = sparse_attention_head(q8[b, h], k8[b, h], v8[b, h], lay, sel["kept"], sel["rows"])
+            head = sparse_attention_head_pcode if p_form == "code" else sparse_attention_head
+            o = head(q8[b, h], k8[b, h], v8[b, h], lay, sel["kept"], sel["rows"])
             o = o * sel["R"][:, None, None].astype(np.float64) + sel["comp"][:, None, :].astype(np.float64)
             o = o.reshape(-1, D)[: min(S, nvis_tok)]
             out[b, : o.shape[0], h] = o
             if lay.q_text_valid > 0:
                 r0 = nvis_tok
-                ot = dense_attention(q8[b, h][r0: r0 + lay.q_text_valid], k8[b, h], v8[b, h], lay.kv_text_valid)
+                if p_form == "code":
+                    ot = dense_rows_pcode(q8[b, h][r0: r0 + lay.q_text_valid], k8[b, h], v8[b, h], lay.kv_text_valid, r0)
+                else:
+                    ot = dense_attention(q8[b, h][r0: r0 + lay.q_text_valid], k8[b, h], v8[b, h], lay.kv_text_valid)
                 out[b, r0: r0 + lay.q_text_valid, h] = ot
             if want_parts:
                 parts.append(sel)

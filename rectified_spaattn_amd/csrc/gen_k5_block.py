@@ -33,7 +33,7 @@ usage: python3 gen_k5_block.py > rsa_attn_block.h
 """
 
 AHEAD = 4          # LDS operand buffers per operand kind (K fragments, V^T fragments)
-COST = dict(sub=4, exp=8, cvt=4, add=4, max=4, mov=4, nop=8, swap=4)
+COST = dict(sub=4, exp=8, cvt=4, cvt8=5, add=4, max=4, mov=4, nop=8, swap=4)
 
 
 class Map:
@@ -252,7 +252,7 @@ class Map8:
         self.end = r
 
 
-def gen_block8(TS):
+def gen_block8(TS, codemap=False):
     m = Map8()
     SC_, SN = (m.SA, m.SB) if TS % 2 == 0 else (m.SB, m.SA)
     TILE8 = 8192
@@ -291,10 +291,23 @@ def gen_block8(TS):
     # order: a group's exponentials, then the PREVIOUS group's packing (a transcendental's result is not read by the next
     # instruction); word j overwrites register j of S_cur[0], whose value the words before it have consumed
     groups = [(s_, i0) for s_ in range(2) for i0 in range(0, 16, 4)]
-    for g, (s_, i0) in enumerate(groups):
-        work += exps(s_, i0)
-        if g >= 1: work += pack(g - 1)
-    work += pack(7)
+    if not codemap:
+        for g, (s_, i0) in enumerate(groups):
+            work += exps(s_, i0)
+            if g >= 1: work += pack(g - 1)
+        work += pack(7)
+    else:
+        # code-map form: the accumulator holds 8 log2(P) + 56, the e4m3 CODE of P up to rounding: one v_cvt_pk_u8_f32 per score
+        # (round to nearest even, saturating at 0: tools/probes/cvt_pk_u8_probe.hip), no exponential, no fp8 conversion.
+        # Word j = register j of S_cur[0]; registers 0..7 are all sources of words 0 and 1, so those two go first (word 1
+        # starts once word 0 has read register 1), the rest in interleaved pairs (no back-to-back dependent conversions).
+        def byte(j, e):
+            sub, w4 = divmod(j, 4)
+            return ("cvt8", f"v_cvt_pk_u8_f32 {vr(SC_ + j)}, {vr(SC_ + 16 * sub + 4 * w4 + e)}, {e}, {vr(SC_ + j)}")
+        work += [byte(0, 0), byte(0, 1), byte(1, 0), byte(0, 2), byte(1, 1), byte(0, 3), byte(1, 2), byte(1, 3)]
+        for j in (2, 4, 6):
+            for e in range(4):
+                work += [byte(j, e), byte(j + 1, e)]
     maxw = [("max", f"v_max_f32 {vr(m.T0)}, {vr(SN)}, {vr(SN + 1)}"), ("max", f"v_max_f32 {vr(m.T1)}, {vr(SN + 2)}, {vr(SN + 3)}")]
     for i in range(2, 16):
         t = m.T0 if i % 2 == 0 else m.T1
@@ -344,11 +357,12 @@ def gen_block8(TS):
 
 
 def main8(out):
-    for TS in range(4):
-        lines, m = gen_block8(TS)
-        out.append(f"#define RSA_K5F8_BLOCK_T{TS} \\")
-        out.append(" \\\n".join(c_string(lines).split("\n")))
-        out.append("")
+    for codemap in (False, True):
+        for TS in range(4):
+            lines, m = gen_block8(TS, codemap)
+            out.append(f"#define RSA_K5F8_BLOCK{'C' if codemap else ''}_T{TS} \\")
+            out.append(" \\\n".join(c_string(lines).split("\n")))
+            out.append("")
     m = Map8()
     outs = [f'"+{{{vr(m.O + 16 * d, 16)}}}"(o[{d}])' for d in range(4)]
     outs += [f'"+{{{vr(m.SA, 16)}}}"(SA[0])', f'"+{{{vr(m.SA + 16, 16)}}}"(SA[1])', f'"+{{{vr(m.SB, 16)}}}"(SB[0])',

@@ -64,7 +64,21 @@ namespace {
 constexpr int D8 = 128;
 constexpr int TILE8 = 8192;   // bytes of one K tile (64 keys x 128) and of one V tile (128 d x 64 keys)
 constexpr int NSLOT = 4;
-constexpr float P_OFFSET = 4.0f, P_THRESH = 4.0f;
+// How P reaches e4m3.  Both forms keep the QK^T accumulator relative to the row's reference m (the chain starts from a block
+// holding the constant), so a score s arrives as U (s - m + OFFSET) + BIAS:
+//   exact form (PIPE_OPT bit 2 clear): U = 1, BIAS = 0: log2(P); P = v_exp_f32, then v_cvt_pk_fp8_f32 (round to nearest even);
+//   code-map form (bit 2 set, product):  U = 8, BIAS = 56: the e4m3 CODE of P on the piecewise-linear log2 of the format
+//     (code c = 8 (e + 7) + m3 means 2^e (1 + m3 / 8), so log2(value) ~ c / 8 - 7 with an error below 0.086 inside a binade);
+//     one v_cvt_pk_u8_f32 per score rounds it (nearest even, negative and NaN -> 0: tools/probes/cvt_pk_u8_probe.hip) and
+//     places the byte.  P is then a function of the score that differs from 2^x by a smooth factor in [1, 1.0615] times the
+//     format's own rounding; numerator (PV) and denominator (row sum, same codes, on the matrix pipe) see the same P.
+//     Measured against exact P: ~1.2x the RMS error of round-to-nearest e4m3 P (tests/diag_fp8_pmap.py), i.e. +0.3 % of the
+//     fp8 path's total error against the bf16 oracle, for 32 v_exp_f32 + 16 conversions -> 32 conversions per tile.
+// OFFSET / THRESH: the reference m moves only when a tile's maximum exceeds it by THRESH (deferred rescale), so
+// log2(P) < OFFSET + THRESH: 8 < log2(448) for the exact form; 8.5 for the code map = code 124 <= 126 (127 is NaN).
+template <bool CODEMAP> struct PMap;
+template <> struct PMap<false> { static constexpr float U = 1.0f, BIAS = 0.0f, OFFSET = 4.0f, THRESH = 4.0f; static constexpr int EXP = 0; };
+template <> struct PMap<true> { static constexpr float U = 8.0f, BIAS = 56.0f, OFFSET = 6.5f, THRESH = 2.0f; static constexpr int EXP = 3; };
 
 __device__ __forceinline__ f32x16 mfma8(i32x8 a, i32x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0, 0, 0);  // e4m3 x e4m3, unscaled
@@ -75,19 +89,31 @@ __device__ __forceinline__ f32x16 mfma8s(i32x8 a, i32x8 b, f32x16 c, int sa, int
 }
 
 // the hand-placed tile block (gen_k5_block.py, RSA_K5F8_*): one asm statement per 64-key tile, registers pinned; TS = tile & 3
-template <int TS>
+template <int TS, bool CODEMAP>
 __device__ __forceinline__ void k5f8_block(f32x16 (&o)[4], const i32x8 (&q)[2], f32x16 (&SA)[2], f32x16 (&SB)[2],
                                            const f32x16& mblk, f32x4& lacc, float& mx, int sca, int scb, const i32x4& ka,
                                            const i32x2& va, int ona) {
-    if constexpr (TS == 0) asm volatile(RSA_K5F8_BLOCK_T0 RSA_K5F8_OPS : RSA_K5F8_CLOBBER, "memory");
-    else if constexpr (TS == 1) asm volatile(RSA_K5F8_BLOCK_T1 RSA_K5F8_OPS : RSA_K5F8_CLOBBER, "memory");
-    else if constexpr (TS == 2) asm volatile(RSA_K5F8_BLOCK_T2 RSA_K5F8_OPS : RSA_K5F8_CLOBBER, "memory");
-    else asm volatile(RSA_K5F8_BLOCK_T3 RSA_K5F8_OPS : RSA_K5F8_CLOBBER, "memory");
+    if constexpr (CODEMAP) {
+        if constexpr (TS == 0) asm volatile(RSA_K5F8_BLOCKC_T0 RSA_K5F8_OPS : RSA_K5F8_CLOBBER, "memory");
+        else if constexpr (TS == 1) asm volatile(RSA_K5F8_BLOCKC_T1 RSA_K5F8_OPS : RSA_K5F8_CLOBBER, "memory");
+        else if constexpr (TS == 2) asm volatile(RSA_K5F8_BLOCKC_T2 RSA_K5F8_OPS : RSA_K5F8_CLOBBER, "memory");
+        else asm volatile(RSA_K5F8_BLOCKC_T3 RSA_K5F8_OPS : RSA_K5F8_CLOBBER, "memory");
+    } else {
+        if constexpr (TS == 0) asm volatile(RSA_K5F8_BLOCK_T0 RSA_K5F8_OPS : RSA_K5F8_CLOBBER, "memory");
+        else if constexpr (TS == 1) asm volatile(RSA_K5F8_BLOCK_T1 RSA_K5F8_OPS : RSA_K5F8_CLOBBER, "memory");
+        else if constexpr (TS == 2) asm volatile(RSA_K5F8_BLOCK_T2 RSA_K5F8_OPS : RSA_K5F8_CLOBBER, "memory");
+        else asm volatile(RSA_K5F8_BLOCK_T3 RSA_K5F8_OPS : RSA_K5F8_CLOBBER, "memory");
+    }
 }
 
-// PIPE_OPT bit 1: the hand-placed block (product); 0: the block as hipcc schedules it (tuning key fp8_variant = 1, A/B only)
+// PIPE_OPT bit 0: the hand-placed block (clear: the block as hipcc schedules it, same arithmetic, for A/B);
+// bit 1: s_setprio around the compiled block; bit 2: the code-map form of P (PMap above).  Product = 7.
 template <int PIPE_OPT>
 __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
+    constexpr bool CODEMAP = (PIPE_OPT & 4) != 0;
+    using PM = PMap<CODEMAP>;
+    constexpr float P_BASE = PM::U * PM::OFFSET + PM::BIAS;   // accumulator value of a score equal to the reference m
+    constexpr float P_GROW = PM::U * PM::THRESH + P_BASE;     // above it the reference moves
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* lds_ones = lds + 2 * NSLOT * TILE8;  // 32 bytes of e4m3 1.0, then 32 bytes of 0
     unsigned short* lds_list = reinterpret_cast<unsigned short*>(lds + 2 * NSLOT * TILE8 + 64);
@@ -181,7 +207,8 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     // ---------------- scales, Q fragments ----------------
     // c = scale_q * scale_k * sm_scale * log2(e) = 2^e exactly (rsa_fp8.hip::scales_kernel): split over the two operands
     const int c_exp = (int)((__float_as_uint(a.scales[3 * a.BH + bh]) >> 23) & 0xFF) - 127;
-    const int sc_a = 127 + (c_exp >> 1), sc_b = 127 + (c_exp - (c_exp >> 1));
+    const int c_exp_u = c_exp + PM::EXP;   // (the code map's unit of 1/8 rides on the same E8M0 operands)
+    const int sc_a = 127 + (c_exp_u >> 1), sc_b = 127 + (c_exp_u - (c_exp_u >> 1));
     const float s_v = a.scales[2 * a.BH + bh];
     i32x8 qf[2];
     {
@@ -228,9 +255,9 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     // B k-block b of column c is P of query row c + 16 (b & 1), lane half b >> 1, so C[a][c] = l(row c + 16 ((a >> 2) & 1))
     // and the lane that owns C rows 4 (l >> 4) .. +3 of column l & 15 is exactly the lane of that query row.
     const int ones_off = ((((lane >> 4) & 1) == ((lane >> 2) & 1)) ? 0 : 32);
-    f32x16 mblk;  // P_OFFSET - m_eff in all 16 registers: the start value of every QK^T chain (m_eff = 0 while m_run = -inf)
+    f32x16 mblk;  // P_BASE - U m_eff in all 16 registers: the start value of every QK^T chain (m_eff = 0 while m_run = -inf)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) mblk[i] = P_OFFSET;
+    for (int i = 0; i < 16; ++i) mblk[i] = P_BASE;
 
     // per-lane read offsets (slot base added per step)
     int koff[2][2][2];  // [sub][ks][chunk]
@@ -279,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) m = fmaxf(m, S[1][i]);
         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
-        return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));  // = score_max - m_eff + P_OFFSET
+        return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));  // = U (score_max - m_eff) + P_BASE
     };
     auto apply_mask = [&](f32x16 (&S)[2], int key0) {
         int kbase = key0 + 4 * hh;
@@ -308,15 +335,15 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
             apply_mask(S_cur, key0);
             mx_cur = rowmax_tile(S_cur);
         }
-        // mx_cur and S_cur are relative to the block's reference: score - m_eff + P_OFFSET
-        const bool grow = (m_run == -INFINITY) ? (mx_cur > -INFINITY) : (mx_cur > P_THRESH + P_OFFSET);
+        // mx_cur and S_cur are relative to the block's reference: U (score - m_eff) + P_BASE
+        const bool grow = (m_run == -INFINITY) ? (mx_cur > -INFINITY) : (mx_cur > P_GROW);
         if (__builtin_amdgcn_ballot_w64(grow) != 0ull) {
             asm volatile("s_nop 15\n\ts_nop 5" ::: "memory");   // the block's last (16-pass) MFMA wrote O: wait states before VALU
             const float m_eff_old = (m_run == -INFINITY) ? 0.0f : m_run;
-            const float m_new = fmaxf(m_run, mx_cur - P_OFFSET + m_eff_old);
+            const float m_new = fmaxf(m_run, (mx_cur - P_BASE) * (1.0f / PM::U) + m_eff_old);
             const float m_eff = (m_new == -INFINITY) ? 0.0f : m_new;
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_eff);
-            const float shift = m_eff - m_eff_old;
+            const float shift = PM::U * (m_eff - m_eff_old);
             m_run = m_new;
 #pragma unroll
             for (int i = 0; i < 4; ++i) lacc[i] *= alpha;
@@ -329,15 +356,15 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) S_cur[sub][i] -= shift;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) mblk[i] = P_OFFSET - m_eff;
+            for (int i = 0; i < 16; ++i) mblk[i] = P_BASE - PM::U * m_eff;
         }
 
         // ---- pipelined block ----
         if constexpr ((PIPE_OPT & 1) != 0) {
             constexpr int tsc = decltype(TS)::value;
             // S_cur is SA on even tiles, SB on odd ones (tile & 1 == TS & 1)
-            if constexpr ((tsc & 1) == 0) k5f8_block<tsc>(o, qf, S_cur, S_nxt, mblk, lacc, mx_nxt, sc_a, sc_b, ka, va, ona);
-            else k5f8_block<tsc>(o, qf, S_nxt, S_cur, mblk, lacc, mx_nxt, sc_a, sc_b, ka, va, ona);
+            if constexpr ((tsc & 1) == 0) k5f8_block<tsc, CODEMAP>(o, qf, S_cur, S_nxt, mblk, lacc, mx_nxt, sc_a, sc_b, ka, va, ona);
+            else k5f8_block<tsc, CODEMAP>(o, qf, S_nxt, S_cur, mblk, lacc, mx_nxt, sc_a, sc_b, ka, va, ona);
             return;
         }
         if constexpr (PIPE_OPT & 2) __builtin_amdgcn_s_setprio(2);
@@ -351,13 +378,19 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int w4 = 0; w4 < 4; ++w4) {
-                float p4[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) p4[e] = __builtin_amdgcn_exp2f(S_cur[sub][4 * w4 + e]);
                 // the packed word is built in a score register that is dead by now (no zero-initialised temporary)
                 int word = __float_as_int(S_cur[0][4 * sub + w4]);
-                word = __builtin_amdgcn_cvt_pk_fp8_f32(p4[0], p4[1], word, false);
-                word = __builtin_amdgcn_cvt_pk_fp8_f32(p4[2], p4[3], word, true);
+                if constexpr (CODEMAP) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        word = (int)__builtin_amdgcn_cvt_pk_u8_f32(S_cur[sub][4 * w4 + e], (unsigned)e, (unsigned)word);
+                } else {
+                    float p4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) p4[e] = __builtin_amdgcn_exp2f(S_cur[sub][4 * w4 + e]);
+                    word = __builtin_amdgcn_cvt_pk_fp8_f32(p4[0], p4[1], word, false);
+                    word = __builtin_amdgcn_cvt_pk_fp8_f32(p4[2], p4[3], word, true);
+                }
                 pb[4 * sub + w4] = word;
             }
         lacc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ld32(lds_ones + ones_off, lds_ones + ones_off + 16), pb,
@@ -507,8 +540,12 @@ int launch_attn8(Attn8Args& a, int BH, hipStream_t s) {
     if (nblocks > 0x7FFFFFFF) return RSA_ERR_UNSUPPORTED;
     if (a.NB_total > 8192) return RSA_ERR_UNSUPPORTED;
     const size_t lds_bytes = (size_t)2 * NSLOT * TILE8 + 64 + (((size_t)a.NB_total * 2 + 15) & ~(size_t)15);
-    if (g_fp8_variant == 1) bsfwd_fp8_kernel<2><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a);   // A/B: hipcc's schedule
-    else bsfwd_fp8_kernel<3><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a);
+    switch (g_fp8_variant) {   // tuning key fp8_variant: 0 = product; the others for A/B and the accuracy comparison
+        case 1: bsfwd_fp8_kernel<6><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a); break;   // product arithmetic, hipcc's schedule
+        case 2: bsfwd_fp8_kernel<3><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a); break;   // exact-exponential P, hand-placed
+        case 3: bsfwd_fp8_kernel<2><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a); break;   // exact-exponential P, hipcc's schedule
+        default: bsfwd_fp8_kernel<7><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a);
+    }
     const int st = rsa_launch_status();
     if (st != RSA_OK || a.tsplit <= 1) return st;
     return rsa_launch_text_combine(a.tpart, a.out, a.osb, a.osh, a.oss, D8, a.H, a.NBv, ntq, a.tsplit, a.q_text_end, a.Sq,

@@ -19,6 +19,7 @@ DEV = "cuda:0"
 
 FP8_MAX_VS_BF16, FP8_MEAN_VS_BF16 = 1.6e-1, 1.5e-2   # measured 1.4e-1 / 1.3e-2; see tests/diag_fp8_scale_granularity.py
 FP8_MAX_VS_FP8, FP8_MEAN_VS_FP8 = 4e-2, 4e-3
+FP8_MAX_VS_PCODE, FP8_MEAN_VS_PCODE = 4e-2, 1e-3     # oracle with the kernel's own P map (p_form="code")
 FP8_ROW_REL_MEDIAN, FP8_ROW_REL_MAX = 0.13, 0.30   # measured: median 0.06-0.11, max 0.07-0.23 (e4m3: 2^-4 relative steps on Q, K, V and P)
 
 
@@ -71,6 +72,12 @@ def test_fp8_operator(case):
     o = out.float().cpu().numpy()
     e8 = np.abs(o - ref8)
     assert e8.max() <= FP8_MAX_VS_FP8 and e8.mean() <= FP8_MEAN_VS_FP8, f"vs fp8 oracle: {e8.max():.3e} {e8.mean():.3e}"
+    # ... and against the oracle that forms P exactly as the kernel does (code map + deferred reference): what is left is
+    # fp32 accumulation, the 2-byte rounding of the output and codes that sit on a rounding boundary
+    ref8c = orc.rectified_attention_fp8(q, k, v, lay, top_k, p, nbr, p_form="code")
+    e8c = np.abs(o - ref8c)
+    print(f"{name}: vs exact-P oracle {e8.max():.3e} / {e8.mean():.3e}; vs code-map oracle {e8c.max():.3e} / {e8c.mean():.3e}")
+    assert e8c.max() <= FP8_MAX_VS_PCODE and e8c.mean() <= FP8_MEAN_VS_PCODE, f"vs code-map oracle: {e8c.max():.3e} {e8c.mean():.3e}"
     ref16 = orc.rectified_attention(q, k, v, lay, top_k, p, nbr)
     e16 = np.abs(o - ref16)
     assert e16.max() <= FP8_MAX_VS_BF16 and e16.mean() <= FP8_MEAN_VS_BF16, \
@@ -333,3 +340,35 @@ def test_fp8_dense_smooth_k():
         e = np.abs(o8[0, :, 1].cpu().numpy() - ref)
         assert e.max() <= FP8_MAX_VS_FP8 and e.mean() <= FP8_MEAN_VS_FP8, f"{e.max():.3e} {e.mean():.3e}"
     assert errs[1] <= 1.5 * errs[0] + 1e-3, errs
+
+
+def test_fp8_p_forms_code_map_against_exact_exponential():
+    """The product forms P through the e4m3 code map (one conversion per score); tuning key fp8_variant also reaches its
+    compiled twin (1: must be bit-identical) and the exact-exponential form (2: v_exp_f32 + round-to-nearest e4m3).  Both
+    forms sit inside the fp8 tolerance of the exact-P oracle, the code map within 1.35x of the exponential form's mean error
+    (simulation: 1.2x, tests/diag_fp8_pmap.py), and against the bf16 oracle -- where the e4m3 rounding of Q, K, V
+    dominates -- the two are indistinguishable (<= 3 %)."""
+    from rectified_spaattn_amd import _core, _lib, synth
+    lay = orc.layout_hunyuan(6 * 128 + 256, 6 * 128 + 200)
+    H, top_k, p = 2, 3, 0.4
+    q, k, v = synth.structured_qkv(977, 1, H, lay.S, 128, smooth=0.0)
+    tq, tk, tv = (torch.from_numpy(x).to(DEV, torch.bfloat16) for x in (q, k, v))
+    q, k, v = (x.float().cpu().numpy() for x in (tq, tk, tv))
+    outs = {}
+    try:
+        for var in (0, 1, 2):
+            assert _lib.lib().rsa_set_tuning(b"fp8_variant", var) == 0
+            outs[var] = _core.rectified_attention(tq, tk, tv, _spec(lay), top_k, p, None, qkv_fp8=True).float().cpu().numpy()
+    finally:
+        _lib.lib().rsa_set_tuning(b"fp8_variant", 0)
+    assert np.array_equal(outs[0], outs[1]), "hand-placed block and its compiled twin must agree bit for bit"
+    ref8 = orc.rectified_attention_fp8(q, k, v, lay, top_k, p, None)
+    ref16 = orc.rectified_attention(q, k, v, lay, top_k, p, None)
+    e_code, e_exp = np.abs(outs[0] - ref8), np.abs(outs[2] - ref8)
+    print(f"vs exact-P oracle: code map {e_code.max():.3e} / {e_code.mean():.3e}, exponential {e_exp.max():.3e} / {e_exp.mean():.3e}")
+    for e in (e_code, e_exp):
+        assert e.max() <= FP8_MAX_VS_FP8 and e.mean() <= FP8_MEAN_VS_FP8
+    assert e_code.mean() <= 1.35 * e_exp.mean()
+    b_code, b_exp = np.abs(outs[0] - ref16).mean(), np.abs(outs[2] - ref16).mean()
+    print(f"vs bf16 oracle (mean): code map {b_code:.4e}, exponential {b_exp:.4e}")
+    assert b_code <= 1.03 * b_exp
