@@ -287,7 +287,8 @@ int rsa_ipc_close(void* dev_ptr);
 int rsa_ipc_offset(const void* dev_ptr, int64_t* offset);                   /* dev_ptr - base of its allocation (a handle names the allocation) */
 
 /* Tuning / diagnostics hook, not part of the data path.  Keys: "k5_tsplit" (0/1: split-KV of the text query blocks),
- * "k3_prefix" (0/1: sorted-head path of K3), "fp8_variant" (1: the e4m3 kernel with its block as hipcc schedules it, for A/B; 0: hand-placed, the product).  The hook
+ * "k3_prefix" (0/1: sorted-head path of K3), "fp8_variant" (0: the product = hand-placed block, P through the e4m3 code map; 1: the same arithmetic as hipcc schedules it;
+ * 2 / 3: P by v_exp_f32 + round-to-nearest e4m3, hand-placed / compiled -- for A/B and the accuracy comparison).  The hook
  * is inert (RSA_ERR_UNSUPPORTED) unless the process was started with the environment variable RSA_TUNING=1. */
 int rsa_set_tuning(const char* key, int value);
 

@@ -103,21 +103,35 @@ def _device_dense(q, k, v, splits, dense_fp8=None, causal=False):
     return torch.cat(outs, 0).transpose(1, 2)
 
 
-def _key_padding_counts(attn_mask, B, S1):
-    """bool mask broadcastable to [b,a,s,s1] that only depends on the key index and is a prefix mask
-    (what get_attn_mask builds) -> valid key count per batch item; anything else is not supported."""
+def _key_mask_rows(attn_mask, B, S1):
+    """bool mask broadcastable to [b,a,s,s1] that only depends on the key index ([b,1,1,s1], what get_attn_mask builds)
+    -> ([b, s1] bool rows, valid key count per batch item, whether every row is a prefix); anything else is not supported."""
     m = attn_mask
     if m.dtype != torch.bool or m.dim() != 4 or m.shape[1] != 1 or m.shape[2] != 1 or m.shape[3] != S1:
-        raise NotImplementedError("device fullattn supports only boolean key-padding masks [b,1,1,s1]")
+        raise NotImplementedError("device fullattn supports only boolean key masks [b,1,1,s1]")
     m = m.reshape(m.shape[0], S1)
     counts = m.sum(-1)
     prefix = (m == (torch.arange(S1, device=m.device)[None, :] < counts[:, None])).all()
-    counts = [int(c) for c in counts.tolist()]  # host sync, as the reference's .item() (hunyuan :502)
-    if not bool(prefix):
-        raise NotImplementedError("device fullattn supports only prefix (padding) key masks")
+    host = torch.cat([counts, prefix.reshape(1).to(counts.dtype)]).tolist()  # ONE host sync, as the reference's .item() (hunyuan :502)
+    counts, prefix = [int(c) for c in host[:-1]], bool(host[-1])
     if len(counts) == 1 and B > 1:
         counts = counts * B
-    return counts
+        m = m.expand(B, S1)
+    return m, counts, prefix
+
+
+def _compact_keys(k, v, rows, counts):
+    """Key masks with holes: the valid keys of every batch item moved to the front (a softmax does not see the order of its
+    keys), so the kernel's prefix limit serves them; tail rows are zero and lie beyond the limit."""
+    B, A, S1, D = k.shape
+    n = max(counts)
+    kc = k.new_zeros(B, A, n, D)
+    vc = v.new_zeros(B, A, n, D)
+    for i in range(B):
+        idx = torch.nonzero(rows[i], as_tuple=False).reshape(-1)
+        kc[i, :, :counts[i]] = k[i].index_select(1, idx)
+        vc[i, :, :counts[i]] = v[i].index_select(1, idx)
+    return kc, vc
 
 
 def fullattn(q, k, v, mode="flash", drop_rate=0, attn_mask=None, causal=False, cu_seqlens_q=None,
@@ -146,7 +160,10 @@ def fullattn(q, k, v, mode="flash", drop_rate=0, attn_mask=None, causal=False, c
             if attn_mask is None:
                 splits = [(S, S1)] * B
             else:
-                splits = [(S, c) for c in _key_padding_counts(attn_mask, B, S1)]
+                rows, counts, prefix = _key_mask_rows(attn_mask, B, S1)
+                if not prefix:
+                    k, v = _compact_keys(k, v, rows, counts)
+                splits = [(S, c) for c in counts]
         return _device_dense(q, k, v, splits, dense_fp8, causal=bool(causal))
     # ---- CPU tensors: the reference's CPU-runnable modes ----
     if mode == "flash":

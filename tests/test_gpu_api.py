@@ -83,10 +83,20 @@ def test_fullattn_device_modes(mode):
         am[..., :n] = True
         o2 = attn.fullattn(q, k, v, mode=mode, attn_mask=am)
         assert np.abs(o2.float().cpu().numpy() - z["vanilla_masked"]).max() <= 2e-2
-        bad = am.clone()
-        bad[..., 3] = False
-        with pytest.raises(NotImplementedError):
-            attn.fullattn(q, k, v, mode=mode, attn_mask=bad)
+        # a key mask with holes (not a padding prefix): served by moving the valid keys to the front
+        from oracle import oracle as orc
+        holes = am.clone()
+        holes[..., 3] = False
+        holes[..., 700:900] = False
+        holes[..., n + 5] = True
+        oh = attn.fullattn(q, k, v, mode=mode, attn_mask=holes).float().cpu().numpy()
+        keep = holes.reshape(-1).cpu().numpy()
+        qf, kf, vf = (x.float().cpu().numpy()[0, 0] for x in (q, k, v))
+        assert np.abs(oh[0, 0] - orc.dense_attention(qf, kf[keep], vf[keep])).max() <= 2e-2
+        with pytest.raises(NotImplementedError):   # a mask that depends on the query row
+            attn.fullattn(q, k, v, mode=mode, attn_mask=torch.ones(1, 1, 1536, 1536, dtype=torch.bool, device=DEV))
+        with pytest.raises(NotImplementedError):   # an additive float mask
+            attn.fullattn(q, k, v, mode=mode, attn_mask=torch.zeros(1, 1, 1, 1536, device=DEV))
     # causal=True (attn.py:60-73): the reference's own vector ("torch" == "vanilla" on CPU; s == s1, so flash-attn's
     # bottom-right alignment of mode "flash" is the same triangle)
     oc = attn.fullattn(q, k, v, mode=mode, causal=True)

@@ -19,7 +19,7 @@ DEV = "cuda:0"
 
 FP8_MAX_VS_BF16, FP8_MEAN_VS_BF16 = 1.6e-1, 1.5e-2   # measured 1.4e-1 / 1.3e-2; see tests/diag_fp8_scale_granularity.py
 FP8_MAX_VS_FP8, FP8_MEAN_VS_FP8 = 4e-2, 4e-3
-FP8_MAX_VS_PCODE, FP8_MEAN_VS_PCODE = 4e-2, 1e-3     # oracle with the kernel's own P map (p_form="code")
+FP8_MAX_VS_PCODE, FP8_MEAN_VS_PCODE = 2e-2, 4e-4     # oracle with the kernel's own P map (p_form="code"); measured <= 1.2e-2 / 2.0e-4
 FP8_ROW_REL_MEDIAN, FP8_ROW_REL_MAX = 0.13, 0.30   # measured: median 0.06-0.11, max 0.07-0.23 (e4m3: 2^-4 relative steps on Q, K, V and P)
 
 

@@ -154,6 +154,15 @@ def _check_config_fp8(name, spec, lay, H, top_k, p, nbr, sample_rows, seed=77):
             # mean bound 6e-3 here (4e-3 in test_gpu_fp8.py): with this generator's sharper attention rows a few keys
             # carry the row, and the e4m3 rounding of their P (2^-4 relative) shows undiluted against the unrounded l
             assert err.max() <= 4e-2 and err.mean() <= 6e-3, f"{name}: fp8 O row-block {i}: {err.max():.3e} {err.mean():.3e}"
+        # the same blocks against the oracle that forms P as the kernel does (e4m3 code map, deferred reference per wave,
+        # 64-key tiles in list order): only fp32 accumulation, the output rounding and boundary codes are left
+        refc = orc.sparse_attention_head_pcode(q8[0, 0], k8[0, 0], v8[0, 0], lay, sel["kept"], sample_rows)
+        refc = refc * sel["R"][:, None, None] + sel["comp"][:, None, :]
+        for a, i in enumerate(sample_rows):
+            n = min(128, lay.S - i * 128)
+            errc = np.abs(o[0, i * 128: i * 128 + n, bh].float().cpu().numpy() - refc[a, :n])
+            print(f"{name}: head {bh} block {i}: vs code-map oracle {errc.max():.3e} / {errc.mean():.3e}")
+            assert errc.max() <= 2e-2 and errc.mean() <= 6e-4, f"{name}: fp8 O vs code-map oracle, row-block {i}: {errc.max():.3e} {errc.mean():.3e}"
         if lay.q_text_valid > 0:
             r0 = lay.NBv * 128
             rows = [r0, r0 + lay.q_text_valid - 1]
