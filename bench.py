@@ -327,8 +327,6 @@ def run_regime(comm, args, wl, regime, q, k, v, spec, steps, warmup, want_call=F
 
     def step(ev):
         call.select()
-        if args.qkv_fp8:
-            call.quantize()
         if ev is not None:
             ev[0].record()
         call.attend()
@@ -505,8 +503,6 @@ def main():
     if world > 1:  # the optional exchange step at the layer boundary: all-gather of O along the head axis
         def gstep(_):
             call.select()
-            if args.qkv_fp8:
-                call.quantize()
             call.attend()
             parallel.gather_heads(call.out)
         # (a failure inside a collective cannot be caught rank by rank -- the peers would hang in it --, so these timed
@@ -533,8 +529,6 @@ def main():
 
             def hstep(_):
                 call.select()
-                if args.qkv_fp8:
-                    call.quantize()
                 call.attend()
                 hg.gather(call.out)
             elh = timed_steps(comm, hstep, args.steps, max(1, args.warmup))
@@ -548,8 +542,6 @@ def main():
 
         def sstep(_):
             call.select()
-            if args.qkv_fp8:
-                call.quantize()
             call.attend()
         with SmiSampler() as smi:
             els = timed_steps(comm, sstep, n_sus, 0)

@@ -66,7 +66,8 @@ typedef struct rsa_out4 {
 
 /* Sizes (in elements) of the intermediate buffers for a layout; all are per call.  Fill the struct with
  * rsa_carve_workspace, or zero it first (memset) and set the members by hand: a member this header adds in a later
- * version is then NULL = "feature not used" (check rsa_version() >= 300 for this layout: 15 members). */
+ * version is then NULL = "feature not used" (check rsa_version() >= 300 for this layout: 15 members; >= 310 for the
+ * block-scaled rsa_fp8_operands). */
 typedef struct rsa_buffers {
     float* qbar;      /* [BH, NBv, D]       block means of visual Q            */
     float* aq;        /* [BH, NBv, D]       mean |Q - qbar|                    */
@@ -202,32 +203,35 @@ int rsa_norm_rope_heads(int B, int H, int S, int D, int dtype, const void* x, in
 /* ---- fp8 operands for K5 (BASELINE config "fp8 Q/K/V on CDNA4 fp8 MFMA"; the reference has no fp8 path, its P/Q
  * rounding rule "operands in the input dtype, fp32 statistics" (rectified_hunyuan_attn.py:61-62, :97) is kept) ---- */
 
-/* e4m3 (OCP e4m3fn) images of one call's Q, K, V, written by rsa_quantize_fp8 and read by rsa_block_sparse_fwd_fp8. */
+/* e4m3 (OCP e4m3fn) images of one call's Q, K, V in the BLOCK-SCALED format, written by rsa_pool_stats_fp8 /
+ * rsa_quantize_fp8 and read by rsa_block_sparse_fwd_fp8.  Per tensor and 128-row block: y = q * sm_scale*log2(e) | k - mu
+ * | v in fp32, A = max |y| over the block's valid rows, scale 2^e with the smallest e such that A * 2^-e <= 448, bytes =
+ * e4m3(y * 2^-e) rounded to nearest even.  mu ("smooth K", exact under softmax) = the mean of up to 8 evenly spaced full
+ * 128-row blocks of K, so nothing needs a pass of its own over a tensor.  The kernel applies the scales through the fp8
+ * MFMA's E8M0 block-scale operands. */
 typedef struct rsa_fp8_operands {
-    uint8_t* q8;    /* [BH, NB_total*128, D]     rows >= S are zero                                            */
-    uint8_t* k8;    /* [BH, NB_total*128, D]     rows >= pool_valid are zero (needs pool_valid >= kv_valid, kv_text_valid);
-                     * in the fused form K minus its per-head mean ("smooth K", exact under softmax; rsa_fp8.hip)   */
-    uint8_t* v8t;   /* [BH, NB_total*2, D, 64]   V^T per 64-key tile, keys in the MFMA k-slot order (rsa_fp8.hip) */
-    float* scales;  /* [4, BH] dequantisation scales of q, k, v and c = scale_q*scale_k*sm_scale*log2(e) (a power of
-                     * two by construction, see rsa_fp8.hip), followed by (3 + 3*NB_total + D)*BH words of scratch / K mean */
+    uint8_t* q8;      /* [BH, NB_total*128, D]     rows >= S are zero                                                       */
+    uint8_t* k8;      /* [BH, NB_total*128, D]     rows >= pool_valid are zero (needs pool_valid >= kv_valid, kv_text_valid) */
+    uint8_t* v8t;     /* [BH, NB_total*2, D, 64]   V^T per 64-key tile, keys in the MFMA k-slot order (rsa_fp8_emit.h)       */
+    uint32_t* scales; /* [BH, NB_total] words: byte 0 / 1 / 2 = E8M0 exponent (127 + e) of the Q / K / V block, byte 3 unused;
+                       * followed by the K mean mu, [BH, D] fp32                                                            */
 } rsa_fp8_operands;
 
 /* Bytes of the four members (member order) and their 256-B-rounded sum.  D = 128 only. */
 int rsa_fp8_operand_bytes(const rsa_layout* lay, size_t sizes[4], size_t* total);
 int rsa_carve_fp8_operands(const rsa_layout* lay, void* ws, size_t ws_bytes, rsa_fp8_operands* out);
 
-/* Per-(b,h) amax of Q, K, V, the scales, and the three e4m3 images: x * fl(1/scale), clamp +-448, round to nearest
- * even. */
+/* Stand-alone producer: mu (one small launch over 8 blocks of K), then ONE pass over Q, K, V that writes the three images
+ * and the block exponents. */
 int rsa_quantize_fp8(const rsa_layout* lay, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
                      const rsa_fp8_operands* ops, void* stream);
 
-/* The same in two halves that fuse into the mask-selection pass: rsa_pool_stats_fp8 = K1 (rsa_pool_stats) with the
- * |x| maxima as a side product of the rows it reads anyway, a small amax launch over the text-tail rows of Q and K,
- * and the scales; rsa_fp8_images = the three images from those scales.  Bit-identical to rsa_quantize_fp8. */
+/* The same fused into the mask-selection pass: K1 (rsa_pool_stats) writes the images of every block it pools in the pass
+ * that pools it (Q and K visual blocks, every V block: the tensors are read from HBM once), a small launch covers the
+ * text-tail blocks of Q and K.  buf gets K1's statistics as rsa_pool_stats would write them; ops is bit-identical to
+ * rsa_quantize_fp8's. */
 int rsa_pool_stats_fp8(const rsa_layout* lay, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v, const rsa_buffers* buf,
                        const rsa_fp8_operands* ops, void* stream);
-int rsa_fp8_images(const rsa_layout* lay, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v, const rsa_fp8_operands* ops,
-                   void* stream);
 
 /* K5 on v_mfma_f32_32x32x64_f8f6f4: same lists, R, comp, text rows and output layout as rsa_block_sparse_fwd;
  * lay->dtype selects the OUTPUT element type. */
@@ -235,7 +239,7 @@ int rsa_block_sparse_fwd_fp8(const rsa_layout* lay, const rsa_fp8_operands* ops,
                              rsa_out4 out, void* stream);
 
 /* The whole operator with fp8 K5: K1..K4 on the 2-byte inputs (the mask is the bf16 path's, bit for bit; K1 in its
- * rsa_pool_stats_fp8 form), then rsa_fp8_images and rsa_block_sparse_fwd_fp8. */
+ * rsa_pool_stats_fp8 form, which leaves the images behind), then rsa_block_sparse_fwd_fp8. */
 int rsa_rectified_attention_fp8(const rsa_layout* lay, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
                                 const uint8_t* neighbor, int top_k, float p_remain, void* workspace,
                                 size_t workspace_bytes, void* fp8_workspace, size_t fp8_workspace_bytes,
@@ -246,7 +250,7 @@ int rsa_rectified_attention_fp8(const rsa_layout* lay, rsa_tensor4 q, rsa_tensor
  * instead of the reference's five elementwise/reduction launches; scratch: >= 2048 floats.  DEVICE pointers. */
 int rsa_rel_l1(const void* a, const void* b, int64_t n, int dtype, float* out2, float* scratch, void* stream);
 
-/* rsa_dense_fwd with e4m3 operands (per-(b,h) scales computed inside): quantisation pass + the fp8 kernel in dense
+/* rsa_dense_fwd with e4m3 operands (block-scaled images produced inside): quantisation pass + the fp8 kernel in dense
  * mode.  workspace: >= *total of rsa_dense_fp8_bytes, 256-B aligned.  D = 128 only. */
 int rsa_dense_fp8_bytes(int B, int H, int Sq, int Sk, int D, size_t* total);
 int rsa_dense_fwd_fp8(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
@@ -288,7 +292,8 @@ int rsa_ipc_offset(const void* dev_ptr, int64_t* offset);                   /* d
 
 /* Tuning / diagnostics hook, not part of the data path.  Keys: "k5_tsplit" (0/1: split-KV of the text query blocks),
  * "k3_prefix" (0/1: sorted-head path of K3), "fp8_variant" (0: the product = hand-placed block, P through the e4m3 code map; 1: the same arithmetic as hipcc schedules it;
- * 2 / 3: P by v_exp_f32 + round-to-nearest e4m3, hand-placed / compiled -- for A/B and the accuracy comparison).  The hook
+ * 2 / 3: P by v_exp_f32 + round-to-nearest e4m3, hand-placed / compiled -- for A/B and the accuracy comparison), "fp8_smooth_k"
+ * (0: the fp8 producers take mu = 0 instead of the sampled K mean, for the same comparison).  The hook
  * is inert (RSA_ERR_UNSUPPORTED) unless the process was started with the environment variable RSA_TUNING=1. */
 int rsa_set_tuning(const char* key, int value);
 

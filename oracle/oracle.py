@@ -375,64 +375,70 @@ def fp8_kslot_key(p: np.ndarray) -> np.ndarray:
     return 32 * (j >> 4) + (j & 3) + 8 * ((j & 15) >> 2) + 4 * h
 
 
-def _fp8_scales(amax3, D: int):
-    """(scale_q, scale_k, scale_v, c) from the three maxima -- the arithmetic of rsa_fp8.hip::scales_kernel."""
-    qk_const = np.float32((1.0 / np.sqrt(float(D))) * 1.44269504)
-    sc = [np.float32(a / E4M3_MAX) if a > 0 else np.float32(1.0) for a in amax3]
-    # c = scale_q * scale_k * sm_scale * log2(e) rounded UP to a power of two by stretching scale_q
-    skc = np.float32(sc[1] * qk_const)
-    c0 = np.float32(sc[0] * skc)
-    mant, e = np.frexp(c0)
-    e = int(e) - (1 if mant == np.float32(0.5) else 0)
-    e = max(-120, min(120, e))
-    c = np.float32(np.ldexp(np.float32(1.0), e))
-    return np.float32(c / skc), sc[1], sc[2], c
+def fp8_qk_const(D: int) -> np.float32:
+    """sm_scale * log2(e) as the library rounds it to fp32 (rsa_fp8.hip: (float)((1 / sqrt(D)) * 1.44269504))."""
+    return np.float32((1.0 / np.sqrt(float(D))) * 1.44269504)
 
 
-def _fp8_images(xs, valid, pads, D, kmean=None):
-    """xs: three [BH, S_i, D] fp32 arrays -> scales [4, BH], images [BH, pads[i], D] (rows >= valid[i] zero).
-    kmean [BH, D] (optional, "smooth K"): subtracted from K before quantisation; the K scale then uses the bound
-    amax|k| + max|mu| exactly as rsa_fp8.hip::scales_kernel does."""
-    BH = xs[0].shape[0]
-    scales = np.ones((4, BH), np.float32)
-    for bh in range(BH):
-        amax = []
-        for i in range(3):
-            xv = xs[i][bh, : valid[i]]
-            a = np.float32(np.max(np.abs(xv))) if xv.size else np.float32(0)
-            if i == 1 and kmean is not None:
-                a = np.float32(a + np.float32(np.max(np.abs(kmean[bh]))))
-            amax.append(a)
-        scales[:, bh] = _fp8_scales(amax, D)
-    imgs = []
-    for i in range(3):
-        img = np.zeros((BH, pads[i], D), np.uint8)
-        for bh in range(BH):
-            xv = xs[i][bh, : valid[i]]
-            if i == 1 and kmean is not None:
-                xv = (xv - kmean[bh][None, :]).astype(np.float32)
-            inv = np.float32(np.float32(1.0) / scales[i, bh])   # the kernels multiply by the reciprocal
-            img[bh, : valid[i]] = quantize_e4m3((xv * inv).astype(np.float32))
-        imgs.append(img)
-    return scales, imgs
+def fp8_block_exponent(amax: np.float32) -> int:
+    """E8M0 byte (127 + e) of a block's power-of-two scale: the smallest e with amax * 2^-e <= 448, clamped to +-120;
+    127 for an all-zero block (rsa_fp8_emit.h::e8m0_of_amax: exponent field and one mantissa compare, no division)."""
+    a = np.float32(amax)
+    if not a > 0:
+        return 127
+    bits = int(np.array(a, np.float32).view(np.uint32))
+    field, frac = (bits >> 23) & 0xFF, bits & 0x7FFFFF
+    if field == 0:                               # subnormal maximum: far below any scale that matters
+        return 127 - 120
+    e = (field - 126) - 9 + (1 if frac > 0x600000 else 0)   # amax = m 2^x, m in [0.5, 1): m > 0.875 needs one more
+    return 127 + max(-120, min(120, e))
 
 
-def fp8_kmean(k, lay: Layout):
-    """"Smooth K" vector of one head from the pooled K block means (contract of rsa_fp8.hip::kmean_kernel):
-    mu[d] = tree16(P_0..P_15) / NBv, P_g = sum in block order of kbar[j][d] over j = g (mod 16), tree16 = xor tree with
-    strides 1, 2, 4, 8 (as contract C6), all in fp32."""
-    nq = lay.NBv
-    D = k.shape[1]
-    if nq == 0:
-        return np.zeros(D, np.float32)
+def fp8_kmean(k, valid: int):
+    """"Smooth K" vector of one head (rsa_fp8.hip::kmean_sample_kernel): the mean of up to 8 evenly spaced 128-row blocks
+    of K -- block j of the nb = max(valid // 128, 1) full blocks for j = floor(i nb / n), i < n = min(nb, 8) -- each block's mean in the pooling
+    pass's arithmetic (contract C2: rows >= valid count as zero, divide by 128), the block means added in order, divided
+    by n; fp32 throughout.  Any vector works in exact arithmetic (q.(k - mu) shifts every score of a query row alike); this
+    one needs 8 blocks of K instead of a pass over it, which is what lets K1 quantise K in the pass that pools it."""
     kk = np.asarray(k, np.float32)
-    kbar, _ = pool(kk[: nq * BLOCK], min(lay.pool_valid, nq * BLOCK), nq, False)
-    part = np.zeros((16, D), np.float32)
-    for j in range(nq):
-        part[j % 16] = (part[j % 16] + kbar[j]).astype(np.float32)
-    for stride in (1, 2, 4, 8):
-        part = (part + part[np.arange(16) ^ stride]).astype(np.float32)
-    return (part[0] / np.float32(nq)).astype(np.float32)
+    D = kk.shape[1]
+    if valid <= 0:
+        return np.zeros(D, np.float32)
+    nb = max(valid // BLOCK, 1)                  # full blocks only (a lone partial block 0 when there is none)
+    n = min(nb, 8)
+    acc = np.zeros(D, np.float32)
+    for i in range(n):
+        j = (i * nb) // n
+        rows = kk[j * BLOCK: min((j + 1) * BLOCK, valid)]
+        m, _ = pool(rows, rows.shape[0], 1, False)
+        acc = (acc + m[0]).astype(np.float32)
+    return (acc / np.float32(n)).astype(np.float32)
+
+
+def fp8_block_images(x, valid: int, pad: int, pre: str, kmean=None):
+    """One tensor of one head [S, D] fp32 -> (image [pad, D] uint8, E8M0 bytes [pad / 128]) in the block-scaled format:
+    y = x * qk_const (pre = "q": one fp32 multiply), x - mu (pre = "k", one fp32 subtract) or x ("v"); per 128-row block
+    amax over its valid rows, power-of-two scale 2^e (fp8_block_exponent), bytes = e4m3(y * 2^-e) round-to-nearest-even;
+    rows >= valid are zero."""
+    D = x.shape[1]
+    nblk = pad // BLOCK
+    img = np.zeros((pad, D), np.uint8)
+    ex = np.full(nblk, 127, np.uint8)
+    xv = np.asarray(x[:valid], np.float32)
+    if pre == "q":
+        y = (xv * fp8_qk_const(D)).astype(np.float32)
+    elif pre == "k" and kmean is not None:
+        y = (xv - kmean[None, :]).astype(np.float32)
+    else:
+        y = xv
+    for j in range(nblk):
+        blk = y[j * BLOCK: (j + 1) * BLOCK]
+        if blk.size == 0:
+            continue
+        eb = fp8_block_exponent(np.float32(np.max(np.abs(blk))))
+        ex[j] = eb
+        img[j * BLOCK: j * BLOCK + blk.shape[0]] = quantize_e4m3(np.ldexp(blk, -(eb - 127)).astype(np.float32))
+    return img, ex
 
 
 def _v8t_from_image(v8):
@@ -441,58 +447,63 @@ def _v8t_from_image(v8):
     return np.ascontiguousarray(v8[:, :, fp8_kslot_key(np.arange(64)), :].transpose(0, 1, 3, 2))
 
 
+def _fp8_operands_rows(xs, valid, pads, smooth_k: bool):
+    """xs: three [BH, S_i, D] fp32 arrays -> dict(q8, k8, v8t, exps [BH, nblk] uint32 = eq | ek << 8 | ev << 16, kmean)."""
+    BH, D = xs[0].shape[0], xs[0].shape[2]
+    nblk = max(pads) // BLOCK
+    exps = np.full((BH, nblk), 127 | (127 << 8) | (127 << 16), np.uint32)
+    kmean = np.zeros((BH, D), np.float32)
+    imgs = [np.zeros((BH, pads[i], D), np.uint8) for i in range(3)]
+    for bh in range(BH):
+        if smooth_k:
+            kmean[bh] = fp8_kmean(xs[1][bh], valid[1])
+        word = np.zeros(nblk, np.uint32)
+        for i, pre in enumerate("qkv"):
+            img, ex = fp8_block_images(xs[i][bh], valid[i], pads[i], pre, kmean[bh] if (smooth_k and i == 1) else None)
+            imgs[i][bh] = img
+            full = np.full(nblk, 127, np.uint32)
+            full[: ex.shape[0]] = ex
+            word |= full << np.uint32(8 * i)
+        exps[bh] = word
+    return dict(exps=exps, kmean=kmean, q8=imgs[0], k8=imgs[1], v8t=_v8t_from_image(imgs[2]), v8=imgs[2])
+
+
 def fp8_operands(q, k, v, lay: Layout, smooth_k: bool = True):
-    """Per-(b,h) scales and e4m3 images exactly as rsa_pool_stats_fp8 + rsa_fp8_images write them (smooth_k=True, the
-    operator's path) or as the stand-alone rsa_quantize_fp8 does (smooth_k=False: no K mean).
-    q, k, v: [B, H, S, D] fp32 -> dict(scales [4, BH] (q, k, v, c), kmean [BH, D], q8/k8 [BH, S_pad, D],
-    v8t [BH, S_pad/64, D, 64])."""
+    """The e4m3 operands of the fp8 K5 exactly as rsa_pool_stats_fp8 (fused into K1) and rsa_quantize_fp8 (stand-alone)
+    write them -- the two are bit-identical: block-scaled images (fp8_block_images) of Q * qk_const, K - mu, V, one E8M0
+    byte per tensor and 128-row block, mu = fp8_kmean (smooth_k = False: mu = 0, kept for the accuracy study).
+    q, k, v: [B, H, S, D] fp32 -> dict(exps [BH, NB_total] uint32, kmean [BH, D], q8 / k8 [BH, S_pad, D],
+    v8t [BH, S_pad / 64, D, 64])."""
     B, H, S, D = q.shape
     BH, SP = B * H, lay.NB_total * BLOCK
     assert lay.pool_valid >= max(lay.kv_valid, lay.kv_text_valid)
     valid = (S, lay.pool_valid, lay.pool_valid)  # the rows the pooling pass counts
     xs = [np.asarray(x, np.float32).reshape(BH, S, D) for x in (q, k, v)]
-    kmean = None
-    if smooth_k:
-        kz = xs[1].copy()
-        kz[:, lay.pool_valid:] = 0                  # rows the pooling pass counts as zero (hunyuan :307-308)
-        kmean = np.stack([fp8_kmean(kz[bh], lay) for bh in range(BH)])
-    scales, imgs = _fp8_images(xs, valid, (SP, SP, SP), D, kmean)
-    return dict(scales=scales, kmean=kmean if kmean is not None else np.zeros((BH, D), np.float32), q8=imgs[0],
-                k8=imgs[1], v8t=_v8t_from_image(imgs[2]))
+    return _fp8_operands_rows(xs, valid, (SP, SP, SP), smooth_k)
 
 
-def fp8_dense_kmean(k):
-    """"Smooth K" vector of the dense fp8 path (contract of rsa_fp8.hip::amax_kernel's column sums + colmean_kernel):
-    per 1024-row chunk, P_g = sum in row order over the chunk's rows g, g+16, ...; wave w adds its four partial sums as
-    (P_4w + P_4w+1) + (P_4w+2 + P_4w+3); the chunk sum is (W0 + W1) + (W2 + W3); mu = (sum over chunks in order) / Sk."""
-    k = np.asarray(k, np.float32)
-    Sk, D = k.shape
-    tot = np.zeros(D, np.float32)
-    for r0 in range(0, Sk, 1024):
-        chunk = k[r0: r0 + 1024]
-        P = np.zeros((16, D), np.float32)
-        for i in range(0, chunk.shape[0], 16):           # rows i + g: one add per g, in row order
-            blk = chunk[i: i + 16]
-            P[: blk.shape[0]] = (P[: blk.shape[0]] + blk).astype(np.float32)
-        W = [((P[4 * w] + P[4 * w + 1]).astype(np.float32) + (P[4 * w + 2] + P[4 * w + 3]).astype(np.float32)).astype(np.float32)
-             for w in range(4)]
-        cs = ((W[0] + W[1]).astype(np.float32) + (W[2] + W[3]).astype(np.float32)).astype(np.float32)
-        tot = (tot + cs).astype(np.float32)
-    return (tot / np.float32(Sk)).astype(np.float32)
+def _fp8_dequant(ops, bh, i, rows, D):
+    """Dequantised rows [0, rows) of tensor i (0 q in ORIGINAL units, 1 k minus mu, 2 v) of head bh, float64."""
+    if i == 2:
+        img = ops["v8"][bh]
+    else:
+        img = ops["q8" if i == 0 else "k8"][bh]
+    ex = ((ops["exps"][bh] >> np.uint32(8 * i)) & np.uint32(0xFF)).astype(np.int64) - 127
+    val = dequantize_e4m3(img).astype(np.float64) * np.exp2(np.repeat(ex, BLOCK)[: img.shape[0]].astype(np.float64))[:, None]
+    if i == 0:
+        val = val / float(fp8_qk_const(D))
+    return val[:rows]
 
 
 def dense_attention_fp8(q, k, v, q_split: Optional[int] = None, kv_split: Optional[int] = None):
-    """Dense attention of ONE head on e4m3 operands as rsa_dense_fwd_fp8 quantises them (per-head scales over all Sq /
-    Sk rows, K minus its column mean), two-segment semantics of attn.py:107-120.  q [Sq, D], k/v [Sk, D] fp32 -> [Sq, D].
-    (With two segments the shift q.mu is still one constant per query row, so both softmaxes are unchanged.)"""
+    """Dense attention of ONE head on e4m3 operands as rsa_dense_fwd_fp8 quantises them (block-scaled images over all Sq /
+    Sk rows, K minus fp8_kmean over its Sk rows), two-segment semantics of attn.py:107-120.  q [Sq, D], k/v [Sk, D] fp32
+    -> [Sq, D].  (With two segments the shift q.mu is still one constant per query row, so both softmaxes are unchanged.)"""
     Sq, D = q.shape
     Sk = k.shape[0]
     pad = lambda n: (n + BLOCK - 1) // BLOCK * BLOCK
-    kmean = fp8_dense_kmean(k)[None]
-    scales, imgs = _fp8_images([q[None], k[None], v[None]], (Sq, Sk, Sk), (pad(Sq), pad(Sk), pad(Sk)), D, kmean)
-    qd = dequantize_e4m3(imgs[0][0, :Sq]) * scales[0, 0]
-    kd = dequantize_e4m3(imgs[1][0, :Sk]) * scales[1, 0]
-    vd = dequantize_e4m3(imgs[2][0, :Sk]) * scales[2, 0]
+    ops = _fp8_operands_rows([q[None], k[None], v[None]], (Sq, Sk, Sk), (pad(Sq), pad(Sk), pad(Sk)), True)
+    qd, kd, vd = (_fp8_dequant(ops, 0, i, n, D) for i, n in ((0, Sq), (1, Sk), (2, Sk)))
     q_split = Sq if q_split is None else q_split
     kv_split = Sk if kv_split is None else kv_split
     out = np.zeros((Sq, D), np.float64)
@@ -506,18 +517,12 @@ def dense_attention_fp8(q, k, v, q_split: Optional[int] = None, kv_split: Option
 
 
 def fp8_dequantized_qkv(q, k, v, lay: Layout, smooth_k: bool = True):
-    """The values the fp8 K5 multiplies: dequantised e4m3 images cropped back to [B, H, S, D] fp32."""
+    """The values the fp8 K5 multiplies, cropped back to [B, H, S, D] fp32: q in its original units (the image holds
+    q * qk_const), k minus its mu, v."""
     B, H, S, D = q.shape
     ops = fp8_operands(q, k, v, lay, smooth_k)
-    res = []
-    for i, name in enumerate(("q8", "k8")):
-        x = dequantize_e4m3(ops[name])[:, :S] * ops["scales"][i][:, None, None]
-        # (k8 holds k - mu: every score of a query row is shifted by q.mu, which no softmax sees)
-        res.append(x.reshape(B, H, S, D).astype(np.float32))
-    inv = np.argsort(fp8_kslot_key(np.arange(64)))
-    vt = dequantize_e4m3(ops["v8t"])                             # [BH, T, D, 64 slots]
-    vv = vt[:, :, :, inv].transpose(0, 1, 3, 2).reshape(B * H, -1, D)[:, :S] * ops["scales"][2][:, None, None]
-    res.append(vv.reshape(B, H, S, D).astype(np.float32))
+    res = [np.stack([_fp8_dequant(ops, bh, i, S, D) for bh in range(B * H)]).reshape(B, H, S, D).astype(np.float32)
+           for i in range(3)]
     return res[0], res[1], res[2], ops
 
 

@@ -16,7 +16,7 @@ reference's own code paths: fullattn(mode="torch" | "vanilla") on CPU tensors (B
 teacache.rel_l1_distance for CPU tensors / small fp32 inputs such as timestep embeddings (bf16 / fp16 device tensors take
 the one-pass HIP reduction rsa_rel_l1).
 """
-__version__ = "0.3.0"
+__version__ = "0.3.1"
 
 
 def set_qkv_fp8(enabled: bool) -> bool:

@@ -206,21 +206,32 @@ def neighbor_on_device(block_neighbor_list, NBv: int, device) -> Optional[torch.
 
 
 def alloc_fp8_operands(spec: LayoutSpec, B: int, H: int, D: int, device) -> Dict[str, torch.Tensor]:
-    """e4m3 images of Q, K, V for the fp8 K5 (include/rsa.h::rsa_fp8_operands)."""
+    """e4m3 images of Q, K, V for the fp8 K5 (include/rsa.h::rsa_fp8_operands).  `scales` is ONE int32 buffer:
+    [BH, NB_total] block-exponent words (byte 0 / 1 / 2 = E8M0 of the Q / K / V block) followed by the K mean, [BH, D]
+    fp32 bit patterns (fp8_exps / fp8_kmean view it)."""
     assert D == 128, "the fp8 block-sparse kernel is built for head_dim 128"
     BH, SP = B * H, spec.NB_total * BLOCK
     return dict(q8=torch.empty((BH, SP, D), dtype=torch.uint8, device=device),
                 k8=torch.empty((BH, SP, D), dtype=torch.uint8, device=device),
                 v8t=torch.empty((BH, SP // 64, D, 64), dtype=torch.uint8, device=device),
-                scales=torch.empty((7 + 3 * spec.NB_total + D, BH), dtype=torch.float32, device=device))  # rows 0..3:
-    # scales of q, k, v and c; then scratch (amax words, K1's per-block maxima) and the [BH, D] K mean at the end
+                scales=torch.zeros((BH * (spec.NB_total + D),), dtype=torch.int32, device=device))
+
+
+def fp8_exps(scales: torch.Tensor, BH: int, NB_total: int) -> torch.Tensor:
+    """[BH, NB_total] int32 block-exponent words of an fp8 operand set (byte 3 masked off)."""
+    return scales[: BH * NB_total].view(BH, NB_total) & 0xFFFFFF
+
+
+def fp8_kmean(scales: torch.Tensor, BH: int, NB_total: int, D: int = 128) -> torch.Tensor:
+    """[BH, D] fp32 "smooth K" vector of an fp8 operand set."""
+    return scales[BH * NB_total:].view(torch.float32).view(BH, D)
 
 
 class StagedCall:
     """One rectified-attention call with its buffers: select() runs K1..K4 (mask-selection pass), attend() runs
     K5.  Both are asynchronous on the current stream.  q, k, v: [B, H, S, D] device tensors.
-    qkv_fp8: K5 runs on e4m3 images of Q, K, V (quantize() + the fp8 MFMA kernel); the mask-selection pass is
-    unchanged, so the kept lists are the 2-byte path's bit for bit."""
+    qkv_fp8: K5 runs on e4m3 images of Q, K, V (written by K1 in its own pass) on the fp8 MFMA; the mask-selection
+    statistics are unchanged, so the kept lists are the 2-byte path's bit for bit."""
 
     def __init__(self, q, k, v, spec: LayoutSpec, top_k: int, p_remain: float, block_neighbor_list=None,
                  qkv_fp8: bool = False, reuse_buffers: bool = False):
@@ -246,17 +257,16 @@ class StagedCall:
             self.fp8 = alloc_fp8_operands(spec, B, H, D, q.device)
             self.cf = RsaFp8Operands(*[self.fp8[n].data_ptr() for n in ("q8", "k8", "v8t", "scales")])
 
-    def quantize(self, standalone: bool = False):
-        """e4m3 images of Q, K, V.  After select() the scales are already there (K1 produced the maxima as a side
-        product); standalone=True runs the self-contained producer (own amax pass) instead."""
+    def quantize(self):
+        """The stand-alone producer of the e4m3 images (rsa_quantize_fp8: one pass over Q, K, V).  select() does not need
+        it: with qkv_fp8 K1 writes the same bytes in the pass that pools the blocks."""
         tq, tk, tv = self.t
-        fn, name = ((self.L.rsa_quantize_fp8, "rsa_quantize_fp8") if standalone
-                    else (self.L.rsa_fp8_images, "rsa_fp8_images"))
         with torch.cuda.device(self.q.device):
-            _lib.check(fn(ctypes.byref(self.lay), tq, tk, tv, ctypes.byref(self.cf), _stream()), name)
+            _lib.check(self.L.rsa_quantize_fp8(ctypes.byref(self.lay), tq, tk, tv, ctypes.byref(self.cf), _stream()),
+                       "rsa_quantize_fp8")
 
     def select_pool(self):
-        """K1 (with the fp8 maxima + scales when qkv_fp8)."""
+        """K1 (writing the e4m3 images of Q, K, V as it goes when qkv_fp8)."""
         L, lay, cb, st = self.L, ctypes.byref(self.lay), ctypes.byref(self.cb), _stream()
         tq, tk, tv = self.t
         with torch.cuda.device(self.q.device):
@@ -305,8 +315,6 @@ def rectified_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, spec:
     call = StagedCall(q, k, v, spec, top_k, p_remain, block_neighbor_list, qkv_fp8=qkv_fp8,
                       reuse_buffers=not return_parts)
     call.select()
-    if qkv_fp8:
-        call.quantize()
     out = call.attend()
     B, H, S, D = q.shape
     res = out if shape_xfuse else out.view(B, S, H * D)
@@ -314,6 +322,8 @@ def rectified_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, spec:
         parts = dict(call.bufs)
         if qkv_fp8:
             parts.update(call.fp8)
+            parts["exps"] = fp8_exps(call.fp8["scales"], B * H, spec.NB_total)
+            parts["kmean"] = fp8_kmean(call.fp8["scales"], B * H, spec.NB_total, D)
         return res, parts
     return res
 

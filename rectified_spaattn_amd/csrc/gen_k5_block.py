@@ -221,7 +221,7 @@ def main():
 #     S_nxt^T (two 32-key halves) = K8(tile+1) . Q8^T + (4 - m)   4 x v_mfma_scale_f32_32x32x64_f8f6f4 (chains start from MB)
 #     P = exp2(S_cur) -> e4m3, packed in place into S_cur[0][0:7] 32 v_exp_f32 + 16 v_cvt_pk_fp8_f32
 #     l += ones . P (row sum on the matrix pipe)                    1 x v_mfma_f32_16x16x128_f8f6f4
-#     O^T += V8^T(tile) . P                                         4 x v_mfma_f32_32x32x64_f8f6f4
+#     O^T += 2^ev V8^T(tile) . P                                    4 x v_mfma_scale_f32_32x32x64_f8f6f4 (V block scale: byte 1)
 #     mx = row max of S_nxt
 # Every A operand is 8 registers = 2 x ds_read_b128, read AHEAD8 MFMAs ahead into a ring of RING8 buffers.  K and V live in
 # 4-slot LDS rings: the tile's slot (TS = tile & 3) is a compile-time constant of the block, so every LDS address is a
@@ -347,7 +347,9 @@ def gen_block8(TS, codemap=False):
             lines.append("s_nop 1")   # the last word of P was packed just above
             lines.append(f"v_mfma_f32_16x16x128_f8f6f4 {vr(m.LACC, 4)}, {a}, {vr(SC_, 8)}, {vr(m.LACC, 4)}")
         else:
-            lines.append(f"v_mfma_f32_32x32x64_f8f6f4 {vr(m.O + 16 * x, 16)}, {a}, {vr(SC_, 8)}, {vr(m.O + 16 * x, 16)}")
+            # (byte 1 of the scale registers: the V block's scale on A, 1.0 on the P operand)
+            lines.append(f"v_mfma_scale_f32_32x32x64_f8f6f4 {vr(m.O + 16 * x, 16)}, {a}, {vr(SC_, 8)}, {vr(m.O + 16 * x, 16)}, "
+                         f"{vr(m.SC)}, {vr(m.SC + 1)} op_sel:[1,1,0] op_sel_hi:[0,0,0]")
         if i + AHEAD8 < n: read(i + AHEAD8)
         # row max of S_nxt: two MFMAs behind the last QK^T MFMA (index 3): from the shadow of PV 0 (index 5) on
         emit_work(10 ** 6 if i == n - 1 else 48, i >= 5)

@@ -17,6 +17,7 @@ static unsigned long long g_dbg_ptr = 0;   // diagnostics build: device buffer f
 #endif
 
 void rsa_set_fp8_variant(int v);
+void rsa_set_fp8_smooth_k(int v);
 int rsa_launch_bsfwd(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int dtype, hipStream_t s);
 
 // Tuning / diagnostics hook (not part of the data path).  The switches are process-global, so the hook only works in a
@@ -36,6 +37,7 @@ extern "C" int rsa_set_tuning(const char* key, int value) {
 #endif
     if (strcmp(key, "k5_tsplit") == 0) { g_k5_tsplit = value; return RSA_OK; }
     if (strcmp(key, "fp8_variant") == 0) { rsa_set_fp8_variant(value); return RSA_OK; }
+    if (strcmp(key, "fp8_smooth_k") == 0) { rsa_set_fp8_smooth_k(value); return RSA_OK; }
     return RSA_ERR_BAD_ARG;
 }
 

@@ -36,7 +36,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct Attn8Args {
     const uint8_t *q8, *k8, *v8t;  // [BH, S_pad, 128], [BH, S_pad, 128], [BH, S_pad/64, 128, 64]
-    const float* scales;           // [3, BH]
+    const uint32_t* exps;          // [BH, exps_stride] E8M0 block exponents: byte 0 Q, byte 1 K, byte 2 V (rsa_fp8_emit.h)
+    int exps_stride;
     unsigned short* out;
     long osb, osh, oss;
     const int32_t* cols;
@@ -48,7 +49,6 @@ struct Attn8Args {
     int kv_valid, kv_text_valid, q_text_end;
     int q_split, kv_split;
     int n_heavy_pad, NBp, BH;
-    float sm_scale_log2e;
     int out_fp16;
     float* tpart;        // split-KV partials of the text query blocks (layout of rsa_attn.hip's combine kernel) or null
     int tsplit, tper;
@@ -83,9 +83,13 @@ template <> struct PMap<true> { static constexpr float U = 8.0f, BIAS = 56.0f, O
 __device__ __forceinline__ f32x16 mfma8(i32x8 a, i32x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0, 0, 0);  // e4m3 x e4m3, unscaled
 }
-// same with E8M0 block scales 2^(sa-127) on A and 2^(sb-127) on B (byte 0 of each lane's scale register)
+// same with E8M0 block scales 2^(sa-127) on A and 2^(sb-127) on B: byte 0 of each lane's scale register ...
 __device__ __forceinline__ f32x16 mfma8s(i32x8 a, i32x8 b, f32x16 c, int sa, int sb) {
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, sa, 0, sb);
+}
+// ... and byte 1 of the same registers (the PV product: V block scale on A, 1.0 on the P operand)
+__device__ __forceinline__ f32x16 mfma8s1(i32x8 a, i32x8 b, f32x16 c, int sa, int sb) {
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 1, sa, 1, sb);
 }
 
 // the hand-placed tile block (gen_k5_block.py, RSA_K5F8_*): one asm statement per 64-key tile, registers pinned; TS = tile & 3
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     constexpr float P_GROW = PM::U * PM::THRESH + P_BASE;     // above it the reference moves
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* lds_ones = lds + 2 * NSLOT * TILE8;  // 32 bytes of e4m3 1.0, then 32 bytes of 0
-    unsigned short* lds_list = reinterpret_cast<unsigned short*>(lds + 2 * NSLOT * TILE8 + 64);
+    unsigned* lds_list = reinterpret_cast<unsigned*>(lds + 2 * NSLOT * TILE8 + 64);
 
     // ---------------- work mapping (as rsa_attn_kernel.hip) ----------------
     int bh, qblk, tsp = 0;
@@ -185,31 +189,34 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
         if (hi_max <= lo_min) n_items = 0;
     }
     n_items = __builtin_amdgcn_readfirstlane(n_items);
-    const bool use_list = list != nullptr;
+    // the walk as LDS entries: key block | its K exponent << 16 | its V exponent << 24 (every mode: a kept list, a split
+    // of the text range or a dense range), so one LDS read per tile brings the block index AND its two scales
+    const uint32_t* ex = a.exps + (long)bh * a.exps_stride;
     if (t < 16) reinterpret_cast<unsigned*>(lds_ones)[t] = t < 8 ? 0x38383838u : 0u;
-    if (use_list) {
-        for (int i = t; i < n_items; i += 256) lds_list[i] = (unsigned short)list[i];
+    for (int i = t; i < n_items; i += 256) {
+        const int blk = list != nullptr ? list[i] : first_blk + i;
+        lds_list[i] = (unsigned)blk | ((ex[blk] >> 8) << 16);
     }
     __syncthreads();
-    auto blk_of = [&](int item) -> int { return use_list ? (int)lds_list[item] : first_blk + item; };
+    auto entry_of = [&](int item) -> unsigned { return lds_list[item]; };
     int n_tiles = 2 * n_items;
     if (n_items > 0) {
-        const int last_blk = blk_of(n_items - 1);
+        const int last_blk = (int)(entry_of(n_items - 1) & 0xFFFFu);
         if (last_blk * RSA_BLOCK + 64 >= hi_max) n_tiles -= 1;
     }
     n_tiles = __builtin_amdgcn_readfirstlane(n_tiles);
-    auto key0_of = [&](int tile) -> int {  // first key of tile `tile` (index clamped: callers guard tile < n_tiles)
+    auto raw_item = [&](int tile) -> unsigned {   // entry of `tile`'s key block, still per lane (index clamped)
         const int it = tile >> 1;
-        const int blk = __builtin_amdgcn_readfirstlane(blk_of(it < n_items ? it : (n_items > 0 ? n_items - 1 : 0)));
-        return blk * RSA_BLOCK + (tile & 1) * 64;
+        return entry_of(it < n_items ? it : (n_items > 0 ? n_items - 1 : 0));
     };
+    auto entry_sc = [&](int tile) -> unsigned { return (unsigned)__builtin_amdgcn_readfirstlane((int)raw_item(tile)); };
+    auto key0_from = [&](unsigned entry, int tile) -> int { return (int)(entry & 0xFFFFu) * RSA_BLOCK + (tile & 1) * 64; };
 
     // ---------------- scales, Q fragments ----------------
-    // c = scale_q * scale_k * sm_scale * log2(e) = 2^e exactly (rsa_fp8.hip::scales_kernel): split over the two operands
-    const int c_exp = (int)((__float_as_uint(a.scales[3 * a.BH + bh]) >> 23) & 0xFF) - 127;
-    const int c_exp_u = c_exp + PM::EXP;   // (the code map's unit of 1/8 rides on the same E8M0 operands)
-    const int sc_a = 127 + (c_exp_u >> 1), sc_b = 127 + (c_exp_u - (c_exp_u >> 1));
-    const float s_v = a.scales[2 * a.BH + bh];
+    // Block scales are powers of two (rsa_fp8_emit.h) and ride on the MFMAs' E8M0 operands: scale register B holds the Q
+    // block's exponent (+ the code map's unit of 1/8) in byte 0 and 1.0 in byte 1; scale register A is rebuilt per tile:
+    // byte 0 = K exponent of the tile whose scores the block computes, byte 1 = V exponent of the tile it multiplies P with.
+    const int sc_b = (int)(((ex[qblk < a.exps_stride ? qblk : 0] & 0xFFu) + (unsigned)PM::EXP) | (127u << 8));
     i32x8 qf[2];
     {
         const uint8_t* qp = a.q8 + ((long)bh * a.Sq_pad + grow) * D8 + 32 * hh;  // rows < Sq_pad always exist (zero-padded)
@@ -291,12 +298,12 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
         return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     };
     // S^T (two 32-key halves) of the tile in K slot `slot`
-    auto qk_tile = [&](int slot, f32x16 (&S)[2]) {
+    auto qk_tile = [&](int slot, f32x16 (&S)[2], int sc_k) {
         const unsigned char* kt_ = lds + slot * TILE8;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
-            S[sub] = mfma8s(ld32(kt_ + koff[sub][0][0], kt_ + koff[sub][0][1]), qf[0], mblk, sc_a, sc_b);
-            S[sub] = mfma8s(ld32(kt_ + koff[sub][1][0], kt_ + koff[sub][1][1]), qf[1], S[sub], sc_a, sc_b);
+            S[sub] = mfma8s(ld32(kt_ + koff[sub][0][0], kt_ + koff[sub][0][1]), qf[0], mblk, sc_k, sc_b);
+            S[sub] = mfma8s(ld32(kt_ + koff[sub][1][0], kt_ + koff[sub][1][1]), qf[1], S[sub], sc_k, sc_b);
         }
     };
     auto rowmax_tile = [&](const f32x16 (&S)[2]) -> float {
@@ -321,10 +328,12 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     };
 
     int kq1 = 0, kq2 = 0, kq3 = 0;  // first keys of tiles t+1, t+2, t+3
+    unsigned sw0 = 0, sw1 = 0, sw2 = 0, sw3 = 0;  // entries >> 16 (K exponent | V exponent << 8) of tiles t .. t+3, wave-uniform
 
     // TS = tile & 3 (compile-time: every LDS address is a loop-invariant VGPR plus an immediate)
     auto step = [&](auto TS, int tile, int key0, f32x16 (&S_cur)[2], float& mx_cur, f32x16 (&S_nxt)[2], float& mx_nxt) {
         const int ts = TS;  // integral_constant (static LDS addresses) or the runtime tile & 3
+        const int sc_a = (int)((sw1 & 0xFFu) | (sw0 & 0xFF00u));   // K(tile + 1) in byte 0, V(tile) in byte 1
         if (tile + 2 < n_tiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -372,7 +381,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
         if constexpr ((PIPE_OPT >> 8) == 2) __builtin_amdgcn_iglp_opt(1);
         if constexpr ((PIPE_OPT >> 8) == 3) __builtin_amdgcn_iglp_opt(2);
         if constexpr ((PIPE_OPT >> 8) == 4) __builtin_amdgcn_iglp_opt(3);
-        qk_tile((ts + 1) & (NSLOT - 1), S_nxt);
+        qk_tile((ts + 1) & (NSLOT - 1), S_nxt, sc_a);
         i32x8 pb;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
@@ -398,7 +407,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
         const unsigned char* vt_ = lds + (NSLOT + ts) * TILE8;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
-            o[dt] = mfma8(ld32(vt_ + dt * 2048 + voff_rd[0], vt_ + dt * 2048 + voff_rd[1]), pb, o[dt]);
+            o[dt] = mfma8s1(ld32(vt_ + dt * 2048 + voff_rd[0], vt_ + dt * 2048 + voff_rd[1]), pb, o[dt], sc_a, sc_b);
         mx_nxt = rowmax_tile(S_nxt);
         if constexpr (PIPE_OPT & 2) __builtin_amdgcn_s_setprio(0);
     };
@@ -408,31 +417,29 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     float mxA = -INFINITY, mxB = -INFINITY;
     int key0 = 0;
     if (n_tiles > 0) {
-        key0 = key0_of(0);
-        kq1 = key0_of(1);
-        kq2 = key0_of(2);
-        kq3 = key0_of(3);
+        const unsigned e0 = entry_sc(0), e1 = entry_sc(1), e2 = entry_sc(2), e3 = entry_sc(3);
+        key0 = key0_from(e0, 0); kq1 = key0_from(e1, 1); kq2 = key0_from(e2, 2); kq3 = key0_from(e3, 3);
+        sw0 = e0 >> 16; sw1 = e1 >> 16; sw2 = e2 >> 16; sw3 = e3 >> 16;
         dma_k(key0, 0);
         dma_v(key0, 0);
         if (n_tiles > 1) { dma_k(kq1, 1); dma_v(kq1, 1); }
         if (n_tiles > 2) dma_k(kq2, 2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        qk_tile(0, SA);
+        qk_tile(0, SA, (int)(sw0 & 0xFFu));
         mxA = rowmax_tile(SA);
     }
     // The kept-list entry of tile+4 is read from LDS one advance() EARLY into a register (pref_raw) and only made scalar
     // here: the LDS round trip (~100 cycles, once per tile and wave) is off the wave's critical path.
-    auto raw_item = [&](int tile) -> int {   // block index of `tile`'s list entry, still per lane (index clamped)
-        const int it = tile >> 1;
-        return blk_of(it < n_items ? it : (n_items > 0 ? n_items - 1 : 0));
-    };
-    int pref_raw = n_tiles > 0 ? raw_item(4) : 0;
-    auto advance = [&](int tile) {  // after finishing `tile`: shift the key queue, tile+4's first key from the prefetched entry
+    unsigned pref_raw = n_tiles > 0 ? raw_item(4) : 0u;
+    auto advance = [&](int tile) {  // after finishing `tile`: shift the queues, tile+4's entry from the prefetched register
         key0 = kq1;
         kq1 = kq2;
         kq2 = kq3;
-        kq3 = __builtin_amdgcn_readfirstlane(pref_raw) * RSA_BLOCK + ((tile + 4) & 1) * 64;
+        sw0 = sw1; sw1 = sw2; sw2 = sw3;
+        const unsigned e4 = (unsigned)__builtin_amdgcn_readfirstlane((int)pref_raw);
+        kq3 = key0_from(e4, tile + 4);
+        sw3 = e4 >> 16;
         pref_raw = raw_item(tile + 5);
     };
     if constexpr ((PIPE_OPT & 1) != 0) {   // four tiles per trip: the ring slot is a compile-time constant of every block
@@ -478,8 +485,8 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int d0 = 32 * dt + 8 * g + 4 * hh;
-                *reinterpret_cast<float2*>(pp + d0) = make_float2(o[dt][4 * g + 0] * s_v, o[dt][4 * g + 1] * s_v);
-                *reinterpret_cast<float2*>(pp + d0 + 2) = make_float2(o[dt][4 * g + 2] * s_v, o[dt][4 * g + 3] * s_v);
+                *reinterpret_cast<float2*>(pp + d0) = make_float2(o[dt][4 * g + 0], o[dt][4 * g + 1]);
+                *reinterpret_cast<float2*>(pp + d0 + 2) = make_float2(o[dt][4 * g + 2], o[dt][4 * g + 3]);
             }
         if (hh == 0) *reinterpret_cast<float2*>(pp + D8) = make_float2(m_run, l_tot);
         return;
@@ -494,7 +501,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
         cp = a.comp + rowi * D8;
     }
     if (zero_r) inv = 0.0f;
-    const float sc = inv * Rv * s_v;
+    const float sc = inv * Rv;
     unsigned short* op = a.out + (long)b * a.osb + (long)h * a.osh + (long)grow * a.oss;
     // (16-byte stores after a v_permlane32_swap regroup, the 2-byte kernel's default, measured neutral here: 9.60 vs 9.60 ms)
 #pragma unroll
@@ -539,7 +546,7 @@ int launch_attn8(Attn8Args& a, int BH, hipStream_t s) {
     if (nblocks <= 0) return RSA_OK;
     if (nblocks > 0x7FFFFFFF) return RSA_ERR_UNSUPPORTED;
     if (a.NB_total > 8192) return RSA_ERR_UNSUPPORTED;
-    const size_t lds_bytes = (size_t)2 * NSLOT * TILE8 + 64 + (((size_t)a.NB_total * 2 + 15) & ~(size_t)15);
+    const size_t lds_bytes = (size_t)2 * NSLOT * TILE8 + 64 + (((size_t)a.NB_total * 4 + 15) & ~(size_t)15);
     switch (g_fp8_variant) {   // tuning key fp8_variant: 0 = product; the others for A/B and the accuracy comparison
         case 1: bsfwd_fp8_kernel<6><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a); break;   // product arithmetic, hipcc's schedule
         case 2: bsfwd_fp8_kernel<3><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a); break;   // exact-exponential P, hand-placed
@@ -572,7 +579,7 @@ extern "C" int rsa_block_sparse_fwd_fp8(const rsa_layout* l, const rsa_fp8_opera
     if (!buf || (l->NBv > 0 && (!buf->cols || !buf->counts))) return RSA_ERR_BAD_ARG;
     if ((buf->R == nullptr) != (buf->comp == nullptr)) return RSA_ERR_BAD_ARG;
     Attn8Args a;
-    a.q8 = ops->q8; a.k8 = ops->k8; a.v8t = ops->v8t; a.scales = ops->scales;
+    a.q8 = ops->q8; a.k8 = ops->k8; a.v8t = ops->v8t; a.exps = ops->scales; a.exps_stride = l->NB_total;
     a.out = static_cast<unsigned short*>(out.ptr); a.osb = out.stride_b; a.osh = out.stride_h; a.oss = out.stride_s;
     a.cols = buf->cols; a.counts = buf->counts; a.R = buf->R; a.comp = buf->comp; a.tpart = buf->tpart;
     a.mode = MODE_SPARSE; a.H = l->H; a.Sq = l->S; a.Sk = l->S;
@@ -581,7 +588,6 @@ extern "C" int rsa_block_sparse_fwd_fp8(const rsa_layout* l, const rsa_fp8_opera
     a.kv_valid = l->kv_valid; a.kv_text_valid = l->kv_text_valid;
     a.q_text_end = l->NBv * RSA_BLOCK + l->q_text_valid;
     a.q_split = 0; a.kv_split = 0;
-    a.sm_scale_log2e = (float)((1.0 / sqrt((double)l->D)) * 1.44269504);
     a.out_fp16 = l->dtype == RSA_FP16;
     return launch_attn8(a, l->B * l->H, static_cast<hipStream_t>(stream));
 }
@@ -599,7 +605,6 @@ extern "C" int rsa_rectified_attention_fp8(const rsa_layout* l, rsa_tensor4 q, r
     if ((st = rsa_pooled_scores(l, k, &buf, stream))) return st;
     if ((st = rsa_select_mask(l, neighbor, top_k, p_remain, &buf, stream))) return st;
     if ((st = rsa_compensation(l, &buf, stream))) return st;
-    if ((st = rsa_fp8_images(l, q, k, v, &ops, stream))) return st;
     return rsa_block_sparse_fwd_fp8(l, &ops, &buf, out, stream);
 }
 
@@ -620,15 +625,18 @@ extern "C" int rsa_dense_fwd_fp8(int B, int H, int Sq, int Sk, int D, int dtype,
     hipStream_t s = static_cast<hipStream_t>(stream);
     if ((st = rsa_dense_quantize_fp8(B, H, Sq, Sk, D, dtype, q, k, v, workspace, workspace_bytes, &ops, s))) return st;
     Attn8Args a;
-    a.q8 = ops.q8; a.k8 = ops.k8; a.v8t = ops.v8t; a.scales = ops.scales;
+    a.q8 = ops.q8; a.k8 = ops.k8; a.v8t = ops.v8t; a.exps = ops.scales;
     a.out = static_cast<unsigned short*>(out.ptr); a.osb = out.stride_b; a.osh = out.stride_h; a.oss = out.stride_s;
     a.cols = nullptr; a.counts = nullptr; a.R = nullptr; a.comp = nullptr; a.tpart = nullptr;
     a.mode = MODE_DENSE; a.H = H; a.Sq = Sq; a.Sk = Sk;
     a.NQB = (Sq + RSA_BLOCK - 1) / RSA_BLOCK; a.NBv = a.NQB; a.NB_total = (Sk + RSA_BLOCK - 1) / RSA_BLOCK;
-    a.Sq_pad = a.NQB * RSA_BLOCK; a.Sk_pad = a.NB_total * RSA_BLOCK;
+    {   // every image of the dense producer is max(Sq, Sk) rounded up to 128 rows high (rsa_fp8.hip::dense_fp8_carve)
+        const int nbm = a.NQB > a.NB_total ? a.NQB : a.NB_total;
+        a.Sq_pad = a.Sk_pad = nbm * RSA_BLOCK;
+        a.exps_stride = nbm;
+    }
     a.kv_valid = Sk; a.kv_text_valid = Sk; a.q_text_end = 0;
     a.q_split = q_split; a.kv_split = kv_split;
-    a.sm_scale_log2e = (float)((1.0 / sqrt((double)D)) * 1.44269504);
     a.out_fp16 = dtype == RSA_FP16;
     return launch_attn8(a, B * H, s);
 }

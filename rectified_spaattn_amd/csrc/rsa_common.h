@@ -89,10 +89,11 @@ static inline int rsa_check_tensor(const rsa_tensor4& t) {
     return RSA_OK;
 }
 
-// K1 with an optional side product for the fp8 path: max |x| of every block it reads, amax_part[3][BH][NB_total]
-// (q blocks < NBv, k blocks < NBv with rows >= pool_valid as zero, v blocks < NB_total likewise).  rsa_stats.hip.
-int rsa_pool_stats_amax(const rsa_layout* l, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v, const rsa_buffers* buf,
-                        float* amax_part, void* stream);
+// K1; with f8 != nullptr (D = 128) it also writes the e4m3 images and block exponents of every block it pools -- q and k
+// blocks < NBv, v blocks < NB_total (rsa_fp8_emit.h).  rsa_stats.hip.
+struct Fp8Emit;
+int rsa_pool_stats_f8(const rsa_layout* l, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v, const rsa_buffers* buf,
+                      const Fp8Emit* f8, void* stream);
 
 // e4m3 images for the dense fp8 kernel, carved out of `ws` (rsa_fp8.hip)
 int rsa_dense_quantize_fp8(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,

@@ -3,6 +3,7 @@
 // is an explicit __builtin_fmaf so the arithmetic equals the fp32 statistics contract (oracle/rsa_oracle.c)
 // bit for bit.  All of this is HBM/LDS-bound integer-and-fp32 work; no MFMA on purpose.
 #include "rsa_common.h"
+#include "rsa_fp8_emit.h"
 
 // =====================================================================================================
 // K1: pool_stats -- block means (and mean |x - mean|) of Q, K, V in one launch.
@@ -19,11 +20,12 @@ struct PoolArgs {
     int nblk[3];     // blocks to produce per tensor
     int valid[3];    // rows >= valid are zero
     int H;
-    float* amax_part;  // optional [3, BH, NB_total]: max |x| of each block this launch reads (fp8 scales); plain stores
     int BH, NB_total;
+    Fp8Emit f8;      // F8 instances only: the e4m3 images of every block this launch pools (rsa_fp8_emit.h)
 };
 
-template <int D, typename Tag>
+// F8: the fp8 operand path's form -- the block is in registers anyway, so its e4m3 image is written in the same pass
+template <int D, typename Tag, bool F8>
 __global__ __launch_bounds__(D * 2) void pool_stats_kernel(PoolArgs a) {
     constexpr int CH = D / 8;        // 16-byte chunks per row
     constexpr int NTH = 16 * CH;     // threads
@@ -52,16 +54,9 @@ __global__ __launch_bounds__(D * 2) void pool_stats_kernel(PoolArgs a) {
             x[i][2 * e + 1] = rsa_to_f32<Tag>((unsigned short)(w[e] >> 16));
         }
     }
-    __shared__ float amx[NW];
-    if (a.amax_part != nullptr) {  // side product for the fp8 path: the block is in registers anyway
-        float m = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(x[i][e]));
-#pragma unroll
-        for (int sft = 1; sft < 64; sft <<= 1) m = fmaxf(m, __shfl_xor(m, sft, 64));
-        if ((t & 63) == 0) amx[t >> 6] = m;  // combined after the first barrier below
+    if constexpr (F8 && D == 128) {
+        __shared__ __attribute__((aligned(16))) unsigned char f8lds[RSA_F8_LDS];
+        fp8_emit_block<Tag>(x, a.f8, which, blk, bh, f8lds);
     }
     __shared__ float red[NW][D];
     float mean[8];
@@ -83,12 +78,6 @@ __global__ __launch_bounds__(D * 2) void pool_stats_kernel(PoolArgs a) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) red[t >> 6][c * 8 + e] = s[e];
         __syncthreads();
-        if (a.amax_part != nullptr && t == 0) {
-            float m = amx[0];
-#pragma unroll
-            for (int w = 1; w < NW; ++w) m = fmaxf(m, amx[w]);
-            a.amax_part[((long)which * a.BH + bh) * a.NB_total + blk] = m;
-        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float tot;
@@ -849,9 +838,9 @@ extern "C" int rsa_carve_workspace(const rsa_layout* l, void* ws, size_t ws_byte
     return RSA_OK;
 }
 
-// K1 with the optional |x| maxima (rsa_common.h); rsa_pool_stats is the amax-less public form
-int rsa_pool_stats_amax(const rsa_layout* l, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v, const rsa_buffers* buf,
-                        float* amax_part, void* stream) {
+// K1, optionally writing the e4m3 images of the blocks it pools (rsa_common.h); rsa_pool_stats is the public form without
+int rsa_pool_stats_f8(const rsa_layout* l, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v, const rsa_buffers* buf,
+                      const Fp8Emit* f8, void* stream) {
     int st = rsa_check_layout(l);
     if (st != RSA_OK) return st;
     if (!buf || !buf->qbar || !buf->aq || !buf->kbar || !buf->ak || !buf->vbar) return RSA_ERR_BAD_ARG;
@@ -869,22 +858,29 @@ int rsa_pool_stats_amax(const rsa_layout* l, rsa_tensor4 q, rsa_tensor4 k, rsa_t
     a.valid[1] = l->pool_valid < vis_tok ? l->pool_valid : vis_tok;
     a.mean[2] = buf->vbar; a.mad[2] = nullptr; a.nblk[2] = l->NB_total; a.valid[2] = l->pool_valid;
     a.H = l->H;
-    a.amax_part = amax_part; a.BH = l->B * l->H; a.NB_total = l->NB_total;
+    a.BH = l->B * l->H; a.NB_total = l->NB_total;
     dim3 grid(l->NB_total, l->B * l->H, 3);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (f8 != nullptr) {
+        if (l->D != 128) return RSA_ERR_UNSUPPORTED;
+        a.f8 = *f8;
+        if (l->dtype == RSA_BF16) pool_stats_kernel<128, bf16_tag, true><<<grid, 256, 0, s>>>(a);
+        else pool_stats_kernel<128, fp16_tag, true><<<grid, 256, 0, s>>>(a);
+        return rsa_launch_status();
+    }
     if (l->D == 128) {
-        if (l->dtype == RSA_BF16) pool_stats_kernel<128, bf16_tag><<<grid, 256, 0, s>>>(a);
-        else pool_stats_kernel<128, fp16_tag><<<grid, 256, 0, s>>>(a);
+        if (l->dtype == RSA_BF16) pool_stats_kernel<128, bf16_tag, false><<<grid, 256, 0, s>>>(a);
+        else pool_stats_kernel<128, fp16_tag, false><<<grid, 256, 0, s>>>(a);
     } else {
-        if (l->dtype == RSA_BF16) pool_stats_kernel<64, bf16_tag><<<grid, 128, 0, s>>>(a);
-        else pool_stats_kernel<64, fp16_tag><<<grid, 128, 0, s>>>(a);
+        if (l->dtype == RSA_BF16) pool_stats_kernel<64, bf16_tag, false><<<grid, 128, 0, s>>>(a);
+        else pool_stats_kernel<64, fp16_tag, false><<<grid, 128, 0, s>>>(a);
     }
     return rsa_launch_status();
 }
 
 extern "C" int rsa_pool_stats(const rsa_layout* l, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
                               const rsa_buffers* buf, void* stream) {
-    return rsa_pool_stats_amax(l, q, k, v, buf, nullptr, stream);
+    return rsa_pool_stats_f8(l, q, k, v, buf, nullptr, stream);
 }
 
 extern "C" int rsa_pooled_scores(const rsa_layout* l, rsa_tensor4 k, const rsa_buffers* buf, void* stream) {
@@ -994,7 +990,7 @@ extern "C" int rsa_estimate_pr_gain(int BH, int NQ, int NK, int D, int dtype, co
     hipStream_t s = static_cast<hipStream_t>(stream);
     for (int which = 0; which < 2; ++which) {
         PoolArgs a;
-        a.amax_part = nullptr; a.BH = BH; a.NB_total = 0;
+        a.BH = BH; a.NB_total = 0;
         const int N = which == 0 ? NQ : NK;
         float* scratch = which == 0 ? scratch_aq : scratch_ak;
         for (int i = 0; i < 3; ++i) {
@@ -1007,11 +1003,11 @@ extern "C" int rsa_estimate_pr_gain(int BH, int NQ, int NK, int D, int dtype, co
         a.H = BH;
         dim3 grid(N, BH, 1);
         if (D == 128) {
-            if (dtype == RSA_BF16) pool_stats_kernel<128, bf16_tag><<<grid, 256, 0, s>>>(a);
-            else pool_stats_kernel<128, fp16_tag><<<grid, 256, 0, s>>>(a);
+            if (dtype == RSA_BF16) pool_stats_kernel<128, bf16_tag, false><<<grid, 256, 0, s>>>(a);
+            else pool_stats_kernel<128, fp16_tag, false><<<grid, 256, 0, s>>>(a);
         } else {
-            if (dtype == RSA_BF16) pool_stats_kernel<64, bf16_tag><<<grid, 128, 0, s>>>(a);
-            else pool_stats_kernel<64, fp16_tag><<<grid, 128, 0, s>>>(a);
+            if (dtype == RSA_BF16) pool_stats_kernel<64, bf16_tag, false><<<grid, 128, 0, s>>>(a);
+            else pool_stats_kernel<64, fp16_tag, false><<<grid, 128, 0, s>>>(a);
         }
     }
     dim3 g((NK + 127) / 128, NQ, BH);
@@ -1034,4 +1030,4 @@ extern "C" const char* rsa_status_string(int status) {
 int g_rsa_last_hip_error = 0;
 extern "C" const char* rsa_last_hip_error(void) { return hipGetErrorString((hipError_t)g_rsa_last_hip_error); }
 
-extern "C" int rsa_version(void) { return 300; }  // 0.3.0: rsa_buffers has 15 members (K3b's union lists gone), rsa_allgather_heads_p2p is stream-ordered (+ state buffers), rsa_ipc_offset
+extern "C" int rsa_version(void) { return 310; }  // 0.3.1: block-scaled fp8 operands (rsa_fp8_operands.scales = E8M0 words + K mean), K1 writes the images, rsa_fp8_images gone; 0.3.0: rsa_buffers has 15 members, rsa_allgather_heads_p2p is stream-ordered (+ state buffers), rsa_ipc_offset

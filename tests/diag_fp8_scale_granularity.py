@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Study (CPU, oracle only): how much of the fp8 operand path's distance to the bf16 oracle is due to the GRANULARITY
-of the e4m3 scales?  Quantises Q, K (minus its mean), V with (a) one scale per head (what rsa_fp8.hip does), (b) one
+of the e4m3 scales?  Quantises Q, K (minus its mean), V with (a) one scale per head (what rsa_fp8.hip did until round 3), (b) one
 power-of-two scale per 128-token block, (c) one power-of-two scale per token row, dequantises, and runs the exact (fp64)
 rectified attention on those values -- so the numbers isolate the operand rounding (P is NOT rounded here).
     python tests/diag_fp8_scale_granularity.py

@@ -1,6 +1,7 @@
 """fp8 (e4m3) K5 on the GPU (BASELINE config 5: fp8 Q/K/V on the CDNA4 fp8 MFMA).
 
-* the quantiser's images and scales equal oracle.fp8_operands byte for byte (integer / byte work: bit-exact)
+* the producer's block-scaled images, block exponents and K mean equal oracle.fp8_operands byte for byte (integer / byte
+  work: bit-exact), whether K1 writes them in its pooling pass or the stand-alone producer does
 * the kept lists, R and comp are the 2-byte path's (the mask-selection pass does not see the fp8 images)
 * the kernel's output is within max|d| <= 4e-2, mean|d| <= 4e-3 of the fp8-aware oracle (same dequantised e4m3
   operands, P kept exact) for N(0,1)-scale V -- measured 2.3e-2 / 2.5e-3, which is the e4m3 rounding of P
@@ -62,9 +63,8 @@ def test_fp8_operator(case):
             assert torch.equal(a, b), n
     # byte-exact operand images
     ref8, sel, ops = orc.rectified_attention_fp8(q, k, v, lay, top_k, p, nbr, want_parts=True)
-    assert np.array_equal(parts["scales"][:4].cpu().numpy(), ops["scales"]), "scales"
-    c = ops["scales"][3]
-    assert (np.frexp(c)[0] == 0.5).all(), "c must be a power of two"
+    assert np.array_equal(parts["kmean"].cpu().numpy(), ops["kmean"]), "K mean"
+    assert np.array_equal(parts["exps"].cpu().numpy().astype(np.uint32), ops["exps"]), "block exponents"
     assert np.array_equal(parts["q8"].cpu().numpy(), ops["q8"]), "q8"
     assert np.array_equal(parts["k8"].cpu().numpy(), ops["k8"]), "k8"
     assert np.array_equal(parts["v8t"].cpu().numpy(), ops["v8t"]), "v8t"
@@ -114,7 +114,8 @@ def test_fp8_rejects_head_dim_64():
 
 
 def test_fp8_large_magnitudes_and_zero_tensor():
-    """Scales follow the data: x1000 inputs quantise to the same bytes; an all-zero V gives scale 1 and comp-only output."""
+    """Scales follow the data: x1024 inputs quantise to the same bytes with every V exponent 10 higher; an all-zero V gives
+    exponent 0 (byte 127) and comp-only output."""
     from rectified_spaattn_amd import _core, synth
     lay = orc.layout_wan(3 * 128, 0)
     q, k, v = synth.structured_qkv(9, 1, 1, lay.S, 128, smooth=0.0)
@@ -122,10 +123,11 @@ def test_fp8_large_magnitudes_and_zero_tensor():
     _, p1 = _core.rectified_attention(tq, tk, tv, _spec(lay), 1, 0.3, None, return_parts=True, qkv_fp8=True)
     _, p2 = _core.rectified_attention(tq, tk, tv * 1024, _spec(lay), 1, 0.3, None, return_parts=True, qkv_fp8=True)
     assert torch.equal(p1["v8t"], p2["v8t"])  # power-of-two rescale: identical bytes
-    assert torch.equal(p1["scales"][2] * 1024, p2["scales"][2])
+    assert torch.equal(((p1["exps"] >> 16) & 0xFF) + 10, (p2["exps"] >> 16) & 0xFF)
+    assert torch.equal(p1["exps"] & 0xFFFF, p2["exps"] & 0xFFFF)
     o, p3 = _core.rectified_attention(tq, tk, torch.zeros_like(tv), _spec(lay), 1, 0.3, None, return_parts=True,
                                       qkv_fp8=True)
-    assert float(p3["scales"][2, 0]) == 1.0
+    assert bool((((p3["exps"] >> 16) & 0xFF) == 127).all())
     assert torch.count_nonzero(o) == 0
 
 
@@ -164,7 +166,7 @@ def test_fp8_batch_and_strided_views():
     out, parts = _core.rectified_attention(tq, tk, tv, _spec(lay), 2, 0.3, None, return_parts=True, qkv_fp8=True)
     qf, kf, vf = (t.float().cpu().numpy() for t in (tq, tk, tv))
     ref, sel, ops = orc.rectified_attention_fp8(qf, kf, vf, lay, 2, 0.3, None, want_parts=True)
-    assert np.array_equal(parts["scales"][:4].cpu().numpy(), ops["scales"])
+    assert np.array_equal(parts["exps"].cpu().numpy().astype(np.uint32), ops["exps"])
     assert np.array_equal(parts["k8"].cpu().numpy(), ops["k8"]) and np.array_equal(parts["v8t"].cpu().numpy(), ops["v8t"])
     err = np.abs(out.float().cpu().numpy() - ref)
     assert err.max() <= FP8_MAX_VS_FP8 and err.mean() <= FP8_MEAN_VS_FP8, f"{err.max():.3e} {err.mean():.3e}"
@@ -176,9 +178,9 @@ def test_fp8_batch_and_strided_views():
 @pytest.mark.parametrize("mk", [lambda: orc.layout_hunyuan(4 * 128 + 256, 4 * 128 + 77), lambda: orc.layout_wan(300, 0),
                                 lambda: orc.layout_flux(3 * 128 + 128, 128)], ids=["hunyuan", "wan", "flux"])
 def test_fp8_fused_and_standalone_producers(mk):
-    """Fused form (rsa_pool_stats_fp8: maxima as K1's side product + text-tail rows, K mean from K1's block means;
-    rsa_fp8_images) and the stand-alone rsa_quantize_fp8 (own amax pass, no K mean) against their oracle contracts:
-    the V image and scale agree between the two."""
+    """Fused form (rsa_pool_stats_fp8: K1 writes the images of the blocks it pools, a small launch the text-tail blocks of
+    Q and K) and the stand-alone rsa_quantize_fp8 (one pass of its own) against the oracle contract, and against each
+    other: bit-identical images, exponents and K mean."""
     from rectified_spaattn_amd import _core, synth
     lay = mk()
     q, k, v = synth.structured_qkv(808, 1, 2, lay.S, 128, smooth=0.0)
@@ -187,30 +189,33 @@ def test_fp8_fused_and_standalone_producers(mk):
     tq, tk, tv = (torch.from_numpy(x).to(DEV, torch.bfloat16) for x in (q, k, v))
     call = _core.StagedCall(tq, tk, tv, _spec(lay), 2, 0.3, None, qkv_fp8=True)
     call.select()
-    call.quantize()
     fused = {n: t.clone() for n, t in call.fp8.items()}
     for t in call.fp8.values():
         t.zero_()
-    call.quantize(standalone=True)
+    call.quantize()
     alone = call.fp8
     qf, kf, vf = (t.float().cpu().numpy() for t in (tq, tk, tv))
-    of, oa = orc.fp8_operands(qf, kf, vf, lay, smooth_k=True), orc.fp8_operands(qf, kf, vf, lay, smooth_k=False)
+    want = orc.fp8_operands(qf, kf, vf, lay)
     BH = 2
-    for got, want, tag in ((fused, of, "fused"), (alone, oa, "stand-alone")):
-        assert np.array_equal(got["scales"][:4].cpu().numpy(), want["scales"]), tag
+    for got, tag in ((fused, "fused"), (alone, "stand-alone")):
+        ex = _core.fp8_exps(got["scales"], BH, lay.NB_total).cpu().numpy().astype(np.uint32)
+        assert np.array_equal(ex, want["exps"]), tag
+        assert np.array_equal(_core.fp8_kmean(got["scales"], BH, lay.NB_total).cpu().numpy(), want["kmean"]), tag
         for n in ("q8", "k8", "v8t"):
             assert np.array_equal(got[n].cpu().numpy(), want[n]), f"{tag} {n}"
-    kmean = fused["scales"].flatten()[-BH * 128:].view(BH, 128).cpu().numpy()
-    assert np.array_equal(kmean, of["kmean"])
-    # V is untouched by the smoothing; Q is not (its scale is stretched against the K scale to make c a power of two)
-    assert torch.equal(fused["v8t"], alone["v8t"]) and torch.equal(fused["scales"][2], alone["scales"][2])
+    # the statistics K1 leaves behind do not depend on whether it also wrote the images
+    plain = _core.StagedCall(tq, tk, tv, _spec(lay), 2, 0.3, None)
+    plain.select()
+    for n in ("qbar", "aq", "kbar", "ak", "vbar", "bitmask", "R", "comp"):
+        assert torch.equal(plain.bufs[n], call.bufs[n]), n
 
 
 def test_fp8_smooth_k_removes_a_common_key_component():
     """Real K tensors carry a large component shared by all tokens; q.(k - mu) only shifts each row's scores, so the
-    fused producer subtracts the per-head mean before quantising.  With a bias of ~6 sigma added to every key the
-    smoothed path stays at the unbiased error level while the unsmoothed images are several times worse."""
-    from rectified_spaattn_amd import _core, synth
+    producer subtracts a mean (of 8 sampled blocks) before quantising.  With a bias of ~6 sigma added to every key the
+    smoothed path stays at the unbiased error level while images without it (tuning key fp8_smooth_k = 0) are several
+    times worse."""
+    from rectified_spaattn_amd import _core, _lib, synth
     lay = orc.layout_wan(6 * 128, 0)
     q, k, v = synth.structured_qkv(515, 1, 2, lay.S, 128, smooth=0.0)
     bias = np.random.default_rng(5).standard_normal(128).astype(np.float32) * 6.0
@@ -219,10 +224,15 @@ def test_fp8_smooth_k_removes_a_common_key_component():
     qf, kf, vf = (t.float().cpu().numpy() for t in (tq, tk, tv))
     ref16 = orc.rectified_attention(qf, kf, vf, lay, 99, 1.5, None)          # keep-all: the mask plays no role
     call = _core.StagedCall(tq, tk, tv, _spec(lay), 99, 1.5, None, qkv_fp8=True)
-    call.select(); call.quantize()
+    call.select()
     smooth = call.attend().float().cpu().numpy().reshape(ref16.shape)
-    call.quantize(standalone=True)                                            # same scales for q and v, no K mean
-    plain = call.attend().float().cpu().numpy().reshape(ref16.shape)
+    try:
+        assert _lib.lib().rsa_set_tuning(b"fp8_smooth_k", 0) == 0
+        call.select()
+        plain = call.attend().float().cpu().numpy().reshape(ref16.shape)
+        assert np.array_equal(call.fp8["k8"].cpu().numpy(), orc.fp8_operands(qf, kf, vf, lay, smooth_k=False)["k8"])
+    finally:
+        _lib.lib().rsa_set_tuning(b"fp8_smooth_k", 1)
     e_s, e_p = np.abs(smooth - ref16).mean(), np.abs(plain - ref16).mean()
     ref8 = orc.rectified_attention_fp8(qf, kf, vf, lay, 99, 1.5, None)
     assert np.abs(smooth - ref8).max() <= FP8_MAX_VS_FP8
@@ -267,7 +277,7 @@ def test_fullattn_dense_fp8_switch():
 
 
 def test_fp8_hip_graph_capture_and_replay():
-    """The fp8 path (K1 with maxima, scales, images, fp8 K5; one memset node) is capturable and replays on new data."""
+    """The fp8 path (K mean, K1 writing the images, tail blocks, fp8 K5) is capturable and replays on new data."""
     from rectified_spaattn_amd import _core, synth
     qa, ka, va = (torch.from_numpy(x).to(DEV, torch.bfloat16) for x in synth.structured_qkv(41, 1, 2, 1024, 128))
     qb, kb, vb = (torch.from_numpy(x * 3.0).to(DEV, torch.bfloat16) for x in synth.structured_qkv(42, 1, 2, 1024, 128))
@@ -277,12 +287,11 @@ def test_fp8_hip_graph_capture_and_replay():
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
-        call.select(); call.quantize(); call.attend()   # warm-up outside capture
+        call.select(); call.attend()   # warm-up outside capture
     torch.cuda.current_stream().wait_stream(s)
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         call.select()
-        call.quantize()
         call.attend()
     q.copy_(qb); k.copy_(kb); v.copy_(vb)
     g.replay()
@@ -313,7 +322,7 @@ def test_fp8_random_layouts(case):
     for bh in range(H):
         kept = orc.unpack_bits(parts["bitmask"][bh].cpu().numpy().view(np.uint32), lay.NB_total)
         assert np.array_equal(kept, sel[bh]["kept"]), f"mask (case {i})"
-    assert np.array_equal(parts["scales"][:4].cpu().numpy(), ops["scales"])
+    assert np.array_equal(parts["exps"].cpu().numpy().astype(np.uint32), ops["exps"])
     for n in ("q8", "k8", "v8t"):
         assert np.array_equal(parts[n].cpu().numpy(), ops[n]), n
     o = out.float().cpu().numpy()

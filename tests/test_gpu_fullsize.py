@@ -135,7 +135,8 @@ def _check_config_fp8(name, spec, lay, H, top_k, p, nbr, sample_rows, seed=77):
     for bh in (0, H - 1):
         qh, kh, vh = (x[0, bh].float().cpu().numpy() for x in (q, k, v))
         q8, k8, v8, ops = orc.fp8_dequantized_qkv(qh[None, None], kh[None, None], vh[None, None], lay)
-        assert np.array_equal(parts["scales"][:4, bh].cpu().numpy(), ops["scales"][:, 0]), f"{name}: scales"
+        assert np.array_equal(parts["exps"][bh].cpu().numpy().astype(np.uint32), ops["exps"][0]), f"{name}: block exponents"
+        assert np.array_equal(parts["kmean"][bh].cpu().numpy(), ops["kmean"][0]), f"{name}: K mean"
         assert np.array_equal(parts["q8"][bh].cpu().numpy(), ops["q8"][0]), f"{name}: q8"
         assert np.array_equal(parts["k8"][bh].cpu().numpy(), ops["k8"][0]), f"{name}: k8"
         assert np.array_equal(parts["v8t"][bh].cpu().numpy(), ops["v8t"][0]), f"{name}: v8t"

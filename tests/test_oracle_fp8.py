@@ -42,7 +42,26 @@ def test_operand_images_layout():
     # slot order: byte p of a V^T row is key fp8_kslot_key(p); the map is a permutation of 0..63
     assert sorted(orc.fp8_kslot_key(np.arange(64))) == list(range(64))
     assert list(orc.fp8_kslot_key(np.arange(8))) == [0, 1, 2, 3, 8, 9, 10, 11]
-    # dequantised values are within half an e4m3 step (2^-4 relative) of the inputs
-    for a, b, s in ((q, q8, ops["scales"][0]), (k, k8, ops["scales"][1]), (v, v8, ops["scales"][2])):
+    # dequantised values are within half an e4m3 step (2^-4 relative to the block maximum) of the inputs (K: of K - mu)
+    km = k - ops["kmean"].reshape(1, 2, 1, 128)
+    for a, b in ((q, q8), (km, k8), (v, v8)):
         err = np.abs(a - b).reshape(2, -1).max(1)
-        assert (err <= 2.0 ** -4 * np.abs(a).reshape(2, -1).max(1) + s).all()
+        assert (err <= 2.0 ** -4 * np.abs(a).reshape(2, -1).max(1) * 1.01).all()
+    # block exponents: the smallest power of two that brings the block maximum under 448
+    for a, want in ((448.0, 0), (449.0, 1), (1.0, -8), (0.0, 0), (224.0, -1), (3e-39, -120), (1e38, 118)):
+        assert orc.fp8_block_exponent(np.float32(a)) - 127 == want, a
+    ex = (ops["exps"][0] >> 16) & 0xFF   # V blocks of head 0: 200 rows = one full block + 72 rows
+    for j in range(2):
+        amax = np.abs(v[0, 0, j * 128: (j + 1) * 128]).max()
+        assert amax * 2.0 ** -(int(ex[j]) - 127) <= 448 < amax * 2.0 ** -(int(ex[j]) - 128)
+
+
+def test_sampled_k_mean_is_a_mean_of_full_blocks():
+    rng = np.random.default_rng(3)
+    k = rng.standard_normal((20 * 128 + 50, 128)).astype(np.float32) + 2.0
+    mu = orc.fp8_kmean(k, k.shape[0])
+    blocks = [(i * 20) // 8 for i in range(8)]
+    want = np.mean([k[j * 128: (j + 1) * 128].mean(0) for j in blocks], axis=0)
+    assert np.abs(mu - want).max() < 1e-5
+    assert np.array_equal(orc.fp8_kmean(k[:100], 100), orc.pool(k[:100], 100, 1, False)[0][0])   # one partial block
+    assert not orc.fp8_kmean(k, 0).any()

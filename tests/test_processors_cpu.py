@@ -187,7 +187,7 @@ def test_cabi_fp8_entry_points_validate_on_the_host():
     assert lib.rsa_carve_fp8_operands(ctypes.byref(lay), ctypes.c_void_p(4096), 16, ctypes.byref(ops)) == -3  # too small
     t = _lib.RsaTensor4(0, 0, 0, 0)
     assert lib.rsa_quantize_fp8(ctypes.byref(lay), t, t, t, None, None) == -1                          # null operands
-    assert lib.rsa_fp8_images(ctypes.byref(lay), t, t, t, ctypes.byref(ops), None) == -1               # null images
+    assert lib.rsa_quantize_fp8(ctypes.byref(lay), t, t, t, ctypes.byref(ops), None) == -1             # null images
     d = ctypes.c_size_t()
     assert lib.rsa_dense_fp8_bytes(1, 2, 300, 500, 128, ctypes.byref(d)) == 0
     assert d.value >= 2 * (384 + 2 * 512) * 128

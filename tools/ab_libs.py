@@ -55,8 +55,6 @@ def main():
     q, k, v = gen_inputs(wl, H, 0, dev, cent)
     call = _core.StagedCall(q, k, v, spec, wl["top_k"], p, make_neighbors(wl, spec, nbr_kind), qkv_fp8=fp8)
     call.select()
-    if fp8:
-        call.quantize()
     torch.cuda.synchronize()
     pairs = call.bufs["counts"].sum().item()
     flops = 4.0 * 128 * 128 * 128 * pairs + 4.0 * 128 * spec.q_text_valid * spec.kv_text_valid * H

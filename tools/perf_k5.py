@@ -99,15 +99,11 @@ def main():
         if os.environ.get("RSA_PERF_NODENSE", "0") == "1":
             for _ in range(3):
                 call.select()
-                if fp8:
-                    call.quantize()
                 call.attend()
             torch.cuda.synchronize()
             return
         for _ in range(2):
             call.select()
-            if fp8:
-                call.quantize()
             call.attend()
         if fp8:
             torch.cuda.synchronize()
@@ -127,7 +123,7 @@ def main():
         spec = _core.LayoutSpec.hunyuan(S, wl["S_vis"] + wl["text_valid"])
         q, k, v = gen_qkv(H, 0, S, wl["S_vis"], D, dev)
         call = _core.StagedCall(q, k, v, spec, wl["top_k"], 0.0, None, qkv_fp8=True)
-        call.select(); call.quantize()
+        call.select()
         pairs = call.bufs["counts"].sum().item()
         flops = 4.0 * D * 128 * 128 * pairs + 4.0 * D * spec.q_text_valid * spec.kv_text_valid * H
         ref = None

@@ -9,5 +9,5 @@ spec = _core.LayoutSpec.hunyuan(S, wl["S_vis"] + wl["text_valid"])
 q, k, v = gen_qkv(24, 0, S, wl["S_vis"], 128, torch.device("cuda:0"))
 call = _core.StagedCall(q, k, v, spec, wl["top_k"], 0.0, None, qkv_fp8=True)
 for _ in range(5):
-    call.select(); call.quantize(); call.quantize(standalone=True)
+    call.select(); call.quantize()   # K1 writing the images, then the stand-alone producer
 torch.cuda.synchronize()

@@ -5,8 +5,8 @@ import csv
 import sys
 
 OURS = ("bsfwd_kernel", "select_mask_kernel", "compensation_kernel", "pool_stats_kernel", "pooled_scores_kernel",
-        "gapr_compare_kernel", "bsfwd_fp8_kernel", "amax_kernel", "scales_kernel", "quant_rows_kernel", "quant_vt_kernel",
-        "permute_tokens_kernel", "qk_norm_rope_kernel", "kmean_kernel", "colmean_kernel", "rel_l1_")
+        "gapr_compare_kernel", "bsfwd_fp8_kernel", "fp8_blocks_kernel", "kmean_sample_kernel", "text_combine",
+        "permute_tokens_kernel", "qk_norm_rope_kernel", "norm_rope_heads", "rel_l1_", "p2p_")
 rows = list(csv.DictReader(open(sys.argv[1])))
 title = sys.argv[2] if len(sys.argv) > 2 else sys.argv[1]
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
