@@ -629,6 +629,8 @@ def main():
     if args.gather_output and gather is not None and "value" in gather:  # headline = the gather-inclusive variant
         res["value"], res["ms_per_step"] = gather["value"], gather["ms_per_step"]
     res.update(extras)
+    if traffic is not None:   # the second wall: memory-side (Infinity Fabric / Infinity Cache) bytes per second under K5
+        res["roofline"]["traffic_tbps"] = round(traffic / max(rec["k5_ms"], 1e-6) / 1e9, 3)
     if "sustained" in extras:
         res["roofline"]["clock"] = extras["sustained"].get("smi")
     if "box_ref" in extras:

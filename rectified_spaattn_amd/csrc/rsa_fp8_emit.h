@@ -90,7 +90,9 @@ __device__ __forceinline__ void fp8_emit_block(const float (&x)[8][8], const Fp8
     float nmu[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) nmu[e] = -(mu[e] * inv);
-    uint2 o[8];
+    // each row's 8 bytes go out as soon as they exist: Q, K row-major to global (16 threads = one 128-byte row), V into the
+    // LDS tile the transpose below reads
+    uint8_t* grow = (which == 0 ? f.q8 : f.k8) + ((long)bh * f.S_pad + (long)blk * RSA_BLOCK) * D + 8 * c;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         float y[8];
@@ -106,18 +108,13 @@ __device__ __forceinline__ void fp8_emit_block(const float (&x)[8][8], const Fp8
         lo = __builtin_amdgcn_cvt_pk_fp8_f32(y[2], y[3], lo, true);
         hi = __builtin_amdgcn_cvt_pk_fp8_f32(y[4], y[5], hi, false);
         hi = __builtin_amdgcn_cvt_pk_fp8_f32(y[6], y[7], hi, true);
-        o[i] = make_uint2((unsigned)lo, (unsigned)hi);
-        if (ragged && blk * RSA_BLOCK + 16 * i + g >= valid) o[i] = make_uint2(0u, 0u);
+        uint2 o = make_uint2((unsigned)lo, (unsigned)hi);
+        if (ragged && blk * RSA_BLOCK + 16 * i + g >= valid) o = make_uint2(0u, 0u);
+        if (which == 2) *reinterpret_cast<uint2*>(lds + (16 * i + g) * RSA_F8_LROW + 8 * c) = o;
+        else *reinterpret_cast<uint2*>(grow + (long)(16 * i + g) * D) = o;
     }
-    if (which < 2) {   // Q, K: row-major bytes, 8 per thread and row (16 threads = one 128-byte row)
-        uint8_t* dst = (which == 0 ? f.q8 : f.k8) + ((long)bh * f.S_pad + (long)blk * RSA_BLOCK) * D + 8 * c;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) *reinterpret_cast<uint2*>(dst + (long)(16 * i + g) * D) = o[i];
-        return;
-    }
-    // V: through LDS into the two transposed 64-key tiles
-#pragma unroll
-    for (int i = 0; i < 8; ++i) *reinterpret_cast<uint2*>(lds + (16 * i + g) * RSA_F8_LROW + 8 * c) = o[i];
+    if (which < 2) return;
+    // V: out of the LDS tile into the two transposed 64-key tiles
     __syncthreads();
     uint8_t* dst = f.v8t + ((long)bh * (f.S_pad / 64) + 2 * blk) * (long)(D * 64);
     // one item per thread: (tile, half jh of the 32 slot bytes of lane half hh, 4 head-dim columns dg): 16 four-byte LDS

@@ -30,8 +30,10 @@ __global__ __launch_bounds__(D * 2) void pool_stats_kernel(PoolArgs a) {
     constexpr int CH = D / 8;        // 16-byte chunks per row
     constexpr int NTH = 16 * CH;     // threads
     constexpr int NW = NTH / 64;     // waves
-    const int which = blockIdx.z;
-    const int blk = blockIdx.x;
+    // F8: the three tensors' blocks interleaved in launch order (V blocks also transpose through LDS: mixed with the
+    // streaming Q / K blocks on a CU they overlap instead of running as one heavy tail)
+    const int which = F8 ? (int)(blockIdx.x % 3) : (int)blockIdx.z;
+    const int blk = F8 ? (int)(blockIdx.x / 3) : (int)blockIdx.x;
     if (blk >= a.nblk[which]) return;
     const int bh = blockIdx.y;
     const int b = bh / a.H, h = bh % a.H;
@@ -54,10 +56,13 @@ __global__ __launch_bounds__(D * 2) void pool_stats_kernel(PoolArgs a) {
             x[i][2 * e + 1] = rsa_to_f32<Tag>((unsigned short)(w[e] >> 16));
         }
     }
-    if constexpr (F8 && D == 128) {
-        __shared__ __attribute__((aligned(16))) unsigned char f8lds[RSA_F8_LDS];
-        fp8_emit_block<Tag>(x, a.f8, which, blk, bh, f8lds);
-    }
+    // F8: the e4m3 image of the block goes out LAST (after the statistics): its V transpose then runs with x dead
+    auto emit_f8 = [&]() {
+        if constexpr (F8 && D == 128) {
+            __shared__ __attribute__((aligned(16))) unsigned char f8lds[RSA_F8_LDS];
+            fp8_emit_block<Tag>(x, a.f8, which, blk, bh, f8lds);
+        }
+    };
     __shared__ float red[NW][D];
     float mean[8];
     // ---- sum -> mean
@@ -94,7 +99,7 @@ __global__ __launch_bounds__(D * 2) void pool_stats_kernel(PoolArgs a) {
         o[0] = make_float4(mean[0], mean[1], mean[2], mean[3]);
         o[1] = make_float4(mean[4], mean[5], mean[6], mean[7]);
     }
-    if (a.mad[which] == nullptr) return;
+    if (a.mad[which] == nullptr) { emit_f8(); return; }
     if (a.ext_mean[which] != nullptr) {
         const float4* em = reinterpret_cast<const float4*>(a.ext_mean[which] + orow);
         const float4 m0 = em[0], m1 = em[1];
@@ -136,6 +141,7 @@ __global__ __launch_bounds__(D * 2) void pool_stats_kernel(PoolArgs a) {
             o[1] = make_float4(r[4], r[5], r[6], r[7]);
         }
     }
+    emit_f8();
 }
 
 // =====================================================================================================
@@ -864,8 +870,9 @@ int rsa_pool_stats_f8(const rsa_layout* l, rsa_tensor4 q, rsa_tensor4 k, rsa_ten
     if (f8 != nullptr) {
         if (l->D != 128) return RSA_ERR_UNSUPPORTED;
         a.f8 = *f8;
-        if (l->dtype == RSA_BF16) pool_stats_kernel<128, bf16_tag, true><<<grid, 256, 0, s>>>(a);
-        else pool_stats_kernel<128, fp16_tag, true><<<grid, 256, 0, s>>>(a);
+        const dim3 grid8(3 * l->NB_total, l->B * l->H, 1);
+        if (l->dtype == RSA_BF16) pool_stats_kernel<128, bf16_tag, true><<<grid8, 256, 0, s>>>(a);
+        else pool_stats_kernel<128, fp16_tag, true><<<grid8, 256, 0, s>>>(a);
         return rsa_launch_status();
     }
     if (l->D == 128) {

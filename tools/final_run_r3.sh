@@ -30,7 +30,8 @@ cp gpurun_out/r3z_pmc_all/summary.txt gpurun_out/r3z_pmc_summary.txt; rm -rf gpu
 RSA_PERF_FP8=1 bash tools/pmc_passes.sh r3z_pmc_fp8 > gpurun_out/r3z_pmc_fp8.txt 2>&1
 cp gpurun_out/r3z_pmc_fp8/summary.txt gpurun_out/r3z_pmc_summary_fp8.txt; rm -rf gpurun_out/r3z_pmc_fp8
 bash tools/pmc_select.sh r3z_pmcsel > /dev/null 2>&1; cp gpurun_out/r3z_pmcsel/summary.txt gpurun_out/r3z_pmc_select.txt; rm -rf gpurun_out/r3z_pmcsel
-RSA_BENCH_ONE_DEVICE=1 python bench.py --gpus 2 --steps 5 --warmup 2 --no-extras --no-cpu-baseline --gather-transports p2p > gpurun_out/r3z_bench_2ranks_one_device.json 2>> gpurun_out/r3z_bench.err
+RSA_BENCH_ONE_DEVICE=1 python bench.py --gpus 2 --steps 5 --warmup 2 --no-extras --no-cpu-baseline --gather-transports p2p | grep "^{" > gpurun_out/r3z_bench_2ranks_one_device.json 2>> gpurun_out/r3z_bench.err
+for HH in 12 6 3; do RSA_PERF_H=$HH RSA_PERF_REGIMES=r2 python tools/perf_k5.py regimes; done > gpurun_out/r3z_rank_shapes.txt 2>&1
 for d in r3z_prof r3z_prof_fp8; do find gpurun_out/$d -name "*kernel_trace.csv" -delete; done
 du -sh gpurun_out
 tail -3 gpurun_out/r3z_tests.txt; cat gpurun_out/r3z_smoke.txt | tail -2; tail -c 600 gpurun_out/r3z_bench.json
