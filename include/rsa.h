@@ -292,7 +292,7 @@ int rsa_ipc_offset(const void* dev_ptr, int64_t* offset);                   /* d
 
 /* Tuning / diagnostics hook, not part of the data path.  Keys: "k5_tsplit" (0/1: split-KV of the text query blocks),
  * "k3_prefix" (0/1: sorted-head path of K3), "fp8_variant" (0: the product = hand-placed block, P through the e4m3 code map; 1: the same arithmetic as hipcc schedules it;
- * 2 / 3: P by v_exp_f32 + round-to-nearest e4m3, hand-placed / compiled -- for A/B and the accuracy comparison), "fp8_smooth_k"
+ * 2: P by v_exp_f32 + round-to-nearest e4m3 -- the two forms the tests compare the product with), "fp8_smooth_k"
  * (0: the fp8 producers take mu = 0 instead of the sampled K mean, for the same comparison).  The hook
  * is inert (RSA_ERR_UNSUPPORTED) unless the process was started with the environment variable RSA_TUNING=1. */
 int rsa_set_tuning(const char* key, int value);

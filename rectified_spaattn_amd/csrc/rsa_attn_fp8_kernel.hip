@@ -1,31 +1,33 @@
-// K5, fp8 operands: block-sparse flash attention forward on v_mfma_f32_32x32x64_f8f6f4 (e4m3 x e4m3 -> f32, twice the
+// K5, fp8 operands: block-sparse flash attention forward on v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3 x e4m3 -> f32, twice the
 // bf16 MFMA rate) with the rectification epilogue fused.  Same work mapping, per-row plan, kept lists and epilogue as
-// the 2-byte kernel (rsa_attn_kernel.hip); the operands are the images written by rsa_fp8.hip.
+// the 2-byte kernel (rsa_attn_kernel.hip); the operands are the block-scaled images of rsa_fp8_emit.h.
 //
 // One workgroup (4 waves, two workgroups per CU) owns one 128-row query block, wave w rows 32w..32w+31, "key on the
 // register, query row on the lane":
 //      S^T[key][q]  = K8 . Q8^T     A = K8 rows (2 x ds_read_b128 of a 128-byte row), B = Q8 (16 registers, loaded once)
 //      O^T[d][q]   += V8^T . P8^T   A = rows of the pre-transposed V tile (2 x ds_read_b128), B = P = the two 32-key score
-//                                   accumulators of a 64-key tile converted in place with v_cvt_pk_fp8_f32
-// The 64 k-slots of the PV product are (lane half h, byte j); rsa_fp8.hip stores V^T with the keys of a tile in exactly
+//                                   accumulators of a 64-key tile converted in place
+// The 64 k-slots of the PV product are (lane half h, byte j); the producer stores V^T with the keys of a tile in exactly
 // that order, so neither operand needs a transposing read or any cross-lane traffic.
-// Scores: the quantiser makes c = scale_q * scale_k * sm_scale * log2(e) an exact power of two (rsa_fp8.hip), which the
-// MFMA applies for free through its E8M0 block-scale operands, and the QK^T chain starts from a 16-register block that
-// holds 4 - m (m = the row's deferred running max), so the accumulator IS log2(P) and the softmax costs one v_exp_f32,
-// one add and half a v_cvt_pk_fp8_f32 per score -- the kernel is VALU-bound, not MFMA-bound.  The running max moves
-// only when a row max grew by more than 2^4, so P <= 2^8 < 448 (e4m3 max) and keeps 2^-9 * 2^-4 relative resolution
-// below the row's reference; that rare move also shifts the scores already computed for the next tile.  The row sum l
-// comes from the matrix pipe too: one v_mfma_f32_16x16x128_f8f6f4 per tile multiplies the SAME packed P operand by a
-// ones/zeros pattern (read from a 64-byte LDS table) chosen so that every lane's accumulator receives the full 64-key sum
-// of its own query row (tools/probes/fp8_rowsum_probe.hip).  So l sums the e4m3-ROUNDED P that the PV product uses --
-// numerator and denominator round together (the reference kernel sums its P before the 2-byte rounding,
-// rectified_hunyuan_attn.py:93-97; with 3 mantissa bits that mismatch would be a 2^-4 relative error on rows carried
-// by a few keys) -- and 32 v_add_f32 per tile leave the VALU.  The V scale, 1/l and R meet in the epilogue.
+// Scales: every 128-row block of Q, K, V carries a power-of-two scale (one E8M0 byte), which the MFMAs apply for free through
+// their block-scale operands: Q block and K tile on the QK^T products (Q already holds q * sm_scale * log2(e)), V tile on
+// the PV products; the kept-list entry a wave reads from LDS per tile carries the key block's two exponents beside its index.
+// Scores: the QK^T chain starts from a 16-register block holding the row's (deferred) reference, so the accumulator is
+// relative to it on arrival, in the unit the P form wants (PMap below): the product turns it into the e4m3 CODE of P with one
+// v_cvt_pk_u8_f32 per score; the verification form (tuning key fp8_variant = 2) takes v_exp_f32 + v_cvt_pk_fp8_f32.  The
+// reference moves only when a tile maximum exceeds it by the form's threshold; that rare move also shifts the scores already
+// computed for the next tile.  The row sum l comes from the matrix pipe too: one v_mfma_f32_16x16x128_f8f6f4 per tile
+// multiplies the SAME packed P operand by a ones/zeros pattern (read from a 64-byte LDS table) chosen so that every lane's
+// accumulator receives the full 64-key sum of its own query row (tools/probes/fp8_rowsum_probe.hip).  So l sums the P that
+// the PV product uses -- numerator and denominator round together (the reference kernel sums its P before the 2-byte
+// rounding, rectified_hunyuan_attn.py:93-97; with 3 mantissa bits that mismatch would be a 2^-4 relative error on rows
+// carried by a few keys).  1/l and R meet in the epilogue.
 //
-// Pipeline (per wave, 64-key tiles, S double-buffered): step t computes S(t+1) while P(t) and O += V(t) P(t) run.
+// Pipeline (per wave, 64-key tiles, S double-buffered): step t computes S(t+1) while P(t) and O += V(t) P(t) run; the body
+// of a step is one hand-placed instruction block (gen_k5_block.py::gen_block8), four copies per loop trip so that the
+// LDS ring slot is a compile-time constant of each.
 // Staging: K and V tiles are 8 KiB each; 4-slot rings; at the head of step t the wave issues its 2+2 LDS-DMA pieces of
-// K(t+3) and V(t+2) behind `s_waitcnt vmcnt(4)` + barrier, so every tile has two full steps to land.  (Issuing them
-// before the barrier wait -- legal with four slots -- measured the same: 9.71 vs 9.66 ms.)
+// K(t+3) and V(t+2) behind `s_waitcnt vmcnt(4)` + barrier, so every tile has two full steps to land.
 #include "rsa_attn.h"
 #include "rsa_attn_block.h"
 
@@ -377,10 +379,6 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
             return;
         }
         if constexpr (PIPE_OPT & 2) __builtin_amdgcn_s_setprio(2);
-        if constexpr ((PIPE_OPT >> 8) == 1) __builtin_amdgcn_iglp_opt(0);
-        if constexpr ((PIPE_OPT >> 8) == 2) __builtin_amdgcn_iglp_opt(1);
-        if constexpr ((PIPE_OPT >> 8) == 3) __builtin_amdgcn_iglp_opt(2);
-        if constexpr ((PIPE_OPT >> 8) == 4) __builtin_amdgcn_iglp_opt(3);
         qk_tile((ts + 1) & (NSLOT - 1), S_nxt, sc_a);
         i32x8 pb;
 #pragma unroll
@@ -547,10 +545,9 @@ int launch_attn8(Attn8Args& a, int BH, hipStream_t s) {
     if (nblocks > 0x7FFFFFFF) return RSA_ERR_UNSUPPORTED;
     if (a.NB_total > 8192) return RSA_ERR_UNSUPPORTED;
     const size_t lds_bytes = (size_t)2 * NSLOT * TILE8 + 64 + (((size_t)a.NB_total * 4 + 15) & ~(size_t)15);
-    switch (g_fp8_variant) {   // tuning key fp8_variant: 0 = product; the others for A/B and the accuracy comparison
+    switch (g_fp8_variant) {   // tuning key fp8_variant: 0 = product; 1, 2 = the two verification forms the tests compare it with
         case 1: bsfwd_fp8_kernel<6><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a); break;   // product arithmetic, hipcc's schedule
         case 2: bsfwd_fp8_kernel<3><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a); break;   // exact-exponential P, hand-placed
-        case 3: bsfwd_fp8_kernel<2><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a); break;   // exact-exponential P, hipcc's schedule
         default: bsfwd_fp8_kernel<7><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a);
     }
     const int st = rsa_launch_status();

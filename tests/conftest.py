@@ -37,7 +37,7 @@ B2_CASES = ["b2_hunyuan_1280", "b2_flux_1280", "b2_cogvideo_994"]
 
 
 # a row longer than 256 columns through the reference (exercises K3's sorted-head path); output stored as fp16
-BIG_CASES = ["big_wan_33280", "big_hunyuan_17664", "big_flux_17408"]
+BIG_CASES = ["big_wan_33280", "big_hunyuan_17664", "big_flux_17408", "big_cogvideo_17634"]
 
 
 def reference_rows(meta, lay):

@@ -217,6 +217,8 @@ def main():
         # path) through the reference: 136 visual blocks + 256 text (200 valid) / 132 visual blocks + 512 text tokens
         ("big_hunyuan_17664", "hunyuan", 1, 1, 17664, 128, 14, 0.3, 1, dict(num_true=17408 + 200)),
         ("big_flux_17408", "flux", 1, 1, 17408, 128, 13, 0.3, 1, dict(text_length=512)),
+        # ... and CogVideoX's layout (head dim 64, 226 text tokens, padded to x128): 136 visual blocks
+        ("big_cogvideo_17634", "cogvideo", 1, 1, 17634, 64, 14, 0.3, 1, dict(text_length=226)),
     ]
     only = os.environ.get("RSA_GOLDEN_ONLY")
     if only:
