@@ -52,15 +52,21 @@ REGIMES = {
     "r1": ("iid", "gilbert", 0.05),        # algorithmic: cumulative-probability rule + true Gilbert neighbours
     "locality": ("spatial", "gilbert", 0.05),  # as r1 on spatially smooth centroids (overlapping kept lists)
 }
-K5_SOURCES = ("rsa_attn_kernel.hip", "rsa_attn.hip", "rsa_attn.h", "rsa_attn_fp8_kernel.hip")
+K5_SOURCES = {False: ("rsa_attn_kernel.hip", "rsa_attn.h", "gen_k5_block.py"),
+              True: ("rsa_attn_fp8_kernel.hip", "rsa_attn.h", "gen_k5_block.py")}
 
 
-def kernel_source_sha() -> str:
-    """sha256 over the K5 sources: profiles/*traffic*.json carry the value they were collected with."""
+def kernel_source_sha(fp8: bool = False) -> str:
+    """sha256 over the CODE of one K5 kernel's sources (the 2-byte kernel or the e4m3 one; `//` and `#` comments, blank
+    lines and indentation do not count): profiles/*traffic*.json carry the value they were collected with."""
     h = hashlib.sha256()
-    for n in K5_SOURCES:
-        with open(os.path.join(ROOT, "rectified_spaattn_amd", "csrc", n), "rb") as f:
-            h.update(f.read())
+    for n in K5_SOURCES[bool(fp8)]:
+        mark = "#" if n.endswith(".py") else "//"
+        with open(os.path.join(ROOT, "rectified_spaattn_amd", "csrc", n), "r") as f:
+            for line in f:
+                code = line.split(mark, 1)[0].strip()
+                if code:
+                    h.update(code.encode() + b"\n")
     return h.hexdigest()[:16]
 
 
@@ -420,9 +426,10 @@ def load_traffic(name):
         d = json.load(open(path))
     except (OSError, ValueError):
         return None, f"profiles/{name} unreadable"
-    if d.get("kernel_source_sha") != kernel_source_sha():
+    sha = kernel_source_sha("fp8" in str(d.get("kernel", "")))
+    if d.get("kernel_source_sha") != sha:
         return None, (f"profiles/{name} was collected from other kernel sources (sha {d.get('kernel_source_sha')} != "
-                      f"{kernel_source_sha()}); re-run tools/pmc_passes.sh")
+                      f"{sha}); re-run tools/pmc_traffic.sh")
     return d.get("traffic_bytes_per_launch"), (f"L2 memory-side bytes/launch from rocprofv3 PMC passes "
                                                f"(profiles/{name}, FETCH_SIZE x2 + WRITE_SIZE); includes Infinity-Cache "
                                                f"hits; l2_hit_rate {d.get('l2_hit_rate')}")
@@ -587,7 +594,7 @@ def main():
                             ms_per_step=round(r2["ms_per_step"], 4), value=round(r2["value"], 3),
                             k5_ms=round(r2["k5_ms"], 4), k5_tflops=round(r2["k5_tflops"], 2),
                             k5_frac=round(r2["k5_tflops"] / peak_, 4), select_pass_ms=round(r2["select_pass_ms"], 4))
-            tb, _ = load_traffic(f"r03_k5_traffic_{rg}.json")
+            tb, _ = load_traffic(f"r03_k5_traffic_{rg}{'_fp8' if args.qkv_fp8 else ''}.json")
             regs[rg]["traffic"] = tb
         extras["regimes"] = regs
 

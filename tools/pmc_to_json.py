@@ -18,7 +18,7 @@ for pat in sys.argv[3:]:
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import kernel_source_sha  # noqa: E402
-res = {"kernel": kern, "kernel_source_sha": kernel_source_sha(), "regime": os.environ.get("RSA_PERF_REGIME", "r2")}
+res = {"kernel": kern, "kernel_source_sha": kernel_source_sha("fp8" in kern), "regime": os.environ.get("RSA_PERF_REGIME", "r2")}
 for k, v in acc.items():
     res[k] = {"mean": sum(v) / len(v), "n": len(v)}
 if "FETCH_SIZE" in acc and "WRITE_SIZE" in acc:
