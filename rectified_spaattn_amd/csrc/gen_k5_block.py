@@ -146,7 +146,9 @@ def gen_block(D, dt, VS, SUB, negm):
             lines.append(t)
             used += COST[k]
 
-    lines.append("s_setprio 2")
+    # (head dim 64: 8 MFMAs per sub-step against the same softmax, the wave is bound by vector issue, and raising its
+    # priority over its partner on the SIMD costs 3-5 %: tools/perf_d64.py, profiles/r03_k5_block.md)
+    if D == 128: lines.append("s_setprio 2")
     for ks in range(min(AHEAD, KS)): k_read(ks)
     emit_work(pre, False)
     for i in range(nm):
@@ -177,7 +179,7 @@ def gen_block(D, dt, VS, SUB, negm):
             tail = sum(int(l.split()[1]) + 1 if l.startswith("s_nop") else 1 for l in lines[n0:])
             if tail < 12: lines.append(f"s_nop {11 - tail}")
     assert wi == len(work) and mi == len(maxw)
-    lines.append("s_setprio 0")
+    if D == 128: lines.append("s_setprio 0")
     return lines, m
 
 

@@ -75,8 +75,8 @@ __device__ __forceinline__ void k5_block_nm(f32x16 (&o)[D / 32], const s16x8 (&q
         else RSA_K5_PICK(RSA_K5_BLOCKN, 64, F16, RSA_K5_OPSN_64, RSA_K5_CLOBBERN_64);
     }
 }
-#ifdef RSA_K5_FORMS
-// A/B build: the compiled block's arithmetic, hand-placed (S, then S - m by v_sub): bit-identical to the block as hipcc emits it
+// the classic form (S, then S - m by v_sub: the compiled block's arithmetic, bit-identical to the block as hipcc emits it):
+// the product at head dim 64, where it measures 4 % faster than the -m form (at 128 the -m form wins by 3.7 %)
 template <int D, typename Tag, int VS, int SUB, typename KA, typename VA>
 __device__ __forceinline__ void k5_block(f32x16 (&o)[D / 32], const s16x8 (&q)[D / 16], f32x16& S_cur, f32x16& S_nxt, float m,
                                          float& l, float& mx, const KA& ka, const VA& va) {
@@ -91,12 +91,13 @@ __device__ __forceinline__ void k5_block(f32x16 (&o)[D / 32], const s16x8 (&q)[D
         else RSA_K5_PICK(RSA_K5_BLOCK, 64, F16, RSA_K5_OPS_64, RSA_K5_CLOBBER_64);
     }
 }
-#endif
 
 // WIDE: 16-byte output stores after a permlane32_swap regroup (needs 16-byte aligned output rows), else 8-byte stores.
-// FORM: 2 = the product (hand-placed block, score chain started from -m).  The A/B and diagnostics builds (make ab / make
-// diag, -DRSA_K5_FORMS) also carry 1 = the hand-placed block with the compiled block's arithmetic and 0 = the block as hipcc
-// schedules it (round 2's kernel); 0 and 1 are bit-identical to each other, 2 differs from them by the rounding order of S - m.
+// FORM: 2 = hand-placed block, score chain started from -m (the product at head dim 128); 1 = hand-placed block with the
+// compiled block's arithmetic (the product at head dim 64); the A/B and diagnostics builds (make ab / make diag,
+// -DRSA_K5_FORMS) carry both at either head dim plus 0 = the block as hipcc schedules it (round 2's kernel).  0 and 1 are
+// bit-identical to each other, 2 differs from them by the rounding order of S - m.
+constexpr int k5_product_form(int D) { return D == 128 ? 2 : 1; }
 template <int D, typename Tag, bool WIDE, int FORM>
 __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
     constexpr int NW = 4;                   // 4 waves x 32 query rows
@@ -389,8 +390,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
             k5_block_nm<D, Tag, vs, sub>(o, qf, S_cur, S_nxt, nm, l_run, mx_nxt, ka, va);
             RSA_STAMP(3);
         }
-#ifdef RSA_K5_FORMS
-        else {   // A/B build: round 2's arithmetic (scores S, reference m_run subtracted in the softmax)
+        else {   // the classic arithmetic (scores S, reference m_run subtracted in the softmax)
             if (__builtin_amdgcn_ballot_w64(mx_cur > m_run + 8.0f) != 0ull) {
                 asm volatile("s_nop 11" ::: "memory");
                 const float m_new = fmaxf(m_run, mx_cur);
@@ -407,7 +407,9 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
             RSA_STAMP(2);
             if constexpr (FORM == 1) {
                 k5_block<D, Tag, vs, sub>(o, qf, S_cur, S_nxt, m_use, l_run, mx_nxt, ka, va);
-            } else {   // the block left to hipcc; iglp_opt(0) = LLVM's small-GEMM MFMA/DS interleave
+            }
+#ifdef RSA_K5_FORMS
+            else {   // A/B build: the block left to hipcc; iglp_opt(0) = LLVM's small-GEMM MFMA/DS interleave
                 __builtin_amdgcn_s_setprio(2);
                 __builtin_amdgcn_iglp_opt(0);
                 if constexpr (sub == 0) qk_sub(std::integral_constant<int, vs>{}, std::integral_constant<int, 1>{}, S_nxt);
@@ -443,9 +445,9 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
                 rowmax_sub(S_nxt, mx_nxt);
                 __builtin_amdgcn_s_setprio(0);
             }
+#endif
             RSA_STAMP(3);
         }
-#endif
     };
 
     // staging: a wait + barrier + issue point in front of every sub-step.  SUB 0 issues V(tile+1) into V(tile-1)'s slot,
@@ -622,7 +624,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
 
 // launch hook used by rsa_attn.hip::launch_attn
 #ifdef RSA_K5_FORMS
-int g_rsa_k5_form = 2;   // A/B and diagnostics builds: tuning key "k5_form" (see the FORM template parameter)
+int g_rsa_k5_form = -1;   // A/B and diagnostics builds: tuning key "k5_form" (see the FORM template parameter); -1 = the product's choice
 #endif
 int rsa_launch_bsfwd(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int dtype, hipStream_t s) {
     // the 16-byte output stores need 16-byte aligned rows; anything else takes the 8-byte form
@@ -630,16 +632,17 @@ int rsa_launch_bsfwd(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int 
 #ifdef RSA_K5_FORMS
 #define RSA_K5(DD, TT) \
     do { \
-        if (!wide) bsfwd_kernel<DD, TT, false, 2><<<grid, 256, lds_bytes, s>>>(a); \
+        if (!wide) bsfwd_kernel<DD, TT, false, k5_product_form(DD)><<<grid, 256, lds_bytes, s>>>(a); \
         else if (g_rsa_k5_form == 0) bsfwd_kernel<DD, TT, true, 0><<<grid, 256, lds_bytes, s>>>(a); \
         else if (g_rsa_k5_form == 1) bsfwd_kernel<DD, TT, true, 1><<<grid, 256, lds_bytes, s>>>(a); \
-        else bsfwd_kernel<DD, TT, true, 2><<<grid, 256, lds_bytes, s>>>(a); \
+        else if (g_rsa_k5_form == 2) bsfwd_kernel<DD, TT, true, 2><<<grid, 256, lds_bytes, s>>>(a); \
+        else bsfwd_kernel<DD, TT, true, k5_product_form(DD)><<<grid, 256, lds_bytes, s>>>(a); \
     } while (0)
 #else
 #define RSA_K5(DD, TT) \
     do { \
-        if (wide) bsfwd_kernel<DD, TT, true, 2><<<grid, 256, lds_bytes, s>>>(a); \
-        else bsfwd_kernel<DD, TT, false, 2><<<grid, 256, lds_bytes, s>>>(a); \
+        if (wide) bsfwd_kernel<DD, TT, true, k5_product_form(DD)><<<grid, 256, lds_bytes, s>>>(a); \
+        else bsfwd_kernel<DD, TT, false, k5_product_form(DD)><<<grid, 256, lds_bytes, s>>>(a); \
     } while (0)
 #endif
     if (D == 128) {

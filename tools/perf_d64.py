@@ -1,6 +1,13 @@
-"""K5 at head_dim 64 (CogVideoX shape: 48 heads, S = 42 496): dense mode and the rectified operator."""
+"""K5 at head_dim 64 (CogVideoX shape: 48 heads, S = 42 496): dense mode and the rectified operator.
+RSA_PERF_AB=1: the A/B library (make ab) with its three loop forms (k5_form 0 = block as hipcc schedules it, 1 = its
+hand-placed twin, 2 = the product's -m form), interleaved."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+AB = os.environ.get("RSA_PERF_AB", "0") == "1"
+if AB:
+    os.environ["RSA_TUNING"] = "1"
+    from rectified_spaattn_amd import _lib
+    _lib.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rectified_spaattn_amd", "librsa_hip_ab.so")
 from rectified_spaattn_amd import _core
 from tools.perf_k5 import timeit
 dev = torch.device("cuda:0")
@@ -19,3 +26,19 @@ fl = 4.0 * D * 128 * 128 * pairs + 4.0 * D * spec.q_text_valid * spec.kv_text_va
 print(f"sparse D=64 cogvideo layout: K5 {med:.3f} ms {fl/med/1e9:.0f} TFLOP/s (kept pairs {pairs})")
 msel, _ = timeit(call.select, n=3, warm=1)
 print(f"select pass {msel:.3f} ms")
+if AB:
+    L = _lib.lib()
+    for rnd in range(2):
+        for form in (0, 1, 2):
+            assert L.rsa_set_tuning(b"k5_form", form) == 0
+            ms, _ = timeit(call.attend, n=5, warm=1)
+            md, _ = timeit(lambda: _core.dense_attention(q, k, v), n=3, warm=1)
+            print(f"round {rnd} k5_form {form}: sparse {ms:.3f} ms {fl/ms/1e9:.0f} TFLOP/s | dense {md:.3f} ms {4.0*S*S*D*H/md/1e9:.0f} TFLOP/s", flush=True)
+    L.rsa_set_tuning(b"k5_form", -1)
+    # forms 0 and 1 share their arithmetic: bit-identical output at head dim 64 too
+    outs = {}
+    for form in (0, 1):
+        L.rsa_set_tuning(b"k5_form", form)
+        outs[form] = call.attend().clone()
+    L.rsa_set_tuning(b"k5_form", -1)
+    print("forms 0 and 1 bit-identical at head dim 64:", bool(torch.equal(outs[0], outs[1])))
