@@ -2,6 +2,7 @@
 lists, counts, R and compensation weights must be identical (the oracle pins sampled rows in test_gpu_fullsize.py; this
 test covers all 21 600 rows per head configuration, including inputs that force the fall-back: plateaus of equal
 probabilities and thresholds the head cannot reach)."""
+import numpy as np
 import pytest
 import torch
 
@@ -88,3 +89,36 @@ def test_text_rows_split_kv_matches_single_workgroup_form(fp8):
     d = (a[:, nv:].float() - b[:, nv:].float()).abs()
     assert float(d.max()) <= (8e-3 if fp8 else 4e-3), float(d.max())
     assert float(a[:, nv + spec.q_text_valid:].abs().max()) == 0.0 and float(a[:, nv:nv + spec.q_text_valid].abs().max()) > 0
+
+
+def test_longest_rows_the_operator_serves_and_the_refusal_beyond():
+    """K3 keeps a row's probabilities, text exponentials and keep bytes in LDS, 16 KB per wave: 2 816 visual blocks (360k
+    tokens) are served -- mask and lists of sampled rows against the oracle --, 3 000 are refused with the library's
+    'unsupported' status (AssertionError, as the reference's own shape asserts), not computed wrongly."""
+    from rectified_spaattn_amd import _core, synth
+    from oracle import oracle as orc
+    D, top_k, p = 64, 20, 0.02
+    nb = 2816
+    S = nb * 128
+    g = torch.Generator(device=DEV).manual_seed(5)
+    cent = torch.randn(nb, D, generator=g, device=DEV) * 1.5
+    def mk():
+        return (cent.repeat_interleave(128, 0) + 0.5 * torch.randn(S, D, generator=g, device=DEV)).to(torch.bfloat16).view(1, 1, S, D)
+    q, k = mk(), mk()
+    v = torch.randn(1, 1, S, D, generator=g, device=DEV).to(torch.bfloat16)
+    out, parts = _core.rectified_attention(q, k, v, _core.LayoutSpec.wan(S, 0), top_k, p, None, return_parts=True)
+    assert torch.isfinite(out.float()).all()
+    lay = orc.layout_wan(S, 0)
+    qf, kf, vf = (x[0, 0].float().cpu().numpy() for x in (q, k, v))
+    rows = [0, 1407, nb - 1]
+    sel = orc.select_head(qf, kf, vf, lay, top_k, p, None, rows=rows)
+    kept = _core.unpack_bitmask(parts["bitmask"], lay.NB_total).cpu().numpy()
+    for a, i in enumerate(rows):
+        assert np.array_equal(kept[0, i], sel["kept"][a].astype(bool)), i
+        n = int(parts["counts"][0, i])
+        assert np.array_equal(parts["cols"][0, i, :n].cpu().numpy(), np.nonzero(sel["kept"][a])[0])
+    del q, k, v, out, parts
+    S2 = 3000 * 128
+    z = torch.zeros(1, 1, S2, D, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(AssertionError):
+        _core.rectified_attention(z, z, z, _core.LayoutSpec.wan(S2, 0), top_k, p, None)
