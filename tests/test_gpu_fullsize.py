@@ -18,9 +18,8 @@ def _gen(H, S, D, seed):
     return gen_qkv(H, 0, S, S, D, torch.device(DEV), seed=seed)
 
 
-def _check_config(name, spec, lay, H, top_k, p, nbr, sample_rows, seed=77):
+def _check_config(name, spec, lay, H, top_k, p, nbr, sample_rows, seed=77, D=128):
     from rectified_spaattn_amd import _core
-    D = 128
     q, k, v = _gen(H, lay.S, D, seed)
     tn = torch.from_numpy(nbr) if nbr is not None else None
     out, bufs = _core.rectified_attention(q, k, v, spec, top_k, p, tn, return_parts=True)
@@ -115,6 +114,15 @@ def test_wan22_ti2v_full_size():
     from rectified_spaattn_amd import _core
     S = 27280
     _check_config("wan22", _core.LayoutSpec.wan(S, 6), orc.layout_wan(S, 6), 4, 53, 0.3, None, [0, 100, 213])
+
+
+def test_cogvideox_768p_full_size():
+    """CogVideoX1.5 81f 768x1280 (scripts/main_cogvideox.py:226-235; not in BASELINE's configs): head dim 64, S = 42 240 +
+    226 text tokens (padded to 332 blocks), top_k = 82; 3 of 48 heads.  Head dim 64 runs the classic form of K5's block."""
+    from rectified_spaattn_amd import _core
+    S = 42466
+    _check_config("cogvideox", _core.LayoutSpec.cogvideo(S, 226), orc.layout_cogvideo(S, 226), 3, 82, 0.3, None,
+                  [0, 165, 329], D=64)
 
 
 def _check_config_fp8(name, spec, lay, H, top_k, p, nbr, sample_rows, seed=77):
