@@ -43,6 +43,9 @@ WORKLOADS = {
                            latent=(21, 45, 80)),
     "wan22_ti2v_720p_121f": dict(H=24, S_vis=27280, text=0, text_valid=0, top_k=53, variant="wan", ffb=6,
                                  latent=(31, 22, 40)),
+    # CogVideoX1.5 81f 768x1280 (scripts/main_cogvideox.py:226-235; not one of BASELINE's configs): head dim 64
+    "cogvideox_768p_81f": dict(H=48, S_vis=42240, text=226, text_valid=226, top_k=82, variant="cogvideo", D=64,
+                               latent=(11, 48, 80)),
     "tiny": dict(H=4, S_vis=4096, text=256, text_valid=200, top_k=6, variant="hunyuan", latent=(4, 32, 32)),
 }
 
@@ -77,6 +80,8 @@ def make_spec(wl):
         return _core.LayoutSpec.hunyuan(S, wl["S_vis"] + wl["text_valid"])
     if wl["variant"] == "flux":
         return _core.LayoutSpec.flux(S, wl["text"])
+    if wl["variant"] == "cogvideo":
+        return _core.LayoutSpec.cogvideo(S, wl["text"])
     return _core.LayoutSpec.wan(S, wl.get("ffb", 0))
 
 
@@ -495,13 +500,15 @@ def main():
     from rectified_spaattn_amd import parallel
     world, rank, dev = comm.world, comm.rank, comm.dev
     wl = WORKLOADS[args.workload]
-    D, H = 128, wl["H"]
+    D, H = wl.get("D", 128), wl["H"]
+    if args.qkv_fp8 and D != 128:
+        sys.exit("bench.py: --qkv-fp8 needs a head-dim-128 workload")
     head0, H_local = parallel.head_shard(H, world, rank)
     S = wl["S_vis"] + wl["text"]
     spec = make_spec(wl)
 
     main_regime = args.regime
-    q, k, v = gen_inputs(wl, H_local, head0, dev, REGIMES[main_regime][0])
+    q, k, v = gen_inputs(wl, H_local, head0, dev, REGIMES[main_regime][0], D=D)
     rec, call = run_regime(comm, args, wl, main_regime, q, k, v, spec, args.steps, args.warmup, want_call=True)
     sample = capture_sparse_sample(call) if (world == 1 and not args.no_cpu_baseline) else None
 
@@ -584,7 +591,7 @@ def main():
                 del call
                 q = k = v = None
                 torch.cuda.empty_cache()
-                q, k, v = gen_inputs(wl, H_local, head0, dev, REGIMES[rg][0])
+                q, k, v = gen_inputs(wl, H_local, head0, dev, REGIMES[rg][0], D=D)
                 r2, call = run_regime(comm, args, wl, rg, q, k, v, spec, max(5, args.steps // 2), 2, want_call=True)
             else:
                 r2 = run_regime(comm, args, wl, rg, q, k, v, spec, max(5, args.steps // 2), 2)
