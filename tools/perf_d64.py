@@ -7,7 +7,7 @@ AB = os.environ.get("RSA_PERF_AB", "0") == "1"
 if AB:
     os.environ["RSA_TUNING"] = "1"
     from rectified_spaattn_amd import _lib
-    _lib.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rectified_spaattn_amd", "librsa_hip_ab.so")
+    _lib.LIB_PATH = os.environ.get("RSA_PERF_LIB") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rectified_spaattn_amd", "librsa_hip_ab.so")
 from rectified_spaattn_amd import _core
 from tools.perf_k5 import timeit
 dev = torch.device("cuda:0")
