@@ -209,7 +209,7 @@ def alloc_fp8_operands(spec: LayoutSpec, B: int, H: int, D: int, device) -> Dict
     """e4m3 images of Q, K, V for the fp8 K5 (include/rsa.h::rsa_fp8_operands).  `scales` is ONE int32 buffer:
     [BH, NB_total] block-exponent words (byte 0 / 1 / 2 = E8M0 of the Q / K / V block) followed by the K mean, [BH, D]
     fp32 bit patterns (fp8_exps / fp8_kmean view it)."""
-    assert D == 128, "the fp8 block-sparse kernel is built for head_dim 128"
+    assert D in (64, 128), "the fp8 block-sparse kernels are built for head_dim 64 and 128"
     BH, SP = B * H, spec.NB_total * BLOCK
     return dict(q8=torch.empty((BH, SP, D), dtype=torch.uint8, device=device),
                 k8=torch.empty((BH, SP, D), dtype=torch.uint8, device=device),

@@ -21,10 +21,10 @@ struct BlocksArgs {
     Fp8Emit f8;
 };
 
-// the K1 load: thread (c, g) gets rows 16 i + g, elements 8c .. 8c+7 of block blk, rows >= valid as zero
-template <typename Tag>
+// the K1 load: thread (c, g) gets rows 16 i + g, elements 8c .. 8c+7 of block blk, rows >= valid as zero (2 D threads)
+template <int D, typename Tag>
 __device__ __forceinline__ void load_block(const unsigned short* base, long ss, int blk, int valid, float (&x)[8][8]) {
-    const int t = threadIdx.x, c = t % 16, g = t / 16;
+    const int t = threadIdx.x, c = t % (D / 8), g = t / (D / 8);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int row = blk * RSA_BLOCK + 16 * i + g;
@@ -39,36 +39,36 @@ __device__ __forceinline__ void load_block(const unsigned short* base, long ss, 
     }
 }
 
-// grid (max block count, BH, tensors)
-template <typename Tag>
-__global__ __launch_bounds__(256) void fp8_blocks_kernel(BlocksArgs a) {
+// grid (max block count, BH, tensors); 2 D threads
+template <int D, typename Tag>
+__global__ __launch_bounds__(2 * D) void fp8_blocks_kernel(BlocksArgs a) {
     const int which = blockIdx.z, bh = blockIdx.y;
     const int blk = a.blk0[which] + blockIdx.x;
     if (blk >= a.blk1[which]) return;
     const int b = bh / a.H, h = bh % a.H;
     float x[8][8];
-    load_block<Tag>(a.src[which] + (long)b * a.sb[which] + (long)h * a.sh[which], a.ss[which], blk, a.f8.valid[which], x);
-    __shared__ __attribute__((aligned(16))) unsigned char f8lds[RSA_F8_LDS];
-    fp8_emit_block<Tag>(x, a.f8, which, blk, bh, f8lds);
+    load_block<D, Tag>(a.src[which] + (long)b * a.sb[which] + (long)h * a.sh[which], a.ss[which], blk, a.f8.valid[which], x);
+    __shared__ __attribute__((aligned(16))) unsigned char f8lds[rsa_f8_lds(D)];
+    fp8_emit_block<D, Tag>(x, a.f8, which, blk, bh, f8lds);
 }
 
-// mu[bh][d]: grid (BH), 256 threads.  Block mean = K1's (contract C2): per thread the 8 rows in order, xor-tree over the
-// row groups of a wave, (w0 + w1) + (w2 + w3) over the waves, times 1/128.
-template <typename Tag>
-__global__ __launch_bounds__(256) void kmean_sample_kernel(const unsigned short* k, long sb, long sh, long ss, int H, int valid,
-                                                           float* kmean) {
-    constexpr int D = 128, CH = 16;
+// mu[bh][d]: grid (BH), 2 D threads.  Block mean = K1's (contract C2): per thread the 8 rows in order, xor-tree over the
+// row groups of a wave, (w0 + w1) + (w2 + w3) over the waves (w0 + w1 at head dim 64), times 1/128.
+template <int D, typename Tag>
+__global__ __launch_bounds__(2 * D) void kmean_sample_kernel(const unsigned short* k, long sb, long sh, long ss, int H, int valid,
+                                                             float* kmean) {
+    constexpr int CH = D / 8, NW = (2 * D) / 64;
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
     const int t = threadIdx.x, c = t % CH;
     const unsigned short* base = k + (long)b * sb + (long)h * sh;
-    __shared__ float red[4][D];
+    __shared__ float red[NW][D];
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int nb = valid / RSA_BLOCK > 0 ? valid / RSA_BLOCK : 1;
     const int n = valid <= 0 ? 0 : (nb < 8 ? nb : 8);
     for (int i = 0; i < n; ++i) {
         const int blk = (int)(((long)i * nb) / n);
         float x[8][8];
-        load_block<Tag>(base, ss, blk, valid, x);
+        load_block<D, Tag>(base, ss, blk, valid, x);
         float s[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256) void kmean_sample_kernel(const unsigned short*
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float tot = (red[0][c * 8 + e] + red[1][c * 8 + e]) + (red[2][c * 8 + e] + red[3][c * 8 + e]);
+            float tot = red[0][c * 8 + e] + red[1][c * 8 + e];
+            if constexpr (NW == 4) tot = tot + (red[2][c * 8 + e] + red[3][c * 8 + e]);
             acc[e] = acc[e] + tot * (1.0f / RSA_BLOCK);
         }
     }
@@ -105,7 +106,7 @@ extern "C" int rsa_fp8_operand_bytes(const rsa_layout* l, size_t sizes[4], size_
     int st = rsa_check_layout(l);
     if (st != RSA_OK) return st;
     if (!sizes || !total) return RSA_ERR_BAD_ARG;
-    if (l->D != 128) return RSA_ERR_UNSUPPORTED;
+    if (l->D != 128 && l->D != 64) return RSA_ERR_UNSUPPORTED;
     const size_t BH = (size_t)l->B * l->H, SP = (size_t)l->NB_total * RSA_BLOCK, D = l->D;
     const size_t s[4] = {BH * SP * D, BH * SP * D, BH * SP * D,
                          ((size_t)l->NB_total + D) * BH * 4};  // block exponents, K mean
@@ -137,27 +138,34 @@ float* kmean_of(const rsa_fp8_operands* ops, int BH, int NB_total) {
 
 int g_fp8_smooth_k = 1;   // tuning key "fp8_smooth_k" (0: mu = 0, for the accuracy comparison of the smoothing)
 
-void launch_kmean(int dtype, const rsa_tensor4& k, int BH, int H, int valid, float* kmean, hipStream_t s) {
-    if (!g_fp8_smooth_k) { (void)hipMemsetAsync(kmean, 0, (size_t)BH * 128 * 4, s); return; }
+void launch_kmean(int D, int dtype, const rsa_tensor4& k, int BH, int H, int valid, float* kmean, hipStream_t s) {
+    if (!g_fp8_smooth_k) { (void)hipMemsetAsync(kmean, 0, (size_t)BH * D * 4, s); return; }
     const unsigned short* kp = static_cast<const unsigned short*>(k.ptr);
-    if (dtype == RSA_BF16) kmean_sample_kernel<bf16_tag><<<BH, 256, 0, s>>>(kp, k.stride_b, k.stride_h, k.stride_s, H, valid, kmean);
-    else kmean_sample_kernel<fp16_tag><<<BH, 256, 0, s>>>(kp, k.stride_b, k.stride_h, k.stride_s, H, valid, kmean);
+#define RSA_KM(DD, TT) kmean_sample_kernel<DD, TT><<<BH, 2 * DD, 0, s>>>(kp, k.stride_b, k.stride_h, k.stride_s, H, valid, kmean)
+    if (D == 128) { if (dtype == RSA_BF16) RSA_KM(128, bf16_tag); else RSA_KM(128, fp16_tag); }
+    else { if (dtype == RSA_BF16) RSA_KM(64, bf16_tag); else RSA_KM(64, fp16_tag); }
+#undef RSA_KM
 }
 
-void launch_blocks(BlocksArgs& a, int dtype, int BH, int ntensors, hipStream_t s) {
+void launch_blocks(BlocksArgs& a, int D, int dtype, int BH, int ntensors, hipStream_t s) {
     int nmax = 0;
     for (int i = 0; i < ntensors; ++i) nmax = a.blk1[i] - a.blk0[i] > nmax ? a.blk1[i] - a.blk0[i] : nmax;
     if (nmax <= 0) return;
     const dim3 g(nmax, BH, ntensors);
-    if (dtype == RSA_BF16) fp8_blocks_kernel<bf16_tag><<<g, 256, 0, s>>>(a);
-    else fp8_blocks_kernel<fp16_tag><<<g, 256, 0, s>>>(a);
+    if (D == 128) {
+        if (dtype == RSA_BF16) fp8_blocks_kernel<128, bf16_tag><<<g, 256, 0, s>>>(a);
+        else fp8_blocks_kernel<128, fp16_tag><<<g, 256, 0, s>>>(a);
+    } else {
+        if (dtype == RSA_BF16) fp8_blocks_kernel<64, bf16_tag><<<g, 128, 0, s>>>(a);
+        else fp8_blocks_kernel<64, fp16_tag><<<g, 128, 0, s>>>(a);
+    }
 }
 
 int fill_args(const rsa_layout* l, const rsa_tensor4& q, const rsa_tensor4& k, const rsa_tensor4& v,
               const rsa_fp8_operands* ops, BlocksArgs& a) {
     int st = rsa_check_layout(l);
     if (st != RSA_OK) return st;
-    if (l->D != 128) return RSA_ERR_UNSUPPORTED;
+    if (l->D != 128 && l->D != 64) return RSA_ERR_UNSUPPORTED;
     if (!ops || !ops->q8 || !ops->k8 || !ops->v8t || !ops->scales) return RSA_ERR_BAD_ARG;
     if ((st = rsa_check_tensor(q)) || (st = rsa_check_tensor(k)) || (st = rsa_check_tensor(v))) return st;
     // every key K5 may read unmasked must be a row the images hold
@@ -189,8 +197,8 @@ extern "C" int rsa_quantize_fp8(const rsa_layout* l, rsa_tensor4 q, rsa_tensor4 
     int st = fill_args(l, q, k, v, ops, a);
     if (st != RSA_OK) return st;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    launch_kmean(l->dtype, k, l->B * l->H, l->H, l->pool_valid, const_cast<float*>(a.f8.kmean), s);
-    launch_blocks(a, l->dtype, l->B * l->H, 3, s);
+    launch_kmean(l->D, l->dtype, k, l->B * l->H, l->H, l->pool_valid, const_cast<float*>(a.f8.kmean), s);
+    launch_blocks(a, l->D, l->dtype, l->B * l->H, 3, s);
     return rsa_launch_status();
 }
 
@@ -201,10 +209,10 @@ extern "C" int rsa_pool_stats_fp8(const rsa_layout* l, rsa_tensor4 q, rsa_tensor
     int st = fill_args(l, q, k, v, ops, a);
     if (st != RSA_OK) return st;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    launch_kmean(l->dtype, k, l->B * l->H, l->H, l->pool_valid, const_cast<float*>(a.f8.kmean), s);
+    launch_kmean(l->D, l->dtype, k, l->B * l->H, l->H, l->pool_valid, const_cast<float*>(a.f8.kmean), s);
     if ((st = rsa_pool_stats_f8(l, q, k, v, buf, &a.f8, stream))) return st;
     a.blk0[0] = a.blk0[1] = l->NBv;   // q and k blocks K1 does not pool
-    launch_blocks(a, l->dtype, l->B * l->H, 2, s);
+    launch_blocks(a, l->D, l->dtype, l->B * l->H, 2, s);
     return rsa_launch_status();
 }
 
@@ -229,7 +237,7 @@ static size_t dense_fp8_carve(int BH, int Sq, int Sk, int D, void* ws, rsa_fp8_o
 
 extern "C" int rsa_dense_fp8_bytes(int B, int H, int Sq, int Sk, int D, size_t* total) {
     if (B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0 || !total) return RSA_ERR_BAD_ARG;
-    if (D != 128) return RSA_ERR_UNSUPPORTED;
+    if (D != 128 && D != 64) return RSA_ERR_UNSUPPORTED;
     *total = dense_fp8_carve(B * H, Sq, Sk, D, nullptr, nullptr, nullptr, nullptr);
     return RSA_OK;
 }
@@ -237,7 +245,7 @@ extern "C" int rsa_dense_fp8_bytes(int B, int H, int Sq, int Sk, int D, size_t* 
 // internal: producer for the dense kernel (declared in rsa_common.h).  Both images are S_pad = max(Sq, Sk) rounded to 128 rows.
 int rsa_dense_quantize_fp8(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
                            void* ws, size_t ws_bytes, rsa_fp8_operands* ops, hipStream_t s) {
-    if (D != 128) return RSA_ERR_UNSUPPORTED;
+    if (D != 128 && D != 64) return RSA_ERR_UNSUPPORTED;
     if (!ws || (reinterpret_cast<uintptr_t>(ws) & 255)) return RSA_ERR_BAD_ARG;
     int sqp, skp;
     if (ws_bytes < dense_fp8_carve(B * H, Sq, Sk, D, ws, ops, &sqp, &skp)) return RSA_ERR_WORKSPACE;
@@ -258,7 +266,7 @@ int rsa_dense_quantize_fp8(int B, int H, int Sq, int Sk, int D, int dtype, rsa_t
     f.kmean = kmean;
     f.qk_const = (float)((1.0 / sqrt((double)D)) * 1.44269504);
     f.S_pad = sqp; f.NB_total = nb;
-    launch_kmean(dtype, k, B * H, H, Sk, kmean, s);
-    launch_blocks(a, dtype, B * H, 3, s);
+    launch_kmean(D, dtype, k, B * H, H, Sk, kmean, s);
+    launch_blocks(a, D, dtype, B * H, 3, s);
     return rsa_launch_status();
 }

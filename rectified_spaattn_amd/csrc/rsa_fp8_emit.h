@@ -2,7 +2,7 @@
 // K1 (pool_stats_kernel): 2 D threads, thread t owns the 8 head-dim elements 8c .. 8c+7 (c = t % (D/8)) of the rows
 // 16 i + g (g = t / (D/8), i = 0..7).  Used by K1 itself (rsa_stats.hip: the pooling pass writes the images of the blocks
 // it pools, so Q, K and V are read from HBM once) and by the stand-alone block kernel of rsa_fp8.hip (text-tail blocks,
-// rsa_quantize_fp8, the dense path).  D = 128 only.
+// rsa_quantize_fp8, the dense path).  D = 128 or 64.
 //
 // Block-scaled format (bit-exact against oracle.fp8_block_images):
 //      y = x * qk_const (Q: one fp32 multiply, qk_const = sm_scale * log2(e))  |  x - mu[d] (K, "smooth K")  |  x (V)
@@ -26,8 +26,8 @@ struct Fp8Emit {
     int valid[3];          // rows >= valid[which] are zero in the image
 };
 
-constexpr int RSA_F8_LROW = 128 + 16;                     // padded LDS row of the V transpose (bytes)
-constexpr int RSA_F8_LDS = RSA_BLOCK * RSA_F8_LROW + 16;  // bytes of LDS fp8_emit_block needs (tile + 4 maxima)
+constexpr int rsa_f8_lrow(int D) { return D + 16; }                              // padded LDS row of the V transpose (bytes)
+constexpr int rsa_f8_lds(int D) { return RSA_BLOCK * rsa_f8_lrow(D) + 16; }      // bytes of LDS fp8_emit_block needs (tile + maxima)
 
 // E8M0 byte of the block scale from the block maximum (exponent field and one mantissa compare; no division)
 __device__ __forceinline__ int rsa_e8m0_of_amax(float amax) {
@@ -40,12 +40,12 @@ __device__ __forceinline__ int rsa_e8m0_of_amax(float amax) {
     return 127 + e;
 }
 
-// x[i][e]: the block as K1 holds it (rows >= valid already zero).  All 256 threads of the block must call it (barriers).
-// lds: RSA_F8_LDS bytes, 16-byte aligned.
-template <typename Tag>
+// x[i][e]: the block as K1 holds it (rows >= valid already zero).  All 2 D threads of the block must call it (barriers).
+// lds: rsa_f8_lds(D) bytes, 16-byte aligned.
+template <int D, typename Tag>
 __device__ __forceinline__ void fp8_emit_block(const float (&x)[8][8], const Fp8Emit& f, int which, int blk, int bh,
                                                unsigned char* lds) {
-    constexpr int D = 128, CH = D / 8;
+    constexpr int CH = D / 8, NW = (2 * D) / 64, RSA_F8_LROW = rsa_f8_lrow(D);
     const int t = threadIdx.x, c = t % CH, g = t / CH;
     const int valid = f.valid[which];
     float mu[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -80,7 +80,8 @@ __device__ __forceinline__ void fp8_emit_block(const float (&x)[8][8], const Fp8
     __syncthreads();   // (the caller may have used this LDS before)
     if ((t & 63) == 0) amx[t >> 6] = m;
     __syncthreads();
-    m = fmaxf(fmaxf(amx[0], amx[1]), fmaxf(amx[2], amx[3]));
+    m = fmaxf(amx[0], amx[1]);
+    if constexpr (NW == 4) m = fmaxf(m, fmaxf(amx[2], amx[3]));
     const int eb = rsa_e8m0_of_amax(m);
     const float inv = __uint_as_float((unsigned)(254 - eb) << 23);   // 2^-(eb - 127), exact
     if (t == 0) reinterpret_cast<uint8_t*>(f.exps + (long)bh * f.NB_total + blk)[which] = (uint8_t)eb;
@@ -121,7 +122,7 @@ __device__ __forceinline__ void fp8_emit_block(const float (&x)[8][8], const Fp8
     // reads [key][4 dg .. 4 dg + 3] (lanes differ in dg first: conflict-free), regrouped by byte into the 16-byte pieces
     // of the four d rows.  Slot j = 16 jh + 4 q + e of lane half hh is key 32 jh + e + 8 q + 4 hh of the tile.
     {
-        const int dg = t & 31, hh = (t >> 5) & 1, jh = (t >> 6) & 1, tile = t >> 7;
+        const int dg = t % (D / 4), hh = (t / (D / 4)) & 1, jh = (t / (D / 2)) & 1, tile = t / D;
         unsigned W[4][4];
 #pragma unroll
         for (int q = 0; q < 4; ++q)

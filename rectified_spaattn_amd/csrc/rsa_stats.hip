@@ -58,9 +58,9 @@ __global__ __launch_bounds__(D * 2) void pool_stats_kernel(PoolArgs a) {
     }
     // F8: the e4m3 image of the block goes out LAST (after the statistics): its V transpose then runs with x dead
     auto emit_f8 = [&]() {
-        if constexpr (F8 && D == 128) {
-            __shared__ __attribute__((aligned(16))) unsigned char f8lds[RSA_F8_LDS];
-            fp8_emit_block<Tag>(x, a.f8, which, blk, bh, f8lds);
+        if constexpr (F8) {
+            __shared__ __attribute__((aligned(16))) unsigned char f8lds[rsa_f8_lds(D)];
+            fp8_emit_block<D, Tag>(x, a.f8, which, blk, bh, f8lds);
         }
     };
     __shared__ float red[NW][D];
@@ -868,11 +868,15 @@ int rsa_pool_stats_f8(const rsa_layout* l, rsa_tensor4 q, rsa_tensor4 k, rsa_ten
     dim3 grid(l->NB_total, l->B * l->H, 3);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (f8 != nullptr) {
-        if (l->D != 128) return RSA_ERR_UNSUPPORTED;
         a.f8 = *f8;
         const dim3 grid8(3 * l->NB_total, l->B * l->H, 1);
-        if (l->dtype == RSA_BF16) pool_stats_kernel<128, bf16_tag, true><<<grid8, 256, 0, s>>>(a);
-        else pool_stats_kernel<128, fp16_tag, true><<<grid8, 256, 0, s>>>(a);
+        if (l->D == 128) {
+            if (l->dtype == RSA_BF16) pool_stats_kernel<128, bf16_tag, true><<<grid8, 256, 0, s>>>(a);
+            else pool_stats_kernel<128, fp16_tag, true><<<grid8, 256, 0, s>>>(a);
+        } else {
+            if (l->dtype == RSA_BF16) pool_stats_kernel<64, bf16_tag, true><<<grid8, 128, 0, s>>>(a);
+            else pool_stats_kernel<64, fp16_tag, true><<<grid8, 128, 0, s>>>(a);
+        }
         return rsa_launch_status();
     }
     if (l->D == 128) {
