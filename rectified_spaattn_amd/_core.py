@@ -346,7 +346,7 @@ def dense_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, q_split: 
     o4 = RsaOut4(out.data_ptr(), out.stride(0), out.stride(2), out.stride(1))
     if qkv_fp8 and causal:
         raise NotImplementedError("causal attention runs on the 2-byte kernel only (no causal form of the e4m3 dense kernel)")
-    if qkv_fp8:  # e4m3 images of q, k, v (per-head scales) + the fp8 MFMA kernel; head_dim 128 only
+    if qkv_fp8:  # block-scaled e4m3 images of q, k, v + the fp8 MFMA kernel (head_dim 64 / 128)
         total = ctypes.c_size_t()
         _lib.check(L.rsa_dense_fp8_bytes(B, H, Sq, Sk, D, ctypes.byref(total)), "rsa_dense_fp8_bytes")
         ws = torch.empty(total.value, dtype=torch.uint8, device=q.device)

@@ -29,7 +29,7 @@ def _check_blocks(bm: int, bn: int):
 
 # PROCESS DEFAULT of the K5 operand precision (a processor / call can override it: processor.qkv_fp8, qkv_fp8=...):
 # False = the input dtype (bf16/fp16, the
-# reference's behaviour), True = e4m3 images of Q, K, V on the fp8 MFMA (head_dim 128 only; other head dims keep the
+# reference's behaviour), True = e4m3 images of Q, K, V on the fp8 MFMA (head_dim 64 / 128; other head dims keep the
 # 2-byte kernel).  Set with rectified_spaattn_amd.set_qkv_fp8(); the reference has no such switch (fp8 is its TODO).
 QKV_FP8 = False
 
@@ -71,7 +71,7 @@ def run(variant: str, query, key, value, top_k, prob_threshold, block_neighbor_l
         raise ValueError(variant)
     return _core.rectified_attention(query, key, value, spec, int(top_k), float(prob_threshold),
                                      block_neighbor_list, shape_xfuse=shape_xfuse,
-                                     qkv_fp8=(QKV_FP8 if qkv_fp8 is None else bool(qkv_fp8)) and D == 128)
+                                     qkv_fp8=(QKV_FP8 if qkv_fp8 is None else bool(qkv_fp8)) and D in (64, 128))
 
 
 # ---- small helpers shared by the processors ---------------------------------------------------------

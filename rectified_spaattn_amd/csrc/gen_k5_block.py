@@ -233,10 +233,11 @@ AHEAD8, RING8 = 3, 4
 
 
 class Map8:
-    def __init__(self):
+    def __init__(self, D8=128):
         r = 0
-        self.O = r; r += 64
-        self.Q = r; r += 16
+        self.D8, self.KS, self.DT = D8, D8 // 64, D8 // 32
+        self.O = r; r += 16 * self.DT
+        self.Q = r; r += 8 * self.KS
         self.SA = r; r += 32
         self.SB = r; r += 32
         self.MB = r; r += 16
@@ -248,26 +249,27 @@ class Map8:
         self.tmp1 = r
         r = (r + 1) & ~1
         self.SC = r; r += 2          # E8M0 scale operands of the QK^T MFMAs
-        self.KA = r; r += 4          # K read addresses [ks][chunk]
+        self.KA = r; r += 2 * self.KS   # K read addresses [ks][chunk]
         self.VA = r; r += 2          # V read addresses [chunk]
         self.ON = r; r += 1          # address of this lane's ones / zeros pattern
         self.end = r
 
 
-def gen_block8(TS, codemap=False):
-    m = Map8()
+def gen_block8(TS, codemap=False, D8=128):
+    m = Map8(D8)
     SC_, SN = (m.SA, m.SB) if TS % 2 == 0 else (m.SB, m.SA)
-    TILE8 = 8192
+    TILE8 = 64 * D8
     kslot = (TS + 1) & 3
     lines, lds_seq = [], []
-    # the nine A operands, in MFMA order: (kind, LDS reads as (address register, immediate) pairs)
+    # the A operands, in MFMA order (nine at head dim 128, five at 64): (kind, LDS reads as (address register, immediate) pairs)
     ops = []
     for sub in range(2):
-        for ks in range(2):
-            off = kslot * TILE8 + sub * 4096
+        for ks in range(m.KS):
+            off = kslot * TILE8 + sub * 32 * D8
             ops.append(("qk", sub, ks, [(m.KA + 2 * ks, off), (m.KA + 2 * ks + 1, off)]))
+    n_qk = len(ops)
     ops.append(("rs", 0, 0, [(m.ON, 0), (m.ON, 16)]))
-    for dt in range(4):
+    for dt in range(m.DT):
         off = (4 + TS) * TILE8 + dt * 2048
         ops.append(("pv", dt, 0, [(m.VA, off), (m.VA + 1, off)]))
 
@@ -353,8 +355,8 @@ def gen_block8(TS, codemap=False):
             lines.append(f"v_mfma_scale_f32_32x32x64_f8f6f4 {vr(m.O + 16 * x, 16)}, {a}, {vr(SC_, 8)}, {vr(m.O + 16 * x, 16)}, "
                          f"{vr(m.SC)}, {vr(m.SC + 1)} op_sel:[1,1,0] op_sel_hi:[0,0,0]")
         if i + AHEAD8 < n: read(i + AHEAD8)
-        # row max of S_nxt: two MFMAs behind the last QK^T MFMA (index 3): from the shadow of PV 0 (index 5) on
-        emit_work(10 ** 6 if i == n - 1 else 48, i >= 5)
+        # row max of S_nxt: two MFMAs behind the last QK^T MFMA (index n_qk - 1): from the shadow of PV 0 (index n_qk + 1) on
+        emit_work(10 ** 6 if i == n - 1 else 48, i >= n_qk + 1)
     assert wi == len(work) and mi == len(maxw)
     lines.append("s_setprio 0")
     return lines, m
@@ -367,6 +369,23 @@ def main8(out):
             out.append(f"#define RSA_K5F8_BLOCK{'C' if codemap else ''}_T{TS} \\")
             out.append(" \\\n".join(c_string(lines).split("\n")))
             out.append("")
+    for TS in range(4):   # head dim 64 (CogVideoX): the product form only
+        lines, m = gen_block8(TS, True, 64)
+        out.append(f"#define RSA_K5F8_BLOCKC64_T{TS} \\")
+        out.append(" \\\n".join(c_string(lines).split("\n")))
+        out.append("")
+    m = Map8(64)
+    outs = [f'"+{{{vr(m.O + 16 * d, 16)}}}"(o[{d}])' for d in range(2)]
+    outs += [f'"+{{{vr(m.SA, 16)}}}"(SA[0])', f'"+{{{vr(m.SA + 16, 16)}}}"(SA[1])', f'"+{{{vr(m.SB, 16)}}}"(SB[0])',
+             f'"+{{{vr(m.SB + 16, 16)}}}"(SB[1])', f'"+{{{vr(m.LACC, 4)}}}"(lacc)', '[mx] "=&v"(mx)']
+    ins = [f'"{{{vr(m.Q, 8)}}}"(q[0])', f'"{{{vr(m.MB, 16)}}}"(mblk)',
+           f'"{{{vr(m.SC)}}}"(sca)', f'"{{{vr(m.SC + 1)}}}"(scb)', f'"{{{vr(m.KA, 2)}}}"(ka)', f'"{{{vr(m.VA, 2)}}}"(va)',
+           f'"{{{vr(m.ON)}}}"(ona)']
+    out.append(f"#define RSA_K5F8_OPS64 : {', '.join(outs)} : {', '.join(ins)}")
+    out.append("#define RSA_K5F8_CLOBBER64 " + ", ".join(f'"v{r}"' for r in range(m.tmp0, m.tmp1)))
+    out.append(f"// e4m3 kernel, head dim 64: O v[0:{m.Q - 1}], Q v[{m.Q}:{m.SA - 1}], SA v[{m.SA}:{m.SB - 1}], SB v[{m.SB}:{m.MB - 1}], "
+               f"reference block v[{m.MB}:{m.LACC - 1}], l v[{m.LACC}:{m.LACC + 3}], temporaries v[{m.tmp0}:{m.tmp1 - 1}], "
+               f"scales v[{m.SC}:{m.SC + 1}], K / V / ones addresses v[{m.KA}:{m.end - 1}]")
     m = Map8()
     outs = [f'"+{{{vr(m.O + 16 * d, 16)}}}"(o[{d}])' for d in range(4)]
     outs += [f'"+{{{vr(m.SA, 16)}}}"(SA[0])', f'"+{{{vr(m.SA + 16, 16)}}}"(SA[1])', f'"+{{{vr(m.SB, 16)}}}"(SB[0])',

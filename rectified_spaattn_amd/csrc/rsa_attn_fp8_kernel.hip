@@ -63,9 +63,7 @@ int rsa_text_split_enabled();
 
 namespace {
 
-constexpr int D8 = 128;
-constexpr int TILE8 = 8192;   // bytes of one K tile (64 keys x 128) and of one V tile (128 d x 64 keys)
-constexpr int NSLOT = 4;
+constexpr int NSLOT = 4;   // K / V tiles are 64 keys x D8 bytes resp. D8 rows x 64 bytes: 64 D8 bytes each (8 KiB at head dim 128)
 // How P reaches e4m3.  Both forms keep the QK^T accumulator relative to the row's reference m (the chain starts from a block
 // holding the constant), so a score s arrives as U (s - m + OFFSET) + BIAS:
 //   exact form (PIPE_OPT bit 2 clear): U = 1, BIAS = 0: log2(P); P = v_exp_f32, then v_cvt_pk_fp8_f32 (round to nearest even);
@@ -95,10 +93,18 @@ __device__ __forceinline__ f32x16 mfma8s1(i32x8 a, i32x8 b, f32x16 c, int sa, in
 }
 
 // the hand-placed tile block (gen_k5_block.py, RSA_K5F8_*): one asm statement per 64-key tile, registers pinned; TS = tile & 3
-template <int TS, bool CODEMAP>
-__device__ __forceinline__ void k5f8_block(f32x16 (&o)[4], const i32x8 (&q)[2], f32x16 (&SA)[2], f32x16 (&SB)[2],
-                                           const f32x16& mblk, f32x4& lacc, float& mx, int sca, int scb, const i32x4& ka,
+template <int TS, bool CODEMAP, int D8, typename KA>
+__device__ __forceinline__ void k5f8_block(f32x16 (&o)[D8 / 32], const i32x8 (&q)[D8 / 64], f32x16 (&SA)[2], f32x16 (&SB)[2],
+                                           const f32x16& mblk, f32x4& lacc, float& mx, int sca, int scb, const KA& ka,
                                            const i32x2& va, int ona) {
+    if constexpr (D8 == 64) {
+        static_assert(CODEMAP, "head dim 64 has the code-map block only");
+        if constexpr (TS == 0) asm volatile(RSA_K5F8_BLOCKC64_T0 RSA_K5F8_OPS64 : RSA_K5F8_CLOBBER64, "memory");
+        else if constexpr (TS == 1) asm volatile(RSA_K5F8_BLOCKC64_T1 RSA_K5F8_OPS64 : RSA_K5F8_CLOBBER64, "memory");
+        else if constexpr (TS == 2) asm volatile(RSA_K5F8_BLOCKC64_T2 RSA_K5F8_OPS64 : RSA_K5F8_CLOBBER64, "memory");
+        else asm volatile(RSA_K5F8_BLOCKC64_T3 RSA_K5F8_OPS64 : RSA_K5F8_CLOBBER64, "memory");
+        return;
+    }
     if constexpr (CODEMAP) {
         if constexpr (TS == 0) asm volatile(RSA_K5F8_BLOCKC_T0 RSA_K5F8_OPS : RSA_K5F8_CLOBBER, "memory");
         else if constexpr (TS == 1) asm volatile(RSA_K5F8_BLOCKC_T1 RSA_K5F8_OPS : RSA_K5F8_CLOBBER, "memory");
@@ -114,8 +120,13 @@ __device__ __forceinline__ void k5f8_block(f32x16 (&o)[4], const i32x8 (&q)[2], 
 
 // PIPE_OPT bit 0: the hand-placed block (clear: the block as hipcc schedules it, same arithmetic, for A/B);
 // bit 1: s_setprio around the compiled block; bit 2: the code-map form of P (PMap above).  Product = 7.
-template <int PIPE_OPT>
+// D8: head dim = bytes per Q / K row (128; 64 = the CogVideoX shape, hand-placed code-map form only).
+template <int PIPE_OPT, int D8 = 128>
 __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
+    constexpr int TILE8 = 64 * D8;        // bytes of one K tile (64 keys x D8) and of one V tile (D8 rows x 64 keys)
+    constexpr int KS8 = D8 / 64;          // QK^T MFMAs per 32-key half (k = 64 each)
+    constexpr int DT8 = D8 / 32;          // 32-row d tiles of O^T
+    constexpr int NPC8 = TILE8 / 4096;    // 1-KiB LDS-DMA pieces per wave and tile operand
     constexpr bool CODEMAP = (PIPE_OPT & 4) != 0;
     using PM = PMap<CODEMAP>;
     constexpr float P_BASE = PM::U * PM::OFFSET + PM::BIAS;   // accumulator value of a score equal to the reference m
@@ -219,11 +230,11 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     // block's exponent (+ the code map's unit of 1/8) in byte 0 and 1.0 in byte 1; scale register A is rebuilt per tile:
     // byte 0 = K exponent of the tile whose scores the block computes, byte 1 = V exponent of the tile it multiplies P with.
     const int sc_b = (int)(((ex[qblk < a.exps_stride ? qblk : 0] & 0xFFu) + (unsigned)PM::EXP) | (127u << 8));
-    i32x8 qf[2];
+    i32x8 qf[KS8];
     {
         const uint8_t* qp = a.q8 + ((long)bh * a.Sq_pad + grow) * D8 + 32 * hh;  // rows < Sq_pad always exist (zero-padded)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < KS8; ++ks) {
             const i32x4 lo = *reinterpret_cast<const i32x4*>(qp + 64 * ks);
             const i32x4 hi = *reinterpret_cast<const i32x4*>(qp + 64 * ks + 16);
             qf[ks] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -233,15 +244,16 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     // ---------------- LDS-DMA staging ----------------
     // K tile [64 keys][128 B]: 1-KiB piece pc = rows 8pc..8pc+7; wave w moves pieces w and w+4 (same swizzle phase).
     // V tile [128 d][64 B]:    1-KiB piece pc = rows 16pc..16pc+15; wave w moves pieces w and w+4.
+    // Head dim 64: both tiles are [64 rows][64 B] = 4 pieces, wave w moves piece w, and K takes V's swizzle.
     // The LDS image is lane-linear, so the bank swizzle is applied to the SOURCE chunk.
     const unsigned char* kbase = a.k8 + (long)bh * a.Sk_pad * D8;
-    const unsigned char* vbase = a.v8t + (long)bh * a.Sk_pad * D8;  // Sk_pad/64 tiles x 8192 bytes
-    const unsigned voffk = (unsigned)((lane >> 3) * 128 + (((lane & 7) ^ (4 * (wv & 1) + (lane >> 4))) << 4));
+    const unsigned char* vbase = a.v8t + (long)bh * a.Sk_pad * D8;  // Sk_pad/64 tiles x TILE8 bytes
     const unsigned voffv = (unsigned)((lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4));
+    const unsigned voffk = D8 == 128 ? (unsigned)((lane >> 3) * 128 + (((lane & 7) ^ (4 * (wv & 1) + (lane >> 4))) << 4)) : voffv;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
     auto dma2 = [&](const unsigned char* tile_src, unsigned lds_dst, unsigned voff) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NPC8; ++j) {
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                          :: "v"(voff), "s"(tile_src + (wv + 4 * j) * 1024), "s"(lds_dst + (wv + 4 * j) * 1024)
                          : "memory");
@@ -253,9 +265,9 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     };
 
     // ---------------- state ----------------
-    f32x16 o[4];
+    f32x16 o[DT8];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
+    for (int dt = 0; dt < DT8; ++dt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) o[dt][i] = 0.0f;
     float m_run = -INFINITY;
@@ -269,25 +281,26 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     for (int i = 0; i < 16; ++i) mblk[i] = P_BASE;
 
     // per-lane read offsets (slot base added per step)
-    int koff[2][2][2];  // [sub][ks][chunk]
+    int koff[2][KS8][2];  // [sub][ks][chunk]
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
         const int row = 32 * sub + r;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < KS8; ++ks)
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2)
-                koff[sub][ks][c2] = row * 128 + (((4 * ks + 2 * hh + c2) ^ ((row >> 1) & 7)) << 4);
+                koff[sub][ks][c2] = D8 == 128 ? row * 128 + (((4 * ks + 2 * hh + c2) ^ ((row >> 1) & 7)) << 4)
+                                              : row * 64 + (((2 * hh + c2) ^ ((row >> 2) & 3)) << 4);
     }
     int voff_rd[2];  // row r of a 32-row d-tile; +2048 per d-tile
 #pragma unroll
     for (int c2 = 0; c2 < 2; ++c2) voff_rd[c2] = r * 64 + (((2 * hh + c2) ^ ((r >> 2) & 3)) << 4);
 
     // read addresses of the hand-placed block (LDS byte addresses; ring slot, sub-tile and d-tile are immediates)
-    i32x4 ka;
+    typename std::conditional<D8 == 128, i32x4, i32x2>::type ka;
     i32x2 va;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int ks = 0; ks < KS8; ++ks)
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2) ka[2 * ks + c2] = (int)lds_base + koff[0][ks][c2];
     va[0] = (int)lds_base + voff_rd[0];
@@ -305,7 +318,8 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             S[sub] = mfma8s(ld32(kt_ + koff[sub][0][0], kt_ + koff[sub][0][1]), qf[0], mblk, sc_k, sc_b);
-            S[sub] = mfma8s(ld32(kt_ + koff[sub][1][0], kt_ + koff[sub][1][1]), qf[1], S[sub], sc_k, sc_b);
+            if constexpr (KS8 == 2)
+                S[sub] = mfma8s(ld32(kt_ + koff[sub][1][0], kt_ + koff[sub][1][1]), qf[1], S[sub], sc_k, sc_b);
         }
     };
     auto rowmax_tile = [&](const f32x16 (&S)[2]) -> float {
@@ -336,8 +350,12 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     auto step = [&](auto TS, int tile, int key0, f32x16 (&S_cur)[2], float& mx_cur, f32x16 (&S_nxt)[2], float& mx_nxt) {
         const int ts = TS;  // integral_constant (static LDS addresses) or the runtime tile & 3
         const int sc_a = (int)((sw1 & 0xFFu) | (sw0 & 0xFF00u));   // K(tile + 1) in byte 0, V(tile) in byte 1
-        if (tile + 2 < n_tiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tile + 2 < n_tiles) {   // (the newest tile's pieces may stay in flight: 2 NPC8 per wave)
+            if constexpr (NPC8 == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __syncthreads();
         if (tile + 3 < n_tiles) dma_k(kq3, (ts + 3) & (NSLOT - 1));
         if (tile + 2 < n_tiles) dma_v(kq2, (ts + 2) & (NSLOT - 1));
@@ -359,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) lacc[i] *= alpha;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
+            for (int dt = 0; dt < DT8; ++dt)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
 #pragma unroll
@@ -374,8 +392,8 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
         if constexpr ((PIPE_OPT & 1) != 0) {
             constexpr int tsc = decltype(TS)::value;
             // S_cur is SA on even tiles, SB on odd ones (tile & 1 == TS & 1)
-            if constexpr ((tsc & 1) == 0) k5f8_block<tsc, CODEMAP>(o, qf, S_cur, S_nxt, mblk, lacc, mx_nxt, sc_a, sc_b, ka, va, ona);
-            else k5f8_block<tsc, CODEMAP>(o, qf, S_nxt, S_cur, mblk, lacc, mx_nxt, sc_a, sc_b, ka, va, ona);
+            if constexpr ((tsc & 1) == 0) k5f8_block<tsc, CODEMAP, D8>(o, qf, S_cur, S_nxt, mblk, lacc, mx_nxt, sc_a, sc_b, ka, va, ona);
+            else k5f8_block<tsc, CODEMAP, D8>(o, qf, S_nxt, S_cur, mblk, lacc, mx_nxt, sc_a, sc_b, ka, va, ona);
             return;
         }
         if constexpr (PIPE_OPT & 2) __builtin_amdgcn_s_setprio(2);
@@ -404,7 +422,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
                                                                 lacc, 0, 0, 0, 0, 0, 0);
         const unsigned char* vt_ = lds + (NSLOT + ts) * TILE8;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
+        for (int dt = 0; dt < DT8; ++dt)
             o[dt] = mfma8s1(ld32(vt_ + dt * 2048 + voff_rd[0], vt_ + dt * 2048 + voff_rd[1]), pb, o[dt], sc_a, sc_b);
         mx_nxt = rowmax_tile(S_nxt);
         if constexpr (PIPE_OPT & 2) __builtin_amdgcn_s_setprio(0);
@@ -479,7 +497,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
         const int rowb = 32 * wv + r;
         float* pp = a.tpart + ((((long)bh * ntq + (qblk - a.NBv)) * a.tsplit + tsp) * RSA_BLOCK + rowb) * (D8 + 2);
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
+        for (int dt = 0; dt < DT8; ++dt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int d0 = 32 * dt + 8 * g + 4 * hh;
@@ -503,7 +521,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     unsigned short* op = a.out + (long)b * a.osb + (long)h * a.osh + (long)grow * a.oss;
     // (16-byte stores after a v_permlane32_swap regroup, the 2-byte kernel's default, measured neutral here: 9.60 vs 9.60 ms)
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
+    for (int dt = 0; dt < DT8; ++dt) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int d0 = 32 * dt + 8 * g + 4 * hh;
@@ -527,7 +545,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
 }
 
 int g_fp8_variant = 0;
-int launch_attn8(Attn8Args& a, int BH, hipStream_t s) {
+int launch_attn8(Attn8Args& a, int BH, int D8, hipStream_t s) {
     const int ntq = a.NQB - a.NBv;
     const int n_txt_items = (a.kv_text_valid + RSA_BLOCK - 1) / RSA_BLOCK;
     a.tsplit = 1; a.tper = n_txt_items;
@@ -544,11 +562,16 @@ int launch_attn8(Attn8Args& a, int BH, hipStream_t s) {
     if (nblocks <= 0) return RSA_OK;
     if (nblocks > 0x7FFFFFFF) return RSA_ERR_UNSUPPORTED;
     if (a.NB_total > 8192) return RSA_ERR_UNSUPPORTED;
-    const size_t lds_bytes = (size_t)2 * NSLOT * TILE8 + 64 + (((size_t)a.NB_total * 4 + 15) & ~(size_t)15);
-    switch (g_fp8_variant) {   // tuning key fp8_variant: 0 = product; 1, 2 = the two verification forms the tests compare it with
-        case 1: bsfwd_fp8_kernel<6><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a); break;   // product arithmetic, hipcc's schedule
-        case 2: bsfwd_fp8_kernel<3><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a); break;   // exact-exponential P, hand-placed
-        default: bsfwd_fp8_kernel<7><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a);
+    const size_t lds_bytes = (size_t)2 * NSLOT * 64 * D8 + 64 + (((size_t)a.NB_total * 4 + 15) & ~(size_t)15);
+    if (D8 == 64) {   // head dim 64: the product form and its compiled twin
+        if (g_fp8_variant == 1) bsfwd_fp8_kernel<6, 64><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a);
+        else bsfwd_fp8_kernel<7, 64><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a);
+    } else {
+        switch (g_fp8_variant) {   // tuning key fp8_variant: 0 = product; 1, 2 = the two verification forms the tests compare it with
+            case 1: bsfwd_fp8_kernel<6><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a); break;   // product arithmetic, hipcc's schedule
+            case 2: bsfwd_fp8_kernel<3><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a); break;   // exact-exponential P, hand-placed
+            default: bsfwd_fp8_kernel<7><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a);
+        }
     }
     const int st = rsa_launch_status();
     if (st != RSA_OK || a.tsplit <= 1) return st;
@@ -570,7 +593,7 @@ extern "C" int rsa_block_sparse_fwd_fp8(const rsa_layout* l, const rsa_fp8_opera
                                         rsa_out4 out, void* stream) {
     int st = rsa_check_layout(l);
     if (st != RSA_OK) return st;
-    if (l->D != 128) return RSA_ERR_UNSUPPORTED;
+    if (l->D != 128 && l->D != 64) return RSA_ERR_UNSUPPORTED;
     if (!ops || !ops->q8 || !ops->k8 || !ops->v8t || !ops->scales) return RSA_ERR_BAD_ARG;
     if ((st = check_out8(out))) return st;
     if (!buf || (l->NBv > 0 && (!buf->cols || !buf->counts))) return RSA_ERR_BAD_ARG;
@@ -586,7 +609,7 @@ extern "C" int rsa_block_sparse_fwd_fp8(const rsa_layout* l, const rsa_fp8_opera
     a.q_text_end = l->NBv * RSA_BLOCK + l->q_text_valid;
     a.q_split = 0; a.kv_split = 0;
     a.out_fp16 = l->dtype == RSA_FP16;
-    return launch_attn8(a, l->B * l->H, static_cast<hipStream_t>(stream));
+    return launch_attn8(a, l->B * l->H, l->D, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int rsa_rectified_attention_fp8(const rsa_layout* l, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
@@ -611,7 +634,7 @@ extern "C" int rsa_dense_fwd_fp8(int B, int H, int Sq, int Sk, int D, int dtype,
                                  rsa_tensor4 v, int q_split, int kv_split, void* workspace, size_t workspace_bytes,
                                  rsa_out4 out, void* stream) {
     if (B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0) return RSA_ERR_BAD_ARG;
-    if (D != 128) return RSA_ERR_UNSUPPORTED;
+    if (D != 128 && D != 64) return RSA_ERR_UNSUPPORTED;
     if (dtype != RSA_BF16 && dtype != RSA_FP16) return RSA_ERR_UNSUPPORTED;
     if (q_split < 0 || q_split > Sq || kv_split < 0 || kv_split > Sk) return RSA_ERR_BAD_ARG;
     int st;
@@ -635,5 +658,5 @@ extern "C" int rsa_dense_fwd_fp8(int B, int H, int Sq, int Sk, int D, int dtype,
     a.kv_valid = Sk; a.kv_text_valid = Sk; a.q_text_end = 0;
     a.q_split = q_split; a.kv_split = kv_split;
     a.out_fp16 = dtype == RSA_FP16;
-    return launch_attn8(a, B * H, s);
+    return launch_attn8(a, B * H, D, s);
 }

@@ -27,7 +27,7 @@ def main():
         two = bool(rng.integers(0, 3) == 0)
         qs = int(rng.integers(0, Sq + 1)) if two else None
         ks = int(rng.integers(0, Sk + 1)) if two else None
-        fp8 = (D == 128) and (not causal) and bool(rng.integers(0, 2))
+        fp8 = (not causal) and bool(rng.integers(0, 2))
         g = torch.Generator().manual_seed(int(rng.integers(0, 1 << 30)))
         dt = torch.float16 if f16 else torch.bfloat16
         q = torch.randn(1, H, Sq, D, generator=g).to(DEV, dt)
@@ -53,7 +53,11 @@ def main():
                     ref = orc.dense_attention(qf, kf, vf, causal=causal)
                 mx = 2e-3 if f16 else 2e-2
             err = np.abs(out[0, :, h] - ref).max()
-            if not err <= mx:
+            if fp8:   # rows that see a handful of keys reproduce V, whose e4m3 step is 6 % of |v|: judge rows relative to themselves
+                rel = np.linalg.norm(out[0, :, h] - ref, axis=-1) / np.maximum(np.linalg.norm(ref, axis=-1), 1e-3)
+                if not rel.max() <= 0.2:
+                    msgs.append(f"head {h} row-relative max {rel.max():.3e} (abs max {err:.3e})")
+            elif not err <= mx:
                 msgs.append(f"head {h} max {err:.3e}")
         if msgs:
             bad += 1

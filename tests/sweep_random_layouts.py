@@ -69,7 +69,7 @@ def run(case):
     err = np.abs(out.float().cpu().numpy() - ref)
     if not (err.max() <= mx and err.mean() <= mean and np.isfinite(err).all()):
         msgs.append(f"O max {err.max():.3e} mean {err.mean():.3e}")
-    if D == 128:
+    if D in (64, 128):
         o8, p8 = _core.rectified_attention(tq, tk, tv, spec, top_k, p, tn, return_parts=True, qkv_fp8=True)
         ref8, _, ops = orc.rectified_attention_fp8(q, k, v, lay, top_k, p, nbr, want_parts=True)
         for n_ in ("q8", "k8", "v8t"):

@@ -21,7 +21,8 @@ DEV = "cuda:0"
 FP8_MAX_VS_BF16, FP8_MEAN_VS_BF16 = 1.6e-1, 1.5e-2   # measured 1.4e-1 / 1.3e-2; see tests/diag_fp8_scale_granularity.py
 FP8_MAX_VS_FP8, FP8_MEAN_VS_FP8 = 4e-2, 4e-3
 FP8_MAX_VS_PCODE, FP8_MEAN_VS_PCODE = 2e-2, 4e-4     # oracle with the kernel's own P map (p_form="code"); measured <= 1.2e-2 / 2.0e-4
-FP8_ROW_REL_MEDIAN, FP8_ROW_REL_MAX = 0.13, 0.30   # measured: median 0.06-0.11, max 0.07-0.23 (e4m3: 2^-4 relative steps on Q, K, V and P)
+FP8_ROW_REL_MEDIAN, FP8_ROW_REL_MAX = 0.13, 0.30   # measured: median 0.06-0.12, max 0.08-0.27 (e4m3: 2^-4 relative steps on Q, K, V and P)
+FP8_ROW_REL_MAX_D64 = 0.40                        # head dim 64: half as many elements average the rounding in a row; measured 0.32-0.33
 
 
 def _spec(lay):
@@ -37,15 +38,20 @@ CASES = [
     ("flux", lambda: orc.layout_flux(9 * 128 + 512, 512), 1, 3, 0.2, 0, torch.float16),
     ("wan_keep_all", lambda: orc.layout_wan(5 * 128, 0), 1, 99, 1.5, -1, torch.bfloat16),
     ("wan_odd_tiles", lambda: orc.layout_wan(4 * 128 + 40, 1), 1, 2, 0.6, 1, torch.bfloat16),
+    # head dim 64 (the CogVideoX shape's head dim): its own K1 / block-kernel instances and K5 block
+    ("cogvideo_d64", lambda: orc.layout_cogvideo(6 * 128 + 226, 226), 2, 2, 0.3, 1, torch.bfloat16, 64),
+    ("wan_ragged_d64", lambda: orc.layout_wan(7 * 128 - 37, 2), 2, 3, 0.3, 1, torch.float16, 64),
+    ("hunyuan_d64", lambda: orc.layout_hunyuan(5 * 128 + 256, 5 * 128 + 131), 1, 2, 0.4, -1, torch.bfloat16, 64),
 ]
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: c[0])
 def test_fp8_operator(case):
     from rectified_spaattn_amd import _core, synth
-    name, mk, H, top_k, p, nbw, dt = case
+    name, mk, H, top_k, p, nbw, dt = case[:7]
+    D = case[7] if len(case) > 7 else 128
     lay = mk()
-    q, k, v = synth.structured_qkv(4242 + len(name), 1, H, lay.S, 128, smooth=0.0)
+    q, k, v = synth.structured_qkv(4242 + len(name), 1, H, lay.S, D, smooth=0.0)
     nbr = synth.banded_neighbors(lay.NBv, nbw) if nbw >= 0 else None
     tq, tk, tv = (torch.from_numpy(x).to(DEV, dt) for x in (q, k, v))
     q, k, v = (x.float().cpu().numpy() for x in (tq, tk, tv))
@@ -80,7 +86,8 @@ def test_fp8_operator(case):
     assert e8c.max() <= FP8_MAX_VS_PCODE and e8c.mean() <= FP8_MEAN_VS_PCODE, f"vs code-map oracle: {e8c.max():.3e} {e8c.mean():.3e}"
     ref16 = orc.rectified_attention(q, k, v, lay, top_k, p, nbr)
     e16 = np.abs(o - ref16)
-    assert e16.max() <= FP8_MAX_VS_BF16 and e16.mean() <= FP8_MEAN_VS_BF16, \
+    # (head dim 64: a row carried by one or two keys reproduces V, whose e4m3 step is 6 % of |v| <= 4: 2.5e-1 there)
+    assert e16.max() <= (FP8_MAX_VS_BF16 if D == 128 else 2.5e-1) and e16.mean() <= FP8_MEAN_VS_BF16, \
         f"vs bf16 oracle: {e16.max():.3e} {e16.mean():.3e}"
     assert np.isfinite(o).all()
     # the same distance per query row, RELATIVE to that row's own output (an absolute bound says little where |O| is
@@ -90,7 +97,8 @@ def test_fp8_operator(case):
     rel = np.linalg.norm(d, axis=-1) / np.maximum(np.linalg.norm(ref16.reshape(S_, H, HD // H), axis=-1), 1e-6)
     print(f"{name}: fp8 vs bf16 oracle, relative L2 per query row: median {np.median(rel):.3f} p99 {np.quantile(rel, 0.99):.3f} "
           f"max {rel.max():.3f}")
-    assert np.median(rel) <= FP8_ROW_REL_MEDIAN and rel.max() <= FP8_ROW_REL_MAX, (np.median(rel), rel.max())
+    assert np.median(rel) <= FP8_ROW_REL_MEDIAN and rel.max() <= (FP8_ROW_REL_MAX if D == 128 else FP8_ROW_REL_MAX_D64), \
+        (np.median(rel), rel.max())
 
 
 def test_fp8_onecall_matches_staged():
@@ -104,13 +112,11 @@ def test_fp8_onecall_matches_staged():
     assert torch.equal(a, b)
 
 
-def test_fp8_rejects_head_dim_64():
-    from rectified_spaattn_amd import _core, synth
-    lay = orc.layout_wan(256, 0)
-    q, k, v = synth.structured_qkv(5, 1, 1, lay.S, 64, smooth=0.0)
-    tq, tk, tv = (torch.from_numpy(x).to(DEV, torch.bfloat16) for x in (q, k, v))
+def test_fp8_rejects_head_dims_it_has_no_kernel_for():
+    from rectified_spaattn_amd import _core
+    z = torch.zeros(1, 1, 256, 32, dtype=torch.bfloat16, device=DEV)
     with pytest.raises(AssertionError):
-        _core.rectified_attention(tq, tk, tv, _spec(lay), 1, 0.3, None, qkv_fp8=True)
+        _core.rectified_attention(z, z, z, _core.LayoutSpec.wan(256, 0), 1, 0.3, None, qkv_fp8=True)
 
 
 def test_fp8_large_magnitudes_and_zero_tensor():
@@ -239,16 +245,17 @@ def test_fp8_smooth_k_removes_a_common_key_component():
     assert e_s <= FP8_MEAN_VS_BF16 and e_p >= 2.0 * e_s, f"smooth {e_s:.3e} plain {e_p:.3e}"
 
 
+@pytest.mark.parametrize("D", [128, 64])
 @pytest.mark.parametrize("Sq,Sk,qs,ks", [(300, 520, None, None), (384, 384, 256, 200), (129, 1000, 1, 64)],
                          ids=["plain", "two_segment", "ragged"])
-def test_fp8_dense_kernel(Sq, Sk, qs, ks):
+def test_fp8_dense_kernel(Sq, Sk, qs, ks, D):
     """rsa_dense_fwd_fp8 (fullattn's device path with e4m3 operands) vs the fp8-aware dense oracle."""
     from rectified_spaattn_amd import _core
     g = torch.Generator().manual_seed(Sq * 7 + Sk)
     H = 2
-    q = torch.randn(1, H, Sq, 128, generator=g).to(DEV, torch.bfloat16)
-    k = torch.randn(1, H, Sk, 128, generator=g).to(DEV, torch.bfloat16)
-    v = torch.randn(1, H, Sk, 128, generator=g).to(DEV, torch.bfloat16)
+    q = torch.randn(1, H, Sq, D, generator=g).to(DEV, torch.bfloat16)
+    k = torch.randn(1, H, Sk, D, generator=g).to(DEV, torch.bfloat16)
+    v = torch.randn(1, H, Sk, D, generator=g).to(DEV, torch.bfloat16)
     out = _core.dense_attention(q, k, v, qs, ks, qkv_fp8=True)          # [1, Sq, H, D]
     ref16 = _core.dense_attention(q, k, v, qs, ks)
     assert torch.isfinite(out.float()).all()
@@ -302,12 +309,12 @@ def test_fp8_hip_graph_capture_and_replay():
 
 def _random_fp8_cases():
     import test_gpu_random_layouts as R
-    return [c for c in R._cases() if c[2] == 128]
+    return R._cases()   # both head dims
 
 
 @pytest.mark.parametrize("case", _random_fp8_cases(), ids=lambda c: f"{c[0]}-{c[1]}")
 def test_fp8_random_layouts(case):
-    """The randomised layouts of test_gpu_random_layouts (head_dim 128 ones) through the fp8 K5: same mask as the 2-byte
+    """The randomised layouts of test_gpu_random_layouts (both head dims) through the fp8 K5: same mask as the 2-byte
     path, byte-exact images, output within the fp8 tolerance of the fp8-aware oracle, no NaN in the awkward corners."""
     from rectified_spaattn_amd import _core, synth
     i, variant, D, H, lay, top_k, p, nbw = case

@@ -125,11 +125,10 @@ def test_cogvideox_768p_full_size():
                   [0, 165, 329], D=64)
 
 
-def _check_config_fp8(name, spec, lay, H, top_k, p, nbr, sample_rows, seed=77):
+def _check_config_fp8(name, spec, lay, H, top_k, p, nbr, sample_rows, seed=77, D=128):
     """fp8 K5 at full size: operand images byte-exact on the sampled heads, kept lists identical to the 2-byte path,
     sampled query blocks against the fp8-aware oracle (tolerances of tests/test_gpu_fp8.py)."""
     from rectified_spaattn_amd import _core
-    D = 128
     q, k, v = _gen(H, lay.S, D, seed)
     tn = torch.from_numpy(nbr) if nbr is not None else None
     out, parts = _core.rectified_attention(q, k, v, spec, top_k, p, tn, return_parts=True, qkv_fp8=True)
@@ -196,3 +195,11 @@ def test_hunyuan_720p_fp8_full_size():
     nbr = jenga_gilbert.gilbert_block_neighbor_mapping(32, 45, 80).numpy()
     _check_config_fp8("hunyuan-fp8", _core.LayoutSpec.hunyuan(S, nt), orc.layout_hunyuan(S, nt), 2, 90, 0.05, nbr,
                       [0, 437, 899])
+
+
+def test_cogvideox_768p_fp8_full_size():
+    """CogVideoX1.5 768p with e4m3 operands: head dim 64 through K1's image form, the tail blocks and the fp8 K5."""
+    from rectified_spaattn_amd import _core
+    S = 42466
+    _check_config_fp8("cogvideox-fp8", _core.LayoutSpec.cogvideo(S, 226), orc.layout_cogvideo(S, 226), 2, 82, 0.3, None,
+                      [0, 165, 329], D=64)
