@@ -217,7 +217,7 @@ typedef struct rsa_fp8_operands {
                        * followed by the K mean mu, [BH, D] fp32                                                            */
 } rsa_fp8_operands;
 
-/* Bytes of the four members (member order) and their 256-B-rounded sum.  D = 128 only. */
+/* Bytes of the four members (member order) and their 256-B-rounded sum.  D = 128 or 64. */
 int rsa_fp8_operand_bytes(const rsa_layout* lay, size_t sizes[4], size_t* total);
 int rsa_carve_fp8_operands(const rsa_layout* lay, void* ws, size_t ws_bytes, rsa_fp8_operands* out);
 
@@ -251,7 +251,7 @@ int rsa_rectified_attention_fp8(const rsa_layout* lay, rsa_tensor4 q, rsa_tensor
 int rsa_rel_l1(const void* a, const void* b, int64_t n, int dtype, float* out2, float* scratch, void* stream);
 
 /* rsa_dense_fwd with e4m3 operands (block-scaled images produced inside): quantisation pass + the fp8 kernel in dense
- * mode.  workspace: >= *total of rsa_dense_fp8_bytes, 256-B aligned.  D = 128 only. */
+ * mode.  workspace: >= *total of rsa_dense_fp8_bytes, 256-B aligned.  D = 128 or 64. */
 int rsa_dense_fp8_bytes(int B, int H, int Sq, int Sk, int D, size_t* total);
 int rsa_dense_fwd_fp8(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
                       int q_split, int kv_split, void* workspace, size_t workspace_bytes, rsa_out4 out, void* stream);
