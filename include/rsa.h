@@ -255,6 +255,10 @@ int rsa_rel_l1(const void* a, const void* b, int64_t n, int dtype, float* out2, 
 int rsa_dense_fp8_bytes(int B, int H, int Sq, int Sk, int D, size_t* total);
 int rsa_dense_fwd_fp8(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
                       int q_split, int kv_split, void* workspace, size_t workspace_bytes, rsa_out4 out, void* stream);
+/* ... with causal = True inside each segment (rsa_dense_causal_fwd's meaning: bottom-right aligned, attn.py:108-116). */
+int rsa_dense_causal_fwd_fp8(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
+                             int q_split, int kv_split, void* workspace, size_t workspace_bytes, rsa_out4 out,
+                             void* stream);
 
 /* ---- multi-GPU: the exchange step at the layer boundary.  The path itself shards by (batch, head) with
  * NO collective (reference: no cross-head dependency anywhere, rectified_hunyuan_attn.py:211-277, gapr_mask.py:15-42);

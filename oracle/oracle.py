@@ -495,7 +495,7 @@ def _fp8_dequant(ops, bh, i, rows, D):
     return val[:rows]
 
 
-def dense_attention_fp8(q, k, v, q_split: Optional[int] = None, kv_split: Optional[int] = None):
+def dense_attention_fp8(q, k, v, q_split: Optional[int] = None, kv_split: Optional[int] = None, causal: bool = False):
     """Dense attention of ONE head on e4m3 operands as rsa_dense_fwd_fp8 quantises them (block-scaled images over all Sq /
     Sk rows, K minus fp8_kmean over its Sk rows), two-segment semantics of attn.py:107-120.  q [Sq, D], k/v [Sk, D] fp32
     -> [Sq, D].  (With two segments the shift q.mu is still one constant per query row, so both softmaxes are unchanged.)"""
@@ -509,6 +509,12 @@ def dense_attention_fp8(q, k, v, q_split: Optional[int] = None, kv_split: Option
     out = np.zeros((Sq, D), np.float64)
     sm = float(D) ** -0.5
     cols = np.arange(Sk)
+    if causal:   # per segment, flash-attn's bottom-right alignment (dense_attention)
+        if q_split > 0 and kv_split > 0:
+            out[:q_split] = dense_attention(qd[:q_split], kd[:kv_split], vd[:kv_split], causal=True)
+        if q_split < Sq and kv_split < Sk:
+            out[q_split:] = dense_attention(qd[q_split:], kd[kv_split:], vd[kv_split:], causal=True)
+        return out
     if q_split > 0:
         out[:q_split] = _masked_attention_rows(qd[:q_split], kd, vd, cols < kv_split, sm)
     if q_split < Sq:

@@ -344,15 +344,15 @@ def dense_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, q_split: 
     kv_split = Sk if kv_split is None else int(kv_split)
     out = torch.empty((B, Sq, H, D), dtype=q.dtype, device=q.device)
     o4 = RsaOut4(out.data_ptr(), out.stride(0), out.stride(2), out.stride(1))
-    if qkv_fp8 and causal:
-        raise NotImplementedError("causal attention runs on the 2-byte kernel only (no causal form of the e4m3 dense kernel)")
     if qkv_fp8:  # block-scaled e4m3 images of q, k, v + the fp8 MFMA kernel (head_dim 64 / 128)
         total = ctypes.c_size_t()
         _lib.check(L.rsa_dense_fp8_bytes(B, H, Sq, Sk, D, ctypes.byref(total)), "rsa_dense_fp8_bytes")
         ws = torch.empty(total.value, dtype=torch.uint8, device=q.device)
         with torch.cuda.device(q.device):
-            _lib.check(L.rsa_dense_fwd_fp8(B, H, Sq, Sk, D, dtype_code(q.dtype), _t4(q), _t4(k), _t4(v), q_split,
-                                           kv_split, ws.data_ptr(), ws.numel(), o4, _stream()), "rsa_dense_fwd_fp8")
+            fn8, name8 = ((L.rsa_dense_causal_fwd_fp8, "rsa_dense_causal_fwd_fp8") if causal
+                          else (L.rsa_dense_fwd_fp8, "rsa_dense_fwd_fp8"))
+            _lib.check(fn8(B, H, Sq, Sk, D, dtype_code(q.dtype), _t4(q), _t4(k), _t4(v), q_split,
+                           kv_split, ws.data_ptr(), ws.numel(), o4, _stream()), name8)
         return out
     fn, name = (L.rsa_dense_causal_fwd, "rsa_dense_causal_fwd") if causal else (L.rsa_dense_fwd, "rsa_dense_fwd")
     with torch.cuda.device(q.device):

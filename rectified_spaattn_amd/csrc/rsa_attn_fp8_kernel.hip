@@ -49,7 +49,7 @@ struct Attn8Args {
     int mode, H, Sq, Sk, Sq_pad, Sk_pad;  // padded rows of q8 and of k8 / v8t
     int NBv, NQB, NB_total;
     int kv_valid, kv_text_valid, q_text_end;
-    int q_split, kv_split;
+    int q_split, kv_split, causal;
     int n_heavy_pad, NBp, BH;
     int out_fp16;
     float* tpart;        // split-KV partials of the text query blocks (layout of rsa_attn.hip's combine kernel) or null
@@ -189,14 +189,33 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
             zero_r = !store_r && grow < a.Sq;
         }
     } else {
+        // dense mode: one or two (query rows, key rows) segments; causal = bottom-right aligned inside a segment (as
+        // rsa_attn_kernel.hip: the flash-attn convention of the reference's "flash" mode, attn.py:108-116)
         const int row0 = qblk * RSA_BLOCK, row1 = row0 + RSA_BLOCK;
-        if (grow < a.q_split) { lo_r = 0; hi_r = a.kv_split; }
-        else { lo_r = a.kv_split; hi_r = a.Sk; }
+        auto seg_hi = [&](int row) -> int {   // one past the last key row `row` may see
+            const bool s1 = row >= a.q_split;
+            const int lo = s1 ? a.kv_split : 0, hi = s1 ? a.Sk : a.kv_split;
+            if (!a.causal) return hi;
+            const int rows = s1 ? a.Sq - a.q_split : a.q_split, rin = row - (s1 ? a.q_split : 0);
+            const int lim = lo + rin + 1 + ((hi - lo) - rows);
+            return lim < lo ? lo : (lim < hi ? lim : hi);
+        };
+        lo_r = grow < a.q_split ? 0 : a.kv_split;
+        hi_r = seg_hi(grow < a.Sq ? grow : a.Sq - 1);
         store_r = grow < a.Sq;
         int lo_min;
-        if (row1 <= a.q_split) { lo_min = 0; lo_max = 0; hi_min = hi_max = a.kv_split; }
-        else if (row0 >= a.q_split) { lo_min = lo_max = a.kv_split; hi_min = hi_max = a.Sk; }
-        else { lo_min = 0; lo_max = a.kv_split; hi_min = a.kv_split; hi_max = a.Sk; }
+        const int rlast = (row1 <= a.Sq ? row1 : a.Sq) - 1;   // last real row of the block
+        if (row1 <= a.q_split) { lo_min = 0; lo_max = 0; }
+        else if (row0 >= a.q_split) { lo_min = lo_max = a.kv_split; }
+        else { lo_min = 0; lo_max = a.kv_split; }
+        // seg_hi grows with the row inside a segment: extremes of the block sit at its first / last row of each segment
+        hi_min = seg_hi(row0);
+        hi_max = seg_hi(rlast);
+        if (row0 < a.q_split && rlast >= a.q_split) {   // the block straddles the two segments
+            const int h0 = seg_hi(a.q_split - 1), h1 = seg_hi(a.q_split);
+            hi_min = hi_min < h1 ? hi_min : h1;
+            hi_max = hi_max > h0 ? hi_max : h0;
+        }
         first_blk = lo_min / RSA_BLOCK;
         n_items = (hi_max + RSA_BLOCK - 1) / RSA_BLOCK - first_blk;
         if (hi_max <= lo_min) n_items = 0;
@@ -607,7 +626,7 @@ extern "C" int rsa_block_sparse_fwd_fp8(const rsa_layout* l, const rsa_fp8_opera
     a.NBv = l->NBv; a.NQB = l->NB_total; a.NB_total = l->NB_total;
     a.kv_valid = l->kv_valid; a.kv_text_valid = l->kv_text_valid;
     a.q_text_end = l->NBv * RSA_BLOCK + l->q_text_valid;
-    a.q_split = 0; a.kv_split = 0;
+    a.q_split = 0; a.kv_split = 0; a.causal = 0;
     a.out_fp16 = l->dtype == RSA_FP16;
     return launch_attn8(a, l->B * l->H, l->D, static_cast<hipStream_t>(stream));
 }
@@ -630,9 +649,9 @@ extern "C" int rsa_rectified_attention_fp8(const rsa_layout* l, rsa_tensor4 q, r
 
 // Dense attention (two-segment varlen semantics of rsa_dense_fwd) with fp8 operands: quantise, then the same kernel in
 // its dense mode.  Workspace: rsa_dense_fp8_bytes.
-extern "C" int rsa_dense_fwd_fp8(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k,
-                                 rsa_tensor4 v, int q_split, int kv_split, void* workspace, size_t workspace_bytes,
-                                 rsa_out4 out, void* stream) {
+static int dense_fwd_fp8(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
+                         int q_split, int kv_split, int causal, void* workspace, size_t workspace_bytes, rsa_out4 out,
+                         void* stream) {
     if (B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0) return RSA_ERR_BAD_ARG;
     if (D != 128 && D != 64) return RSA_ERR_UNSUPPORTED;
     if (dtype != RSA_BF16 && dtype != RSA_FP16) return RSA_ERR_UNSUPPORTED;
@@ -656,7 +675,19 @@ extern "C" int rsa_dense_fwd_fp8(int B, int H, int Sq, int Sk, int D, int dtype,
         a.exps_stride = nbm;
     }
     a.kv_valid = Sk; a.kv_text_valid = Sk; a.q_text_end = 0;
-    a.q_split = q_split; a.kv_split = kv_split;
+    a.q_split = q_split; a.kv_split = kv_split; a.causal = causal;
     a.out_fp16 = dtype == RSA_FP16;
     return launch_attn8(a, B * H, D, s);
+}
+
+extern "C" int rsa_dense_fwd_fp8(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k,
+                                 rsa_tensor4 v, int q_split, int kv_split, void* workspace, size_t workspace_bytes,
+                                 rsa_out4 out, void* stream) {
+    return dense_fwd_fp8(B, H, Sq, Sk, D, dtype, q, k, v, q_split, kv_split, 0, workspace, workspace_bytes, out, stream);
+}
+
+extern "C" int rsa_dense_causal_fwd_fp8(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k,
+                                        rsa_tensor4 v, int q_split, int kv_split, void* workspace, size_t workspace_bytes,
+                                        rsa_out4 out, void* stream) {
+    return dense_fwd_fp8(B, H, Sq, Sk, D, dtype, q, k, v, q_split, kv_split, 1, workspace, workspace_bytes, out, stream);
 }

@@ -27,7 +27,7 @@ def main():
         two = bool(rng.integers(0, 3) == 0)
         qs = int(rng.integers(0, Sq + 1)) if two else None
         ks = int(rng.integers(0, Sk + 1)) if two else None
-        fp8 = (not causal) and bool(rng.integers(0, 2))
+        fp8 = bool(rng.integers(0, 2))
         g = torch.Generator().manual_seed(int(rng.integers(0, 1 << 30)))
         dt = torch.float16 if f16 else torch.bfloat16
         q = torch.randn(1, H, Sq, D, generator=g).to(DEV, dt)
@@ -40,7 +40,7 @@ def main():
         for h in range(H):
             qf, kf, vf = (t[0, h].float().cpu().numpy() for t in (q, k, v))
             if fp8:
-                ref = orc.dense_attention_fp8(qf, kf, vf, qs, ks)
+                ref = orc.dense_attention_fp8(qf, kf, vf, qs, ks, causal=causal)
                 mx = 8e-2
             else:
                 if two:

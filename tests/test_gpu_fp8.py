@@ -388,3 +388,27 @@ def test_fp8_p_forms_code_map_against_exact_exponential():
     b_code, b_exp = np.abs(outs[0] - ref16).mean(), np.abs(outs[2] - ref16).mean()
     print(f"vs bf16 oracle (mean): code map {b_code:.4e}, exponential {b_exp:.4e}")
     assert b_code <= 1.03 * b_exp
+
+
+@pytest.mark.parametrize("D", [128, 64])
+@pytest.mark.parametrize("Sq,Sk,qs,ks", [(700, 700, None, None), (300, 1000, None, None), (1000, 300, None, None),
+                                         (640, 640, 200, 260)], ids=["square", "more_keys", "fewer_keys", "two_segments"])
+def test_fp8_dense_kernel_causal(Sq, Sk, qs, ks, D):
+    """The e4m3 dense kernel's causal form (bottom-right aligned inside each segment, as rsa_dense_causal_fwd): rows that
+    see no key give zeros; against the fp8-aware oracle and, loosely, the 2-byte kernel."""
+    from rectified_spaattn_amd import _core
+    g = torch.Generator().manual_seed(Sq + 3 * Sk + D)
+    H = 2
+    q = torch.randn(1, H, Sq, D, generator=g).to(DEV, torch.bfloat16)
+    k = torch.randn(1, H, Sk, D, generator=g).to(DEV, torch.bfloat16)
+    v = torch.randn(1, H, Sk, D, generator=g).to(DEV, torch.bfloat16)
+    out = _core.dense_attention(q, k, v, qs, ks, qkv_fp8=True, causal=True)
+    ref16 = _core.dense_attention(q, k, v, qs, ks, causal=True)
+    assert torch.isfinite(out.float()).all()
+    for h in range(H):
+        ref = orc.dense_attention_fp8(*(t[0, h].float().cpu().numpy() for t in (q, k, v)), qs, ks, causal=True)
+        got = out[0, :, h].float().cpu().numpy()
+        rel = np.linalg.norm(got - ref, axis=-1) / np.maximum(np.linalg.norm(ref, axis=-1), 1e-3)
+        assert rel.max() <= 0.2 and np.median(rel) <= 0.05, (rel.max(), np.median(rel))   # rows with 1-2 keys reproduce V
+    d16 = (out.float() - ref16.float()).abs()
+    assert d16.mean() <= FP8_MEAN_VS_BF16

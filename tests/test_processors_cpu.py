@@ -181,7 +181,10 @@ def test_cabi_fp8_entry_points_validate_on_the_host():
     assert lib.rsa_fp8_operand_bytes(ctypes.byref(lay), ctypes.byref(s4), ctypes.byref(tot)) == 0
     assert list(s4)[:3] == [2 * 256 * 128] * 3 and tot.value >= 3 * 2 * 256 * 128
     lay64 = _lib.RsaLayout(1, 2, 64, 256, 2, 2, 0, 256, 256, 2, 0, 0, 256, 0)
-    assert lib.rsa_fp8_operand_bytes(ctypes.byref(lay64), ctypes.byref(s4), ctypes.byref(tot)) == -2   # head_dim 64
+    assert lib.rsa_fp8_operand_bytes(ctypes.byref(lay64), ctypes.byref(s4), ctypes.byref(tot)) == 0    # head_dim 64 is served
+    assert list(s4)[:3] == [2 * 256 * 64] * 3
+    lay32 = _lib.RsaLayout(1, 2, 32, 256, 2, 2, 0, 256, 256, 2, 0, 0, 256, 0)
+    assert lib.rsa_fp8_operand_bytes(ctypes.byref(lay32), ctypes.byref(s4), ctypes.byref(tot)) == -2   # head_dim 32 is not
     ops = _lib.RsaFp8Operands()
     assert lib.rsa_carve_fp8_operands(ctypes.byref(lay), None, 0, ctypes.byref(ops)) == -1             # null workspace
     assert lib.rsa_carve_fp8_operands(ctypes.byref(lay), ctypes.c_void_p(4096), 16, ctypes.byref(ops)) == -3  # too small
@@ -191,7 +194,8 @@ def test_cabi_fp8_entry_points_validate_on_the_host():
     d = ctypes.c_size_t()
     assert lib.rsa_dense_fp8_bytes(1, 2, 300, 500, 128, ctypes.byref(d)) == 0
     assert d.value >= 2 * (384 + 2 * 512) * 128
-    assert lib.rsa_dense_fp8_bytes(1, 2, 300, 500, 64, ctypes.byref(d)) == -2
+    assert lib.rsa_dense_fp8_bytes(1, 2, 300, 500, 64, ctypes.byref(d)) == 0 and d.value >= 3 * 2 * 512 * 64
+    assert lib.rsa_dense_fp8_bytes(1, 2, 300, 500, 32, ctypes.byref(d)) == -2
     assert lib.rsa_dense_fp8_bytes(0, 2, 300, 500, 128, ctypes.byref(d)) == -1
     # the tuning hook is inert unless the process opted in with RSA_TUNING=1 (then unknown keys are bad arguments)
     assert lib.rsa_set_tuning(b"no_such_key", 1) == (-1 if os.environ.get("RSA_TUNING") == "1" else -2)
