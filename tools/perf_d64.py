@@ -4,6 +4,9 @@ hand-placed twin, 2 = the product's -m form), interleaved."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 AB = os.environ.get("RSA_PERF_AB", "0") == "1"
+if os.environ.get("RSA_PERF_LIB") and not AB:
+    from rectified_spaattn_amd import _lib as _l0
+    _l0.LIB_PATH = os.path.abspath(os.environ["RSA_PERF_LIB"])
 if AB:
     os.environ["RSA_TUNING"] = "1"
     from rectified_spaattn_amd import _lib
@@ -42,3 +45,10 @@ if AB:
         outs[form] = call.attend().clone()
     L.rsa_set_tuning(b"k5_form", -1)
     print("forms 0 and 1 bit-identical at head dim 64:", bool(torch.equal(outs[0], outs[1])))
+if os.environ.get("RSA_PERF_FP8", "0") == "1":   # the e4m3 operand path at this shape (K1 writing the images + fp8 K5)
+    call8 = _core.StagedCall(q2, k2, v2, spec, 82, 0.0, None, qkv_fp8=True)
+    call8.select(); torch.cuda.synchronize()
+    for rnd in range(3):
+        m8, _ = timeit(call8.attend, n=7, warm=2)
+        ms8, _ = timeit(call8.select, n=5, warm=1)
+        print(f"round {rnd} fp8 sparse: K5 {m8:.3f} ms {fl/m8/1e9:.0f} TFLOP/s | select pass (with images) {ms8:.3f} ms", flush=True)
