@@ -83,11 +83,26 @@ class LayoutSpec:
 
 def check_head_dim(D: int) -> None:
     """The reference asserts head_dim in {16, 32, 64, 128} (rectified_hunyuan_attn.py:119-121); the gfx950 kernels are
-    built for 64 and 128 (every model the reference ships: 128, CogVideoX 64).  16 / 32 are rejected here, before
-    anything is allocated, with the same AssertionError type."""
+    built for 64 and 128 (every model the reference ships: 128, CogVideoX 64).  16 / 32 reach them zero-padded
+    (pad_small_head_dim) through rectified_attention / dense_attention; a StagedCall takes 64 / 128 only."""
     assert D in (16, 32, 64, 128), "head_dim must be in {16, 32, 64, 128}"  # reference :121
-    assert D in (64, 128), (f"head_dim {D}: the MI355X kernels are built for head_dim 64 and 128 "
-                            "(no reference pipeline uses 16 or 32)")
+    assert D in (64, 128), (f"head_dim {D}: the MI355X kernels are built for head_dim 64 and 128; pass head_dim 16 / 32 "
+                            "through rectified_attention / dense_attention, which zero-pad them")
+
+
+# head dims the reference's assert admits but no kernel is built for (no reference pipeline uses them) -> the padded head
+# dim that serves them EXACTLY: D' = 4 D, so (D') ** -0.5 is exactly half of D ** -0.5 (also after rounding to fp32) and
+# doubling Q -- exact in a binary format -- restores every score: pooled scores, GAPR comparison, softmax statistics and
+# hence the block mask are bit-identical to the native-D contract; zero columns add exact zeros to every dot product,
+# mean and deviation.  Costs 4x the MFMA work of a native kernel: a compatibility path, not a fast one.
+_PAD_HEAD_DIM = {16: 64, 32: 128}
+
+
+def pad_small_head_dim(q, k, v):
+    """[B, H, S, D] with D in {16, 32} -> (2 q | 0, k | 0, v | 0) with D' = 4 D columns (see _PAD_HEAD_DIM)."""
+    D = q.shape[-1]
+    pad = (0, _PAD_HEAD_DIM[D] - D)
+    return torch.nn.functional.pad(q * 2, pad), torch.nn.functional.pad(k, pad), torch.nn.functional.pad(v, pad)
 
 
 def dtype_code(dtype: torch.dtype) -> int:
@@ -311,6 +326,13 @@ def rectified_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, spec:
     K1 pool_stats -> K2 pooled_scores -> K3 select_mask -> K4 compensation -> K5 block_sparse_fwd on the
     current stream; no host synchronisation, no K/V mutation (the reference zeroes masked K/V rows in place,
     hunyuan :307-308; here they are treated as zero by predication)."""
+    if q.shape[-1] in _PAD_HEAD_DIM:   # head dim 16 / 32: served zero-padded (exactly; see _PAD_HEAD_DIM)
+        B, H, S, D = q.shape
+        r = rectified_attention(*pad_small_head_dim(q, k, v), spec, top_k, p_remain, block_neighbor_list, return_parts,
+                                True, qkv_fp8)
+        o = (r[0] if return_parts else r)[..., :D]
+        o = o.contiguous() if shape_xfuse else o.reshape(B, S, H * D)
+        return (o, r[1]) if return_parts else o
     # return_parts hands the buffers to the caller, so those calls get their own set
     call = StagedCall(q, k, v, spec, top_k, p_remain, block_neighbor_list, qkv_fp8=qkv_fp8,
                       reuse_buffers=not return_parts)
@@ -334,6 +356,8 @@ def dense_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, q_split: 
     Rows < q_split attend kv [0, kv_split); rows >= q_split attend kv [kv_split, Sk) (attn.py:107-120); causal: inside a
     segment key j is visible to row i iff j <= i + (keys - rows) (2-byte kernel only)."""
     _require_device(q, k, v)
+    if q.shape[-1] in _PAD_HEAD_DIM and k.shape[-1] == q.shape[-1] == v.shape[-1]:   # head dim 16 / 32: zero-padded, exact
+        return dense_attention(*pad_small_head_dim(q, k, v), q_split, kv_split, qkv_fp8, causal)[..., :q.shape[-1]].contiguous()
     L = _lib.lib()
     B, H, Sq, D = q.shape
     Sk = k.shape[2]
@@ -373,6 +397,11 @@ def rectified_attention_onecall(q: torch.Tensor, k: torch.Tensor, v: torch.Tenso
     """Same operator through the single C entry point rsa_rectified_attention with one caller-provided workspace
     (what a non-Python host would call).  Returns ([B, S, H*D], workspace)."""
     _require_device(q, k, v)
+    if q.shape[-1] in _PAD_HEAD_DIM:   # head dim 16 / 32: zero-padded, exact
+        B, H, S, D = q.shape
+        o, workspace = rectified_attention_onecall(*pad_small_head_dim(q, k, v), spec, top_k, p_remain, block_neighbor_list,
+                                                   workspace, qkv_fp8)
+        return o.view(B, S, H, -1)[..., :D].reshape(B, S, H * D), workspace
     L = _lib.lib()
     B, H, S, D = q.shape
     q, k, v = _as_bhsd(q), _as_bhsd(k), _as_bhsd(v)

@@ -310,3 +310,41 @@ def test_dense_kernel_at_the_maximum_sequence_length(fp8):
     with pytest.raises((AssertionError, RuntimeError)):                      # one block more is refused
         _core.dense_attention(q[:, :, :256], torch.zeros(1, 1, S + 128, D, dtype=torch.bfloat16, device=DEV),
                               torch.zeros(1, 1, S + 128, D, dtype=torch.bfloat16, device=DEV))
+
+
+@pytest.mark.parametrize("D", [16, 32])
+def test_head_dims_16_and_32_are_served_exactly_through_zero_padding(D):
+    """The reference's assert admits head_dim 16 and 32 (rectified_hunyuan_attn.py:119-121); no kernel is built for them, so
+    they run zero-padded to 4 D with Q doubled: (4 D) ** -0.5 is exactly half of D ** -0.5, so every statistic of the mask
+    selection -- probabilities, GAPR bytes, R, the kept mask -- equals the oracle's at the NATIVE head dim bit for bit, and
+    the output is within the usual tolerance.  Sparse operator (both operand paths), one-call form, dense incl. causal."""
+    from rectified_spaattn_amd import _core, synth
+    from oracle import oracle as orc
+    lay = orc.layout_hunyuan(5 * 128 + 256, 5 * 128 + 131)
+    H, top_k, p = 2, 2, 0.3
+    q, k, v = synth.structured_qkv(31 + D, 1, H, lay.S, D, smooth=0.0)
+    tq, tk, tv = (torch.from_numpy(x).to(DEV, torch.bfloat16) for x in (q, k, v))
+    q, k, v = (x.float().cpu().numpy() for x in (tq, tk, tv))
+    spec = _core.LayoutSpec(lay.S, lay.NB_total, lay.NBv, lay.n_txt, lay.kv_valid, lay.pool_valid, lay.text_end_block,
+                            lay.ffb, lay.q_text_valid, lay.kv_text_valid)
+    out, bufs = _core.rectified_attention(tq, tk, tv, spec, top_k, p, None, return_parts=True)
+    assert out.shape == (1, lay.S, H * D)
+    ref, parts = orc.rectified_attention(q, k, v, lay, top_k, p, None, want_parts=True)
+    for bh in range(H):
+        kept = orc.unpack_bits(bufs["bitmask"][bh].cpu().numpy().view(np.uint32), lay.NB_total)
+        assert np.array_equal(kept, parts[bh]["kept"]) and np.array_equal(bufs["unrel"][bh].cpu().numpy(), parts[bh]["unrel"])
+        assert np.array_equal(bufs["probs"][bh].cpu().numpy(), parts[bh]["probs"])
+        assert np.array_equal(bufs["R"][bh].cpu().numpy(), parts[bh]["R"])
+    err = np.abs(out.float().cpu().numpy() - ref)
+    assert err.max() <= 2e-2 and err.mean() <= 2e-3, (err.max(), err.mean())
+    one, _ = _core.rectified_attention_onecall(tq, tk, tv, spec, top_k, p, None)
+    assert torch.equal(one, out)
+    o8 = _core.rectified_attention(tq, tk, tv, spec, top_k, p, None, qkv_fp8=True)
+    e8 = np.abs(o8.float().cpu().numpy() - ref)
+    assert e8.mean() <= 2e-2 and np.isfinite(e8).all()
+    for causal in (False, True):
+        od = _core.dense_attention(tq[:, :, :700], tk[:, :, :500], tv[:, :, :500], causal=causal).float().cpu().numpy()
+        assert od.shape == (1, 700, H, D)
+        for h in range(H):
+            rd = orc.dense_attention(q[0, h, :700], k[0, h, :500], v[0, h, :500], causal=causal)
+            assert np.abs(od[0, :, h] - rd).max() <= 2e-2

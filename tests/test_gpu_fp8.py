@@ -114,7 +114,7 @@ def test_fp8_onecall_matches_staged():
 
 def test_fp8_rejects_head_dims_it_has_no_kernel_for():
     from rectified_spaattn_amd import _core
-    z = torch.zeros(1, 1, 256, 32, dtype=torch.bfloat16, device=DEV)
+    z = torch.zeros(1, 1, 256, 48, dtype=torch.bfloat16, device=DEV)   # (16 / 32 are served zero-padded; 48 is no head dim of the reference)
     with pytest.raises(AssertionError):
         _core.rectified_attention(z, z, z, _core.LayoutSpec.wan(256, 0), 1, 0.3, None, qkv_fp8=True)
 
