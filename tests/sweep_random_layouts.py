@@ -19,7 +19,7 @@ def cases(seed, n, nbv_max=40):
     rng = np.random.default_rng(seed)
     for i in range(n):
         variant = ["wan", "hunyuan", "flux", "cogvideo"][int(rng.integers(0, 4))]
-        D = int(rng.choice([64, 128]))
+        D = int(rng.choice([16, 32, 64, 128]))   # 16 / 32: the zero-padded path
         H = int(rng.integers(1, 3))
         nbv = int(rng.integers(1, nbv_max + 1))
         if variant == "wan":
