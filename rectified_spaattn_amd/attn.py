@@ -1,7 +1,9 @@
 """Dense attention entry point `fullattn` -- same signature, layouts and modes as the reference's
 rectified_spaattn/attn.py:60-154, served by the HIP dense kernel (rsa_dense_fwd) for device tensors.
 
-causal=True is served too (per-row key limits of the same kernel; flash-attn's bottom-right alignment inside each segment).
+causal=True is served for "torch" / "vanilla" (per-row key limits of the same kernel).  In mode "flash" it is IGNORED, as in the
+reference: attn.py:107-116 hands flash_attn_varlen_func only the cu_seqlens / max_seqlen arguments, so its flash mode is never
+causal (a warning says so once).
 Modes on DEVICE tensors all run the same gfx950 kernel (there is no flash-attn / SDPA dependency):
   "flash"   two-segment varlen semantics from cu_seqlens_q / cu_seqlens_kv (attn.py:107-120)
   "torch"   plain attention, optional boolean key-padding mask [b,1,1,s1] (attn.py:101-106)
@@ -10,6 +12,7 @@ CPU tensors: "torch" and "vanilla" keep the reference's own CPU behaviour (plain
 BASELINE config 1, the CPU-runnable plumbing case); "flash" needs the device and raises.
 """
 import math
+import warnings
 
 import torch
 import torch.nn.functional as F
@@ -24,6 +27,7 @@ MEMORY_LAYOUT = {
     "torch": (lambda x: x, lambda x: x),
     "vanilla": (lambda x: x, lambda x: x),
 }
+_WARNED_FLASH_CAUSAL = False
 
 
 def get_cu_seqlens(img_seq_len, txt_seq_len, text_len, device="cuda"):
@@ -164,6 +168,14 @@ def fullattn(q, k, v, mode="flash", drop_rate=0, attn_mask=None, causal=False, c
                 if not prefix:
                     k, v = _compact_keys(k, v, rows, counts)
                 splits = [(S, c) for c in counts]
+        if causal and mode == "flash":
+            # the reference's flash branch does not forward `causal` (attn.py:107-116): same call, same (non-causal) result
+            global _WARNED_FLASH_CAUSAL
+            if not _WARNED_FLASH_CAUSAL:
+                _WARNED_FLASH_CAUSAL = True
+                warnings.warn("fullattn(mode='flash', causal=True): the reference ignores `causal` in flash mode "
+                              "(attn.py:107-116); so does this implementation -- use mode='torch' for causal attention")
+            causal = False
         return _device_dense(q, k, v, splits, dense_fp8, causal=bool(causal))
     # ---- CPU tensors: the reference's CPU-runnable modes ----
     if mode == "flash":

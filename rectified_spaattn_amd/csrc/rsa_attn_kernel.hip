@@ -164,8 +164,9 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
         }
     } else {
         // dense mode: one or two (query rows, key rows) segments (attn.py:107-120); causal = bottom-right aligned inside a
-        // segment (the flash-attn convention the reference's "flash" mode forwards, attn.py:108-116; equal to the top-left
-        // form of its "torch" / "vanilla" modes whenever a segment has as many keys as rows)
+        // segment (flash-attn's convention; equal to the top-left form of the reference's "torch" / "vanilla" modes,
+        // attn.py:101-106 / :129-133, whenever a segment has as many keys as rows -- the only case the Python side lets
+        // through.  The reference's "flash" mode never passes `causal` on, attn.py:107-116, and neither does attn.py here)
         const int row0 = qblk * 128, row1 = row0 + 128;
         auto seg_hi = [&](int row) -> int {   // one past the last key row `row` may see
             const bool s1 = row >= a.q_split;
