@@ -68,3 +68,40 @@ def case_inputs(meta):
         lay = orc.layout_wan(meta["S"], meta.get("ffb", 0))
     nbr = synth.banded_neighbors(lay.NBv, meta["nb_width"]) if meta["nb_width"] >= 0 else None
     return q, k, v, lay, nbr
+
+
+# round 4: the reference's own mask builder at BASELINE's FULL sizes, one head (make_golden.py headline)
+HEADLINE_CASES = ["hunyuan_115456", "flux_66048", "wan_75600"]
+
+
+def load_headline_case(name):
+    """tests/golden/headline_<name>.npz -> (meta, dict one_hot [NBv, NB_total], nogapr [NBv, NBv], num_blocks_needed [NBv],
+    probs_rowsum, probs_sample (every NBv//8-th row), mismatch_rows / mismatch_margin as recorded by the generator)."""
+    z = np.load(os.path.join(GOLDEN, f"headline_{name}.npz"))
+    meta = ast.literal_eval(str(z["meta"]))
+    oh = np.unpackbits(z["one_hot"], axis=-1)[..., : int(z["one_hot_shape"][-1])]
+    ng = np.unpackbits(z["nogapr"], axis=-1)[..., : int(z["nogapr_shape"][-1])]
+    return meta, dict(one_hot=oh, nogapr=ng, num_blocks_needed=z["num_blocks_needed"].astype(np.int32),
+                      probs_rowsum=z["probs_rowsum"], probs_sample=z["probs_sample"],
+                      mismatch_rows=z["mismatch_rows"], mismatch_margin=z["mismatch_margin"])
+
+
+def headline_inputs(meta):
+    """One head of the headline fixture: q, k, v [S, D] fp32 (bf16-representable; the numpy twin of the device generator),
+    oracle Layout, neighbour matrix (true Gilbert neighbours for the HunyuanVideo case).  k / v rows past the layout's
+    pooling limit are zeroed, as the reference operator does in place (hunyuan :307-308)."""
+    from oracle import oracle as orc
+    from rectified_spaattn_amd import synth
+    from rectified_spaattn_amd.utils import jenga_gilbert
+    S, D = meta["S"], meta["D"]
+    q, k, v = synth.structured_qkv(meta["seed"], 1, 1, S, D)
+    var = meta["variant"]
+    nbr = None
+    if var == "hunyuan":
+        lay = orc.layout_hunyuan(S, meta["num_true"])
+        nbr = jenga_gilbert.gilbert_block_neighbor_mapping(*meta["gilbert"]).numpy()
+    elif var == "flux":
+        lay = orc.layout_flux(S, meta["text_length"])
+    else:
+        lay = orc.layout_wan(S, meta["ffb"])
+    return q[0, 0], k[0, 0], v[0, 0], lay, nbr

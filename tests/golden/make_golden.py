@@ -510,6 +510,126 @@ def processors_round3():
     print("processors_r3.npz:", {k: v.shape for k, v in res.items()})
 
 
+def headline():
+    """Round 4: the reference's OWN mask builder at BASELINE's full sizes, one head, fp32 statistics.
+
+    `_build_block_index_with_importance_optimized` (hunyuan :171-280, flux :170-279, wan21 :171-273) is reached through the
+    whole operator (so key / value zeroing, padding, `attenable`, text block range are the operator's own), with the Triton
+    kernel and the flash call replaced by zero stubs -- only the mask-selection outputs are taken.  Inputs =
+    synth.structured_qkv (the CPU twin of the device generator, independent block centroids = bench regime R2), the
+    HunyuanVideo case with the true Gilbert neighbour matrix.  Stored: bit-packed one-hot mask, bit-packed GAPR mask, and
+    num_blocks_needed recomputed from the reference's returned probabilities with the reference's own torch expression
+    (sort descending, cumsum, <= p, +1, max with top_k: hunyuan :226-238) -- all < 1 MB per layout.
+
+    NO reseeding: if a row of the oracle differs from the reference, its margins are printed and stored
+    (`mismatch_rows`, `mismatch_margin`) and the tests report them.
+    """
+    _install_stubs()
+    import rectified_spaattn.attn as ref_attn
+    import rectified_spaattn.rectified_hunyuan_attn as ref_hy
+    import rectified_spaattn.rectified_flux_attn as ref_fx
+    import rectified_spaattn.rectified_wan21_attn as ref_wan
+    from oracle import oracle as orc
+    from rectified_spaattn_amd import synth
+    from rectified_spaattn_amd.utils import jenga_gilbert
+
+    torch.set_num_threads(8)
+    outdir = os.path.dirname(os.path.abspath(__file__))
+    ref_attn.flash_attn_varlen_func = lambda q, k, v, *a, **kw: torch.zeros_like(q)
+    for m in (ref_hy, ref_fx, ref_wan):
+        m._triton_block_sparse_attention_onehot = lambda q, k, v, *a, **kw: torch.zeros_like(q)
+        if hasattr(m, "flash_attn_varlen_func"):
+            m.flash_attn_varlen_func = ref_attn.flash_attn_varlen_func
+
+    cases = [
+        # name, variant, S, top_k, p, seed, kwargs   (test_gpu_fullsize.py's configurations)
+        ("hunyuan_115456", "hunyuan", 115456, 90, 0.05, 20251301, dict(num_true=115400, gilbert=(32, 45, 80))),
+        ("flux_66048", "flux", 66048, 51, 0.3, 20251302, dict(text_length=512)),
+        ("wan_75600", "wan", 75600, 147, 0.3, 20251303, dict(ffb=28)),
+    ]
+    only = os.environ.get("RSA_GOLDEN_ONLY")
+    for name, variant, S, top_k, p, seed, kw in cases:
+        if only and not name.startswith(only):
+            continue
+        D, B, H = 128, 1, 1
+        q, k, v = synth.structured_qkv(seed, B, H, S, D)
+        tq, tk, tv = (torch.from_numpy(x.copy()) for x in (q, k, v))
+        nbr = None
+        if variant == "hunyuan":
+            nt = kw["num_true"]
+            lay = orc.layout_hunyuan(S, nt)
+            mask = torch.zeros(B, 1, 1, S, dtype=torch.bool)
+            mask[..., :nt] = True
+            cu = torch.tensor([0, nt, S], dtype=torch.int32)
+            mod, extra = ref_hy, {}
+            call = dict(attn_mask=mask, cu_seqlens_q=cu, cu_seqlens_kv=cu, max_seqlen_q=S, max_seqlen_kv=S)
+            nbr = jenga_gilbert.gilbert_block_neighbor_mapping(*kw["gilbert"]).numpy()
+        elif variant == "flux":
+            lay = orc.layout_flux(S, kw["text_length"])
+            cu = torch.tensor([0, S, S], dtype=torch.int32)
+            mod, extra = ref_fx, dict(text_length=kw["text_length"])
+            call = dict(attn_mask=None, cu_seqlens_q=cu, cu_seqlens_kv=cu, max_seqlen_q=S, max_seqlen_kv=S)
+        else:
+            lay = orc.layout_wan(S, kw["ffb"])
+            cu = torch.tensor([0, S, S], dtype=torch.int32)
+            mod, extra = ref_wan, dict(first_frame_blocks=kw["ffb"])
+            call = dict(attn_mask=None, cu_seqlens_q=cu, cu_seqlens_kv=cu, max_seqlen_q=S, max_seqlen_kv=S)
+        tnbr = torch.from_numpy(nbr) if nbr is not None else None
+        captured = {}
+        orig_builder = mod._build_block_index_with_importance_optimized
+
+        def spy(*a, **k_):
+            r = orig_builder(*a, **k_)
+            captured["one_hot"], captured["probs"], captured["nogapr"] = (x.clone() for x in r)
+            return r
+
+        mod._build_block_index_with_importance_optimized = spy
+        try:
+            mod.rectified_block_sparse_attention(tq, tk, tv, top_k=top_k, block_neighbor_list=tnbr, p_remain_rates=p,
+                                                 **call, **extra)
+        finally:
+            mod._build_block_index_with_importance_optimized = orig_builder
+        one_hot = captured["one_hot"][0, 0].numpy().astype(np.uint8)     # [NBv, NB_total]
+        nogapr = captured["nogapr"][0, 0].numpy().astype(np.uint8)       # [NBv, NBv]
+        rprobs = captured["probs"][0, 0]                                 # [NBv, L] fp32
+        sp, _ = torch.sort(rprobs, dim=-1, descending=True)
+        nbn = torch.maximum((torch.cumsum(sp, dim=-1) <= p).sum(-1) + 1, torch.tensor(top_k)).numpy().astype(np.int32)
+        # ---- the oracle on the same head (test infrastructure talking to test infrastructure) ----
+        qh, kh, vh = q[0, 0], k[0, 0].copy(), v[0, 0].copy()
+        if lay.pool_valid < lay.S:
+            kh[lay.pool_valid:] = 0
+            vh[lay.pool_valid:] = 0
+        sel = orc.select_head(qh, kh, vh, lay, top_k, p, nbr)
+        bad_rows = [i for i in range(lay.NBv) if not (np.array_equal(sel["kept"][i], one_hot[i])
+                                                      and np.array_equal(sel["unrel"][i], nogapr[i]))]
+        dpr = float(np.abs(sel["probs"] - rprobs.numpy()).max())
+        nn_eq = int((np.maximum(sel["n_needed"], top_k) == nbn).sum())
+        print(f"headline {name}: NBv={lay.NBv} L={lay.L} kept={one_hot.mean():.4f} unrel={nogapr.mean():.4f} "
+              f"rows differing from the oracle: {len(bad_rows)}  max|dprobs|={dpr:.2e}  n_needed equal on {nn_eq}/{lay.NBv}")
+        margins = []
+        for i in bad_rows:
+            # margins of the row: smallest distance of the sorted cumulative sum to p, smallest gap between adjacent sorted
+            # probabilities around the cut, smallest |gain - err| of a flipped GAPR bit
+            po = np.sort(sel["probs"][i])[::-1].astype(np.float64)
+            cs = np.cumsum(po)
+            cut = int(nbn[i])
+            gap = float(po[max(cut - 2, 0): cut + 1][:-1].min() - po[max(cut - 2, 0): cut + 1][1:].max()) if cut >= 2 else 0.0
+            margins.append((i, float(np.abs(cs - p).min()), gap, int((sel["kept"][i] != one_hot[i]).sum()),
+                            int((sel["unrel"][i] != nogapr[i]).sum())))
+            print(f"   row {i}: min|cumsum - p| = {margins[-1][1]:.3e}, prob gap at the cut = {gap:.3e}, "
+                  f"mask bits differing {margins[-1][3]}, GAPR bits differing {margins[-1][4]}")
+        meta = dict(variant=variant, S=S, D=D, top_k=top_k, p=p, seed=seed, **kw)
+        np.savez_compressed(os.path.join(outdir, f"headline_{name}.npz"), meta=np.array(repr(meta)),
+                            one_hot=np.packbits(one_hot, axis=-1), one_hot_shape=np.array(one_hot.shape),
+                            nogapr=np.packbits(nogapr, axis=-1), nogapr_shape=np.array(nogapr.shape),
+                            num_blocks_needed=nbn.astype(np.int16),
+                            probs_rowsum=rprobs.sum(-1).numpy().astype(np.float32),
+                            probs_sample=rprobs[:: max(1, lay.NBv // 8)].numpy().astype(np.float32),
+                            mismatch_rows=np.array(bad_rows, np.int32),
+                            mismatch_margin=np.array(margins, np.float64).reshape(-1, 5))
+
+
+
 def _load_script(name, extra_stubs=()):
     """Execute /root/reference/scripts/<name>.py as a module (its __main__ block does not run) with the diffusers /
     torchvision-dependent imports replaced by inert stand-ins."""
@@ -808,7 +928,9 @@ def gilbert():
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "gilbert":
+    if len(sys.argv) > 1 and sys.argv[1] == "headline":
+        headline()
+    elif len(sys.argv) > 1 and sys.argv[1] == "gilbert":
         _install_stubs()
         gilbert()
     elif len(sys.argv) > 1 and sys.argv[1] == "processors_r2":

@@ -203,3 +203,36 @@ def test_cogvideox_768p_fp8_full_size():
     S = 42466
     _check_config_fp8("cogvideox-fp8", _core.LayoutSpec.cogvideo(S, 226), orc.layout_cogvideo(S, 226), 2, 82, 0.3, None,
                       [0, 165, 329], D=64)
+
+
+@pytest.mark.parametrize("name", ["hunyuan_115456", "flux_66048", "wan_75600"])
+def test_full_size_masks_against_the_reference_itself(name):
+    """Round 4: the HIP mask-selection pass at BASELINE's full sizes against the REFERENCE's own builder
+    (`_build_block_index_with_importance_optimized` run at that size on CPU, tests/golden/make_golden.py headline; inputs =
+    the numpy twin of the device generator, uploaded): kept bitmask, GAPR bytes and the per-row count, every row of the head,
+    bit for bit.  A differing row fails with its index (the generator stores the oracle-side margins)."""
+    from conftest import headline_inputs, load_headline_case
+    from rectified_spaattn_amd import _core
+    meta, gold = load_headline_case(name)
+    q, k, v, lay, nbr = headline_inputs(meta)
+    var = meta["variant"]
+    if var == "hunyuan":
+        spec = _core.LayoutSpec.hunyuan(meta["S"], meta["num_true"])
+    elif var == "flux":
+        spec = _core.LayoutSpec.flux(meta["S"], meta["text_length"])
+    else:
+        spec = _core.LayoutSpec.wan(meta["S"], meta["ffb"])
+    tq, tk, tv = (torch.from_numpy(x).to(DEV, torch.bfloat16)[None, None] for x in (q, k, v))
+    tn = torch.from_numpy(nbr) if nbr is not None else None
+    out, bufs = _core.rectified_attention(tq, tk, tv, spec, meta["top_k"], meta["p"], tn, return_parts=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    kept = _core.unpack_bitmask(bufs["bitmask"], lay.NB_total).cpu().numpy()[0]
+    unrel = bufs["unrel"][0].cpu().numpy()
+    bad = [i for i in range(lay.NBv) if not np.array_equal(kept[i], gold["one_hot"][i].astype(bool))]
+    assert not bad, f"{name}: kept mask differs from the reference's on rows {bad[:8]} ({len(bad)} of {lay.NBv})"
+    badg = [i for i in range(lay.NBv) if not np.array_equal(unrel[i] != 0, gold["nogapr"][i].astype(bool))]
+    assert not badg, f"{name}: GAPR mask differs from the reference's on rows {badg[:8]} ({len(badg)} of {lay.NBv})"
+    assert np.array_equal(bufs["counts"][0].cpu().numpy(), gold["one_hot"].sum(-1))
+    step = max(1, lay.NBv // 8)
+    np.testing.assert_allclose(bufs["probs"][0].cpu().numpy()[::step], gold["probs_sample"], rtol=2e-5, atol=1e-7)

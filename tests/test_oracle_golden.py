@@ -5,7 +5,8 @@ import os
 import numpy as np
 import pytest
 
-from conftest import B2_CASES, BIG_CASES, GOLDEN, OP_CASES, case_inputs, load_op_case, reference_rows
+from conftest import (B2_CASES, BIG_CASES, GOLDEN, HEADLINE_CASES, OP_CASES, case_inputs, headline_inputs, load_headline_case,
+                      load_op_case, reference_rows)
 from oracle import oracle as orc
 
 
@@ -45,6 +46,30 @@ def test_long_row_case_matches_reference(name):
     for a, i in enumerate(rows):
         err = np.abs(o[a] - gold["out"][0, i * 128:(i + 1) * 128].astype(np.float64))
         assert err.max() < 2.5e-3, f"{name}: block {i}: {err.max()}"
+
+
+@pytest.mark.parametrize("name", HEADLINE_CASES)
+def test_headline_size_mask_selection_matches_reference(name):
+    """BASELINE's FULL sizes (900 + 2 / 512 + 4 / 591 key blocks per row): every row of one head of the oracle's mask
+    selection against the reference's own `_build_block_index_with_importance_optimized` run at that size
+    (make_golden.py headline: one-hot mask, GAPR mask, num_blocks_needed).  A differing row is reported with its margins,
+    not reseeded away."""
+    meta, gold = load_headline_case(name)
+    assert gold["mismatch_rows"].size == 0, f"{name}: generator recorded rows differing from the oracle: {gold['mismatch_margin']}"
+    q, k, v, lay, nbr = headline_inputs(meta)
+    if lay.pool_valid < lay.S:
+        k, v = k.copy(), v.copy()
+        k[lay.pool_valid:] = 0
+        v[lay.pool_valid:] = 0
+    sel = orc.select_head(q, k, v, lay, meta["top_k"], meta["p"], nbr)
+    bad = [i for i in range(lay.NBv) if not np.array_equal(sel["kept"][i], gold["one_hot"][i])]
+    assert not bad, f"{name}: kept mask differs from the reference on rows {bad[:8]} ({len(bad)} rows)"
+    badg = [i for i in range(lay.NBv) if not np.array_equal(sel["unrel"][i], gold["nogapr"][i])]
+    assert not badg, f"{name}: GAPR mask differs from the reference on rows {badg[:8]} ({len(badg)} rows)"
+    assert np.array_equal(np.maximum(sel["n_needed"], meta["top_k"]), gold["num_blocks_needed"])
+    step = max(1, lay.NBv // 8)
+    np.testing.assert_allclose(sel["probs"][::step], gold["probs_sample"], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(sel["probs"].sum(-1), gold["probs_rowsum"], rtol=1e-5)
 
 
 def test_estimate_pr_gain_matches_reference():
