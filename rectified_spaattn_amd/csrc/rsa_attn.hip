@@ -19,6 +19,8 @@ static unsigned long long g_dbg_ptr = 0;   // diagnostics build: device buffer f
 void rsa_set_fp8_variant(int v);
 void rsa_set_fp8_smooth_k(int v);
 int rsa_launch_bsfwd(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int dtype, hipStream_t s);
+int rsa_launch_bsfwd64(const AttnArgs& a, dim3 grid, size_t lds_bytes, int dtype, hipStream_t s);
+static int g_k5_w64 = 0;        // head dim 128: 1 = the 64-rows-per-wave kernel (rsa_attn_kernel64.hip)
 
 // Tuning / diagnostics hook (not part of the data path).  The switches are process-global, so the hook only works in a
 // process that opted in with the environment variable RSA_TUNING=1 (the A/B tools and the variant tests); a production
@@ -36,6 +38,7 @@ extern "C" int rsa_set_tuning(const char* key, int value) {
     if (strcmp(key, "dbg_hi") == 0) { g_dbg_ptr = (g_dbg_ptr & 0xFFFFFFFFull) | ((unsigned long long)(unsigned)value << 32); return RSA_OK; }
 #endif
     if (strcmp(key, "k5_tsplit") == 0) { g_k5_tsplit = value; return RSA_OK; }
+    if (strcmp(key, "k5_w64") == 0) { g_k5_w64 = value; return RSA_OK; }
     if (strcmp(key, "fp8_variant") == 0) { rsa_set_fp8_variant(value); return RSA_OK; }
     if (strcmp(key, "fp8_smooth_k") == 0) { rsa_set_fp8_smooth_k(value); return RSA_OK; }
     return RSA_ERR_BAD_ARG;
@@ -124,7 +127,8 @@ static int launch_attn(AttnArgs& a, int BH, int D, int dtype, hipStream_t s) {
     if (nblocks > 0x7FFFFFFF) return RSA_ERR_UNSUPPORTED;
     if (a.NB_total > 8192) return RSA_ERR_UNSUPPORTED;  // kept list lives in LDS as u16, 16 KiB max
     const size_t lds_bytes = (size_t)4 * 64 * D * 2 + (((size_t)a.NB_total * 2 + 15) & ~(size_t)15);
-    const int st = rsa_launch_bsfwd(a, dim3((unsigned)nblocks), lds_bytes, D, dtype, s);
+    const int st = (D == 128 && g_k5_w64) ? rsa_launch_bsfwd64(a, dim3((unsigned)nblocks), lds_bytes, dtype, s)
+                                          : rsa_launch_bsfwd(a, dim3((unsigned)nblocks), lds_bytes, D, dtype, s);
     if (st != RSA_OK || a.tsplit <= 1) return st;
     return launch_text_combine(a, BH, D, dtype, s);
 }

@@ -1,0 +1,530 @@
+// K5, 64-rows-per-wave form (head dim 128): block-sparse flash attention forward for gfx950 with the rectification
+// epilogue fused -- same semantics, work mapping, per-row plan and epilogue as bsfwd_kernel (rsa_attn_kernel.hip; the
+// reference kernel it follows: rectified_hunyuan_attn.py:15-105), different occupancy model:
+//
+//   one workgroup = 2 waves = one 128-row query block, wave w owns rows 64w .. 64w+63 as two 32-row halves and the WHOLE
+//   512-entry register file of its SIMD (one wave per SIMD; two workgroups per CU).  O (128 registers) and the Q
+//   fragments (64) live in the accumulator file, owned by the asm statements; S, P, the -m blocks and the LDS operand rings
+//   in the arch VGPRs.  Every K fragment (ds_read_b128) and every V^T fragment (ds_read_b64_tr_b16) read from LDS feeds
+//   TWO MFMAs, one per row half: 24 LDS operand reads per 32 MFMAs instead of per 16.
+//
+// The pipelined block (one 32-key sub-step: 16 QK^T MFMAs of sub-step u+1, softmax of u, 16 PV MFMAs of u, row maxima of
+// u+1) is generated, hand-placed asm with every register pinned: gen_k5_block64.py -> rsa_attn_block64.h, which also
+// documents the register map and the schedule.  LDS-DMA staging (global_load_lds_dwordx4, 1 KiB per wave-instruction, 8
+// pieces per wave and 64-key tile) is issued INSIDE the block, one piece per fourth MFMA gap, the two waves of the workgroup
+// in different gaps, so that the CU's texture addresser sees the pieces spread over the sub-step; boundary tiles (rows
+// clamped to the last valid key) are staged from C++ in front of the block, which then runs its no-DMA form.
+//
+// LDS = [K0 K1 V0 V1 | kept list (u16)], 64-key tiles, images and swizzle exactly as in rsa_attn_kernel.hip.  At the head of
+// sub-step (t,0) the workgroup waits for V(t) (vmcnt(8): K(t+1) may stay in flight), barrier, and issues V(t+1) into
+// V(t-1)'s slot during the block; at the head of (t,1) for K(t+1), barrier, K(t+2) into K(t)'s slot.
+#include "rsa_attn.h"
+#include "rsa_attn_block64.h"
+
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+#define RSA_K5W_PICK(TT) \
+    do { \
+        if constexpr (VS == 0 && SUB == 0) asm volatile(RSA_K5W_BLOCK_##TT##_V0_S0 RSA_K5W_OPS : RSA_K5W_CL, "memory"); \
+        else if constexpr (VS == 0 && SUB == 1) asm volatile(RSA_K5W_BLOCK_##TT##_V0_S1 RSA_K5W_OPS : RSA_K5W_CL, "memory"); \
+        else if constexpr (VS == 1 && SUB == 0) asm volatile(RSA_K5W_BLOCK_##TT##_V1_S0 RSA_K5W_OPS : RSA_K5W_CL, "memory"); \
+        else asm volatile(RSA_K5W_BLOCK_##TT##_V1_S1 RSA_K5W_OPS : RSA_K5W_CL, "memory"); \
+    } while (0)
+#define RSA_K5W_CL RSA_K5W_CLOBBER_TMP, RSA_K5W_CLOBBER_O, RSA_K5W_CLOBBER_DMA
+
+// The block (ONE asm statement per slot / sub-step parity).  dm != 0: it also issues this wave's 8 LDS-DMA pieces of one
+// 64-key tile: source = (ghi:glo) + j * gstep + per-lane offset vo0 (even j) / vo1 (odd j), LDS destination ldst + j * 2048.
+template <typename Tag, int VS, int SUB>
+__device__ __forceinline__ void k5w_block(f32x16 (&SA)[2], f32x16 (&SB)[2], const f32x16 (&nm)[2], float (&l)[2], float (&mx)[2],
+                                          const i32x8& ka, const i32x8& va, unsigned dm, unsigned glo, unsigned ghi, unsigned ldst,
+                                          unsigned gstep, unsigned vo0, unsigned vo1) {
+    if constexpr (std::is_same<Tag, bf16_tag>::value) RSA_K5W_PICK(BF16);
+    else RSA_K5W_PICK(F16);
+}
+
+// one Q fragment (4 registers, pinned to v[96:99]) -> its place in the accumulator file
+template <int Hh, int KSI>
+__device__ __forceinline__ void k5w_qwrite(const s16x8& f) {
+#define RSA_QW(HH, KK) asm volatile(RSA_K5W_QWRITE_H##HH##_K##KK :: "{v[96:99]}"(f) : RSA_K5W_CLOBBER_Q)
+    if constexpr (Hh == 0) {
+        if constexpr (KSI == 0) RSA_QW(0, 0); else if constexpr (KSI == 1) RSA_QW(0, 1); else if constexpr (KSI == 2) RSA_QW(0, 2);
+        else if constexpr (KSI == 3) RSA_QW(0, 3); else if constexpr (KSI == 4) RSA_QW(0, 4); else if constexpr (KSI == 5) RSA_QW(0, 5);
+        else if constexpr (KSI == 6) RSA_QW(0, 6); else RSA_QW(0, 7);
+    } else {
+        if constexpr (KSI == 0) RSA_QW(1, 0); else if constexpr (KSI == 1) RSA_QW(1, 1); else if constexpr (KSI == 2) RSA_QW(1, 2);
+        else if constexpr (KSI == 3) RSA_QW(1, 3); else if constexpr (KSI == 4) RSA_QW(1, 4); else if constexpr (KSI == 5) RSA_QW(1, 5);
+        else if constexpr (KSI == 6) RSA_QW(1, 6); else RSA_QW(1, 7);
+    }
+#undef RSA_QW
+}
+// one 32 x 32 tile of O (rows of half Hh, d = 32 DTI .. +31) out of the accumulator file
+template <int Hh, int DTI>
+__device__ __forceinline__ f32x16 k5w_oread() {
+    f32x16 t;
+#define RSA_OR(HH, DD) asm volatile(RSA_K5W_OREAD_H##HH##_D##DD : "={v[96:111]}"(t))
+    if constexpr (Hh == 0) {
+        if constexpr (DTI == 0) RSA_OR(0, 0); else if constexpr (DTI == 1) RSA_OR(0, 1); else if constexpr (DTI == 2) RSA_OR(0, 2); else RSA_OR(0, 3);
+    } else {
+        if constexpr (DTI == 0) RSA_OR(1, 0); else if constexpr (DTI == 1) RSA_OR(1, 1); else if constexpr (DTI == 2) RSA_OR(1, 2); else RSA_OR(1, 3);
+    }
+#undef RSA_OR
+    return t;
+}
+
+// blockIdx -> (batch*head, query block, key-range part of a split text block); false = padding workgroup
+__device__ __forceinline__ bool k5w_map(const AttnArgs& a, int work, int& bh, int& qblk, int& tsp) {
+    tsp = 0;
+    if (work < a.n_heavy_pad) {
+        const int ntq = a.NQB - a.NBv;
+        const int per_bh = ntq * a.tsplit;      // text blocks x key-range splits (tsplit = 1: no split)
+        if (ntq <= 0 || work >= a.BH * per_bh) return false;
+        bh = work / per_bh;
+        const int rem = work % per_bh;
+        qblk = a.NBv + rem / a.tsplit;
+        tsp = rem % a.tsplit;
+    } else {
+        const int v = work - a.n_heavy_pad;
+        bh = v / a.NBp;
+        const int j = v % a.NBp;
+        const int chunk = a.NBp >> 3;
+        qblk = (j & 7) * chunk + (j >> 3);
+        if (qblk >= a.NBv) return false;
+    }
+    return true;
+}
+
+// WIDE: 16-byte output stores after a permlane32_swap regroup (needs 16-byte aligned output rows), else 8-byte stores.
+template <typename Tag, bool WIDE>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) void bsfwd64_kernel(AttnArgs a) {
+    constexpr int D = 128;
+    constexpr int NW = 2;                   // 2 waves x 64 query rows
+    constexpr int KS = D / 16;
+    constexpr int DT = D / 32;
+    constexpr int TILE_BYTES = 64 * D * 2;
+    constexpr int NPC = TILE_BYTES / 1024 / NW;  // 8 one-KiB pieces per wave per tile operand
+    using E = Elem<Tag>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned short* lds_list = reinterpret_cast<unsigned short*>(lds + 4 * TILE_BYTES);
+
+    // ---------------- work mapping: dense text-row blocks first, then the sparse blocks chunked per XCD ----------------
+    int bh, qblk, tsp;
+    if (!k5w_map(a, blockIdx.x, bh, qblk, tsp)) return;
+    const int b = bh / a.H, h = bh % a.H;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    int grow[2];
+    grow[0] = qblk * 128 + 64 * wv + r;
+    grow[1] = grow[0] + 32;
+
+    // ---------------- per-row plan (per row half) ----------------
+    int lo_r[2] = {0, 0}, hi_r[2] = {0, 0};
+    int n_items, first_blk = 0, lo_max, hi_min, hi_max;
+    const int32_t* list = nullptr;
+    if (a.mode == MODE_SPARSE) {
+        if (qblk < a.NBv) {
+            const long rowi = (long)bh * a.NBv + qblk;
+            list = a.cols + rowi * a.NB_total;
+            n_items = a.counts[rowi];
+            lo_max = 0; hi_min = hi_max = a.kv_valid;
+            hi_r[0] = hi_r[1] = a.kv_valid;
+        } else {
+            n_items = (a.kv_text_valid + RSA_BLOCK - 1) / RSA_BLOCK;
+            if (a.tsplit > 1) {
+                first_blk = tsp * a.tper;
+                n_items = n_items - first_blk < a.tper ? n_items - first_blk : a.tper;
+                if (n_items < 0) n_items = 0;
+            }
+            lo_max = 0; hi_min = hi_max = a.kv_text_valid;
+            hi_r[0] = hi_r[1] = a.kv_text_valid;
+        }
+    } else {
+        // dense mode: one or two (query rows, key rows) segments; causal = bottom-right aligned inside a segment (see
+        // rsa_attn_kernel.hip for the conventions)
+        const int row0 = qblk * 128, row1 = row0 + 128;
+        auto seg_hi = [&](int row) -> int {
+            const bool s1 = row >= a.q_split;
+            const int lo = s1 ? a.kv_split : 0, hi = s1 ? a.Sk : a.kv_split;
+            if (!a.causal) return hi;
+            const int rows = s1 ? a.Sq - a.q_split : a.q_split, rin = row - (s1 ? a.q_split : 0);
+            const int lim = lo + rin + 1 + ((hi - lo) - rows);
+            return lim < lo ? lo : (lim < hi ? lim : hi);
+        };
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            lo_r[x] = grow[x] < a.q_split ? 0 : a.kv_split;
+            hi_r[x] = seg_hi(grow[x] < a.Sq ? grow[x] : a.Sq - 1);
+        }
+        int lo_min;
+        const int rlast = (row1 <= a.Sq ? row1 : a.Sq) - 1;
+        if (row1 <= a.q_split) { lo_min = 0; lo_max = 0; }
+        else if (row0 >= a.q_split) { lo_min = lo_max = a.kv_split; }
+        else { lo_min = 0; lo_max = a.kv_split; }
+        hi_min = seg_hi(row0);
+        hi_max = seg_hi(rlast);
+        if (row0 < a.q_split && rlast >= a.q_split) {
+            const int h0 = seg_hi(a.q_split - 1), h1 = seg_hi(a.q_split);
+            hi_min = hi_min < h1 ? hi_min : h1;
+            hi_max = hi_max > h0 ? hi_max : h0;
+        }
+        first_blk = lo_min / RSA_BLOCK;
+        n_items = (hi_max + RSA_BLOCK - 1) / RSA_BLOCK - first_blk;
+        if (hi_max <= lo_min) n_items = 0;
+    }
+    n_items = __builtin_amdgcn_readfirstlane(n_items);
+    // the kept list (sparse visual blocks) or the plain block range (text rows, dense mode) as u16 entries in LDS: the main
+    // loop reads its next block index from there in every mode
+    for (int i = t; i < n_items; i += 64 * NW) lds_list[i] = (unsigned short)(list ? list[i] : first_blk + i);
+    __syncthreads();
+    auto blk_of = [&](int item) -> int { return (int)lds_list[item]; };
+    int n_tiles = 2 * n_items;
+    if (n_items > 0) {
+        const int last_blk = blk_of(n_items - 1);
+        if (last_blk * RSA_BLOCK + 64 >= hi_max) n_tiles -= 1;
+    }
+    n_tiles = __builtin_amdgcn_readfirstlane(n_tiles);
+    const int kv_limit = hi_max < a.Sk ? hi_max : a.Sk;
+    auto key0_of = [&](int tile) -> int {
+        const int it = tile >> 1;
+        const int blk = __builtin_amdgcn_readfirstlane(blk_of(it < n_items ? it : (n_items > 0 ? n_items - 1 : 0)));
+        return blk * RSA_BLOCK + (tile & 1) * 64;
+    };
+
+    // ---------------- Q fragments (B operand) -> accumulator file; O = 0 ----------------
+    asm volatile(RSA_K5W_OZERO ::: RSA_K5W_CLOBBER_O);
+    {
+        auto load_frag = [&](int x, int ks) -> s16x8 {
+            const unsigned short* qp = a.q + (long)b * a.qsb + (long)h * a.qsh + (long)grow[x] * a.qss + 8 * hh;
+            uint4 raw = make_uint4(0, 0, 0, 0);
+            if (grow[x] < a.Sq) raw = *reinterpret_cast<const uint4*>(qp + 16 * ks);
+            const unsigned w4[4] = {raw.x, raw.y, raw.z, raw.w};
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f[2 * e] = rsa_to_f32<Tag>((unsigned short)(w4[e] & 0xFFFF)) * a.qk_scale;
+                f[2 * e + 1] = rsa_to_f32<Tag>((unsigned short)(w4[e] >> 16)) * a.qk_scale;
+            }
+            return E::cvt8(f);
+        };
+#define RSA_QF(HH, KK) k5w_qwrite<HH, KK>(load_frag(HH, KK))
+        RSA_QF(0, 0); RSA_QF(0, 1); RSA_QF(0, 2); RSA_QF(0, 3); RSA_QF(0, 4); RSA_QF(0, 5); RSA_QF(0, 6); RSA_QF(0, 7);
+        RSA_QF(1, 0); RSA_QF(1, 1); RSA_QF(1, 2); RSA_QF(1, 3); RSA_QF(1, 4); RSA_QF(1, 5); RSA_QF(1, 6); RSA_QF(1, 7);
+#undef RSA_QF
+    }
+
+    // ---------------- LDS-DMA staging ----------------
+    // (hipcc does 64-bit address arithmetic on the vector unit even when it is wave-uniform and then hands the VGPR pair to an
+    // "s" operand as is: every base that reaches the staging asm is made scalar explicitly, half by half)
+    auto uni64 = [](const unsigned char* p) -> const unsigned char* {
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)p);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)p >> 32));
+        return reinterpret_cast<const unsigned char*>(((unsigned long)hi << 32) | lo);
+    };
+    const unsigned char* kbase = uni64(reinterpret_cast<const unsigned char*>(a.k + (long)b * a.ksb + (long)h * a.ksh));
+    const unsigned char* vbase = uni64(reinterpret_cast<const unsigned char*>(a.v + (long)b * a.vsb + (long)h * a.vsh));
+    // A 64-key tile = 16 one-KiB pieces of 4 rows; wave w moves pieces 2j + w (rows 8j + 4w .. +3), j = 0..7.  The XOR
+    // swizzle of a row's source chunk depends on (row & 3) and ((row >> 2) & 3) = (2j + w) & 3: two per-lane offsets
+    // (even / odd j), the piece walks a scalar base by 8 rows.
+    const int rsub = lane >> 4, cl = lane & 15;
+    const int rowl = 4 * wv + rsub;
+    const int gsw0 = cl ^ ((rsub << 2) | wv), gsw1 = cl ^ ((rsub << 2) | (2 + wv));
+    const unsigned vok0 = (unsigned)(((long)rowl * a.kss + gsw0 * 8) * 2), vok1 = (unsigned)(((long)rowl * a.kss + gsw1 * 8) * 2);
+    const unsigned vov0 = (unsigned)(((long)rowl * a.vss + gsw0 * 8) * 2), vov1 = (unsigned)(((long)rowl * a.vss + gsw1 * 8) * 2);
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const unsigned krow = (unsigned)(a.kss * 2), vrow = (unsigned)(a.vss * 2);   // bytes per key row (< 4 GiB)
+    const unsigned kstep = 8 * krow, vstep = 8 * vrow;                            // bytes per 8-row group
+    // staging from C++ (prologue, boundary tiles): the 64-key tile starting at key `key_first` -> LDS byte offset `lds_off`
+    auto dma = [&](int is_v, int key_first, unsigned lds_off) {
+        const unsigned ld0 = lds_base + lds_off + wv * 1024;
+        const unsigned char* base = is_v ? vbase : kbase;
+        const unsigned rowb = is_v ? vrow : krow;
+        if (key_first + 64 <= kv_limit) {
+            const unsigned char* tb = uni64(base + (unsigned long)(unsigned)key_first * rowb);
+            const long step = is_v ? (long)vstep : (long)kstep;
+#pragma unroll
+            for (int j = 0; j < NPC; ++j) {
+                const unsigned vo = is_v ? ((j & 1) ? vov1 : vov0) : ((j & 1) ? vok1 : vok0);
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                             :: "v"(vo), "s"(tb + j * step), "s"(ld0 + j * 2048) : "memory");
+            }
+        } else {   // the tile runs past the last valid key: rows clamped (their scores are masked)
+#pragma unroll
+            for (int j = 0; j < NPC; ++j) {
+                int krow_ = key_first + 8 * j + rowl;
+                krow_ = krow_ < kv_limit ? krow_ : kv_limit - 1;
+                const unsigned vo = (unsigned)((unsigned long)(unsigned)krow_ * rowb) + ((j & 1) ? gsw1 : gsw0) * 16;
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                             :: "v"(vo), "s"(base), "s"(ld0 + j * 2048) : "memory");
+            }
+        }
+    };
+
+    // ---------------- state ----------------
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.0f, 0.0f};
+    // m_ref = the finite reference the scores are taken against, nm = its negation in 16 registers (C operand of the first
+    // QK^T MFMA), thr = how far a new row maximum may exceed it before the rescale (-inf until the row has seen a finite score)
+    float m_ref[2] = {0.0f, 0.0f}, thr[2] = {-INFINITY, -INFINITY};
+    f32x16 nm[2];
+    asm volatile(RSA_K5W_NMZERO RSA_K5W_OPS_NMZERO);
+
+    // per-lane LDS read addressing (sub-tile 0 / slot 0; slot, sub-tile and k-step are immediates of the block)
+    const int kswz = ((r & 3) << 2) | ((r >> 2) & 3);
+    const int g4 = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+    i32x8 ka, va;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) ka[ks] = (int)lds_base + r * 256 + (((2 * ks + hh) ^ kswz) << 4);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        const int ch = 4 * dt + 2 * (g4 & 1) + (tp >> 1);
+        va[2 * dt] = (int)lds_base + tile_off<D>(4 * hh + tq, ch) + 8 * (tp & 1);
+        va[2 * dt + 1] = (int)lds_base + tile_off<D>(4 * hh + tq + 8, ch) + 8 * (tp & 1);
+    }
+
+    int kq1 = 0, kq2 = 0;  // first keys of tile+1 / tile+2
+    // what the next block stages: 0 = nothing (or done from C++), else the operands of its in-block LDS-DMA
+    unsigned blk_dma = 0;
+    unsigned d_glo = 0, d_ghi = 0, d_ld = 0, d_step = 0, d_vo0 = 0, d_vo1 = 0;
+
+    // The part of a sub-step behind its staging point: rare branches (boundary mask, deferred rescale), then the block.
+    auto half = [&](auto VS, auto SUB, int key0, f32x16 (&SA)[2], f32x16 (&SB)[2], float (&mxA)[2], float (&mxB)[2]) {
+        constexpr int vs = decltype(VS)::value, sub = decltype(SUB)::value;
+        float (&mx_cur)[2] = sub == 0 ? mxA : mxB;
+        float (&mx_nxt)[2] = sub == 0 ? mxB : mxA;
+        const int kfirst = key0 + 32 * sub;
+        if (kfirst < lo_max || kfirst + 32 > hi_min) {   // boundary tile: scores outside the row's key range -> -inf, new row maxima
+            const int kb0 = kfirst + 4 * hh - lo_r[0], kb1 = kfirst + 4 * hh - lo_r[1];
+            const int sp0 = hi_r[0] > lo_r[0] ? hi_r[0] - lo_r[0] : 0, sp1 = hi_r[1] > lo_r[1] ? hi_r[1] - lo_r[1] : 0;
+            const float ninf = -INFINITY;
+            float (&mx)[2] = mx_cur;
+            if constexpr (sub == 0) {
+                asm volatile(RSA_K5W_MASK_A RSA_K5W_OPS_MASK_A : "v146", "vcc");
+                asm volatile(RSA_K5W_ROWMAX_A RSA_K5W_OPS_ROWMAX_A : "v146", "v147", "v148", "v149");
+            } else {
+                asm volatile(RSA_K5W_MASK_B RSA_K5W_OPS_MASK_B : "v146", "vcc");
+                asm volatile(RSA_K5W_ROWMAX_B RSA_K5W_OPS_ROWMAX_B : "v146", "v147", "v148", "v149");
+            }
+        }
+        // S_cur, mx_cur are relative to m_ref as it was when they were computed, and that is still m_ref
+        if (__builtin_amdgcn_ballot_w64(mx_cur[0] > thr[0] || mx_cur[1] > thr[1]) != 0ull) {
+            float al[2], de[2], ng[2];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                const bool move = __builtin_amdgcn_ballot_w64(mx_cur[x] > thr[x]) != 0ull;   // per half, wave-uniform
+                const bool first = thr[x] == -INFINITY;
+                float delta = first ? mx_cur[x] : fmaxf(mx_cur[x], 0.0f);
+                if (delta == -INFINITY || !move) delta = 0.0f;      // nothing but masked keys so far / this half stays
+                else thr[x] = 8.0f;
+                const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);   // (first: O and l are still zero)
+                m_ref[x] += delta;
+                l_run[x] *= alpha;
+                al[x] = alpha; de[x] = delta; ng[x] = -m_ref[x];
+            }
+            const float al0 = al[0], al1 = al[1], de0 = de[0], de1 = de[1], ng0 = ng[0], ng1 = ng[1];
+            if constexpr (sub == 0) asm volatile(RSA_K5W_RESCALE_A RSA_K5W_OPS_RESCALE_A : RSA_K5W_CLOBBER_TMP, RSA_K5W_CLOBBER_O);
+            else asm volatile(RSA_K5W_RESCALE_B RSA_K5W_OPS_RESCALE_B : RSA_K5W_CLOBBER_TMP, RSA_K5W_CLOBBER_O);
+        }
+        k5w_block<Tag, vs, sub>(SA, SB, nm, l_run, mx_nxt, ka, va, blk_dma, d_glo, d_ghi, d_ld, d_step, d_vo0, d_vo1);
+    };
+
+    // staging point in front of every sub-step: wait (the newest group, issued during the previous sub-step, may stay in
+    // flight), barrier, then decide what this sub-step stages: SUB 0 V(tile+1) into V(tile-1)'s slot, SUB 1 K(tile+2) into
+    // K(tile)'s slot -- inside the block when the tile is full, from here (rows clamped) when it crosses the last valid key.
+    auto stage = [&](auto VS, auto SUB, int tile) {
+        constexpr int vs = decltype(VS)::value, sub = decltype(SUB)::value;
+        if (tile + 1 < n_tiles) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        blk_dma = 0;
+        const bool want = sub == 0 ? tile + 1 < n_tiles : tile + 2 < n_tiles;
+        if (want) {
+            const int kf = sub == 0 ? kq1 : kq2;
+            const unsigned off = sub == 0 ? (2 + (vs ^ 1)) * TILE_BYTES : vs * TILE_BYTES;
+            if (kf + 64 <= kv_limit) {
+                const unsigned char* tb = (sub == 0 ? vbase : kbase) + (unsigned long)(unsigned)kf * (sub == 0 ? vrow : krow);
+                d_glo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)tb);
+                d_ghi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)tb >> 32));
+                d_ld = lds_base + off + wv * 1024;
+                d_step = sub == 0 ? vstep : kstep;
+                d_vo0 = sub == 0 ? vov0 : vok0;
+                d_vo1 = sub == 0 ? vov1 : vok1;
+                blk_dma = 1;
+            } else {
+                dma(sub == 0 ? 1 : 0, kf, off);
+            }
+        }
+    };
+
+    // ---------------- prologue + main loop ----------------
+    f32x16 SA[2], SB[2];
+    float mxA[2] = {-INFINITY, -INFINITY}, mxB[2] = {-INFINITY, -INFINITY};
+    int key0 = 0;
+    if (n_tiles > 0) {
+        key0 = key0_of(0);
+        kq1 = key0_of(1);
+        kq2 = key0_of(2);
+        dma(0, key0, 0);
+        dma(1, key0, 2 * TILE_BYTES);
+        if (n_tiles > 1) dma(0, kq1, TILE_BYTES);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        float (&mx)[2] = mxA;
+        if constexpr (std::is_same<Tag, bf16_tag>::value)
+            asm volatile(RSA_K5W_QK0_BF16 RSA_K5W_OPS_QK0 : RSA_K5W_CLOBBER_TMP, "memory");
+        else
+            asm volatile(RSA_K5W_QK0_F16 RSA_K5W_OPS_QK0 : RSA_K5W_CLOBBER_TMP, "memory");
+    }
+    // kept-list entry of tile+3 read from LDS one advance() early (pref_raw), made scalar at use
+    auto raw_item = [&](int tile) -> int {
+        const int it = tile >> 1;
+        return blk_of(it < n_items ? it : (n_items > 0 ? n_items - 1 : 0));
+    };
+    int pref_raw = n_tiles > 0 ? raw_item(3) : 0;
+    auto advance = [&](int tile) {
+        key0 = kq1;
+        kq1 = kq2;
+        kq2 = __builtin_amdgcn_readfirstlane(pref_raw) * RSA_BLOCK + ((tile + 3) & 1) * 64;
+        pref_raw = raw_item(tile + 4);
+    };
+    {
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        auto tile_step = [&](auto VS, int tile) {
+            stage(VS, I0{}, tile);
+            half(VS, I0{}, key0, SA, SB, mxA, mxB);
+            stage(VS, I1{}, tile);
+            half(VS, I1{}, key0, SA, SB, mxA, mxB);
+        };
+        int tile = 0;
+        for (; tile + 1 < n_tiles; tile += 2) {
+            tile_step(I0{}, tile);
+            advance(tile);
+            tile_step(I1{}, tile + 1);
+            advance(tile + 1);
+        }
+        if (tile < n_tiles) tile_step(I0{}, tile);
+    }
+
+    // ---------------- epilogue ----------------
+    asm volatile("s_nop 11" ::: "memory");   // (the last block's last MFMA -> the reads of O below)
+    // Everything the epilogue needs from the arguments is read AGAIN here, through a pointer the compiler cannot see through:
+    // kept live in scalar registers across the main loop (15 pointers / strides) it pushes uniform values of the loop into
+    // vector registers, which an "s" operand of the staging asm cannot take.
+    const AttnArgs* ep = (const AttnArgs*)(const void*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ep));
+    const AttnArgs& e = *ep;
+    int bh2, qblk2, tsp2;
+    {
+        int work2 = blockIdx.x;
+        asm volatile("" : "+s"(work2));
+        k5w_map(e, work2, bh2, qblk2, tsp2);
+    }
+    const int b2 = bh2 / e.H, h2 = bh2 % e.H;
+    const bool partial = e.mode == MODE_SPARSE && e.tsplit > 1 && qblk2 >= e.NBv;
+    const bool rectify = e.mode == MODE_SPARSE && qblk2 < e.NBv && e.R != nullptr;
+    auto finish_half = [&](auto HX) {
+        constexpr int x = decltype(HX)::value;
+        const int grow2 = qblk2 * 128 + 64 * wv + 32 * x + r;
+        const float mrun = thr[x] == -INFINITY ? -INFINITY : m_ref[x];
+        const auto swl = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run[x]), __float_as_uint(l_run[x]), false, false);
+        const float l_tot = __uint_as_float(swl[0]) + __uint_as_float(swl[1]);
+        if (partial) {
+            // split-KV partial of a text block: unnormalised O (fp32), m (log2 domain) and l per row (merged by
+            // text_combine_kernel, rsa_attn.hip)
+            const int ntq = e.NQB - e.NBv;
+            const int rowb = 64 * wv + 32 * x + r;
+            float* pp = e.tpart + ((((long)bh2 * ntq + (qblk2 - e.NBv)) * e.tsplit + tsp2) * RSA_BLOCK + rowb) * (D + 2);
+            auto put = [&](int dt, const f32x16& o) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d0 = 32 * dt + 8 * g + 4 * hh;
+                    *reinterpret_cast<float2*>(pp + d0) = make_float2(o[4 * g + 0], o[4 * g + 1]);
+                    *reinterpret_cast<float2*>(pp + d0 + 2) = make_float2(o[4 * g + 2], o[4 * g + 3]);
+                }
+            };
+            put(0, k5w_oread<x, 0>()); put(1, k5w_oread<x, 1>()); put(2, k5w_oread<x, 2>()); put(3, k5w_oread<x, 3>());
+            if (hh == 0) *reinterpret_cast<float2*>(pp + D) = make_float2(mrun, l_tot);
+            return;
+        }
+        // rows that are stored / written as zeros (padded text rows), from the row index (not kept live across the main loop)
+        const bool text_blk = e.mode == MODE_SPARSE && qblk2 >= e.NBv;
+        const bool st_r = grow2 < (text_blk ? e.q_text_end : e.Sq);
+        const bool zr = text_blk && !st_r && grow2 < e.Sq;
+        if (!(st_r || zr)) return;
+        float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
+        float Rv = 1.0f;
+        const float* cp = nullptr;
+        if (rectify) {
+            const long rowi = (long)bh2 * e.NBv + qblk2;
+            Rv = e.R[rowi];
+            cp = e.comp + rowi * D;
+        }
+        if (zr) inv = 0.0f;
+        const float sc = inv * Rv;
+        unsigned short* op = e.out + (long)b2 * e.osb + (long)h2 * e.osh + (long)grow2 * e.oss;
+        // O * sc + comp: one fma rounded to fp32, THEN the conversion to the storage type (what the oracle does); the empty asm
+        // keeps hipcc from folding fma + conversion into v_fma_mixlo_f16 in one store form and not in the other
+        auto fin = [&](float acc, float c) -> float {
+            float rr = __builtin_fmaf(acc, sc, c);
+            asm volatile("" : "+v"(rr));
+            return rr;
+        };
+        auto put = [&](int dt, const f32x16& o) {
+            if constexpr (WIDE) {
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    uint2 pk[2];
+#pragma unroll
+                    for (int gi = 0; gi < 2; ++gi) {
+                        const int g = 2 * gp + gi;
+                        const int d0 = 32 * dt + 8 * g + 4 * hh;
+                        float4 c4 = make_float4(0, 0, 0, 0);
+                        if (cp && !zr) c4 = *reinterpret_cast<const float4*>(cp + d0);
+                        const float v0 = fin(o[4 * g + 0], c4.x);
+                        const float v1 = fin(o[4 * g + 1], c4.y);
+                        const float v2 = fin(o[4 * g + 2], c4.z);
+                        const float v3 = fin(o[4 * g + 3], c4.w);
+                        pk[gi].x = (unsigned)E::from_f32(v0) | ((unsigned)E::from_f32(v1) << 16);
+                        pk[gi].y = (unsigned)E::from_f32(v2) | ((unsigned)E::from_f32(v3) << 16);
+                    }
+                    const auto sx = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
+                    const auto sy = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
+                    uint4 w4;
+                    w4.x = sx[0]; w4.y = sy[0]; w4.z = sx[1]; w4.w = sy[1];
+                    *reinterpret_cast<uint4*>(op + 32 * dt + 8 * (2 * gp + hh)) = w4;
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d0 = 32 * dt + 8 * g + 4 * hh;
+                    float4 c4 = make_float4(0, 0, 0, 0);
+                    if (cp && !zr) c4 = *reinterpret_cast<const float4*>(cp + d0);
+                    const float v0 = fin(o[4 * g + 0], c4.x);
+                    const float v1 = fin(o[4 * g + 1], c4.y);
+                    const float v2 = fin(o[4 * g + 2], c4.z);
+                    const float v3 = fin(o[4 * g + 3], c4.w);
+                    uint2 pk;
+                    pk.x = (unsigned)E::from_f32(v0) | ((unsigned)E::from_f32(v1) << 16);
+                    pk.y = (unsigned)E::from_f32(v2) | ((unsigned)E::from_f32(v3) << 16);
+                    *reinterpret_cast<uint2*>(op + d0) = pk;
+                }
+            }
+        };
+        put(0, k5w_oread<x, 0>()); put(1, k5w_oread<x, 1>()); put(2, k5w_oread<x, 2>()); put(3, k5w_oread<x, 3>());
+    };
+    finish_half(std::integral_constant<int, 0>{});
+    finish_half(std::integral_constant<int, 1>{});
+    (void)m_run;
+}
+
+// launch hook used by rsa_attn.hip::launch_attn (head dim 128 only)
+int rsa_launch_bsfwd64(const AttnArgs& a, dim3 grid, size_t lds_bytes, int dtype, hipStream_t s) {
+    const bool wide = !(((uintptr_t)a.out & 15) || ((a.osb | a.osh | a.oss) & 7));
+    if (dtype == RSA_BF16) {
+        if (wide) bsfwd64_kernel<bf16_tag, true><<<grid, 128, lds_bytes, s>>>(a);
+        else bsfwd64_kernel<bf16_tag, false><<<grid, 128, lds_bytes, s>>>(a);
+    } else {
+        if (wide) bsfwd64_kernel<fp16_tag, true><<<grid, 128, lds_bytes, s>>>(a);
+        else bsfwd64_kernel<fp16_tag, false><<<grid, 128, lds_bytes, s>>>(a);
+    }
+    return rsa_launch_status();
+}
