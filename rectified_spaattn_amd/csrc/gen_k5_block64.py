@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
-"""Generator of the 64-rows-per-wave form of K5's pipelined block (rsa_attn_block64.h), head dim 128.
+"""Generator of the 64-rows-per-wave form of K5's main loop (rsa_attn_block64.h), head dim 128.
 
 One wave owns 64 query rows (two 32-row halves h = 0, 1) and the WHOLE register file of its SIMD (one wave per SIMD, 512
 registers): every K fragment and every V^T fragment read from LDS feeds TWO MFMAs (one per row half), so the LDS operand
-reads per MFMA halve against the 32-row form (24 reads per 32 MFMAs instead of per 16).  One block = one 32-key sub-step:
+reads per MFMA halve against the 32-row form (24 reads per 32 MFMAs instead of per 16).  One block = one 32-key sub-step u:
 
-    S_nxt[h]^T = K(sub-tile u+1) . Q[h]^T - m[h]     16 MFMAs   ks = 0..7, h = 0, 1  (A = K rows by ds_read_b128, B = Q[h]
+    S_nxt[h]^T = K(u+1) . Q[h]^T - m[h]               16 MFMAs   ks = 0..7, h = 0, 1  (A = K rows by ds_read_b128, B = Q[h]
                                                                 from the ACCUMULATOR file, C of the first = the -m block)
     P[h]       = exp2(S_cur[h])                       in place, fp32; row sums; packed to the 2-byte type
-    O[h]^T    += V(sub-tile u)^T . P[h]^T             16 MFMAs   (k2, dt) = 8 V^T fragments x h (A = V^T by ds_read_b64_tr_b16,
+    O[h]^T    += V(u)^T . P[h]^T                      16 MFMAs   (k2, dt) = 8 V^T fragments x h (A = V^T by ds_read_b64_tr_b16,
                                                                 B = packed P[h], C = D = O[h][dt] in the ACCUMULATOR file)
     mx[h]      = row max of S_nxt[h]
 
@@ -17,30 +17,41 @@ hipcc keep the tile in arch VGPRs and copy 128 registers in and out around every
     O[h][dt]  a[16*(4h+dt) : +15]   (a0..a127)         Q[h][ks]  a[128 + 4*(8h+ks) : +3]   (a128..a191)
 Arch VGPRs, pinned through physical-register constraints:
     SA[h] v[16h : +15]   SB[h] v[32+16h : +15]   -m[h] v[64+16h : +15]   P[h] v[96+8h : +7]   K ring v[112:127]   V ring v[128:143]
-    scratch v144..v149   K read addresses v[152:159]   V read addresses v[160:167]
+    scratch v144..v149   K read addresses v[152:159]   V read addresses v[160:167]   DMA lane offsets v[168:169] (K), v[170:171] (V)
 
-Schedule: the vector work is dealt into the 32 MFMA gaps by issue cost (cdna_hip_programming.md: <= 5 single-issue
-instructions per v_mfma_f32_32x32x16 gap, at most one of them a v_exp_f32, costs summing to <= 24 cycles hide) in deadline
-order: exponentials + packing of the first 16 keys (needed by PV MFMA 16), of the second 16 keys (MFMA 24), row sums, then
-the two row maxima interleaved with each other so that the v_permlane32_swap wait states are other useful instructions.
+LDS: K and V each live in a ring of FOUR 32-key half-tiles (8 KiB, image and swizzle of rsa_attn_kernel.hip); half-tile x
+sits in slot x & 3, so the slot is a compile-time constant of block U = u & 3.  Block u reads K(u+1) and V(u) and stages
+V(u+3) into V(u-1)'s slot and K(u+4) into K(u)'s slot: every LDS-DMA piece (global_load_lds_dwordx4, 1 KiB) has two to three
+sub-steps to land, and the wait in front of block u is the constant vmcnt(16) (the 8 + 8 pieces of blocks u-2, u-1 may fly).
 
-LDS-DMA inside the block: the wave's 8 one-KiB pieces of the tile being staged are issued in 8 gaps of the block (every
-fourth), so that the pieces reach the CU's texture addresser spread over the sub-step instead of as a burst behind the
-barrier (the 32-row kernel's staging point costs each wave ~450 cycles for 4 pieces: 8 waves x 4 pieces queue at one
-addresser, profiles/r03_k5_block.md).  The source address walks in SGPRs (s90:s91 base, s92 LDS destination), the swizzled
-per-lane source offset alternates between two VGPRs (pieces on even / odd 8-row groups).  When the sub-step stages nothing
-from inside the block (boundary tiles, staged by the C++ side in front of it with clamped rows; the last tiles) operand
-`dm` is 0 and every piece is branched over (s_cbranch_vccz): ONE statement per (slot parity, sub-step parity) -- alternative
-statements that define the same pinned tiles make hipcc copy the tiles around every one of them.
+Schedule inside a block: the vector work is dealt into the 32 MFMA gaps by issue cost (cdna_hip_programming.md: <= 5
+single-issue instructions per v_mfma_f32_32x32x16 gap, costs summing to <= 24 cycles hide) in deadline order: exponentials +
+packing of the first 16 keys (needed by PV MFMA 16), of the second 16 keys (MFMA 24), row sums, then the two row maxima
+interleaved with each other.  The wave's 8 DMA pieces (4 of K, 4 of V) take every fourth gap: they reach the CU's texture
+addresser spread over the sub-step instead of as a burst behind the barrier (the 32-row kernel's staging point costs each wave
+~450 cycles for 4 pieces: 8 waves x 4 pieces queue at one addresser, profiles/r03_k5_block.md).  Their source addresses WALK in
+scalar registers -- a half-tile is 32 consecutive keys, a kept block 128 -- and are re-based once per kept block.
 
-usage: python3 gen_k5_block64.py > rsa_attn_block64.h
+Two products:
+  * RSA_K5W_LOOP_*: the steady-state loop as ONE asm statement: per kept 128-key block four blocks (U = 0..3), each behind
+    `s_waitcnt vmcnt(16)` + `s_barrier`; list entry of the block after next read from LDS in the shadow, scalar re-basing of
+    the DMA walkers, the deferred-rescale test after every block with the rescale itself out of line.  With one wave per SIMD
+    nothing overlaps the instructions BETWEEN blocks (the first form of this kernel spent ~300 cycles per sub-step in hipcc's
+    glue: stamps in profiles/r04_k5_w64.md), so the steady state contains none.
+  * RSA_K5W_BLOCK_*_U{0..3}: the same block without DMA as a statement of its own, for the sub-steps the loop does not take
+    (boundary blocks: masked scores, clamped rows -- staged from C++), plus the rare-path helpers (mask, row maxima, rescale)
+    and the accumulator-file housekeeping.  One statement per U: alternative statements that define the same pinned tiles make
+    hipcc copy the tiles around every one of them.
+
+usage: python3 gen_k5_block64.py > rsa_attn_block64.h        (python3 gen_k5_block64.py stats: per-gap issue costs)
 """
 import sys
 
 AHEAD = 4
 COST = dict(exp=8, cvt=5, add=4, max=4, mov=4, swap=4, lds=4, wait=1, dma=24)
 D, KS, DT = 128, 8, 4
-TILE = 64 * D * 2
+HALF = 32 * D * 2             # bytes of a 32-key half-tile
+VRING = 4 * HALF              # LDS offset of the V ring
 
 # ---- register map ----
 SA = [0, 16]
@@ -52,8 +63,20 @@ PS = [144, 145]
 T = [146, 147, 148, 149]
 TMP0, TMP1 = 96, 150          # clobbered temporaries [TMP0, TMP1)
 KA, VA = 152, 160
-AO = lambda h, dt: 16 * (4 * h + dt)           # noqa: E731
-AQ = lambda h, ks: 128 + 4 * (8 * h + ks)      # noqa: E731
+VOK, VOV = 168, 170           # per-lane DMA source offsets (even / odd 8-row group) of K and V
+# scalar registers owned by the loop statement
+S_KB, S_KL, S_VB, S_VL, S_BLK, S_CNT, S_T0, S_T2, S_K128, S_V128, S_KST, S_VST = 80, 82, 84, 86, 87, 88, 90, 92, 94, 95, 96, 97
+S_CLOB = list(range(80, 98))
+DMA_GAPS = [4 * j + 1 for j in range(8)]      # the 8 gaps that carry the wave's LDS-DMA pieces: every fourth gap
+STATS = None
+
+
+def AO(h, dt):
+    return 16 * (4 * h + dt)
+
+
+def AQ(h, ks):
+    return 128 + 4 * (8 * h + ks)
 
 
 def vr(a, n=1):
@@ -64,16 +87,20 @@ def ar(a, n=1):
     return f"a{a}" if n == 1 else f"a[{a}:{a + n - 1}]"
 
 
-DMA_GAPS = [4 * j + 1 for j in range(8)]      # the 8 gaps that carry the wave's LDS-DMA pieces: every fourth gap
+def sr(a, n=1):
+    return f"s{a}" if n == 1 else f"s[{a}:{a + n - 1}]"
 
 
-def gen_block(dt, VS, SUB, budget=None):
+def gen_block(dt, U, dma, chain=None):
+    """Block U.  dma: issue the wave's pieces from the scalar walkers.  chain (the loop): the block does not open with its K
+    reads -- the previous block issued them in its tail -- and issues the NEXT block's first four K reads itself, behind the
+    lines of `chain` (the sub-step boundary: vmcnt wait, barrier, ...), which sit in front of MFMA 30: behind the wait for the
+    last V^T fragment, so every LDS read of this sub-step has returned when the barrier releases the slots."""
     mf = "v_mfma_f32_32x32x16_bf16" if dt == "bf16" else "v_mfma_f32_32x32x16_f16"
     cv = "v_cvt_pk_bf16_f32" if dt == "bf16" else "v_cvt_pk_f16_f32"
-    SC, SN = (SA, SB) if SUB == 0 else (SB, SA)
-    kslot, ksub = (VS, 1) if SUB == 0 else (VS ^ 1, 0)
-    koff = kslot * TILE + ksub * 32 * D * 2
-    vbase = (2 + VS) * TILE
+    SC, SN = (SA, SB) if U % 2 == 0 else (SB, SA)
+    koff = ((U + 1) & 3) * HALF
+    voff = VRING + U * HALF
     lines, lds_seq = [], []
 
     def k_read(ks):
@@ -82,7 +109,7 @@ def gen_block(dt, VS, SUB, budget=None):
 
     def v_read(p):
         k2, d = divmod(p, DT)
-        off = vbase + (2 * SUB + k2) * 16 * D * 2
+        off = voff + k2 * 16 * D * 2
         b = VF + 4 * (p % AHEAD)
         lines.append(f"ds_read_b64_tr_b16 {vr(b, 2)}, {vr(VA + 2 * d)} offset:{off}")
         lines.append(f"ds_read_b64_tr_b16 {vr(b + 2, 2)}, {vr(VA + 2 * d + 1)} offset:{off}")
@@ -101,43 +128,41 @@ def gen_block(dt, VS, SUB, budget=None):
         for h in (0, 1):
             EXP += [(h, 2 * g), (h, 2 * g + 1)]
     pos = {e: n for n, e in enumerate(EXP)}
-    others = []        # (kind, text, exponentials that must have been issued, earliest gap, deadline MFMA or None)
+    cvq = []           # (kind, text, exponentials that must have been issued)
     for k2 in (0, 1):
         for j in range(4):
             for h in (0, 1):
                 need = max(pos[(h, 8 * k2 + 2 * j)], pos[(h, 8 * k2 + 2 * j + 1)]) + 1
-                others.append(("cvt", f"{cv} {vr(P[h] + 4 * k2 + j)}, {vr(SC[h] + 8 * k2 + 2 * j)}, {vr(SC[h] + 8 * k2 + 2 * j + 1)}",
-                               need, -1, 16 + 8 * k2))
+                cvq.append(("cvt", f"{cv} {vr(P[h] + 4 * k2 + j)}, {vr(SC[h] + 8 * k2 + 2 * j)}, {vr(SC[h] + 8 * k2 + 2 * j + 1)}", need))
     adds = []
     for h in (0, 1):
-        adds.append([("add", f"v_add_f32 {vr(PS[h])}, {vr(SC[h])}, {vr(SC[h] + 1)}", pos[(h, 1)] + 1, -1, None)]
-                    + [("add", f"v_add_f32 {vr(PS[h])}, {vr(PS[h])}, {vr(SC[h] + i)}", pos[(h, i)] + 1, -1, None) for i in range(2, 16)]
-                    + [("add", f"v_add_f32 %[l{h}], %[l{h}], {vr(PS[h])}", 32, -1, None)])
+        adds.append([("add", f"v_add_f32 {vr(PS[h])}, {vr(SC[h])}, {vr(SC[h] + 1)}", pos[(h, 1)] + 1)]
+                    + [("add", f"v_add_f32 {vr(PS[h])}, {vr(PS[h])}, {vr(SC[h] + i)}", pos[(h, i)] + 1) for i in range(2, 16)]
+                    + [("add", f"v_add_f32 %[l{h}], %[l{h}], {vr(PS[h])}", 32)])
     addq = [x for pair in zip(*adds) for x in pair]      # the two halves' chains interleaved
     E = 17             # S_nxt[1]'s last MFMA is MFMA 15: its readers sit two or more MFMAs behind it
     maxq = []
     for h in (0, 1):
-        maxq += [("max", f"v_max_f32 {vr(T[2 * h])}, {vr(SN[h])}, {vr(SN[h] + 1)}", 0, E, None)]
+        maxq += [("max", f"v_max_f32 {vr(T[2 * h])}, {vr(SN[h])}, {vr(SN[h] + 1)}")]
     for h in (0, 1):
-        maxq += [("max", f"v_max_f32 {vr(T[2 * h + 1])}, {vr(SN[h] + 2)}, {vr(SN[h] + 3)}", 0, E, None)]
+        maxq += [("max", f"v_max_f32 {vr(T[2 * h + 1])}, {vr(SN[h] + 2)}, {vr(SN[h] + 3)}")]
     for i in range(2, 8):
         for h in (0, 1):
             t = T[2 * h + (i & 1)]
-            maxq += [("max", f"v_max3_f32 {vr(t)}, {vr(t)}, {vr(SN[h] + 2 * i)}, {vr(SN[h] + 2 * i + 1)}", 0, E, None)]
-    maxq += [("max", f"v_max_f32 {vr(T[2 * h])}, {vr(T[2 * h])}, {vr(T[2 * h + 1])}", 0, E, None) for h in (0, 1)]
-    maxq += [("mov", f"v_mov_b32 {vr(T[2 * h + 1])}, {vr(T[2 * h])}", 0, E, None) for h in (0, 1)]
+            maxq += [("max", f"v_max3_f32 {vr(t)}, {vr(t)}, {vr(SN[h] + 2 * i)}, {vr(SN[h] + 2 * i + 1)}")]
+    maxq += [("max", f"v_max_f32 {vr(T[2 * h])}, {vr(T[2 * h])}, {vr(T[2 * h + 1])}") for h in (0, 1)]
+    maxq += [("mov", f"v_mov_b32 {vr(T[2 * h + 1])}, {vr(T[2 * h])}") for h in (0, 1)]
     # v_permlane32_swap: 2 wait states behind the VALU write of either operand and in front of a reader of its results: the
     # other half's mov / swap and one s_nop each way ("tail": emitted as one unit, never split by other vector work)
     tail = ["s_nop 0", f"v_permlane32_swap_b32 {vr(T[0])}, {vr(T[1])}", f"v_permlane32_swap_b32 {vr(T[2])}, {vr(T[3])}", "s_nop 0",
             f"v_max_f32 %[mx0], {vr(T[0])}, {vr(T[1])}", f"v_max_f32 %[mx1], {vr(T[2])}, {vr(T[3])}"]
 
-    dgaps = DMA_GAPS
+    dgaps = DMA_GAPS if dma else []
     pre = 64
     ei = 0             # exponentials issued
-    cvq = list(others)
     last_exp_line = -10
 
-    def emit_slot(cycles, gap, next_mfma, final=False):
+    def emit_slot(cycles, gap, final=False):
         """Fill one slot: up to two exponentials while there are any, then whatever is ready, by issue cost."""
         nonlocal ei, last_exp_line
         used = 0
@@ -145,26 +170,22 @@ def gen_block(dt, VS, SUB, budget=None):
         progress = True
         while progress and (used < cycles or final):
             progress = False
-            # 1. packing whose inputs are ready (deadline work)
             if cvq and cvq[0][2] <= ei and len(lines) - last_exp_line >= 1 + (1 if cvq[0][2] == ei else 0):
-                k, t, need, e, dl = cvq.pop(0)
+                k, t, need = cvq.pop(0)
                 lines.append(t); used += COST[k]; progress = True
                 continue
-            # 2. an exponential (at most two per slot outside the prologue region)
             if ei < len(EXP) and (nexp < 2 or gap < 0 or final):
                 h, i = EXP[ei]
                 lines.append(f"v_exp_f32 {vr(SC[h] + i)}, {vr(SC[h] + i)}")
                 last_exp_line = len(lines) - 1
                 ei += 1; nexp += 1; used += COST["exp"]; progress = True
                 continue
-            # 3. row sums
             if addq and addq[0][2] <= ei and len(lines) - last_exp_line >= 2:
-                k, t, need, e, dl = addq.pop(0)
+                k, t, need = addq.pop(0)
                 lines.append(t); used += COST[k]; progress = True
                 continue
-            # 4. row maxima of S_nxt
-            if maxq and maxq[0][3] <= gap:
-                k, t, need, e, dl = maxq.pop(0)
+            if maxq and gap >= E:
+                k, t = maxq.pop(0)
                 lines.append(t); used += COST[k]; progress = True
                 continue
             if not maxq and not addq and not cvq and ei == len(EXP) and tail and gap >= E:
@@ -174,26 +195,23 @@ def gen_block(dt, VS, SUB, budget=None):
     dma_j = 0
 
     def dma_piece():
+        """K and V pieces alternate; M0 <- LDS destination; the SALU add between the M0 write and the load is the required wait state"""
         nonlocal dma_j
-        # skipped as a whole when this sub-step stages nothing from inside the block (vcc = 0, set at the head)
-        lines.append(f"s_cbranch_vccz .Lk5w_%=_{dma_j}")
-        # M0 <- LDS destination of this piece; the SALU add between the M0 write and the load is the required wait state
-        lines.append("s_mov_b32 m0, s92")
-        lines.append("s_add_u32 s92, s92, 2048")
-        lines.append(f"global_load_lds_dwordx4 %[vo{dma_j & 1}], s[90:91]")
-        lines.append("s_add_u32 s90, s90, %[st]")
-        lines.append("s_addc_u32 s91, s91, 0")
-        lines.append(f".Lk5w_%=_{dma_j}:")
+        j, isv = divmod(dma_j, 2)
+        base, ldsw, st, vo = (S_VB, S_VL, S_VST, VOV) if isv else (S_KB, S_KL, S_KST, VOK)
+        lines.append(f"s_mov_b32 m0, {sr(ldsw)}")
+        lines.append(f"s_add_u32 {sr(ldsw)}, {sr(ldsw)}, 2048")
+        lines.append(f"global_load_lds_dwordx4 {vr(vo + (j & 1))}, {sr(base, 2)}")
+        lines.append(f"s_add_u32 {sr(base)}, {sr(base)}, {sr(st)}")
+        lines.append(f"s_addc_u32 {sr(base + 1)}, {sr(base + 1)}, 0")
         dma_j += 1
 
-    lines.append("s_cmp_lg_u32 %[dm], 0")
-    lines.append("s_cselect_b64 vcc, -1, 0")
-    lines.append("s_mov_b32 s90, %[glo]")
-    lines.append("s_mov_b32 s91, %[ghi]")
-    lines.append("s_mov_b32 s92, %[ld]")
-    for ks in range(AHEAD):
-        k_read(ks)
-    emit_slot(pre, -1, 0)
+    if chain is None:
+        for ks in range(AHEAD):
+            k_read(ks)
+    else:
+        lds_seq.extend(((("K", ks), 1)) for ks in range(AHEAD))      # in flight since the previous block's tail
+    emit_slot(pre, -1)
     usage = []
     for i in range(32):
         if i < 16:
@@ -214,23 +232,24 @@ def gen_block(dt, VS, SUB, budget=None):
                 text = "\n".join(lines)
                 for hh in (0, 1):
                     for jj in range(4):
-                        assert f"{cv} {vr(P[hh] + 4 * k2 + jj)}," in text, (dt, VS, SUB, "P not packed before PV", p)
+                        assert f"{cv} {vr(P[hh] + 4 * k2 + jj)}," in text, (dt, U, "P not packed before PV", p)
                 wait_for(("V", p))
+            if chain is not None and i == 30:
+                lines.extend(chain)
+                nk = ((U + 2) & 3) * HALF
+                lines.extend(f"ds_read_b128 {vr(KF + 4 * ks, 4)}, {vr(KA + ks)} offset:{nk}" for ks in range(AHEAD))
             lines.append(f"{mf} {ar(AO(h, d), 16)}, {vr(VF + 4 * (p % AHEAD), 4)}, {vr(P[h] + 4 * k2, 4)}, {ar(AO(h, d), 16)}")
             fixed = 0
             if h == 1 and p + AHEAD < 2 * DT:
                 v_read(p + AHEAD); fixed += 2 * COST["lds"]
         if i in dgaps:
             dma_piece(); fixed += COST["dma"]
-        usage.append(fixed + emit_slot(budget - fixed if budget else 24 - fixed, i, i + 1, final=(i == 31)))
-    assert ei == len(EXP) and not cvq and not addq and not maxq and not tail, (dt, VS, SUB, "vector work left over")
+        usage.append(fixed + emit_slot(24 - fixed, i, final=(i == 31)))
+    assert ei == len(EXP) and not cvq and not addq and not maxq and not tail, (dt, U, "vector work left over")
     assert dma_j == len(dgaps)
     if STATS is not None:
-        STATS.append((dt, VS, SUB, usage))
+        STATS.append((dt, U, dma, usage))
     return lines
-
-
-STATS = None
 
 
 def rowmax_lines(S):
@@ -253,13 +272,10 @@ def rowmax_lines(S):
 
 
 def gen_qk0(dt):
-    """Prologue: S_A[h] = K(slot 0, sub-tile 0) . Q[h]^T - m[h], row maxima -- the block's first half without a softmax."""
+    """Prologue: S_A[h] = K(half-tile 0, slot 0) . Q[h]^T - m[h], row maxima -- the block's first half without a softmax."""
     mf = "v_mfma_f32_32x32x16_bf16" if dt == "bf16" else "v_mfma_f32_32x32x16_f16"
     SN = SA
-    lines = []
-    for ks in range(KS):
-        lines.append(f"ds_read_b128 {vr(KF + 4 * (ks % AHEAD), 4)}, {vr(KA + ks)}" if ks < AHEAD else None)
-    lines = [l for l in lines if l]
+    lines = [f"ds_read_b128 {vr(KF + 4 * (ks % AHEAD), 4)}, {vr(KA + ks)}" for ks in range(AHEAD)]
     for ks in range(KS):
         # reads outstanding behind fragment ks when it is needed: those issued after it so far
         lines.append(f"s_waitcnt lgkmcnt({min(AHEAD - 1, KS - 1 - ks)})")
@@ -274,6 +290,116 @@ def gen_qk0(dt):
     return lines
 
 
+def rescale_core(S, al, de, ng):
+    """O[h] *= al[h], S[h] -= de[h], -m[h] = ng[h] for both halves (operand names given per half)."""
+    lines = ["s_nop 11"]     # the last PV MFMA of the preceding block wrote O: 12 wait states before it is read
+    for h in (0, 1):
+        for g in range(0, 64, 8):
+            base = AO(h, 0) + g
+            lines += [f"v_accvgpr_read_b32 {vr(TMP0 + j)}, {ar(base + j)}" for j in range(8)]
+            lines += [f"v_mul_f32 {vr(TMP0 + j)}, {vr(TMP0 + j)}, {al[h]}" for j in range(8)]
+            lines += [f"v_accvgpr_write_b32 {ar(base + j)}, {vr(TMP0 + j)}" for j in range(8)]
+        lines += [f"v_sub_f32 {vr(S[h] + i)}, {vr(S[h] + i)}, {de[h]}" for i in range(16)]
+        lines += [f"v_mov_b32 {vr(NM[h] + i)}, {ng[h]}" for i in range(16)]
+    return lines
+
+
+def rescale_decide():
+    """The deferred-rescale decision of rsa_attn_kernel64.hip::half in asm (both halves): from mx[h], thr[h], m_ref[h], l[h] to
+    al = v144/v145, de = v146/v147, ng = v148/v149 (and the updated thr, m_ref, l).  A half moves iff ANY of its rows exceeds its
+    threshold (wave-uniform, like the C++ side's ballot); first = the row has not seen a finite score yet (thr = -inf)."""
+    L = []
+    mv, fin = sr(S_T0, 2), sr(S_T2, 2)
+    for h in (0, 1):
+        al, de, ng = vr(144 + h), vr(146 + h), vr(148 + h)
+        mx, th, mr, l = f"%[mx{h}]", f"%[th{h}]", f"%[mr{h}]", f"%[l{h}]"
+        L += [f"v_cmp_gt_f32 vcc, {mx}, {th}",                     # rows above their threshold
+              "s_cmp_lg_u64 vcc, 0",
+              f"s_cselect_b64 {mv}, -1, 0",                        # move: any row of this half (all lanes or none)
+              f"v_max_f32 {de}, 0, {mx}",                          # delta = first ? mx : max(mx, 0)
+              f"v_cmp_eq_f32 vcc, {th}, %[ninf]",                  # first
+              f"v_cndmask_b32 {de}, {de}, {mx}, vcc",
+              f"v_cmp_neq_f32 {fin}, {de}, %[ninf]",               # delta finite (not "nothing but masked keys so far")
+              f"s_and_b64 {mv}, {mv}, {fin}",                      # lanes that move their reference
+              f"v_cndmask_b32 {de}, 0, {de}, {mv}",                # the others: delta = 0
+              f"v_exp_f32 {al}, -{de}",
+              f"v_cndmask_b32 {th}, {th}, %[eight], {mv}",
+              f"v_add_f32 {mr}, {mr}, {de}",
+              f"v_cndmask_b32 {al}, {al}, 1.0, vcc",               # first: alpha = 1 (O and l are still zero)
+              f"v_xor_b32 {ng}, 0x80000000, {mr}",
+              f"v_mul_f32 {l}, {l}, {al}",
+              f"v_sub_f32 {mx}, {mx}, {de}"]                      # the row maximum follows its scores to the new reference
+    return L
+
+
+def gen_loop(dt, diag=False):
+    """The steady-state loop, one asm statement (see the file docstring).  Operands: cnt (kept blocks to process, >= 0),
+    blk0 / blk1 (block index of the first one and of its successor), la (VGPR: LDS byte address of the list entry two blocks
+    ahead), kb / vb (64-bit bases of this head's K / V), krow / vrow (bytes per key row), ldsk / ldsv (LDS address of the wave's
+    first piece in slot 0 of the K / V ring)."""
+    t0, t1 = sr(S_T0), sr(S_T0 + 1)
+    L = [f"s_mov_b32 {sr(S_CNT)}, %[cnt]",
+         f"s_cmp_eq_u32 {sr(S_CNT)}, 0",
+         "s_cbranch_scc1 .Lk5w_done_%=",
+         f"s_lshl_b32 {sr(S_K128)}, %[krow], 7", f"s_lshl_b32 {sr(S_V128)}, %[vrow], 7",
+         f"s_lshl_b32 {sr(S_KST)}, %[krow], 3", f"s_lshl_b32 {sr(S_VST)}, %[vrow], 3",
+         f"s_mov_b32 {sr(S_BLK)}, %[blk1]",
+         # V walker: the kept block being processed, its last half-tile (key 96): vb + blk0 * vrow128 + 96 * vrow
+         f"s_mul_i32 {t0}, %[blk0], {sr(S_V128)}", f"s_mul_hi_u32 {t1}, %[blk0], {sr(S_V128)}",
+         f"s_mov_b64 {sr(S_VB, 2)}, %[vb]",
+         f"s_add_u32 {sr(S_VB)}, {sr(S_VB)}, {t0}", f"s_addc_u32 {sr(S_VB + 1)}, {sr(S_VB + 1)}, {t1}",
+         f"s_mul_i32 {t0}, %[vrow], 96",
+         f"s_add_u32 {sr(S_VB)}, {sr(S_VB)}, {t0}", f"s_addc_u32 {sr(S_VB + 1)}, {sr(S_VB + 1)}, 0"]
+    def boundary(diag):
+        """end of a sub-step: the pieces of two blocks ago have landed, every wave has finished its LDS reads"""
+        if not diag:
+            return ["s_waitcnt vmcnt(16)", "s_barrier"]
+        tm, tt = sr(98, 2), sr(S_T2)
+        return [f"s_memtime {tm}", "s_waitcnt lgkmcnt(0)", f"s_mov_b32 {tt}, s98", "s_waitcnt vmcnt(16)",
+                f"s_memtime {tm}", "s_waitcnt lgkmcnt(0)", f"s_sub_u32 {tt}, s98, {tt}", f"s_add_u32 s100, s100, {tt}",
+                f"s_mov_b32 {tt}, s98", "s_barrier",
+                f"s_memtime {tm}", "s_waitcnt lgkmcnt(0)", f"s_sub_u32 {tt}, s98, {tt}", f"s_add_u32 s101, s101, {tt}"]
+    # entry: the boundary in front of the first block and its first K reads (slot 1: U = 0 reads K(u+1))
+    L += boundary(False) + [f"ds_read_b128 {vr(KF + 4 * ks, 4)}, {vr(KA + ks)} offset:{HALF}" for ks in range(AHEAD)]
+    if diag:
+        L += ["s_mov_b32 s100, 0", "s_mov_b32 s101, 0"]
+    L += [".Lk5w_loop_%=:"]
+    for U in range(4):
+        head = []
+        if U == 0:     # K walker: the next kept block, key 0; K pieces go to slot 0.., V pieces to slot 3
+            head += [f"s_mul_i32 {t0}, {sr(S_BLK)}, {sr(S_K128)}", f"s_mul_hi_u32 {t1}, {sr(S_BLK)}, {sr(S_K128)}",
+                     f"s_mov_b64 {sr(S_KB, 2)}, %[kb]",
+                     f"s_add_u32 {sr(S_KB)}, {sr(S_KB)}, {t0}", f"s_addc_u32 {sr(S_KB + 1)}, {sr(S_KB + 1)}, {t1}",
+                     f"s_mov_b32 {sr(S_KL)}, %[ldsk]", f"s_add_u32 {sr(S_VL)}, %[ldsv], {3 * HALF}"]
+        if U == 1:     # V walker: the next kept block, key 0; V pieces to slot 0..
+            head += [f"s_mul_i32 {t0}, {sr(S_BLK)}, {sr(S_V128)}", f"s_mul_hi_u32 {t1}, {sr(S_BLK)}, {sr(S_V128)}",
+                     f"s_mov_b64 {sr(S_VB, 2)}, %[vb]",
+                     f"s_add_u32 {sr(S_VB)}, {sr(S_VB)}, {t0}", f"s_addc_u32 {sr(S_VB + 1)}, {sr(S_VB + 1)}, {t1}",
+                     f"s_mov_b32 {sr(S_VL)}, %[ldsv]"]
+        tail = boundary(diag)
+        if U == 1:     # list entry of the block after next: an LDS read older than every K read of block 2 (made scalar in block 3)
+            tail = tail + ["ds_read_u16 %[lv], %[la]"]
+        blk = gen_block(dt, U, True, chain=tail)
+        if U == 3:     # (read two blocks ago) -> the next iteration's block index; advance the list pointer
+            blk += [f"v_readfirstlane_b32 {sr(S_BLK)}, %[lv]", "v_add_u32 %[la], 2, %[la]"]
+        # deferred-rescale test on the scores the NEXT block consumes (S_nxt of this block)
+        tst = ["v_cmp_gt_f32 vcc, %[mx0], %[th0]", f"v_cmp_gt_f32 {sr(S_T2, 2)}, %[mx1], %[th1]",
+               f"s_or_b64 vcc, vcc, {sr(S_T2, 2)}", f"s_cbranch_vccnz .Lk5w_resc{U}_%="]
+        L += head + blk + tst + [f".Lk5w_back{U}_%=:"]
+    L += [f"s_sub_u32 {sr(S_CNT)}, {sr(S_CNT)}, 1", f"s_cmp_lg_u32 {sr(S_CNT)}, 0", "s_cbranch_scc1 .Lk5w_loop_%=",
+          "s_waitcnt lgkmcnt(0)",       # (the K reads the last block issued for its successor: nothing may land behind the statement)
+          "s_branch .Lk5w_done_%="]
+    for U in range(4):
+        S = SB if U % 2 == 0 else SA          # S_nxt of block U
+        L += [f".Lk5w_resc{U}_%=:"] + (["s_add_u32 s101, s101, 0x1000000"] if diag else []) + rescale_decide()
+        L += rescale_core(S, [vr(144), vr(145)], [vr(146), vr(147)], [vr(148), vr(149)])
+        L += [f"s_branch .Lk5w_back{U}_%="]
+    L += [".Lk5w_done_%=:"]
+    if diag:
+        L += ["s_mov_b32 %[d0], s100", "s_mov_b32 %[d1], s101"]
+    return L
+
+
 def c_string(lines):
     return " \\\n".join(f'    "{l}\\n\\t"' for l in lines)
 
@@ -281,11 +407,16 @@ def c_string(lines):
 def main():
     out = ["// GENERATED by gen_k5_block64.py -- do not edit; edit the generator (its docstring says what this is).", "#pragma once", ""]
     for dt in ("bf16", "f16"):
-        for VS in (0, 1):
-            for SUB in (0, 1):
-                out.append(f"#define RSA_K5W_BLOCK_{dt.upper()}_V{VS}_S{SUB} \\")
-                out.append(c_string(gen_block(dt, VS, SUB)))
-                out.append("")
+        for U in range(4):
+            out.append(f"#define RSA_K5W_BLOCK_{dt.upper()}_U{U} \\")
+            out.append(c_string(gen_block(dt, U, False)))
+            out.append("")
+        out.append(f"#define RSA_K5W_LOOP_{dt.upper()} \\")
+        out.append(c_string(gen_loop(dt)))
+        out.append("")
+        out.append(f"#define RSA_K5W_LOOP_{dt.upper()}_DIAG \\")
+        out.append(c_string(gen_loop(dt, diag=True)))
+        out.append("")
         out.append(f"#define RSA_K5W_QK0_{dt.upper()} \\")
         out.append(c_string(gen_qk0(dt)))
         out.append("")
@@ -309,17 +440,8 @@ def main():
         out.append("")
         # deferred rescale of both halves: O[h] *= al[h], S[h] -= de[h], -m[h] = ng[h] (a half that does not move gets 1, 0
         # and its old -m: exact no-ops)
-        lines = ["s_nop 11"]     # the last PV MFMA of the preceding block wrote O: 12 wait states before it is read
-        for h in (0, 1):
-            for g in range(0, 64, 8):
-                base = AO(h, 0) + g
-                lines += [f"v_accvgpr_read_b32 {vr(TMP0 + j)}, {ar(base + j)}" for j in range(8)]
-                lines += [f"v_mul_f32 {vr(TMP0 + j)}, {vr(TMP0 + j)}, %[al{h}]" for j in range(8)]
-                lines += [f"v_accvgpr_write_b32 {ar(base + j)}, {vr(TMP0 + j)}" for j in range(8)]
-            lines += [f"v_sub_f32 {vr(S[h] + i)}, {vr(S[h] + i)}, %[de{h}]" for i in range(16)]
-            lines += [f"v_mov_b32 {vr(NM[h] + i)}, %[ng{h}]" for i in range(16)]
         out.append(f"#define RSA_K5W_RESCALE_{nmx} \\")
-        out.append(c_string(lines))
+        out.append(c_string(rescale_core(S, ["%[al0]", "%[al1]"], ["%[de0]", "%[de1]"], ["%[ng0]", "%[ng1]"])))
         out.append("")
     out.append("#define RSA_K5W_NMZERO \\")
     out.append(c_string([f"v_mov_b32 {vr(NM[0] + i)}, 0" for i in range(32)]))
@@ -339,11 +461,20 @@ def main():
             out.append(c_string([f"v_accvgpr_read_b32 {vr(TMP0 + j)}, {ar(AO(h, d) + j)}" for j in range(16)]))
             out.append("")
     # operand lists
-    outs = [f'"+{{{vr(SA[h], 16)}}}"(SA[{h}])' for h in (0, 1)] + [f'"+{{{vr(SB[h], 16)}}}"(SB[{h}])' for h in (0, 1)]
-    outs += ['[l0] "+v"(l[0])', '[l1] "+v"(l[1])', '[mx0] "=&v"(mx[0])', '[mx1] "=&v"(mx[1])']
+    souts = [f'"+{{{vr(SA[h], 16)}}}"(SA[{h}])' for h in (0, 1)] + [f'"+{{{vr(SB[h], 16)}}}"(SB[{h}])' for h in (0, 1)]
+    outs = souts + ['[l0] "+v"(l[0])', '[l1] "+v"(l[1])', '[mx0] "=&v"(mx[0])', '[mx1] "=&v"(mx[1])']
     ins = [f'"{{{vr(NM[h], 16)}}}"(nm[{h}])' for h in (0, 1)] + [f'"{{{vr(KA, 8)}}}"(ka)', f'"{{{vr(VA, 8)}}}"(va)']
-    dma = ['[dm] "s"(dm)', '[glo] "s"(glo)', '[ghi] "s"(ghi)', '[ld] "s"(ldst)', '[st] "s"(gstep)', '[vo0] "v"(vo0)', '[vo1] "v"(vo1)']
-    out.append(f"#define RSA_K5W_OPS : {', '.join(outs)} : {', '.join(ins + dma)}")
+    out.append(f"#define RSA_K5W_OPS : {', '.join(outs)} : {', '.join(ins)}")
+    nmio = [f'"+{{{vr(NM[h], 16)}}}"(nm[{h}])' for h in (0, 1)]
+    louts = souts + nmio + ['[l0] "+v"(l[0])', '[l1] "+v"(l[1])', '[mx0] "+v"(mx[0])', '[mx1] "+v"(mx[1])',
+                            '[th0] "+v"(thr[0])', '[th1] "+v"(thr[1])', '[mr0] "+v"(m_ref[0])', '[mr1] "+v"(m_ref[1])',
+                            '[la] "+v"(la)', '[lv] "=&v"(lv)']
+    lins = [f'"{{{vr(KA, 8)}}}"(ka)', f'"{{{vr(VA, 8)}}}"(va)', f'"{{{vr(VOK, 2)}}}"(vok)', f'"{{{vr(VOV, 2)}}}"(vov)',
+            '[cnt] "s"(cnt)', '[blk0] "s"(blk0)', '[blk1] "s"(blk1)', '[kb] "s"(kb)', '[vb] "s"(vb)', '[krow] "s"(krow)',
+            '[vrow] "s"(vrow)', '[ldsk] "s"(ldsk)', '[ldsv] "s"(ldsv)', '[ninf] "v"(ninf)', '[eight] "v"(eight)']
+    out.append(f"#define RSA_K5W_OPS_LOOP : {', '.join(louts)} : {', '.join(lins)}")
+    dl = louts + ['[d0] "=s"(d0)', '[d1] "=s"(d1)']
+    out.append(f"#define RSA_K5W_OPS_LOOP_DIAG : {', '.join(dl)} : {', '.join(lins)}")
     outs0 = [f'"+{{{vr(SA[h], 16)}}}"(SA[{h}])' for h in (0, 1)] + ['[mx0] "=&v"(mx[0])', '[mx1] "=&v"(mx[1])']
     out.append(f"#define RSA_K5W_OPS_QK0 : {', '.join(outs0)} : {', '.join(ins[:3])}")
     for nmx, S in (("A", SA), ("B", SB)):
@@ -351,8 +482,7 @@ def main():
         out.append(f"#define RSA_K5W_OPS_ROWMAX_{nmx} : {', '.join(so)}, [mx0] \"=&v\"(mx[0]), [mx1] \"=&v\"(mx[1]) :")
         out.append(f"#define RSA_K5W_OPS_MASK_{nmx} : {', '.join(so)} : [kb0] \"v\"(kb0), [kb1] \"v\"(kb1), [sp0] \"v\"(sp0), "
                    f"[sp1] \"v\"(sp1), [ninf] \"v\"(ninf)")
-        no = [f'"+{{{vr(NM[h], 16)}}}"(nm[{h}])' for h in (0, 1)]
-        out.append(f"#define RSA_K5W_OPS_RESCALE_{nmx} : {', '.join(so + no)} : [al0] \"v\"(al0), [al1] \"v\"(al1), "
+        out.append(f"#define RSA_K5W_OPS_RESCALE_{nmx} : {', '.join(so + nmio)} : [al0] \"v\"(al0), [al1] \"v\"(al1), "
                    f"[de0] \"v\"(de0), [de1] \"v\"(de1), [ng0] \"v\"(ng0), [ng1] \"v\"(ng1)")
     out.append(f"#define RSA_K5W_OPS_NMZERO : \"={{{vr(NM[0], 16)}}}\"(nm[0]), \"={{{vr(NM[1], 16)}}}\"(nm[1])")
     tmp = ", ".join(f'"v{r}"' for r in range(TMP0, TMP1))
@@ -361,20 +491,23 @@ def main():
     out.append(f"#define RSA_K5W_CLOBBER_TMP {tmp}")
     out.append(f"#define RSA_K5W_CLOBBER_O {acc_o}")
     out.append(f"#define RSA_K5W_CLOBBER_Q {acc_q}")
-    out.append('#define RSA_K5W_CLOBBER_DMA "s90", "s91", "s92", "vcc"')
+    out.append("#define RSA_K5W_CLOBBER_LOOP " + ", ".join(f'"s{r}"' for r in S_CLOB) + ', "vcc", "scc"')
+    out.append('#define RSA_K5W_CLOBBER_LOOP_DIAG "s98", "s99", "s100", "s101"')
     out.append(f"// O a[0:127], Q a[128:191]; SA v[0:31], SB v[32:63], -m v[64:95], temporaries v[{TMP0}:{TMP1 - 1}] "
-               f"(P v[96:111], K ring v[112:127], V ring v[128:143]), K addresses v[{KA}:{KA + 7}], V addresses v[{VA}:{VA + 7}]")
+               f"(P v[96:111], K ring v[112:127], V ring v[128:143]), K addresses v[{KA}:{KA + 7}], V addresses v[{VA}:{VA + 7}], "
+               f"DMA lane offsets v[{VOK}:{VOV + 1}]; the loop statement owns s[{S_CLOB[0]}:{S_CLOB[-1]}]")
     print("\n".join(out))
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "stats":
         STATS = []
-        import io, contextlib
+        import contextlib
+        import io
         with contextlib.redirect_stdout(io.StringIO()):
             main()
-        for dt, VS, SUB, usage in STATS:
-            if dt == "bf16" and VS == 0:
-                print(f"S{SUB}: per-gap issue cost {usage}  total {sum(usage)}")
+        for dt, U, dma, usage in STATS:
+            if dt == "bf16" and U == 0:
+                print(f"U{U} dma={dma}: per-gap issue cost {usage}  total {sum(usage)}")
     else:
         main()

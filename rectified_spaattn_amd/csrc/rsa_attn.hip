@@ -120,6 +120,7 @@ static int launch_attn(AttnArgs& a, int BH, int D, int dtype, hipStream_t s) {
     }
     const int n_heavy = ntq > 0 ? BH * ntq * a.tsplit : 0;
     a.BH = BH;
+    a.w64_flags = g_k5_w64 >> 1;
     a.n_heavy_pad = (n_heavy + 7) & ~7;
     a.NBp = (a.NBv + 7) & ~7;
     const long nblocks = (long)a.n_heavy_pad + (long)BH * a.NBp;
@@ -127,7 +128,7 @@ static int launch_attn(AttnArgs& a, int BH, int D, int dtype, hipStream_t s) {
     if (nblocks > 0x7FFFFFFF) return RSA_ERR_UNSUPPORTED;
     if (a.NB_total > 8192) return RSA_ERR_UNSUPPORTED;  // kept list lives in LDS as u16, 16 KiB max
     const size_t lds_bytes = (size_t)4 * 64 * D * 2 + (((size_t)a.NB_total * 2 + 15) & ~(size_t)15);
-    const int st = (D == 128 && g_k5_w64) ? rsa_launch_bsfwd64(a, dim3((unsigned)nblocks), lds_bytes, dtype, s)
+    const int st = (D == 128 && (g_k5_w64 & 1)) ? rsa_launch_bsfwd64(a, dim3((unsigned)nblocks), lds_bytes, dtype, s)
                                           : rsa_launch_bsfwd(a, dim3((unsigned)nblocks), lds_bytes, D, dtype, s);
     if (st != RSA_OK || a.tsplit <= 1) return st;
     return launch_text_combine(a, BH, D, dtype, s);

@@ -8,38 +8,39 @@
 //   in the arch VGPRs.  Every K fragment (ds_read_b128) and every V^T fragment (ds_read_b64_tr_b16) read from LDS feeds
 //   TWO MFMAs, one per row half: 24 LDS operand reads per 32 MFMAs instead of per 16.
 //
-// The pipelined block (one 32-key sub-step: 16 QK^T MFMAs of sub-step u+1, softmax of u, 16 PV MFMAs of u, row maxima of
-// u+1) is generated, hand-placed asm with every register pinned: gen_k5_block64.py -> rsa_attn_block64.h, which also
-// documents the register map and the schedule.  LDS-DMA staging (global_load_lds_dwordx4, 1 KiB per wave-instruction, 8
-// pieces per wave and 64-key tile) is issued INSIDE the block, one piece per fourth MFMA gap, the two waves of the workgroup
-// in different gaps, so that the CU's texture addresser sees the pieces spread over the sub-step; boundary tiles (rows
-// clamped to the last valid key) are staged from C++ in front of the block, which then runs its no-DMA form.
+// With one wave per SIMD nothing hides an instruction that sits between two MFMA streams, so the steady state is ONE
+// generated asm statement (gen_k5_block64.py -> rsa_attn_block64.h, which documents register map, LDS rings and schedule):
+// per kept 128-key block four 32-key sub-steps, each = vmcnt(16) + barrier + a hand-placed block of 32 MFMAs with the
+// softmax, the LDS operand reads, the wave's 8 LDS-DMA pieces (half-tiles u+3 of V and u+4 of K: two to three sub-steps of
+// flight) and the scalar bookkeeping (list entry, DMA address walkers) in the MFMA shadows, and the deferred-rescale test,
+// whose rare body sits out of line inside the statement.  C++ keeps the prologue, the epilogue and the sub-steps the loop
+// does not take: kept blocks whose scores need the boundary mask or whose successor's rows must be clamped (the last one
+// or two of a list, the diagonal blocks of a causal call) run block by block, staged from here.
 //
-// LDS = [K0 K1 V0 V1 | kept list (u16)], 64-key tiles, images and swizzle exactly as in rsa_attn_kernel.hip.  At the head of
-// sub-step (t,0) the workgroup waits for V(t) (vmcnt(8): K(t+1) may stay in flight), barrier, and issues V(t+1) into
-// V(t-1)'s slot during the block; at the head of (t,1) for K(t+1), barrier, K(t+2) into K(t)'s slot.
+// LDS = [K ring: 4 x 8 KiB | V ring: 4 x 8 KiB | list (u16)]: half-tile x (32 keys) of the walk sits in slot x & 3.
 #include "rsa_attn.h"
 #include "rsa_attn_block64.h"
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-#define RSA_K5W_PICK(TT) \
-    do { \
-        if constexpr (VS == 0 && SUB == 0) asm volatile(RSA_K5W_BLOCK_##TT##_V0_S0 RSA_K5W_OPS : RSA_K5W_CL, "memory"); \
-        else if constexpr (VS == 0 && SUB == 1) asm volatile(RSA_K5W_BLOCK_##TT##_V0_S1 RSA_K5W_OPS : RSA_K5W_CL, "memory"); \
-        else if constexpr (VS == 1 && SUB == 0) asm volatile(RSA_K5W_BLOCK_##TT##_V1_S0 RSA_K5W_OPS : RSA_K5W_CL, "memory"); \
-        else asm volatile(RSA_K5W_BLOCK_##TT##_V1_S1 RSA_K5W_OPS : RSA_K5W_CL, "memory"); \
-    } while (0)
-#define RSA_K5W_CL RSA_K5W_CLOBBER_TMP, RSA_K5W_CLOBBER_O, RSA_K5W_CLOBBER_DMA
-
-// The block (ONE asm statement per slot / sub-step parity).  dm != 0: it also issues this wave's 8 LDS-DMA pieces of one
-// 64-key tile: source = (ghi:glo) + j * gstep + per-lane offset vo0 (even j) / vo1 (odd j), LDS destination ldst + j * 2048.
-template <typename Tag, int VS, int SUB>
+// block U without LDS-DMA (the C++-driven sub-steps)
+template <typename Tag, int U>
 __device__ __forceinline__ void k5w_block(f32x16 (&SA)[2], f32x16 (&SB)[2], const f32x16 (&nm)[2], float (&l)[2], float (&mx)[2],
-                                          const i32x8& ka, const i32x8& va, unsigned dm, unsigned glo, unsigned ghi, unsigned ldst,
-                                          unsigned gstep, unsigned vo0, unsigned vo1) {
-    if constexpr (std::is_same<Tag, bf16_tag>::value) RSA_K5W_PICK(BF16);
-    else RSA_K5W_PICK(F16);
+                                          const i32x8& ka, const i32x8& va) {
+#define RSA_K5W_CL RSA_K5W_CLOBBER_TMP, RSA_K5W_CLOBBER_O
+    if constexpr (std::is_same<Tag, bf16_tag>::value) {
+        if constexpr (U == 0) asm volatile(RSA_K5W_BLOCK_BF16_U0 RSA_K5W_OPS : RSA_K5W_CL, "memory");
+        else if constexpr (U == 1) asm volatile(RSA_K5W_BLOCK_BF16_U1 RSA_K5W_OPS : RSA_K5W_CL, "memory");
+        else if constexpr (U == 2) asm volatile(RSA_K5W_BLOCK_BF16_U2 RSA_K5W_OPS : RSA_K5W_CL, "memory");
+        else asm volatile(RSA_K5W_BLOCK_BF16_U3 RSA_K5W_OPS : RSA_K5W_CL, "memory");
+    } else {
+        if constexpr (U == 0) asm volatile(RSA_K5W_BLOCK_F16_U0 RSA_K5W_OPS : RSA_K5W_CL, "memory");
+        else if constexpr (U == 1) asm volatile(RSA_K5W_BLOCK_F16_U1 RSA_K5W_OPS : RSA_K5W_CL, "memory");
+        else if constexpr (U == 2) asm volatile(RSA_K5W_BLOCK_F16_U2 RSA_K5W_OPS : RSA_K5W_CL, "memory");
+        else asm volatile(RSA_K5W_BLOCK_F16_U3 RSA_K5W_OPS : RSA_K5W_CL, "memory");
+    }
+#undef RSA_K5W_CL
 }
 
 // one Q fragment (4 registers, pinned to v[96:99]) -> its place in the accumulator file
@@ -100,11 +101,11 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int NW = 2;                   // 2 waves x 64 query rows
     constexpr int KS = D / 16;
     constexpr int DT = D / 32;
-    constexpr int TILE_BYTES = 64 * D * 2;
-    constexpr int NPC = TILE_BYTES / 1024 / NW;  // 8 one-KiB pieces per wave per tile operand
+    constexpr int HALF = 32 * D * 2;        // bytes of a 32-key half-tile
+    constexpr int VRING = 4 * HALF;
     using E = Elem<Tag>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    unsigned short* lds_list = reinterpret_cast<unsigned short*>(lds + 4 * TILE_BYTES);
+    unsigned short* lds_list = reinterpret_cast<unsigned short*>(lds + 8 * HALF);
 
     // ---------------- work mapping: dense text-row blocks first, then the sparse blocks chunked per XCD ----------------
     int bh, qblk, tsp;
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             hi_r[0] = hi_r[1] = a.kv_valid;
         } else {
             n_items = (a.kv_text_valid + RSA_BLOCK - 1) / RSA_BLOCK;
-            if (a.tsplit > 1) {
+            if (a.tsplit > 1) {   // split-KV: this workgroup's slice of the key blocks
                 first_blk = tsp * a.tper;
                 n_items = n_items - first_blk < a.tper ? n_items - first_blk : a.tper;
                 if (n_items < 0) n_items = 0;
@@ -172,23 +173,15 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (hi_max <= lo_min) n_items = 0;
     }
     n_items = __builtin_amdgcn_readfirstlane(n_items);
-    // the kept list (sparse visual blocks) or the plain block range (text rows, dense mode) as u16 entries in LDS: the main
-    // loop reads its next block index from there in every mode
-    for (int i = t; i < n_items; i += 64 * NW) lds_list[i] = (unsigned short)(list ? list[i] : first_blk + i);
+    // the kept list (sparse visual blocks) or the plain block range (text rows, dense mode) as u16 entries in LDS: the walk
+    // reads its block indices from there in every mode (one entry of slack: the loop looks two blocks ahead)
+    for (int i = t; i < n_items + 2; i += 64 * NW)
+        lds_list[i] = (unsigned short)(i < n_items ? (list ? list[i] : first_blk + i) : 0);
     __syncthreads();
-    auto blk_of = [&](int item) -> int { return (int)lds_list[item]; };
-    int n_tiles = 2 * n_items;
-    if (n_items > 0) {
-        const int last_blk = blk_of(n_items - 1);
-        if (last_blk * RSA_BLOCK + 64 >= hi_max) n_tiles -= 1;
-    }
-    n_tiles = __builtin_amdgcn_readfirstlane(n_tiles);
+    auto blk_of = [&](int item) -> int { return __builtin_amdgcn_readfirstlane((int)lds_list[item]); };
+    const int n_sub = 4 * n_items;            // 32-key sub-steps: four per kept block (scores past the row's range are masked)
     const int kv_limit = hi_max < a.Sk ? hi_max : a.Sk;
-    auto key0_of = [&](int tile) -> int {
-        const int it = tile >> 1;
-        const int blk = __builtin_amdgcn_readfirstlane(blk_of(it < n_items ? it : (n_items > 0 ? n_items - 1 : 0)));
-        return blk * RSA_BLOCK + (tile & 1) * 64;
-    };
+    auto key_of = [&](int x) -> int { return blk_of(x >> 2) * RSA_BLOCK + (x & 3) * 32; };   // first key of half-tile x
 
     // ---------------- Q fragments (B operand) -> accumulator file; O = 0 ----------------
     asm volatile(RSA_K5W_OZERO ::: RSA_K5W_CLOBBER_O);
@@ -222,52 +215,42 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
     const unsigned char* kbase = uni64(reinterpret_cast<const unsigned char*>(a.k + (long)b * a.ksb + (long)h * a.ksh));
     const unsigned char* vbase = uni64(reinterpret_cast<const unsigned char*>(a.v + (long)b * a.vsb + (long)h * a.vsh));
-    // A 64-key tile = 16 one-KiB pieces of 4 rows; wave w moves pieces 2j + w (rows 8j + 4w .. +3), j = 0..7.  The XOR
+    // A 32-key half-tile = 8 one-KiB pieces of 4 rows; wave w moves pieces 2j + w (rows 8j + 4w .. +3), j = 0..3.  The XOR
     // swizzle of a row's source chunk depends on (row & 3) and ((row >> 2) & 3) = (2j + w) & 3: two per-lane offsets
-    // (even / odd j), the piece walks a scalar base by 8 rows.
+    // (even / odd j); the piece walks a scalar base by 8 rows.
     const int rsub = lane >> 4, cl = lane & 15;
     const int rowl = 4 * wv + rsub;
     const int gsw0 = cl ^ ((rsub << 2) | wv), gsw1 = cl ^ ((rsub << 2) | (2 + wv));
-    const unsigned vok0 = (unsigned)(((long)rowl * a.kss + gsw0 * 8) * 2), vok1 = (unsigned)(((long)rowl * a.kss + gsw1 * 8) * 2);
-    const unsigned vov0 = (unsigned)(((long)rowl * a.vss + gsw0 * 8) * 2), vov1 = (unsigned)(((long)rowl * a.vss + gsw1 * 8) * 2);
-    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
     const unsigned krow = (unsigned)(a.kss * 2), vrow = (unsigned)(a.vss * 2);   // bytes per key row (< 4 GiB)
-    const unsigned kstep = 8 * krow, vstep = 8 * vrow;                            // bytes per 8-row group
-    // staging from C++ (prologue, boundary tiles): the 64-key tile starting at key `key_first` -> LDS byte offset `lds_off`
-    auto dma = [&](int is_v, int key_first, unsigned lds_off) {
+    u32x2 vok, vov;
+    vok[0] = rowl * krow + gsw0 * 16; vok[1] = rowl * krow + gsw1 * 16;
+    vov[0] = rowl * vrow + gsw0 * 16; vov[1] = rowl * vrow + gsw1 * 16;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    // staging from C++ (prologue, boundary blocks): the 32-key half-tile starting at key `key_first` -> LDS byte offset
+    // `lds_off`; rows past the last valid key are clamped to it (their scores are masked)
+    auto dma_half = [&](int is_v, int key_first, unsigned lds_off) {
         const unsigned ld0 = lds_base + lds_off + wv * 1024;
         const unsigned char* base = is_v ? vbase : kbase;
         const unsigned rowb = is_v ? vrow : krow;
-        if (key_first + 64 <= kv_limit) {
-            const unsigned char* tb = uni64(base + (unsigned long)(unsigned)key_first * rowb);
-            const long step = is_v ? (long)vstep : (long)kstep;
 #pragma unroll
-            for (int j = 0; j < NPC; ++j) {
-                const unsigned vo = is_v ? ((j & 1) ? vov1 : vov0) : ((j & 1) ? vok1 : vok0);
-                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                             :: "v"(vo), "s"(tb + j * step), "s"(ld0 + j * 2048) : "memory");
-            }
-        } else {   // the tile runs past the last valid key: rows clamped (their scores are masked)
-#pragma unroll
-            for (int j = 0; j < NPC; ++j) {
-                int krow_ = key_first + 8 * j + rowl;
-                krow_ = krow_ < kv_limit ? krow_ : kv_limit - 1;
-                const unsigned vo = (unsigned)((unsigned long)(unsigned)krow_ * rowb) + ((j & 1) ? gsw1 : gsw0) * 16;
-                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                             :: "v"(vo), "s"(base), "s"(ld0 + j * 2048) : "memory");
-            }
+        for (int j = 0; j < 4; ++j) {
+            int krow_ = key_first + 8 * j + rowl;
+            krow_ = krow_ < kv_limit ? krow_ : kv_limit - 1;
+            const unsigned vo = (unsigned)krow_ * rowb + ((j & 1) ? gsw1 : gsw0) * 16;
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                         :: "v"(vo), "s"(base), "s"(ld0 + j * 2048) : "memory");
         }
     };
 
     // ---------------- state ----------------
-    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.0f, 0.0f};
+    float l_run[2] = {0.0f, 0.0f};
     // m_ref = the finite reference the scores are taken against, nm = its negation in 16 registers (C operand of the first
     // QK^T MFMA), thr = how far a new row maximum may exceed it before the rescale (-inf until the row has seen a finite score)
     float m_ref[2] = {0.0f, 0.0f}, thr[2] = {-INFINITY, -INFINITY};
     f32x16 nm[2];
     asm volatile(RSA_K5W_NMZERO RSA_K5W_OPS_NMZERO);
 
-    // per-lane LDS read addressing (sub-tile 0 / slot 0; slot, sub-tile and k-step are immediates of the block)
+    // per-lane LDS read addressing (half-tile rows 0..31 of slot 0; slot and k-step are immediates of the block)
     const int kswz = ((r & 3) << 2) | ((r >> 2) & 3);
     const int g4 = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
     i32x8 ka, va;
@@ -280,30 +263,29 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         va[2 * dt + 1] = (int)lds_base + tile_off<D>(4 * hh + tq + 8, ch) + 8 * (tp & 1);
     }
 
-    int kq1 = 0, kq2 = 0;  // first keys of tile+1 / tile+2
-    // what the next block stages: 0 = nothing (or done from C++), else the operands of its in-block LDS-DMA
-    unsigned blk_dma = 0;
-    unsigned d_glo = 0, d_ghi = 0, d_ld = 0, d_step = 0, d_vo0 = 0, d_vo1 = 0;
+#ifdef RSA_K5_DIAG
+    // diagnostics build: s_memtime around the phases of the walk, summed per wave (scalar registers)
+    unsigned long long tprev = 0, tsum[4] = {0, 0, 0, 0}, tkern0;
+    auto stamp_now = [&]() -> unsigned long long {
+        unsigned long long tt;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt) :: "memory");
+        return tt;
+    };
+    tkern0 = stamp_now();
+#define RSA_STAMP0() do { tprev = stamp_now(); } while (0)
+#define RSA_STAMP(i) do { const unsigned long long tn_ = stamp_now(); tsum[i] += tn_ - tprev; tprev = tn_; } while (0)
+#else
+#define RSA_STAMP0() do { } while (0)
+#define RSA_STAMP(i) do { } while (0)
+#endif
 
-    // The part of a sub-step behind its staging point: rare branches (boundary mask, deferred rescale), then the block.
-    auto half = [&](auto VS, auto SUB, int key0, f32x16 (&SA)[2], f32x16 (&SB)[2], float (&mxA)[2], float (&mxB)[2]) {
-        constexpr int vs = decltype(VS)::value, sub = decltype(SUB)::value;
-        float (&mx_cur)[2] = sub == 0 ? mxA : mxB;
-        float (&mx_nxt)[2] = sub == 0 ? mxB : mxA;
-        const int kfirst = key0 + 32 * sub;
-        if (kfirst < lo_max || kfirst + 32 > hi_min) {   // boundary tile: scores outside the row's key range -> -inf, new row maxima
-            const int kb0 = kfirst + 4 * hh - lo_r[0], kb1 = kfirst + 4 * hh - lo_r[1];
-            const int sp0 = hi_r[0] > lo_r[0] ? hi_r[0] - lo_r[0] : 0, sp1 = hi_r[1] > lo_r[1] ? hi_r[1] - lo_r[1] : 0;
-            const float ninf = -INFINITY;
-            float (&mx)[2] = mx_cur;
-            if constexpr (sub == 0) {
-                asm volatile(RSA_K5W_MASK_A RSA_K5W_OPS_MASK_A : "v146", "vcc");
-                asm volatile(RSA_K5W_ROWMAX_A RSA_K5W_OPS_ROWMAX_A : "v146", "v147", "v148", "v149");
-            } else {
-                asm volatile(RSA_K5W_MASK_B RSA_K5W_OPS_MASK_B : "v146", "vcc");
-                asm volatile(RSA_K5W_ROWMAX_B RSA_K5W_OPS_ROWMAX_B : "v146", "v147", "v148", "v149");
-            }
-        }
+    f32x16 SA[2], SB[2];
+    float mxA[2] = {-INFINITY, -INFINITY}, mxB[2] = {-INFINITY, -INFINITY};
+    const float ninf = -INFINITY, eight = 8.0f;
+
+    // deferred rescale of the scores the next block consumes (S_cur = SA for even sub-steps), C++-driven form
+    auto rescale_check = [&](auto UC, float (&mx_cur)[2], f32x16 (&SA)[2], f32x16 (&SB)[2], f32x16 (&nm)[2]) {
+        constexpr int U = decltype(UC)::value;
         // S_cur, mx_cur are relative to m_ref as it was when they were computed, and that is still m_ref
         if (__builtin_amdgcn_ballot_w64(mx_cur[0] > thr[0] || mx_cur[1] > thr[1]) != 0ull) {
             float al[2], de[2], ng[2];
@@ -317,54 +299,57 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);   // (first: O and l are still zero)
                 m_ref[x] += delta;
                 l_run[x] *= alpha;
+                mx_cur[x] -= delta;     // the row maximum follows its scores to the new reference (the test may run again on them)
                 al[x] = alpha; de[x] = delta; ng[x] = -m_ref[x];
             }
             const float al0 = al[0], al1 = al[1], de0 = de[0], de1 = de[1], ng0 = ng[0], ng1 = ng[1];
-            if constexpr (sub == 0) asm volatile(RSA_K5W_RESCALE_A RSA_K5W_OPS_RESCALE_A : RSA_K5W_CLOBBER_TMP, RSA_K5W_CLOBBER_O);
+            if constexpr ((U & 1) == 0) asm volatile(RSA_K5W_RESCALE_A RSA_K5W_OPS_RESCALE_A : RSA_K5W_CLOBBER_TMP, RSA_K5W_CLOBBER_O);
             else asm volatile(RSA_K5W_RESCALE_B RSA_K5W_OPS_RESCALE_B : RSA_K5W_CLOBBER_TMP, RSA_K5W_CLOBBER_O);
         }
-        k5w_block<Tag, vs, sub>(SA, SB, nm, l_run, mx_nxt, ka, va, blk_dma, d_glo, d_ghi, d_ld, d_step, d_vo0, d_vo1);
     };
-
-    // staging point in front of every sub-step: wait (the newest group, issued during the previous sub-step, may stay in
-    // flight), barrier, then decide what this sub-step stages: SUB 0 V(tile+1) into V(tile-1)'s slot, SUB 1 K(tile+2) into
-    // K(tile)'s slot -- inside the block when the tile is full, from here (rows clamped) when it crosses the last valid key.
-    auto stage = [&](auto VS, auto SUB, int tile) {
-        constexpr int vs = decltype(VS)::value, sub = decltype(SUB)::value;
-        if (tile + 1 < n_tiles) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    // One C++-driven sub-step u (U = u & 3): wait + barrier, staging of V(u+3) and K(u+4) (rows clamped), boundary mask and
+    // deferred rescale on S_cur, block U.
+    auto step = [&](auto UC, int u, f32x16 (&SA)[2], f32x16 (&SB)[2], f32x16 (&nm)[2]) {
+        constexpr int U = decltype(UC)::value;
+        float (&mx_cur)[2] = (U & 1) == 0 ? mxA : mxB;
+        float (&mx_nxt)[2] = (U & 1) == 0 ? mxB : mxA;
+        if (u + 4 <= n_sub) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        blk_dma = 0;
-        const bool want = sub == 0 ? tile + 1 < n_tiles : tile + 2 < n_tiles;
-        if (want) {
-            const int kf = sub == 0 ? kq1 : kq2;
-            const unsigned off = sub == 0 ? (2 + (vs ^ 1)) * TILE_BYTES : vs * TILE_BYTES;
-            if (kf + 64 <= kv_limit) {
-                const unsigned char* tb = (sub == 0 ? vbase : kbase) + (unsigned long)(unsigned)kf * (sub == 0 ? vrow : krow);
-                d_glo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)tb);
-                d_ghi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)tb >> 32));
-                d_ld = lds_base + off + wv * 1024;
-                d_step = sub == 0 ? vstep : kstep;
-                d_vo0 = sub == 0 ? vov0 : vok0;
-                d_vo1 = sub == 0 ? vov1 : vok1;
-                blk_dma = 1;
+        if (u + 3 < n_sub) dma_half(1, key_of(u + 3), VRING + ((U + 3) & 3) * HALF);
+        if (u + 4 < n_sub) dma_half(0, key_of(u + 4), U * HALF);
+        const int kfirst = key_of(u);
+        if (kfirst < lo_max || kfirst + 32 > hi_min) {   // scores outside the row's key range -> -inf, new row maxima
+            const int kb0 = kfirst + 4 * hh - lo_r[0], kb1 = kfirst + 4 * hh - lo_r[1];
+            const int sp0 = hi_r[0] > lo_r[0] ? hi_r[0] - lo_r[0] : 0, sp1 = hi_r[1] > lo_r[1] ? hi_r[1] - lo_r[1] : 0;
+            float (&mx)[2] = mx_cur;
+            if constexpr ((U & 1) == 0) {
+                asm volatile(RSA_K5W_MASK_A RSA_K5W_OPS_MASK_A : "v146", "vcc");
+                asm volatile(RSA_K5W_ROWMAX_A RSA_K5W_OPS_ROWMAX_A : "v146", "v147", "v148", "v149");
             } else {
-                dma(sub == 0 ? 1 : 0, kf, off);
+                asm volatile(RSA_K5W_MASK_B RSA_K5W_OPS_MASK_B : "v146", "vcc");
+                asm volatile(RSA_K5W_ROWMAX_B RSA_K5W_OPS_ROWMAX_B : "v146", "v147", "v148", "v149");
             }
+        }
+        rescale_check(UC, mx_cur, SA, SB, nm);
+        k5w_block<Tag, U>(SA, SB, nm, l_run, mx_nxt, ka, va);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    auto run_items = [&](int i_begin, int i_end) {   // kept blocks [i_begin, i_end), C++-driven
+        for (int i = i_begin; i < i_end; ++i) {
+            step(I0{}, 4 * i, SA, SB, nm); step(I1{}, 4 * i + 1, SA, SB, nm); step(I2{}, 4 * i + 2, SA, SB, nm); step(I3{}, 4 * i + 3, SA, SB, nm);
         }
     };
 
-    // ---------------- prologue + main loop ----------------
-    f32x16 SA[2], SB[2];
-    float mxA[2] = {-INFINITY, -INFINITY}, mxB[2] = {-INFINITY, -INFINITY};
-    int key0 = 0;
-    if (n_tiles > 0) {
-        key0 = key0_of(0);
-        kq1 = key0_of(1);
-        kq2 = key0_of(2);
-        dma(0, key0, 0);
-        dma(1, key0, 2 * TILE_BYTES);
-        if (n_tiles > 1) dma(0, kq1, TILE_BYTES);
+    // ---------------- prologue: half-tiles K(0..3), V(0..2); scores of sub-step 0 ----------------
+    if (n_sub > 0) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) dma_half(0, key_of(x), x * HALF);
+#pragma unroll
+        for (int x = 0; x < 3; ++x) dma_half(1, key_of(x), VRING + x * HALF);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         float (&mx)[2] = mxA;
@@ -373,42 +358,51 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         else
             asm volatile(RSA_K5W_QK0_F16 RSA_K5W_OPS_QK0 : RSA_K5W_CLOBBER_TMP, "memory");
     }
-    // kept-list entry of tile+3 read from LDS one advance() early (pref_raw), made scalar at use
-    auto raw_item = [&](int tile) -> int {
-        const int it = tile >> 1;
-        return blk_of(it < n_items ? it : (n_items > 0 ? n_items - 1 : 0));
-    };
-    int pref_raw = n_tiles > 0 ? raw_item(3) : 0;
-    auto advance = [&](int tile) {
-        key0 = kq1;
-        kq1 = kq2;
-        kq2 = __builtin_amdgcn_readfirstlane(pref_raw) * RSA_BLOCK + ((tile + 3) & 1) * 64;
-        pref_raw = raw_item(tile + 4);
-    };
+    RSA_STAMP0();
+    // Which kept blocks the asm loop takes: [i0, i1) such that no score of block i needs the boundary mask and block i + 1
+    // (whose half-tiles the loop stages while it works on i) exists and lies inside the valid keys: i0 = the leading blocks
+    // below lo_max (second segment of a two-segment dense call), i1 from the end of the ascending list.
+    int i0 = 0;
+    while (i0 < n_items && blk_of(i0) * RSA_BLOCK < lo_max) ++i0;
+    int nfull = n_items;
+    while (nfull > i0 && blk_of(nfull - 1) * RSA_BLOCK + RSA_BLOCK > hi_min) --nfull;
+    const int i1 = (nfull - 1 > i0 && !(a.w64_flags & 1)) ? nfull - 1 : i0;
+    run_items(0, i0);
+    RSA_STAMP(0);
     {
-        using I0 = std::integral_constant<int, 0>;
-        using I1 = std::integral_constant<int, 1>;
-        auto tile_step = [&](auto VS, int tile) {
-            stage(VS, I0{}, tile);
-            half(VS, I0{}, key0, SA, SB, mxA, mxB);
-            stage(VS, I1{}, tile);
-            half(VS, I1{}, key0, SA, SB, mxA, mxB);
-        };
-        int tile = 0;
-        for (; tile + 1 < n_tiles; tile += 2) {
-            tile_step(I0{}, tile);
-            advance(tile);
-            tile_step(I1{}, tile + 1);
-            advance(tile + 1);
-        }
-        if (tile < n_tiles) tile_step(I0{}, tile);
+        rescale_check(I0{}, mxA, SA, SB, nm);
+        const unsigned cnt = (unsigned)(i1 - i0);
+        const unsigned blk0 = cnt ? (unsigned)blk_of(i0) : 0u, blk1 = cnt ? (unsigned)blk_of(i0 + 1) : 0u;
+        unsigned la = lds_base + 8 * HALF + 2 * (i0 + 2), lv;
+        const unsigned long kb = (unsigned long)(uintptr_t)kbase, vb = (unsigned long)(uintptr_t)vbase;
+        const unsigned ldsk = lds_base + wv * 1024, ldsv = lds_base + VRING + wv * 1024;
+        float (&l)[2] = l_run;
+        float (&mx)[2] = mxA;
+#ifdef RSA_K5_DIAG
+        unsigned d0 = 0, d1 = 0;   // in-loop stamps: cycles parked on the vmcnt wait / on the barrier (+ rescales taken << 24)
+        if constexpr (std::is_same<Tag, bf16_tag>::value)
+            asm volatile(RSA_K5W_LOOP_BF16_DIAG RSA_K5W_OPS_LOOP_DIAG : RSA_K5W_CLOBBER_TMP, RSA_K5W_CLOBBER_O, RSA_K5W_CLOBBER_LOOP,
+                         RSA_K5W_CLOBBER_LOOP_DIAG, "memory");
+        else
+            asm volatile(RSA_K5W_LOOP_F16_DIAG RSA_K5W_OPS_LOOP_DIAG : RSA_K5W_CLOBBER_TMP, RSA_K5W_CLOBBER_O, RSA_K5W_CLOBBER_LOOP,
+                         RSA_K5W_CLOBBER_LOOP_DIAG, "memory");
+        tsum[3] = ((unsigned long long)d1 << 32) | d0;
+#else
+        if constexpr (std::is_same<Tag, bf16_tag>::value)
+            asm volatile(RSA_K5W_LOOP_BF16 RSA_K5W_OPS_LOOP : RSA_K5W_CLOBBER_TMP, RSA_K5W_CLOBBER_O, RSA_K5W_CLOBBER_LOOP, "memory");
+        else
+            asm volatile(RSA_K5W_LOOP_F16 RSA_K5W_OPS_LOOP : RSA_K5W_CLOBBER_TMP, RSA_K5W_CLOBBER_O, RSA_K5W_CLOBBER_LOOP, "memory");
+#endif
+        (void)lv;
     }
+    RSA_STAMP(1);
+    run_items(i1, n_items);
+    RSA_STAMP(2);
 
     // ---------------- epilogue ----------------
     asm volatile("s_nop 11" ::: "memory");   // (the last block's last MFMA -> the reads of O below)
-    // Everything the epilogue needs from the arguments is read AGAIN here, through a pointer the compiler cannot see through:
-    // kept live in scalar registers across the main loop (15 pointers / strides) it pushes uniform values of the loop into
-    // vector registers, which an "s" operand of the staging asm cannot take.
+    // Everything the epilogue needs from the arguments is read AGAIN here, through a pointer the compiler cannot see through
+    // (kept live in scalar registers across the walk it costs 25 of them).
     const AttnArgs* ep = (const AttnArgs*)(const void*)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(ep));
     const AttnArgs& e = *ep;
@@ -513,12 +507,20 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
     finish_half(std::integral_constant<int, 0>{});
     finish_half(std::integral_constant<int, 1>{});
-    (void)m_run;
+#ifdef RSA_K5_DIAG
+    if (e.dbg && lane == 0) {   // [leading C++ blocks, asm loop, trailing C++ blocks, -, kept blocks, kernel cycles, blocks in the loop]
+        const unsigned long long tend = stamp_now();
+        unsigned long long* o8 = e.dbg + ((long)blockIdx.x * 4 + wv) * 8;
+        o8[0] = tsum[0]; o8[1] = tsum[1]; o8[2] = tsum[2]; o8[3] = tsum[3]; o8[4] = (unsigned long long)n_items;
+        o8[5] = tend - tkern0; o8[6] = (unsigned long long)(i1 - i0); o8[7] = tend;
+    }
+#endif
 }
 
 // launch hook used by rsa_attn.hip::launch_attn (head dim 128 only)
 int rsa_launch_bsfwd64(const AttnArgs& a, dim3 grid, size_t lds_bytes, int dtype, hipStream_t s) {
     const bool wide = !(((uintptr_t)a.out & 15) || ((a.osb | a.osh | a.oss) & 7));
+    lds_bytes += 16;   // the loop reads its list two entries ahead
     if (dtype == RSA_BF16) {
         if (wide) bsfwd64_kernel<bf16_tag, true><<<grid, 128, lds_bytes, s>>>(a);
         else bsfwd64_kernel<bf16_tag, false><<<grid, 128, lds_bytes, s>>>(a);
