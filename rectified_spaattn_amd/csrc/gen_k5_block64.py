@@ -17,7 +17,7 @@ hipcc keep the tile in arch VGPRs and copy 128 registers in and out around every
     O[h][dt]  a[16*(4h+dt) : +15]   (a0..a127)         Q[h][ks]  a[128 + 4*(8h+ks) : +3]   (a128..a191)
 Arch VGPRs, pinned through physical-register constraints:
     SA[h] v[16h : +15]   SB[h] v[32+16h : +15]   -m[h] v[64+16h : +15]   P[h] v[96+8h : +7]   K ring v[112:127]   V ring v[128:143]
-    scratch v144..v149   K read addresses v[152:159]   V read addresses v[160:167]   DMA lane offsets v[168:169] (K), v[170:171] (V)
+    scratch v144..v149   K read addresses v[152:159]   V read addresses v[160:167]   DMA lane offsets v[168:171] (K), v[172:175] (V)
 
 LDS: K and V each live in a ring of FOUR 32-key half-tiles (8 KiB, image and swizzle of rsa_attn_kernel.hip); half-tile x
 sits in slot x & 3, so the slot is a compile-time constant of block U = u & 3.  Block u reads K(u+1) and V(u) and stages
@@ -29,8 +29,10 @@ single-issue instructions per v_mfma_f32_32x32x16 gap, costs summing to <= 24 cy
 packing of the first 16 keys (needed by PV MFMA 16), of the second 16 keys (MFMA 24), row sums, then the two row maxima
 interleaved with each other.  The wave's 8 DMA pieces (4 of K, 4 of V) take every fourth gap: they reach the CU's texture
 addresser spread over the sub-step instead of as a burst behind the barrier (the 32-row kernel's staging point costs each wave
-~450 cycles for 4 pieces: 8 waves x 4 pieces queue at one addresser, profiles/r03_k5_block.md).  Their source addresses WALK in
-scalar registers -- a half-tile is 32 consecutive keys, a kept block 128 -- and are re-based once per kept block.
+~450 cycles for 4 pieces: 8 waves x 4 pieces queue at one addresser, profiles/r03_k5_block.md).  A piece costs the wave ~39
+cycles of issue that no MFMA of its own overlaps (tools/probes/dma_issue_probe.hip), so nothing else rides with it: the
+source bases WALK in scalar registers -- a half-tile is 32 consecutive keys, a kept block 128 -- one step per block, re-based
+once per kept block; the rows of piece j come from lane-offset register j, the LDS destination from M0 + instruction offset.
 
 Two products:
   * RSA_K5W_LOOP_*: the steady-state loop as ONE asm statement: per kept 128-key block four blocks (U = 0..3), each behind
@@ -48,7 +50,7 @@ usage: python3 gen_k5_block64.py > rsa_attn_block64.h        (python3 gen_k5_blo
 import sys
 
 AHEAD = 4
-COST = dict(exp=8, cvt=5, add=4, max=4, mov=4, swap=4, lds=4, wait=1, dma=24)
+COST = dict(exp=8, cvt=5, add=4, max=4, mov=4, swap=4, lds=4, wait=1, dma=24)   # (a piece measures 39: tools/probes/dma_issue_probe.hip)
 D, KS, DT = 128, 8, 4
 HALF = 32 * D * 2             # bytes of a 32-key half-tile
 VRING = 4 * HALF              # LDS offset of the V ring
@@ -63,7 +65,7 @@ PS = [144, 145]
 T = [146, 147, 148, 149]
 TMP0, TMP1 = 96, 150          # clobbered temporaries [TMP0, TMP1)
 KA, VA = 152, 160
-VOK, VOV = 168, 170           # per-lane DMA source offsets (even / odd 8-row group) of K and V
+VOK, VOV = 168, 172           # per-lane DMA source offsets of the wave's four K pieces / four V pieces of a half-tile
 # scalar registers owned by the loop statement
 S_KB, S_KL, S_VB, S_VL, S_BLK, S_CNT, S_T0, S_T2, S_K128, S_V128, S_KST, S_VST = 80, 82, 84, 86, 87, 88, 90, 92, 94, 95, 96, 97
 S_CLOB = list(range(80, 98))
@@ -195,15 +197,19 @@ def gen_block(dt, U, dma, chain=None):
     dma_j = 0
 
     def dma_piece():
-        """K and V pieces alternate; M0 <- LDS destination; the SALU add between the M0 write and the load is the required wait state"""
+        """Pieces in the order K0 K1 V0 V1 K2 K3 V2 V3.  One M0 value (the LDS destination) serves two pieces: the second one
+        carries the instruction offset 2048, which moves BOTH its LDS destination and its source -- its lane offset register
+        has the 2048 subtracted.  The source base is the half-tile's row 0 (re-based once per block); lane offset register j
+        holds the rows of piece j.  One SALU instruction per two pieces instead of four per piece."""
         nonlocal dma_j
-        j, isv = divmod(dma_j, 2)
-        base, ldsw, st, vo = (S_VB, S_VL, S_VST, VOV) if isv else (S_KB, S_KL, S_KST, VOK)
-        lines.append(f"s_mov_b32 m0, {sr(ldsw)}")
-        lines.append(f"s_add_u32 {sr(ldsw)}, {sr(ldsw)}, 2048")
-        lines.append(f"global_load_lds_dwordx4 {vr(vo + (j & 1))}, {sr(base, 2)}")
-        lines.append(f"s_add_u32 {sr(base)}, {sr(base)}, {sr(st)}")
-        lines.append(f"s_addc_u32 {sr(base + 1)}, {sr(base + 1)}, 0")
+        pair, sub = divmod(dma_j, 2)
+        isv, hi = pair & 1, pair >> 1
+        base, ldsw, vo = (S_VB, S_VL, VOV) if isv else (S_KB, S_KL, VOK)
+        j = 2 * hi + sub
+        if sub == 0:
+            lines.append(f"s_add_u32 m0, {sr(ldsw)}, {4096 * hi}")
+            lines.append("s_nop 0")      # (M0 write -> LDS-DMA: one wait state)
+        lines.append(f"global_load_lds_dwordx4 {vr(vo + j)}, {sr(base, 2)}" + (" offset:2048" if sub else ""))
         dma_j += 1
 
     if chain is None:
@@ -342,7 +348,7 @@ def gen_loop(dt, diag=False):
          f"s_cmp_eq_u32 {sr(S_CNT)}, 0",
          "s_cbranch_scc1 .Lk5w_done_%=",
          f"s_lshl_b32 {sr(S_K128)}, %[krow], 7", f"s_lshl_b32 {sr(S_V128)}, %[vrow], 7",
-         f"s_lshl_b32 {sr(S_KST)}, %[krow], 3", f"s_lshl_b32 {sr(S_VST)}, %[vrow], 3",
+         f"s_lshl_b32 {sr(S_KST)}, %[krow], 5", f"s_lshl_b32 {sr(S_VST)}, %[vrow], 5",
          f"s_mov_b32 {sr(S_BLK)}, %[blk1]",
          # V walker: the kept block being processed, its last half-tile (key 96): vb + blk0 * vrow128 + 96 * vrow
          f"s_mul_i32 {t0}, %[blk0], {sr(S_V128)}", f"s_mul_hi_u32 {t1}, %[blk0], {sr(S_V128)}",
@@ -354,15 +360,15 @@ def gen_loop(dt, diag=False):
         """end of a sub-step: the pieces of two blocks ago have landed, every wave has finished its LDS reads"""
         if not diag:
             return ["s_waitcnt vmcnt(16)", "s_barrier"]
-        tm, tt = sr(98, 2), sr(S_T2)
-        return [f"s_memtime {tm}", "s_waitcnt lgkmcnt(0)", f"s_mov_b32 {tt}, s98", "s_waitcnt vmcnt(16)",
-                f"s_memtime {tm}", "s_waitcnt lgkmcnt(0)", f"s_sub_u32 {tt}, s98, {tt}", f"s_add_u32 s100, s100, {tt}",
-                f"s_mov_b32 {tt}, s98", "s_barrier",
-                f"s_memtime {tm}", "s_waitcnt lgkmcnt(0)", f"s_sub_u32 {tt}, s98, {tt}", f"s_add_u32 s101, s101, {tt}"]
+        tm, tt = sr(76, 2), sr(S_T2)
+        return [f"s_memtime {tm}", "s_waitcnt lgkmcnt(0)", f"s_mov_b32 {tt}, s76", "s_waitcnt vmcnt(16)",
+                f"s_memtime {tm}", "s_waitcnt lgkmcnt(0)", f"s_sub_u32 {tt}, s76, {tt}", f"s_add_u32 s78, s78, {tt}",
+                f"s_mov_b32 {tt}, s76", "s_barrier",
+                f"s_memtime {tm}", "s_waitcnt lgkmcnt(0)", f"s_sub_u32 {tt}, s76, {tt}", f"s_add_u32 s79, s79, {tt}"]
     # entry: the boundary in front of the first block and its first K reads (slot 1: U = 0 reads K(u+1))
     L += boundary(False) + [f"ds_read_b128 {vr(KF + 4 * ks, 4)}, {vr(KA + ks)} offset:{HALF}" for ks in range(AHEAD)]
     if diag:
-        L += ["s_mov_b32 s100, 0", "s_mov_b32 s101, 0"]
+        L += ["s_mov_b32 s78, 0", "s_mov_b32 s79, 0"]
     L += [".Lk5w_loop_%=:"]
     for U in range(4):
         head = []
@@ -380,6 +386,10 @@ def gen_loop(dt, diag=False):
         if U == 1:     # list entry of the block after next: an LDS read older than every K read of block 2 (made scalar in block 3)
             tail = tail + ["ds_read_u16 %[lv], %[la]"]
         blk = gen_block(dt, U, True, chain=tail)
+        # the DMA walkers step to the next half-tile (re-based at U = 0 / 1 above where a new kept block starts)
+        blk += [f"s_add_u32 {sr(S_KB)}, {sr(S_KB)}, {sr(S_KST)}", f"s_addc_u32 {sr(S_KB + 1)}, {sr(S_KB + 1)}, 0",
+                f"s_add_u32 {sr(S_VB)}, {sr(S_VB)}, {sr(S_VST)}", f"s_addc_u32 {sr(S_VB + 1)}, {sr(S_VB + 1)}, 0",
+                f"s_add_u32 {sr(S_KL)}, {sr(S_KL)}, {HALF}", f"s_add_u32 {sr(S_VL)}, {sr(S_VL)}, {HALF}"]
         if U == 3:     # (read two blocks ago) -> the next iteration's block index; advance the list pointer
             blk += [f"v_readfirstlane_b32 {sr(S_BLK)}, %[lv]", "v_add_u32 %[la], 2, %[la]"]
         # deferred-rescale test on the scores the NEXT block consumes (S_nxt of this block)
@@ -391,12 +401,12 @@ def gen_loop(dt, diag=False):
           "s_branch .Lk5w_done_%="]
     for U in range(4):
         S = SB if U % 2 == 0 else SA          # S_nxt of block U
-        L += [f".Lk5w_resc{U}_%=:"] + (["s_add_u32 s101, s101, 0x1000000"] if diag else []) + rescale_decide()
+        L += [f".Lk5w_resc{U}_%=:"] + (["s_add_u32 s79, s79, 0x1000000"] if diag else []) + rescale_decide()
         L += rescale_core(S, [vr(144), vr(145)], [vr(146), vr(147)], [vr(148), vr(149)])
         L += [f"s_branch .Lk5w_back{U}_%="]
     L += [".Lk5w_done_%=:"]
     if diag:
-        L += ["s_mov_b32 %[d0], s100", "s_mov_b32 %[d1], s101"]
+        L += ["s_mov_b32 %[d0], s78", "s_mov_b32 %[d1], s79"]
     return L
 
 
@@ -469,7 +479,7 @@ def main():
     louts = souts + nmio + ['[l0] "+v"(l[0])', '[l1] "+v"(l[1])', '[mx0] "+v"(mx[0])', '[mx1] "+v"(mx[1])',
                             '[th0] "+v"(thr[0])', '[th1] "+v"(thr[1])', '[mr0] "+v"(m_ref[0])', '[mr1] "+v"(m_ref[1])',
                             '[la] "+v"(la)', '[lv] "=&v"(lv)']
-    lins = [f'"{{{vr(KA, 8)}}}"(ka)', f'"{{{vr(VA, 8)}}}"(va)', f'"{{{vr(VOK, 2)}}}"(vok)', f'"{{{vr(VOV, 2)}}}"(vov)',
+    lins = [f'"{{{vr(KA, 8)}}}"(ka)', f'"{{{vr(VA, 8)}}}"(va)', f'"{{{vr(VOK, 4)}}}"(vok)', f'"{{{vr(VOV, 4)}}}"(vov)',
             '[cnt] "s"(cnt)', '[blk0] "s"(blk0)', '[blk1] "s"(blk1)', '[kb] "s"(kb)', '[vb] "s"(vb)', '[krow] "s"(krow)',
             '[vrow] "s"(vrow)', '[ldsk] "s"(ldsk)', '[ldsv] "s"(ldsv)', '[ninf] "v"(ninf)', '[eight] "v"(eight)']
     out.append(f"#define RSA_K5W_OPS_LOOP : {', '.join(louts)} : {', '.join(lins)}")
@@ -492,7 +502,7 @@ def main():
     out.append(f"#define RSA_K5W_CLOBBER_O {acc_o}")
     out.append(f"#define RSA_K5W_CLOBBER_Q {acc_q}")
     out.append("#define RSA_K5W_CLOBBER_LOOP " + ", ".join(f'"s{r}"' for r in S_CLOB) + ', "vcc", "scc"')
-    out.append('#define RSA_K5W_CLOBBER_LOOP_DIAG "s98", "s99", "s100", "s101"')
+    out.append('#define RSA_K5W_CLOBBER_LOOP_DIAG "s76", "s77", "s78", "s79"')
     out.append(f"// O a[0:127], Q a[128:191]; SA v[0:31], SB v[32:63], -m v[64:95], temporaries v[{TMP0}:{TMP1 - 1}] "
                f"(P v[96:111], K ring v[112:127], V ring v[128:143]), K addresses v[{KA}:{KA + 7}], V addresses v[{VA}:{VA + 7}], "
                f"DMA lane offsets v[{VOK}:{VOV + 1}]; the loop statement owns s[{S_CLOB[0]}:{S_CLOB[-1]}]")

@@ -79,7 +79,6 @@ struct AttnArgs {
     float* tpart;                             // split-KV partials of the text query blocks, or null
     int tsplit, tper;                         // workgroups per text block, key blocks per workgroup
     float qk_scale;
-    int w64_flags;                            // 64-row kernel, experiments: bit 0 = keep the asm loop empty (C++-driven blocks only)
 #ifdef RSA_K5_DIAG
     unsigned long long* dbg;                  // diagnostics build only (make diag): per-wave s_memtime sums, see tools/diag_k5.py
 #endif

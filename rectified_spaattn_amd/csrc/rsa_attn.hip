@@ -20,7 +20,7 @@ void rsa_set_fp8_variant(int v);
 void rsa_set_fp8_smooth_k(int v);
 int rsa_launch_bsfwd(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int dtype, hipStream_t s);
 int rsa_launch_bsfwd64(const AttnArgs& a, dim3 grid, size_t lds_bytes, int dtype, hipStream_t s);
-static int g_k5_w64 = 0;        // head dim 128: 1 = the 64-rows-per-wave kernel (rsa_attn_kernel64.hip)
+static int g_k5_w64 = 1;        // head dim 128: bit 0 = the 64-rows-per-wave kernel (rsa_attn_kernel64.hip, the product); 0 = the 32-row kernel (A/B)
 
 // Tuning / diagnostics hook (not part of the data path).  The switches are process-global, so the hook only works in a
 // process that opted in with the environment variable RSA_TUNING=1 (the A/B tools and the variant tests); a production
@@ -120,7 +120,6 @@ static int launch_attn(AttnArgs& a, int BH, int D, int dtype, hipStream_t s) {
     }
     const int n_heavy = ntq > 0 ? BH * ntq * a.tsplit : 0;
     a.BH = BH;
-    a.w64_flags = g_k5_w64 >> 1;
     a.n_heavy_pad = (n_heavy + 7) & ~7;
     a.NBp = (a.NBv + 7) & ~7;
     const long nblocks = (long)a.n_heavy_pad + (long)BH * a.NBp;

@@ -546,12 +546,22 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
     if (!done && (store_r || zero_r)) {
         float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
         float Rv = 1.0f;
-        const float* cp = nullptr;
-        if (rectify) {
+        // the compensation values this lane adds (d = 32 dt + 8 g + 4 hh + 0..3) and R: all loads issued here, back to back,
+        // one wait (loaded per (dt, g) inside the store loop each load's latency is exposed in turn: round 4, profiles/r04_k5_w64.md)
+        float4 cv[DT][4];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) cv[dt][g] = make_float4(0, 0, 0, 0);
+        if (rectify && !zero_r) {
             const long rowi = (long)bh * a.NBv + qblk;
-            Rv = a.R[rowi];
-            cp = a.comp + rowi * D;
+            const float* cp = a.comp + rowi * D;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) cv[dt][g] = *reinterpret_cast<const float4*>(cp + 32 * dt + 8 * g + 4 * hh);
         }
+        if (rectify) Rv = a.R[(long)bh * a.NBv + qblk];
         if (zero_r) inv = 0.0f;
         const float sc = inv * Rv;
         unsigned short* op = a.out + (long)b * a.osb + (long)h * a.osh + (long)grow * a.oss;
@@ -575,9 +585,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
 #pragma unroll
                     for (int gi = 0; gi < 2; ++gi) {
                         const int g = 2 * gp + gi;
-                        const int d0 = 32 * dt + 8 * g + 4 * hh;
-                        float4 c4 = make_float4(0, 0, 0, 0);
-                        if (cp && !zero_r) c4 = *reinterpret_cast<const float4*>(cp + d0);
+                        const float4 c4 = cv[dt][g];
                         const float v0 = fin(o[dt][4 * g + 0], c4.x);
                         const float v1 = fin(o[dt][4 * g + 1], c4.y);
                         const float v2 = fin(o[dt][4 * g + 2], c4.z);
@@ -599,8 +607,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int d0 = 32 * dt + 8 * g + 4 * hh;
-                    float4 c4 = make_float4(0, 0, 0, 0);
-                    if (cp && !zero_r) c4 = *reinterpret_cast<const float4*>(cp + d0);
+                    const float4 c4 = cv[dt][g];
                     const float v0 = fin(o[dt][4 * g + 0], c4.x);
                     const float v1 = fin(o[dt][4 * g + 1], c4.y);
                     const float v2 = fin(o[dt][4 * g + 2], c4.z);

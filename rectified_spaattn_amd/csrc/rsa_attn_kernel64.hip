@@ -22,7 +22,7 @@
 #include "rsa_attn_block64.h"
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // block U without LDS-DMA (the C++-driven sub-steps)
 template <typename Tag, int U>
@@ -222,9 +222,14 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int rowl = 4 * wv + rsub;
     const int gsw0 = cl ^ ((rsub << 2) | wv), gsw1 = cl ^ ((rsub << 2) | (2 + wv));
     const unsigned krow = (unsigned)(a.kss * 2), vrow = (unsigned)(a.vss * 2);   // bytes per key row (< 4 GiB)
-    u32x2 vok, vov;
-    vok[0] = rowl * krow + gsw0 * 16; vok[1] = rowl * krow + gsw1 * 16;
-    vov[0] = rowl * vrow + gsw0 * 16; vov[1] = rowl * vrow + gsw1 * 16;
+    // lane offsets of the wave's four pieces of a half-tile, for the loop's staging: piece j = rows 8j + rowl; odd pieces carry
+    // the instruction offset 2048 (their LDS destination), which also moves the source: taken out here
+    u32x4 vok, vov;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        vok[j] = (8 * j + rowl) * krow + ((j & 1) ? gsw1 : gsw0) * 16 - ((j & 1) ? 2048u : 0u);
+        vov[j] = (8 * j + rowl) * vrow + ((j & 1) ? gsw1 : gsw0) * 16 - ((j & 1) ? 2048u : 0u);
+    }
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
     // staging from C++ (prologue, boundary blocks): the 32-key half-tile starting at key `key_first` -> LDS byte offset
     // `lds_off`; rows past the last valid key are clamped to it (their scores are masked)
@@ -359,6 +364,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             asm volatile(RSA_K5W_QK0_F16 RSA_K5W_OPS_QK0 : RSA_K5W_CLOBBER_TMP, "memory");
     }
     RSA_STAMP0();
+#ifdef RSA_K5_DIAG
+    const unsigned long long tprologue = tprev - tkern0;
+#endif
     // Which kept blocks the asm loop takes: [i0, i1) such that no score of block i needs the boundary mask and block i + 1
     // (whose half-tiles the loop stages while it works on i) exists and lies inside the valid keys: i0 = the leading blocks
     // below lo_max (second segment of a two-segment dense call), i1 from the end of the ascending list.
@@ -366,7 +374,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     while (i0 < n_items && blk_of(i0) * RSA_BLOCK < lo_max) ++i0;
     int nfull = n_items;
     while (nfull > i0 && blk_of(nfull - 1) * RSA_BLOCK + RSA_BLOCK > hi_min) --nfull;
-    const int i1 = (nfull - 1 > i0 && !(a.w64_flags & 1)) ? nfull - 1 : i0;
+    const int i1 = nfull - 1 > i0 ? nfull - 1 : i0;
     run_items(0, i0);
     RSA_STAMP(0);
     {
@@ -415,6 +423,24 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int b2 = bh2 / e.H, h2 = bh2 % e.H;
     const bool partial = e.mode == MODE_SPARSE && e.tsplit > 1 && qblk2 >= e.NBv;
     const bool rectify = e.mode == MODE_SPARSE && qblk2 < e.NBv && e.R != nullptr;
+    // the compensation row of this query block, the 64 values this lane adds (d = 32 dt + 8 g + 4 hh + 0..3), and R: ALL loads
+    // issued here, back to back, one wait -- per (dt, g) inside the store loop each load's latency (L2 / HBM: 1-2 k cycles)
+    // is exposed in turn: 30 k of a wave's 535 k cycles with nothing else on the SIMD to cover it (stamps: profiles/r04_k5_w64.md)
+    float4 cv[DT][4];
+    float Rv = 1.0f;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) cv[dt][g] = make_float4(0, 0, 0, 0);
+    if (rectify) {
+        const long rowi = (long)bh2 * e.NBv + qblk2;
+        const float* cp = e.comp + rowi * D;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) cv[dt][g] = *reinterpret_cast<const float4*>(cp + 32 * dt + 8 * g + 4 * hh);
+        Rv = e.R[rowi];
+    }
     auto finish_half = [&](auto HX) {
         constexpr int x = decltype(HX)::value;
         const int grow2 = qblk2 * 128 + 64 * wv + 32 * x + r;
@@ -445,13 +471,6 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const bool zr = text_blk && !st_r && grow2 < e.Sq;
         if (!(st_r || zr)) return;
         float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
-        float Rv = 1.0f;
-        const float* cp = nullptr;
-        if (rectify) {
-            const long rowi = (long)bh2 * e.NBv + qblk2;
-            Rv = e.R[rowi];
-            cp = e.comp + rowi * D;
-        }
         if (zr) inv = 0.0f;
         const float sc = inv * Rv;
         unsigned short* op = e.out + (long)b2 * e.osb + (long)h2 * e.osh + (long)grow2 * e.oss;
@@ -470,9 +489,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                     for (int gi = 0; gi < 2; ++gi) {
                         const int g = 2 * gp + gi;
-                        const int d0 = 32 * dt + 8 * g + 4 * hh;
-                        float4 c4 = make_float4(0, 0, 0, 0);
-                        if (cp && !zr) c4 = *reinterpret_cast<const float4*>(cp + d0);
+                        float4 c4 = cv[dt][g];
+                        if (zr) c4 = make_float4(0, 0, 0, 0);
                         const float v0 = fin(o[4 * g + 0], c4.x);
                         const float v1 = fin(o[4 * g + 1], c4.y);
                         const float v2 = fin(o[4 * g + 2], c4.z);
@@ -490,8 +508,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int d0 = 32 * dt + 8 * g + 4 * hh;
-                    float4 c4 = make_float4(0, 0, 0, 0);
-                    if (cp && !zr) c4 = *reinterpret_cast<const float4*>(cp + d0);
+                    float4 c4 = cv[dt][g];
+                    if (zr) c4 = make_float4(0, 0, 0, 0);
                     const float v0 = fin(o[4 * g + 0], c4.x);
                     const float v1 = fin(o[4 * g + 1], c4.y);
                     const float v2 = fin(o[4 * g + 2], c4.z);
@@ -512,7 +530,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const unsigned long long tend = stamp_now();
         unsigned long long* o8 = e.dbg + ((long)blockIdx.x * 4 + wv) * 8;
         o8[0] = tsum[0]; o8[1] = tsum[1]; o8[2] = tsum[2]; o8[3] = tsum[3]; o8[4] = (unsigned long long)n_items;
-        o8[5] = tend - tkern0; o8[6] = (unsigned long long)(i1 - i0); o8[7] = tend;
+        o8[5] = tend - tkern0; o8[6] = (unsigned long long)(i1 - i0); o8[7] = (tprologue << 32) | ((tend - tprev) & 0xFFFFFFFFull);
     }
 #endif
 }

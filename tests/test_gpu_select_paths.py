@@ -122,3 +122,36 @@ def test_longest_rows_the_operator_serves_and_the_refusal_beyond():
     z = torch.zeros(1, 1, S2, D, dtype=torch.bfloat16, device=DEV)
     with pytest.raises(AssertionError):
         _core.rectified_attention(z, z, z, _core.LayoutSpec.wan(S2, 0), top_k, p, None)
+
+
+@pytest.mark.parametrize("name", ["hunyuan_1280", "wan_pad_1450", "flux_1536"])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_k5_32row_kernel_still_serves_head_dim_128(name, dt):
+    """Head dim 128 runs the 64-rows-per-wave K5 (rsa_attn_kernel64.hip) since round 4; the 32-row kernel (the product at head
+    dim 64, reachable at 128 through the tuning key k5_w64 = 0 for A/B) must keep giving the same answer: both against the
+    oracle, and against each other within one output ulp (the row sums are added in a different order)."""
+    from conftest import case_inputs, load_op_case
+    from oracle import oracle as orc
+    from rectified_spaattn_amd import _core, _lib
+    from test_gpu_parity import TOL, _spec
+    meta, _ = load_op_case(name)
+    q, k, v, lay, nbr = case_inputs(meta)
+    tq, tk, tv = (torch.from_numpy(x).to("cuda:0", dt) for x in (q, k, v))
+    q, k, v = (x.float().cpu().numpy() for x in (tq, tk, tv))
+    ref = orc.rectified_attention(q, k, v, lay, meta["top_k"], meta["p"], nbr)
+    outs = []
+    try:
+        for w in (1, 0):
+            assert _lib.lib().rsa_set_tuning(b"k5_w64", w) == 0
+            out = _core.rectified_attention(tq, tk, tv, _spec(lay), meta["top_k"], meta["p"],
+                                            torch.from_numpy(nbr) if nbr is not None else None)
+            torch.cuda.synchronize()
+            outs.append(out.float().cpu().numpy().reshape(ref.shape))
+    finally:
+        _lib.lib().rsa_set_tuning(b"k5_w64", 1)
+    mx, mean = TOL[dt]
+    for o in outs:
+        err = np.abs(o - ref)
+        assert err.max() <= mx and err.mean() <= mean
+    ulp = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10
+    assert np.abs(outs[0] - outs[1]).max() <= ulp * max(1.0, np.abs(ref).max())

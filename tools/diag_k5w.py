@@ -46,6 +46,7 @@ def main():
     tail_sub = sparse[:, 2] / (4.0 * (sparse[:, 4] - sparse[:, 6]))
     tot_sub = sparse[:, 5] / (4.0 * sparse[:, 4])
     outside = sparse[:, 5] - sparse[:, 0] - sparse[:, 1] - sparse[:, 2]
+    prol, epil = sparse[:, 7] >> 32, sparse[:, 7] & 0xFFFFFFFF
     vmw = (sparse[:, 3] & 0xFFFFFFFF) / (4.0 * sparse[:, 6])
     barw = ((sparse[:, 3] >> 32) & 0xFFFFFF) / (4.0 * sparse[:, 6])
     resc = ((sparse[:, 3] >> 56) & 0xFF)
@@ -53,7 +54,7 @@ def main():
     print(f"w64 diag build: {a.elapsed_time(b):.3f} ms | waves {len(sparse)} | kept blocks {sparse[:, 4].mean():.1f}, in the asm loop "
           f"{sparse[:, 6].mean():.1f} | cycles per 32-key sub-step: asm loop {loop_sub.mean():.0f} (p10 {q(loop_sub, .1):.0f} p90 {q(loop_sub, .9):.0f}) "
           f"of which parked on vmcnt {vmw.mean():.0f} (p90 {q(vmw, .9):.0f}), on the barrier {barw.mean():.0f} (p90 {q(barw, .9):.0f}) incl. ~70 per stamp; "
-          f"rescales per wave {resc.mean():.2f} | C++-driven tail {tail_sub.mean():.0f} | whole kernel / sub-step {tot_sub.mean():.0f} | prologue + epilogue per wave {outside.mean():.0f}",
+          f"rescales per wave {resc.mean():.2f} | C++-driven tail {tail_sub.mean():.0f} | whole kernel / sub-step {tot_sub.mean():.0f} | prologue + epilogue per wave {outside.mean():.0f} (prologue {prol.mean():.0f}, epilogue {epil.mean():.0f})",
           flush=True)
     L.rsa_set_tuning(b"dbg_lo", 0); L.rsa_set_tuning(b"dbg_hi", 0)
 
