@@ -477,9 +477,10 @@ def main():
     ap.add_argument("--gather-output", action="store_true",
                     help="N > 1: report only the variant with the all-gather of O along heads inside the timed region "
                          "(default: both variants are measured and reported)")
-    ap.add_argument("--gather-transports", default="",
-                    help="N > 1: also time the exchange through the library's own transports: comma list of rccl (rsa_"
-                         "allgather_heads) and p2p (rsa_allgather_heads_p2p); each is reported beside the torch.distributed one")
+    ap.add_argument("--gather-transports", default="rccl,p2p",
+                    help="N > 1: the exchange is also timed through the library's own transports: comma list of rccl (rsa_"
+                         "allgather_heads) and p2p (rsa_allgather_heads_p2p); each is reported beside the torch.distributed one "
+                         "('' = none)")
     ap.add_argument("--dry", action="store_true", help="host logic only (gloo, CPU): for the multi-process tests")
     args = ap.parse_args()
 
@@ -522,7 +523,11 @@ def main():
         # alone, the set-up of the library's own transports below, is agreed on across ranks before anyone enters it.)
         elg = timed_steps(comm, gstep, args.steps, max(1, args.warmup))
         elg, _, _, _, per_rank_g = parallel.reduce_step_stats(elg, 0.0, 0.0, 0.0, comm.stat_dev)
-        gather = dict(ms_per_step=round(elg / args.steps * 1e3, 4),
+        try:
+            rccl_ver = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:  # noqa: BLE001
+            rccl_ver = "unknown"
+        gather = dict(ranks=world, rccl_version=rccl_ver, ms_per_step=round(elg / args.steps * 1e3, 4),
                       value=round(rec["flops"] / (elg / args.steps) / 1e12, 3),
                       bytes_per_rank=int(call.out.numel() * call.out.element_size()),
                       transport="torch.distributed all_gather (RCCL)")
@@ -545,8 +550,18 @@ def main():
                 hg.gather(call.out)
             elh = timed_steps(comm, hstep, args.steps, max(1, args.warmup))
             elh, _, _, _, _ = parallel.reduce_step_stats(elh, 0.0, 0.0, 0.0, comm.stat_dev)
-            gather[tr] = dict(ms_per_step=round(elh / args.steps * 1e3, 4),
-                              value=round(rec["flops"] / (elh / args.steps) / 1e12, 3))
+            # a p2p wait that gave up (a peer's slab did not arrive within 4 s) leaves stale data behind a valid-looking time:
+            # the time-out word is read on every rank and the stage is reported as failed if any rank saw one
+            terr = None
+            try:
+                hg.check()
+            except Exception as e:  # noqa: BLE001
+                terr = repr(e)[:200]
+            if comm.all_ok(terr is None):
+                gather[tr] = dict(ms_per_step=round(elh / args.steps * 1e3, 4),
+                                  value=round(rec["flops"] / (elh / args.steps) / 1e12, 3))
+            else:
+                gather[tr] = {"error": terr or "a wait timed out on another rank"}
             hg.close()
     if world == 1 and not args.no_extras:
         # sustained: >= 6 s of back-to-back steps of the headline regime, with the clock / power the chip holds meanwhile

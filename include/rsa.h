@@ -282,11 +282,15 @@ int rsa_allgather_heads(void* comm, int world, const void* local, void* staging,
  * rank's full buffer), arrival signalled through IPC-shared device flags and awaited by a one-workgroup kernel on the same
  * stream: stream-ordered end to end, no host barrier, no host synchronisation.
  *   full_of_rank / state_of_rank: HOST arrays of `world` device pointers (own buffers at index rank; the others opened with
- *   rsa_ipc_open + rsa_ipc_offset).  state = rsa_p2p_state_bytes() bytes per rank, zeroed ONCE by its owner before the
- *   first exchange; its word 1 turns nonzero (missing rank + 1) if a wait gave up after 4 s.
+ *   rsa_ipc_open + rsa_ipc_offset).  state = the block rsa_p2p_state_alloc() returns (FINE-GRAINED device memory, zeroed: peers
+ *   write its flags over xGMI while this GPU polls them, which the memory model only defines for fine-grained allocations;
+ *   rsa_p2p_state_bytes() of it are used); its word 1 turns nonzero (missing rank + 1) if a wait gave up after 4 s.
  * Every rank must call this the same number of times.  A rank may overwrite a peer's full buffer as soon as that peer has
  * issued its NEXT exchange, so alternate between two full buffers and consume each on the stream that issued the exchange. */
 int rsa_p2p_state_bytes(void);
+int rsa_p2p_state_alloc(void** state);   /* fine-grained, zeroed, IPC-exportable; one per rank and exchange object */
+int rsa_p2p_state_free(void* state);
+int rsa_p2p_state_timeout(const void* state, int* missing_rank_plus_1);   /* synchronous read of the time-out word */
 int rsa_allgather_heads_p2p(int world, int rank, const void* local, void* const* full_of_rank, void* const* state_of_rank,
                             int64_t rows, int64_t local_row_bytes, void* stream);
 int rsa_ipc_export(const void* dev_ptr, void* handle64);                    /* 64-byte handle of a device allocation */

@@ -119,12 +119,16 @@ def lib():
     L.rsa_allgather_heads.argtypes = [vp, i32, vp, vp, vp, i64, i64, vp]
     L.rsa_allgather_heads_p2p.argtypes = [i32, i32, vp, P(vp), P(vp), i64, i64, vp]
     L.rsa_p2p_state_bytes.restype = i32
+    L.rsa_p2p_state_alloc.argtypes = [P(vp)]
+    L.rsa_p2p_state_free.argtypes = [vp]
+    L.rsa_p2p_state_timeout.argtypes = [vp, P(i32)]
     L.rsa_ipc_offset.argtypes = [vp, P(i64)]
     L.rsa_ipc_export.argtypes = [vp, vp]
     L.rsa_ipc_open.argtypes = [vp, i32, P(vp)]
     L.rsa_ipc_close.argtypes = [vp]
     for name in ("rsa_comm_unique_id", "rsa_comm_create", "rsa_comm_destroy", "rsa_allgather_heads",
-                 "rsa_allgather_heads_p2p", "rsa_ipc_export", "rsa_ipc_open", "rsa_ipc_close", "rsa_ipc_offset"):
+                 "rsa_allgather_heads_p2p", "rsa_ipc_export", "rsa_ipc_open", "rsa_ipc_close", "rsa_ipc_offset",
+                 "rsa_p2p_state_alloc", "rsa_p2p_state_free", "rsa_p2p_state_timeout"):
         getattr(L, name).restype = i32
     for name in ("rsa_fp8_operand_bytes", "rsa_carve_fp8_operands", "rsa_quantize_fp8", "rsa_block_sparse_fwd_fp8",
                  "rsa_rectified_attention_fp8", "rsa_pool_stats_fp8", "rsa_dense_fp8_bytes",
@@ -152,7 +156,7 @@ EXPORTED = ("rsa_version", "rsa_buffer_bytes", "rsa_carve_workspace", "rsa_pool_
             "rsa_carve_fp8_operands", "rsa_quantize_fp8", "rsa_block_sparse_fwd_fp8", "rsa_rectified_attention_fp8",
             "rsa_pool_stats_fp8", "rsa_dense_fp8_bytes", "rsa_dense_fwd_fp8", "rsa_dense_causal_fwd_fp8", "rsa_rel_l1",
             "rsa_comm_unique_id", "rsa_comm_create", "rsa_comm_destroy", "rsa_allgather_heads",
-            "rsa_allgather_heads_p2p", "rsa_p2p_state_bytes", "rsa_ipc_export", "rsa_ipc_open", "rsa_ipc_close",
+            "rsa_allgather_heads_p2p", "rsa_p2p_state_bytes", "rsa_p2p_state_alloc", "rsa_p2p_state_free", "rsa_p2p_state_timeout", "rsa_ipc_export", "rsa_ipc_open", "rsa_ipc_close",
             "rsa_ipc_offset")
 
 

@@ -226,6 +226,37 @@ __global__ __launch_bounds__(64) void p2p_wait_kernel(unsigned* state, int world
 
 extern "C" int rsa_p2p_state_bytes(void) { return P2P_WORDS * 4; }
 
+// The exchange state is polled by this GPU while PEERS write it over xGMI (flags) -- and written by this GPU into peers.  Cross-
+// agent visibility of such polling is only defined for FINE-GRAINED memory (the AMDGPU memory model; a plain hipMalloc block is
+// coarse-grained: a system-scope acquire load may keep hitting a stale L2 line).  So the library allocates the state block itself,
+// fine-grained, zeroed; the caller IPC-exports it like any allocation (the data buffers stay ordinary device memory).
+extern "C" int rsa_p2p_state_alloc(void** state) {
+    if (!state) return RSA_ERR_BAD_ARG;
+    *state = nullptr;
+    void* p = nullptr;
+    int st = hip_status(hipExtMallocWithFlags(&p, 4096, hipDeviceMallocFinegrained));
+    if (st != RSA_OK) return st;
+    st = hip_status(hipMemset(p, 0, 4096));
+    if (st == RSA_OK) st = hip_status(hipDeviceSynchronize());
+    if (st != RSA_OK) { (void)hipFree(p); return st; }
+    *state = p;
+    return RSA_OK;
+}
+
+// word 1 of a state block (0, or the rank a wait gave up on + 1), read back synchronously
+extern "C" int rsa_p2p_state_timeout(const void* state, int* missing_rank_plus_1) {
+    if (!state || !missing_rank_plus_1) return RSA_ERR_BAD_ARG;
+    unsigned w[2] = {0, 0};
+    const int st = hip_status(hipMemcpy(w, state, 8, hipMemcpyDeviceToHost));
+    *missing_rank_plus_1 = (int)w[P2P_TIMEOUT];
+    return st;
+}
+
+extern "C" int rsa_p2p_state_free(void* state) {
+    if (!state) return RSA_OK;
+    return hip_status(hipFree(state));
+}
+
 extern "C" int rsa_allgather_heads_p2p(int world, int rank, const void* local, void* const* full_of_rank,
                                        void* const* state_of_rank, int64_t rows, int64_t local_row_bytes, void* stream) {
     if (!local || !full_of_rank || !state_of_rank || world <= 0 || world > P2P_MAX_WORLD || rank < 0 || rank >= world ||

@@ -65,16 +65,17 @@ class HeadGather:
     is followed by an agreement (all ranks learn whether anyone failed) BEFORE the next collective, so a failure raises on
     every rank instead of leaving the others inside a collective.
 
-    p2p: the result alternates between two buffers (a peer may overwrite buffer A of this rank as soon as this rank has
-    issued the exchange that fills buffer B), so consume a gather's result on the issuing stream before the gather after
-    the next one; `check()` reads the time-out word (synchronises)."""
+    p2p: the result alternates between two buffers, and a peer may start overwriting the buffer of gather n as soon as THIS
+    rank's copy kernel of gather n + 1 has run (that lets the peer pass its wait n + 1 and issue copy n + 2 into it): consume a
+    gather's result on the issuing stream BEFORE the next gather() is issued (include/rsa.h says the same).  `check()` reads
+    the time-out word (synchronises); a timed-out wait leaves stale slabs in the result, so call it before trusting a run."""
 
     def __init__(self, B: int, S: int, H_local: int, D: int, dtype: torch.dtype, device, transport: str = "rccl",
-                 group=None):
+                 group=None, lib=None):
         from . import _lib
         if transport not in ("rccl", "p2p"):
             raise ValueError(f"unknown transport {transport!r}")
-        self.L = _lib.lib()
+        self.L = lib if lib is not None else _lib.lib()   # (lib: a stand-in with the same entry points, for the host-logic tests)
         self._check = _lib.check
         self.transport, self.group = transport, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -89,7 +90,7 @@ class HeadGather:
         self._calls = 0
         vp = ctypes.c_void_p
         try:
-            with torch.cuda.device(self.device):
+            with self._devctx():
                 if transport == "rccl":
                     self.full = torch.empty((B, S, self.world * H_local * D), dtype=dtype, device=self.device)
                     idbuf = (ctypes.c_ubyte * 128)()
@@ -105,47 +106,56 @@ class HeadGather:
                                 "rsa_comm_create")
                     self.staging = torch.empty((self.world, B * S, H_local * D), dtype=dtype, device=self.device)
                 else:
-                    # one allocation: [exchange state | full buffer 0 | full buffer 1]; a single IPC handle + offsets
-                    nstate = (self.L.rsa_p2p_state_bytes() + 255) // 256 * 256
+                    # two allocations, two IPC handles per rank: the exchange state (FINE-GRAINED memory from the library: peers
+                    # write its flags over xGMI while this GPU polls them -- cross-agent visibility of that is only defined for
+                    # fine-grained allocations) and one ordinary block [full buffer 0 | full buffer 1]
                     nfull = self.rows * self.world * self.row_bytes
                     nfull_pad = (nfull + 255) // 256 * 256
-                    self._blob = torch.zeros(nstate + 2 * nfull_pad, dtype=torch.uint8, device=self.device)
-                    torch.cuda.current_stream(self.device).synchronize()   # the zeroed state is in memory before any peer writes
-                    self._fulls = [self._blob[nstate + i * nfull_pad: nstate + i * nfull_pad + nfull].view(dtype)
+                    self._state = vp()
+                    self._blob = torch.empty(2 * nfull_pad, dtype=torch.uint8, device=self.device)
+                    self._fulls = [self._blob[i * nfull_pad: i * nfull_pad + nfull].view(dtype)
                                    .view(B, S, self.world * H_local * D) for i in range(2)]
                     self.full = self._fulls[0]
-                    h = (ctypes.c_ubyte * 64)()
+                    hs, hd = (ctypes.c_ubyte * 64)(), (ctypes.c_ubyte * 64)()
                     off = ctypes.c_int64()
 
                     def export():
-                        self._check(self.L.rsa_ipc_export(vp(self._blob.data_ptr()), h), "rsa_ipc_export")
+                        self._check(self.L.rsa_p2p_state_alloc(ctypes.byref(self._state)), "rsa_p2p_state_alloc")   # zeroed, synchronised
+                        self._check(self.L.rsa_ipc_export(self._state, hs), "rsa_ipc_export(state)")
+                        self._check(self.L.rsa_ipc_export(vp(self._blob.data_ptr()), hd), "rsa_ipc_export")
                         self._check(self.L.rsa_ipc_offset(vp(self._blob.data_ptr()), ctypes.byref(off)), "rsa_ipc_offset")
                     self._agree(self._local(export), "rsa_ipc_export")
-                    mine = (bytes(h), int(off.value),
-                            self.device.index if self.device.index is not None else torch.cuda.current_device())
+                    dev_idx = self.device.index if self.device.index is not None else (
+                        torch.cuda.current_device() if self.device.type == "cuda" else 0)
+                    mine = (bytes(hs), bytes(hd), int(off.value), dev_idx)
                     allh = [None] * self.world
                     if self.world > 1:
                         dist.all_gather_object(allh, mine, group=group)
                     else:
                         allh = [mine]
-                    bases = [0] * self.world
+                    sbases, dbases = [0] * self.world, [0] * self.world
 
                     def open_peers():
-                        for r, (hb, off_r, dev_idx) in enumerate(allh):
+                        for r, (hsb, hdb, off_r, dev_idx) in enumerate(allh):
                             if r == self.rank:
-                                bases[r] = self._blob.data_ptr()
+                                sbases[r], dbases[r] = self._state.value, self._blob.data_ptr()
                                 continue
-                            ptr = vp()
-                            self._check(self.L.rsa_ipc_open((ctypes.c_ubyte * 64).from_buffer_copy(hb), int(dev_idx),
-                                                            ctypes.byref(ptr)), "rsa_ipc_open")
-                            self._opened.append(ptr)
-                            bases[r] = ptr.value + off_r
+                            for hb, dst, add in ((hsb, sbases, 0), (hdb, dbases, off_r)):
+                                ptr = vp()
+                                self._check(self.L.rsa_ipc_open((ctypes.c_ubyte * 64).from_buffer_copy(hb), int(dev_idx),
+                                                                ctypes.byref(ptr)), "rsa_ipc_open")
+                                self._opened.append(ptr)
+                                dst[r] = ptr.value + add
                     self._agree(self._local(open_peers), "rsa_ipc_open")
-                    self._states = (vp * self.world)(*[b for b in bases])
-                    self._peer_fulls = [(vp * self.world)(*[b + nstate + i * nfull_pad for b in bases]) for i in range(2)]
+                    self._states = (vp * self.world)(*sbases)
+                    self._peer_fulls = [(vp * self.world)(*[b + i * nfull_pad for b in dbases]) for i in range(2)]
         except BaseException:
             self.close()   # handles already opened / the communicator do not outlive a failed construction
             raise
+
+    def _devctx(self):
+        import contextlib
+        return torch.cuda.device(self.device) if self.device.type == "cuda" else contextlib.nullcontext()
 
     @staticmethod
     def _local(fn):
@@ -176,7 +186,7 @@ class HeadGather:
         assert flat.shape[1] * flat.element_size() == self.row_bytes and flat.device == self.device
         vp = ctypes.c_void_p
         st = vp(torch.cuda.current_stream(self.device).cuda_stream)
-        with torch.cuda.device(self.device):
+        with self._devctx():
             if self.transport == "rccl":
                 self._check(self.L.rsa_allgather_heads(self.comm, self.world, vp(flat.data_ptr()),
                                                        vp(self.staging.data_ptr()), vp(self.full.data_ptr()), self.rows,
@@ -195,7 +205,10 @@ class HeadGather:
         if self.transport != "p2p":
             return
         torch.cuda.current_stream(self.device).synchronize()
-        word = int(self._blob[:8].view(torch.int32)[1].item())
+        w = ctypes.c_int32(0)
+        with self._devctx():
+            self._check(self.L.rsa_p2p_state_timeout(self._state, ctypes.byref(w)), "rsa_p2p_state_timeout")
+        word = int(w.value)
         if word:
             from ._lib import RsaError
             raise RsaError(f"HeadGather(p2p): rank {self.rank} timed out waiting for rank {word - 1}")
@@ -204,6 +217,9 @@ class HeadGather:
         for ptr in getattr(self, "_opened", []):
             self.L.rsa_ipc_close(ptr)
         self._opened = []
+        if getattr(self, "_state", None):
+            self.L.rsa_p2p_state_free(self._state)
+            self._state = ctypes.c_void_p()
         if getattr(self, "comm", None):
             self.L.rsa_comm_destroy(self.comm)
             self.comm = ctypes.c_void_p()

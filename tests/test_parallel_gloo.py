@@ -91,5 +91,73 @@ def test_comm_entry_points_validate_arguments_on_the_host():
     peers[0], peers[1], states[0], states[1] = 16, 32, 4096, 8192
     assert L.rsa_allgather_heads_p2p(2, 0, vp(16), peers, states, 4, 24, None) == -1    # rows not 16-byte multiples
     assert L.rsa_p2p_state_bytes() == 1024
+    assert L.rsa_p2p_state_alloc(None) == -1 and L.rsa_p2p_state_timeout(None, None) == -1 and L.rsa_p2p_state_free(None) == 0
     assert L.rsa_ipc_export(None, None) == -1 and L.rsa_ipc_open(None, 0, None) == -1 and L.rsa_ipc_close(None) == -1
     assert L.rsa_ipc_offset(None, None) == -1
+
+
+class _FakeLib:
+    """Stand-in for the exchange entry points of the C-ABI (host logic only): every call succeeds, except `fail_call` on
+    `fail_rank`, which returns a HIP-launch style error code."""
+
+    def __init__(self, rank, fail_rank, fail_call):
+        self.rank, self.fail_rank, self.fail_call, self.calls = rank, fail_rank, fail_call, []
+
+    def __getattr__(self, name):
+        def fn(*a):
+            self.calls.append(name)
+            if name == self.fail_call and self.rank == self.fail_rank:
+                return -5
+            if name == "rsa_p2p_state_alloc":
+                a[0]._obj.value = 0x1000
+            if name == "rsa_ipc_open":
+                a[2]._obj.value = 0x2000
+            if name == "rsa_comm_create":
+                a[3]._obj.value = 0x3000
+            return 0
+        return fn
+
+
+def _setup_failure_worker(rank, world, port, q, transport, fail_call):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rectified_spaattn_amd._lib import RsaError
+        fake = _FakeLib(rank, 1, fail_call)
+        try:
+            parallel.HeadGather(1, 8, 2, 16, torch.bfloat16, "cpu", transport=transport, lib=fake)
+            q.put((rank, "constructed", fake.calls))
+        except RsaError as e:
+            q.put((rank, "RsaError: " + str(e), fake.calls))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("transport,fail_call", [("p2p", "rsa_ipc_export"), ("p2p", "rsa_ipc_open"), ("p2p", "rsa_p2p_state_alloc"),
+                                                 ("rccl", "rsa_comm_unique_id")])
+def test_head_gather_setup_failure_on_one_rank_raises_on_all(transport, fail_call):
+    """A set-up step of the library's own transports that fails on ONE rank (IPC refused, allocation failed, librccl missing)
+    must raise on EVERY rank before the next collective -- nobody is left waiting inside one -- and must release what the
+    failed construction had already opened.  (For rccl only rank 0 creates the id, so that is where it can fail alone.)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + ((os.getpid() * 7 + hash(fail_call)) % 2000)
+    procs = [ctx.Process(target=_setup_failure_worker, args=(r, 2, port, q, transport, fail_call if transport == "p2p" else fail_call))
+             for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=60) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    if transport == "rccl":   # the id is created on rank 0 only: a rank-1 stub failure never triggers -> both construct
+        assert all(r[1] == "constructed" for r in res)
+        return
+    for rank, what, calls in res:
+        assert what.startswith("RsaError"), (rank, what)
+        assert ("this rank" in what) == (rank == 1) and ("another rank" in what) == (rank == 0)
+        if "rsa_ipc_open" in calls and fail_call == "rsa_ipc_open" and rank == 0:
+            assert "rsa_ipc_close" in calls           # what was opened before the agreement is closed again
+        if "rsa_p2p_state_alloc" in calls and not (rank == 1 and fail_call == "rsa_p2p_state_alloc"):
+            assert "rsa_p2p_state_free" in calls
