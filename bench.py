@@ -55,7 +55,7 @@ REGIMES = {
     "r1": ("iid", "gilbert", 0.05),        # algorithmic: cumulative-probability rule + true Gilbert neighbours
     "locality": ("spatial", "gilbert", 0.05),  # as r1 on spatially smooth centroids (overlapping kept lists)
 }
-K5_SOURCES = {False: ("rsa_attn_kernel.hip", "rsa_attn.h", "gen_k5_block.py"),
+K5_SOURCES = {False: ("rsa_attn_kernel64.hip", "gen_k5_block64.py", "rsa_attn_kernel.hip", "rsa_attn.h", "gen_k5_block.py"),
               True: ("rsa_attn_fp8_kernel.hip", "rsa_attn.h", "gen_k5_block.py")}
 
 
@@ -394,18 +394,32 @@ def api_record(comm, wl, spec, q, k, v, steps, warmup, staged_ms, with_processor
                 m.bias.zero_()
             return m
 
+        class RMS(torch.nn.Module):   # diffusers' RMSNorm over the head dim (qk_norm="rms_norm"), as the HunyuanVideo blocks carry
+            def __init__(self, d, eps=1e-6):
+                super().__init__()
+                self.weight = torch.nn.Parameter(torch.ones(d, device=dev, dtype=dt))
+                self.eps, self.bias = eps, None
+
+            def forward(self, x):
+                dt_in = x.dtype
+                var = x.to(torch.float32).pow(2).mean(-1, keepdim=True)
+                x = x * torch.rsqrt(var + self.eps)
+                return (x.to(self.weight.dtype) * self.weight).to(dt_in)
+
         attn = types.SimpleNamespace(heads=H, to_q=lin(), to_k=lin(), to_v=lin(),
-                                     to_out=torch.nn.ModuleList([lin(), torch.nn.Identity()]), norm_q=None,
-                                     norm_k=None, add_q_proj=None, add_k_proj=None, add_v_proj=None,
+                                     to_out=torch.nn.ModuleList([lin(), torch.nn.Identity()]), norm_q=RMS(D),
+                                     norm_k=RMS(D), add_q_proj=None, add_k_proj=None, add_v_proj=None,
                                      norm_added_q=None, norm_added_k=None, to_add_out=None)
         proc = rh.RectifiedHunyuanVideoSpaAttnProcessor2_0("sparse", wl["top_k"], None, 0.0, 0)
         hs = torch.randn(1, wl["S_vis"], dim, generator=g, device=dev, dtype=torch.float32).to(dt)
         ehs = torch.randn(1, wl["text"], dim, generator=g, device=dev, dtype=torch.float32).to(dt)
         mask = (torch.arange(S, device=dev) < num_true)[None, None, None, :]
+        ang = torch.rand(wl["S_vis"], D, generator=g, device=dev, dtype=torch.float32) * 6.2831853
+        rope = (torch.cos(ang), torch.sin(ang))   # (cos, sin) tables of the visual tokens, diffusers' real form
 
         def proc_step(_):
             with torch.no_grad():
-                proc(attn, hs, encoder_hidden_states=ehs, attention_mask=mask)
+                proc(attn, hs, encoder_hidden_states=ehs, attention_mask=mask, image_rotary_emb=rope)
 
         def gemm_step(_):  # the projections alone (what the processor adds around the operator)
             with torch.no_grad():
@@ -413,12 +427,72 @@ def api_record(comm, wl, spec, q, k, v, steps, warmup, staged_ms, with_processor
                 attn.to_q(x), attn.to_k(x), attn.to_v(x)
                 attn.to_out[0](x[:, :wl["S_vis"]])
 
+        from rectified_spaattn_amd import _operator as _op
         n = max(3, steps // 4)
-        elp = timed_steps(comm, proc_step, n, 2)
+        elp = timed_steps(comm, proc_step, n, 2)          # the fused QK-norm + RoPE producer is what runs
         elg = timed_steps(comm, gemm_step, n, 2)
+        _op.FUSED_PRODUCER = False                        # the same call through the module-by-module path (PyTorch ops)
+        try:
+            elu = timed_steps(comm, proc_step, max(2, n // 2), 1)
+            nu = max(2, n // 2)
+        finally:
+            _op.FUSED_PRODUCER = True
         rec.update(processor_ms=round(elp / n * 1e3, 4), projections_ms=round(elg / n * 1e3, 4),
-                   processor_minus_projections_ms=round((elp - elg) / n * 1e3, 4))
+                   processor_minus_projections_ms=round((elp - elg) / n * 1e3, 4),
+                   processor_unfused_ms=round(elu / nu * 1e3, 4),
+                   fused_producer_saves_ms=round(elu / nu * 1e3 - elp / n * 1e3, 4),
+                   processor_what="RectifiedHunyuanVideoSpaAttnProcessor2_0 (single-stream block: projections of the "
+                                  "[visual | text] sequence, RMSNorm on q / k heads, RoPE on the visual tokens, sparse operator, "
+                                  "to_out) on a stand-in attention module with random weights")
     return rec
+
+
+def fp8_records(comm, args, call_bf16, q, k, v, spec, wl, dev):
+    """e4m3 operands beside the 2-byte ones, in the default line (BASELINE config 5 has no row of its own otherwise):
+    (i) quality -- the SAME layer (headline workload, locality regime: the data with the structure of real attention maps) through
+    K5-fp8 and through the 2-byte K5, relative L1 / max distance of the two outputs (same kept lists: the selection pass reads
+    the 2-byte inputs in both); (ii) speed -- that layer with qkv_fp8, and BASELINE config 5 (Wan2.2-TI2V 720p 121f) with
+    2-byte and with e4m3 operands."""
+    import torch
+    from rectified_spaattn_amd import _core
+    out = {}
+    call_bf16.select(); call_bf16.attend()
+    torch.cuda.synchronize()
+    ref = call_bf16.out.float()
+    _, nbr_kind, p = REGIMES["locality"]
+    c8 = _core.StagedCall(q, k, v, spec, wl["top_k"], p, make_neighbors(wl, spec, nbr_kind), qkv_fp8=True)
+
+    def st8(_):
+        c8.select()
+        c8.attend()
+    el = timed_steps(comm, st8, 5, 2)
+    d = (c8.out.float() - ref).abs()
+    pairs = float(c8.bufs["counts"].sum().item())
+    fl = 4.0 * 128 * 128 * 128 * pairs + 4.0 * 128 * spec.q_text_valid * spec.kv_text_valid * q.shape[1]
+    out["fp8_vs_bf16"] = dict(what="HunyuanVideo 720p layer, locality regime: K5 on e4m3 Q/K/V/P vs K5 on the bf16 operands, same kept lists",
+                              rel_l1=round(float(d.sum() / ref.abs().sum()), 5), max_abs=round(float(d.max()), 4),
+                              mean_abs=round(float(d.mean()), 5), out_rms=round(float(ref.pow(2).mean().sqrt()), 4),
+                              fp8_layer_ms=round(el / 5 * 1e3, 4), fp8_layer_tflops=round(fl / (el / 5) / 1e12, 1))
+    del c8, d, ref
+    torch.cuda.empty_cache()
+    w5 = WORKLOADS["wan22_ti2v_720p_121f"]
+    s5 = make_spec(w5)
+    q5, k5, v5 = gen_inputs(w5, w5["H"], 0, dev, "iid")
+    rec5 = {}
+    for f8 in (False, True):
+        c5 = _core.StagedCall(q5, k5, v5, s5, w5["top_k"], 0.0, None, qkv_fp8=f8)
+
+        def st5(_):
+            c5.select()
+            c5.attend()
+        el5 = timed_steps(comm, st5, 10, 3)
+        pr5 = float(c5.bufs["counts"].sum().item())
+        fl5 = 4.0 * 128 * 128 * 128 * pr5
+        rec5["e4m3" if f8 else "bf16"] = dict(ms_per_layer=round(el5 / 10 * 1e3, 4), tflops=round(fl5 / (el5 / 10) / 1e12, 1))
+        del c5
+    rec5["what"] = "BASELINE config 5: Wan2.2-TI2V 720p 121f, S = 27 280, 24 heads, top_k 53 (regime r2), whole layer (select + K5)"
+    out["config5_wan22_ti2v"] = rec5
+    return out
 
 
 def load_traffic(name):
@@ -473,7 +547,8 @@ def main():
                     help="K5 on e4m3 images of Q/K/V (fp8 MFMA); the quantisation pass is inside the timed step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the headline regime (no r1/locality/api/sustained)")
-    ap.add_argument("--via-api", action="store_true", help="also time a processor __call__ end to end")
+    ap.add_argument("--via-api", action="store_true", help="(kept for old command lines: the processor timing is on by default)")
+    ap.add_argument("--no-processor", action="store_true", help="skip the processor __call__ timing of the api record")
     ap.add_argument("--gather-output", action="store_true",
                     help="N > 1: report only the variant with the all-gather of O along heads inside the timed region "
                          "(default: both variants are measured and reported)")
@@ -595,7 +670,7 @@ def main():
             extras["box_ref"] = {"error": repr(e)[:200]}
         if not args.qkv_fp8 and wl["variant"] == "hunyuan" and main_regime == "r2":
             extras["api"] = api_record(comm, wl, spec, q, k, v, args.steps, args.warmup, rec["ms_per_step"],
-                                       args.via_api)
+                                       not args.no_processor)
         regs = {}
         for rg in REGIMES:
             if rg == main_regime:
@@ -614,16 +689,22 @@ def main():
                             ms_per_step=round(r2["ms_per_step"], 4), value=round(r2["value"], 3),
                             k5_ms=round(r2["k5_ms"], 4), k5_tflops=round(r2["k5_tflops"], 2),
                             k5_frac=round(r2["k5_tflops"] / peak_, 4), select_pass_ms=round(r2["select_pass_ms"], 4))
-            tb, _ = load_traffic(f"r03_k5_traffic_{rg}{'_fp8' if args.qkv_fp8 else ''}.json")
+            tb, _ = load_traffic(f"r04_k5_traffic_{rg}{'_fp8' if args.qkv_fp8 else ''}.json")
             regs[rg]["traffic"] = tb
         extras["regimes"] = regs
+        if not args.qkv_fp8 and args.workload == "hunyuan_720p_128f":
+            # (`call`, q, k, v now hold the locality regime: the last one of REGIMES)
+            try:
+                extras["fp8"] = fp8_records(comm, args, call, q, k, v, spec, wl, dev)
+            except Exception as e:  # noqa: BLE001
+                extras["fp8"] = {"error": repr(e)[:300]}
 
     if rank != 0:
         comm.close()
         return
 
     peak = MFMA_FP8_PEAK_TFLOPS if args.qkv_fp8 else MFMA_BF16_PEAK_TFLOPS
-    tname = f"r03_k5_traffic_{main_regime}{'_fp8' if args.qkv_fp8 else ''}.json"
+    tname = f"r04_k5_traffic_{main_regime}{'_fp8' if args.qkv_fp8 else ''}.json"
     traffic, tnote = (None, "N > 1: traffic is collected at N = 1")
     if world == 1 and args.workload == "hunyuan_720p_128f":
         traffic, tnote = load_traffic(tname)
@@ -643,7 +724,8 @@ def main():
                    "imbalance": round(max(per_rank_ms) / (sum(per_rank_ms) / len(per_rank_ms)), 4),
                    "gather_output": gather},
         "roofline": {"kernel": "bsfwd_fp8_kernel (K5 block_sparse_fwd_fp8)" if args.qkv_fp8 else
-                     "bsfwd_kernel<128,bf16_tag,...> (K5 block_sparse_fwd)", "bound": "mfma",
+                     ("bsfwd64_kernel<bf16_tag,...> (K5 block_sparse_fwd, 64 rows per wave)" if D == 128 else
+                      "bsfwd_kernel<64,bf16_tag,...> (K5 block_sparse_fwd)"), "bound": "mfma",
                      "achieved": round(rec["k5_tflops"], 2), "peak": peak, "unit": "TFLOP/s",
                      "frac": round(rec["k5_tflops"] / peak, 4), "traffic": traffic, "traffic_note": tnote,
                      "compulsory_bytes": 4 * 2 * H_local * S * D,

@@ -510,6 +510,83 @@ def processors_round3():
     print("processors_r3.npz:", {k: v.shape for k, v in res.items()})
 
 
+def processors_round4():
+    """Round-4 vectors: (i) the Flux processor's SPARSE branch through the reference (double-stream block, 1024 image + 512
+    text tokens, processor ids 0 and 57 -- the gate `processor_id < 37 or >= 57`, rectified_flux_attn.py:493) with the
+    reference's kept mask and operator output of the same call, and the dense warm-up layer id 40; (ii) the Wan2.1 I2V
+    processor with an IMAGE CONTEXT (257 CLIP tokens + 512 text tokens through add_k_proj / add_v_proj / norm_added_k,
+    rectified_wan21_attn.py:512-632).  Shim for (ii): `sdpa_kernel(FLASH_ATTENTION)` has no CPU fp32 kernel -> null context."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers
+    import rectified_spaattn.attn as ref_attn
+    import rectified_spaattn.rectified_flux_attn as ref_fx
+    import rectified_spaattn.rectified_wan21_attn as ref_wan
+    ref_attn.flash_attn_varlen_func = _varlen_sdpa
+    for m in (ref_fx, ref_wan):
+        if hasattr(m, "flash_attn_varlen_func"):
+            m.flash_attn_varlen_func = _varlen_sdpa
+    if not getattr(ref_fx, "_rsa_wrapped", False):
+        _wrap_kernel(ref_fx)
+        ref_fx._rsa_wrapped = True
+    ref_wan.sdpa_kernel = lambda *a, **k: contextlib.nullcontext()
+    from rectified_spaattn_amd import synth
+    outdir = os.path.dirname(os.path.abspath(__file__))
+    res = {}
+    heads, hd = 2, 128
+    dim = heads * hd
+
+    def spied(mod, key, fn):
+        cap = {}
+        ob, oc = mod._build_block_index_with_importance_optimized, mod.block_sparse_attention_combined
+
+        def sb(*a, **k):
+            r = ob(*a, **k)
+            cap["one_hot"] = r[0].clone()
+            return r
+
+        def sc(*a, **k):
+            r = oc(*a, **k)
+            cap["op_out"] = r.clone()
+            return r
+        mod._build_block_index_with_importance_optimized, mod.block_sparse_attention_combined = sb, sc
+        try:
+            out = fn()
+        finally:
+            mod._build_block_index_with_importance_optimized, mod.block_sparse_attention_combined = ob, oc
+        oh = cap["one_hot"].numpy().astype(np.uint8)
+        res[key + "_mask"] = np.packbits(oh, axis=-1)
+        res[key + "_mask_shape"] = np.array(oh.shape)
+        res[key + "_op_out"] = cap["op_out"].float().numpy().astype(np.float16)
+        return out
+
+    with torch.no_grad():
+        a = helpers.fake_attn(103, heads, hd, added=True)
+        hs_f, enc_f = helpers.hidden(103, 20, 1, 1024, dim), helpers.hidden(103, 21, 1, 512, dim)
+        rope_f = helpers.rope_tables(1536, hd)
+        nbr = torch.from_numpy(synth.banded_neighbors(8, 1))
+        for pid in (0, 57):
+            pr = ref_fx.RectifiedFluxSpaAttnProcessor2_0("sparse", 2, nbr, 0.3, pid, 512)
+            o, e = spied(ref_fx, f"fx_sparse_id{pid}", lambda: pr(a, hs_f, enc_f, None, rope_f))
+            res[f"fx_sparse_id{pid}_out"], res[f"fx_sparse_id{pid}_enc"] = o.numpy().astype(np.float16), e.numpy().astype(np.float16)
+            assert pr.current_step == 1
+        pr = ref_fx.RectifiedFluxSpaAttnProcessor2_0("sparse", 2, nbr, 0.3, 40, 512)     # warm-up layers 37..56: dense
+        o, e = pr(a, hs_f, enc_f, None, rope_f)
+        res["fx_sparse_id40_out"], res["fx_sparse_id40_enc"] = o.numpy().astype(np.float16), e.numpy().astype(np.float16)
+        # Wan2.1 I2V cross attention with an image context: [257 image tokens | 512 text tokens]
+        ai = helpers.fake_attn_wan_i2v(112, heads, hd)
+        hs, enc = helpers.hidden(111, 20, 1, 900, dim), helpers.hidden(112, 24, 1, 257 + 512, dim)
+        pw = ref_wan.RectifiedWanI2VSpaAttnProcessor2_0("flash", 2, None, 0.3, 5, 0)
+        res["wan21_i2v_imgctx"] = pw(ai, hs, enc, None, None).numpy().astype(np.float16)
+    # ids 0 and 57 see the same inputs: the second call is stored as "equal to the first" (asserted here), not as arrays
+    same = all(np.array_equal(res[f"fx_sparse_id0{k}"], res[f"fx_sparse_id57{k}"]) for k in ("_mask", "_op_out", "_out", "_enc"))
+    assert same
+    for k in ("_mask", "_mask_shape", "_op_out", "_out", "_enc"):
+        del res[f"fx_sparse_id57{k}"]
+    res["fx_sparse_id57_equals_id0"] = np.array(1)
+    np.savez_compressed(os.path.join(outdir, "processors_r4.npz"), **res)
+    print("processors_r4.npz:", {k: v.shape for k, v in res.items()})
+
+
 def headline():
     """Round 4: the reference's OWN mask builder at BASELINE's full sizes, one head, fp32 statistics.
 
@@ -930,6 +1007,9 @@ def gilbert():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "headline":
         headline()
+    elif len(sys.argv) > 1 and sys.argv[1] == "processors_r4":
+        _install_stubs()
+        processors_round4()
     elif len(sys.argv) > 1 and sys.argv[1] == "gilbert":
         _install_stubs()
         gilbert()

@@ -4,7 +4,7 @@
 # usage: bash tools/pmc_traffic.sh <out-subdir-of-gpurun_out> <regime: r2|r1|locality> [fp8]
 R=$PWD; OUT=$R/gpurun_out/$1; mkdir -p $OUT
 export RSA_PERF_REGIME=$2 RSA_PERF_NODENSE=1
-KERN=bsfwd_kernel
+KERN=bsfwd
 if [ "$3" = "fp8" ]; then export RSA_PERF_FP8=1; KERN=bsfwd_fp8; fi
 cd /tmp; export TMPDIR=/tmp
 N=0
