@@ -99,8 +99,17 @@ _PAD_HEAD_DIM = {16: 64, 32: 128}
 
 
 def pad_small_head_dim(q, k, v):
-    """[B, H, S, D] with D in {16, 32} -> (2 q | 0, k | 0, v | 0) with D' = 4 D columns (see _PAD_HEAD_DIM)."""
+    """[B, H, S, D] with D in {16, 32} -> (2 q | 0, k | 0, v | 0) with D' = 4 D columns (see _PAD_HEAD_DIM).
+
+    The doubling is exact unless it overflows: bfloat16 has fp32's range, float16 does not -- a float16 |q| above 32 752 would
+    become inf where the native head-dim contract is finite, so that case is refused (one device reduction + host sync, on this
+    compatibility path only).  With return_parts the statistics come back in the PADDED problem's shape and scale: qbar / aq /
+    kbar / ak / vbar / comp have 4 D columns (the last 3 D zero), qbar and aq are those of 2 q; scores, probabilities, GAPR
+    bytes, R, w, the mask and the lists are the native problem's, bit for bit; the fp8 images are those of the padded tensors."""
     D = q.shape[-1]
+    if q.dtype == torch.float16 and bool((q.abs() > 32752).any()):
+        raise _lib.RsaError(f"head_dim {D} runs zero-padded with Q doubled, which overflows float16 for |q| > 32752; "
+                            "use bfloat16 inputs or scale Q down")
     pad = (0, _PAD_HEAD_DIM[D] - D)
     return torch.nn.functional.pad(q * 2, pad), torch.nn.functional.pad(k, pad), torch.nn.functional.pad(v, pad)
 

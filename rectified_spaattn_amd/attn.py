@@ -126,16 +126,13 @@ def _key_mask_rows(attn_mask, B, S1):
 
 def _compact_keys(k, v, rows, counts):
     """Key masks with holes: the valid keys of every batch item moved to the front (a softmax does not see the order of its
-    keys), so the kernel's prefix limit serves them; tail rows are zero and lie beyond the limit."""
-    B, A, S1, D = k.shape
+    keys), so the kernel's prefix limit serves them.  No host synchronisation: a stable argsort of the inverted mask lists the
+    valid key indices first, in order; one gather per tensor; the rows behind an item's count are other (finite) keys that lie
+    beyond its limit."""
     n = max(counts)
-    kc = k.new_zeros(B, A, n, D)
-    vc = v.new_zeros(B, A, n, D)
-    for i in range(B):
-        idx = torch.nonzero(rows[i], as_tuple=False).reshape(-1)
-        kc[i, :, :counts[i]] = k[i].index_select(1, idx)
-        vc[i, :, :counts[i]] = v[i].index_select(1, idx)
-    return kc, vc
+    order = torch.argsort((~rows).to(torch.uint8), dim=1, stable=True)[:, :n]          # [B, n]
+    idx = order[:, None, :, None].expand(-1, k.shape[1], -1, k.shape[3])
+    return torch.gather(k, 2, idx), torch.gather(v, 2, idx)
 
 
 def fullattn(q, k, v, mode="flash", drop_rate=0, attn_mask=None, causal=False, cu_seqlens_q=None,
@@ -165,6 +162,9 @@ def fullattn(q, k, v, mode="flash", drop_rate=0, attn_mask=None, causal=False, c
                 splits = [(S, S1)] * B
             else:
                 rows, counts, prefix = _key_mask_rows(attn_mask, B, S1)
+                if min(counts) == 0:
+                    # (the reference's SDPA returns NaN for a row without keys: nothing a caller can use -- refuse clearly)
+                    raise ValueError("fullattn: attn_mask leaves a batch item without any key")
                 if not prefix:
                     k, v = _compact_keys(k, v, rows, counts)
                 splits = [(S, c) for c in counts]

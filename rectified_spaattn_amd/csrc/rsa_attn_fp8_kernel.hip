@@ -529,11 +529,23 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     if (!(store_r || zero_r)) return;
     float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
     float Rv = 1.0f;
-    const float* cp = nullptr;
+    // the compensation values this lane adds and R: all loads issued here, back to back, one wait (loaded per (dt, g) inside the
+    // store loop each load's latency is exposed in turn: round 4, profiles/r04_k5_w64.md)
+    float4 cv[DT8][4];
+#pragma unroll
+    for (int dt = 0; dt < DT8; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) cv[dt][g] = make_float4(0, 0, 0, 0);
     if (rectify) {
         const long rowi = (long)bh * a.NBv + qblk;
+        if (!zero_r) {
+            const float* cp = a.comp + rowi * D8;
+#pragma unroll
+            for (int dt = 0; dt < DT8; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) cv[dt][g] = *reinterpret_cast<const float4*>(cp + 32 * dt + 8 * g + 4 * hh);
+        }
         Rv = a.R[rowi];
-        cp = a.comp + rowi * D8;
     }
     if (zero_r) inv = 0.0f;
     const float sc = inv * Rv;
@@ -544,8 +556,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int d0 = 32 * dt + 8 * g + 4 * hh;
-            float4 c4 = make_float4(0, 0, 0, 0);
-            if (cp && !zero_r) c4 = *reinterpret_cast<const float4*>(cp + d0);
+            const float4 c4 = cv[dt][g];
             const float v0 = o[dt][4 * g + 0] * sc + c4.x;
             const float v1 = o[dt][4 * g + 1] * sc + c4.y;
             const float v2 = o[dt][4 * g + 2] * sc + c4.z;

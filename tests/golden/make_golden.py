@@ -994,6 +994,16 @@ def gilbert():
             res[f"h2l_{tag}"] = np.asarray(h2l, np.int32)
             res[f"nbr16_{tag}"] = np.packbits(nb.numpy(), axis=-1)
             res[f"nbr16n_{tag}"] = np.array(nb.shape[0])
+    # round 4: transpose_order (reference :290-346, :458-504)
+    for (t, h, w) in [(2, 6, 10), (3, 5, 7), (4, 12, 16)]:
+        for to in ([2, 1, 0], [1, 0, 2], [0, 2, 1]):
+            with contextlib.redirect_stdout(io.StringIO()):
+                l2h, h2l = ref.gilbert_mapping(t, h, w, transpose_order=to)
+                nbt = ref.gilbert_block_neighbor_mapping(t, h, w, block_size=16, transpose_order=to)
+                nb0 = ref.gilbert_block_neighbor_mapping(t, h, w, block_size=16)
+            assert torch.equal(nbt, nb0)      # the reference ignores transpose_order in the neighbour function
+            res[f"tr_l2h_{t}x{h}x{w}_{''.join(map(str, to))}"] = np.asarray(l2h, np.int32)
+            res[f"tr_h2l_{t}x{h}x{w}_{''.join(map(str, to))}"] = np.asarray(h2l, np.int32)
     with contextlib.redirect_stdout(io.StringIO()):
         l2h, h2l = ref.gilbert_mapping(32, 45, 80, axis_order=("w", "h", "t"))
         nb = ref.gilbert_block_neighbor_mapping(32, 45, 80, axis_order=("w", "h", "t"))

@@ -42,7 +42,24 @@ def test_hunyuan_latent_full_size_digest():
 
 
 def test_argument_errors():
-    with pytest.raises(NotImplementedError):
-        jg.gilbert_mapping(2, 2, 2, transpose_order=[2, 1, 0])
+    with pytest.raises(ValueError):
+        jg.gilbert_mapping(2, 2, 2, transpose_order=[2, 1])
     with pytest.raises(ValueError):
         jg.gilbert_mapping(2, 2, 2, axis_order=("w", "w", "t"))
+
+
+def test_transpose_order_matches_reference():
+    """gilbert_mapping(transpose_order=...) (reference utils/jenga_gilbert.py:290-346, :458-504): the curve of the permuted box
+    read at the permuted coordinates; gilbert_block_neighbor_mapping accepts the argument and ignores it, as the reference does."""
+    import torch
+    for (t, h, w) in [(2, 6, 10), (3, 5, 7), (4, 12, 16)]:
+        for to in ([2, 1, 0], [1, 0, 2], [0, 2, 1]):
+            tag = f"{t}x{h}x{w}_{''.join(map(str, to))}"
+            l2h, h2l = jg.gilbert_mapping(t, h, w, transpose_order=to)
+            assert np.array_equal(np.asarray(l2h, np.int32), G[f"tr_l2h_{tag}"]), tag
+            assert np.array_equal(np.asarray(h2l, np.int32), G[f"tr_h2l_{tag}"]), tag
+            assert torch.equal(jg.gilbert_block_neighbor_mapping(t, h, w, block_size=16, transpose_order=to),
+                               jg.gilbert_block_neighbor_mapping(t, h, w, block_size=16))
+    import pytest
+    with pytest.raises(ValueError):
+        jg.gilbert_mapping(2, 3, 4, transpose_order=[0, 1, 1])
