@@ -1,13 +1,12 @@
 #!/usr/bin/env python3
-"""What clock and board power does the chip hold under K5?  Loops one K5 form for a few seconds while a thread samples
-`rocm-smi --showclocks --showpower --json` (and hwmon power if readable), for several forms of the A/B build and the dense call."""
+"""What clock and board power does the chip hold under K5?  Loops one K5 kernel for a few seconds while a thread samples
+`rocm-smi --showclocks --showpower --json` (and hwmon power if readable): the 64-row and the 32-row kernel, sparse R2 and dense."""
 import ctypes, glob, json, os, subprocess, sys, threading, time
 os.environ["RSA_TUNING"] = "1"
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from rectified_spaattn_amd import _lib
-_lib.LIB_PATH = os.path.join(ROOT, "rectified_spaattn_amd", "librsa_hip_ab.so")
 from bench import REGIMES, WORKLOADS, gen_inputs, make_neighbors, make_spec
 from rectified_spaattn_amd import _core
 
@@ -57,12 +56,11 @@ def main():
         ms = a.elapsed_time(b) / n
         print(f"{tag}: {ms:.3f} ms/call over {n} calls; samples (last 4 of {len(samples)}):", flush=True)
         for s in samples[-4:]: print("    ", s, flush=True)
-    for form in (1, 2, 0):
-        assert L.rsa_set_tuning(b"k5_form", form) == 0
-        run_for(call.attend, float(os.environ.get("SECS", "5")), f"sparse form {form}")
-    L.rsa_set_tuning(b"k5_form", 2)
-    run_for(lambda: _core.dense_attention(qd, qd, qd), 4, "dense16k form 5")
-    L.rsa_set_tuning(b"k5_form", 2)
+    for w64 in (1, 0, 1):   # the 64-rows-per-wave K5 (the product at head dim 128) and the 32-row kernel
+        assert L.rsa_set_tuning(b"k5_w64", w64) == 0
+        run_for(call.attend, float(os.environ.get("SECS", "5")), f"sparse R2, {'64' if w64 else '32'}-row K5")
+        run_for(lambda: _core.dense_attention(qd, qd, qd), 3, f"dense 16k, {'64' if w64 else '32'}-row K5")
+    L.rsa_set_tuning(b"k5_w64", 1)
 
 if __name__ == "__main__":
     main()

@@ -4,7 +4,7 @@ kernels lumped) for profiles/.  usage: summarize_prof.py <kernel_stats.csv> <tit
 import csv
 import sys
 
-OURS = ("bsfwd_kernel", "select_mask_kernel", "compensation_kernel", "pool_stats_kernel", "pooled_scores_kernel",
+OURS = ("bsfwd_kernel", "bsfwd64_kernel", "select_mask_kernel", "compensation_kernel", "pool_stats_kernel", "pooled_scores_kernel",
         "gapr_compare_kernel", "bsfwd_fp8_kernel", "fp8_blocks_kernel", "kmean_sample_kernel", "text_combine",
         "permute_tokens_kernel", "qk_norm_rope_kernel", "norm_rope_heads", "rel_l1_", "p2p_")
 rows = list(csv.DictReader(open(sys.argv[1])))
