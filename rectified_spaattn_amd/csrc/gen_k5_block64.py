@@ -69,6 +69,7 @@ VOK, VOV = 168, 172           # per-lane DMA source offsets of the wave's four K
 # scalar registers owned by the loop statement
 S_KB, S_KL, S_VB, S_VL, S_BLK, S_CNT, S_T0, S_T2, S_K128, S_V128, S_KST, S_VST = 80, 82, 84, 86, 87, 88, 90, 92, 94, 95, 96, 97
 S_CLOB = list(range(80, 98))
+LOOP_PRE = 24                 # issue cycles of vector work the loop's blocks put in front of their first MFMA (the boundary blocks: 64)
 DMA_GAPS = [4 * j + 1 for j in range(8)]      # the 8 gaps that carry the wave's LDS-DMA pieces: every fourth gap
 STATS = None
 
@@ -93,8 +94,8 @@ def sr(a, n=1):
     return f"s{a}" if n == 1 else f"s[{a}:{a + n - 1}]"
 
 
-def gen_block(dt, U, dma, chain=None):
-    """Block U.  dma: issue the wave's pieces from the scalar walkers.  chain (the loop): the block does not open with its K
+def gen_block(dt, U, dma, chain=None, xf=frozenset(), dma_cost=None, pre=64, salu=None):
+    """Block U.  xf: experiment flags of the A/B forms (gen_forms; timing only, the results of most are garbage).  Block U.  dma: issue the wave's pieces from the scalar walkers.  chain (the loop): the block does not open with its K
     reads -- the previous block issued them in its tail -- and issues the NEXT block's first four K reads itself, behind the
     lines of `chain` (the sub-step boundary: vmcnt wait, barrier, ...), which sit in front of MFMA 30: behind the wait for the
     last V^T fragment, so every LDS read of this sub-step has returned when the barrier releases the slots."""
@@ -106,10 +107,14 @@ def gen_block(dt, U, dma, chain=None):
     lines, lds_seq = [], []
 
     def k_read(ks):
+        if "nolds" in xf:
+            return
         lines.append(f"ds_read_b128 {vr(KF + 4 * (ks % AHEAD), 4)}, {vr(KA + ks)} offset:{koff}")
         lds_seq.append((("K", ks), 1))
 
     def v_read(p):
+        if "nolds" in xf:
+            return
         k2, d = divmod(p, DT)
         off = voff + k2 * 16 * D * 2
         b = VF + 4 * (p % AHEAD)
@@ -118,6 +123,8 @@ def gen_block(dt, U, dma, chain=None):
         lds_seq.append((("V", p), 2))
 
     def wait_for(tag):
+        if "nolds" in xf:
+            return
         idx = [i for i, (t, _) in enumerate(lds_seq) if t == tag][-1]
         after = sum(c for _, c in lds_seq[idx + 1:])
         lines.append(f"s_waitcnt lgkmcnt({after})")
@@ -159,8 +166,21 @@ def gen_block(dt, U, dma, chain=None):
     tail = ["s_nop 0", f"v_permlane32_swap_b32 {vr(T[0])}, {vr(T[1])}", f"v_permlane32_swap_b32 {vr(T[2])}, {vr(T[3])}", "s_nop 0",
             f"v_max_f32 %[mx0], {vr(T[0])}, {vr(T[1])}", f"v_max_f32 %[mx1], {vr(T[2])}, {vr(T[3])}"]
 
+    if "novalu" in xf:
+        EXP, cvq, addq, maxq, tail = [], [], [], [], []
+    if "noadd" in xf:
+        addq = []
+    if "nomax" in xf:
+        maxq, tail = [], []
+    if "nocvt" in xf:
+        cvq = []
+    if "noexp" in xf:
+        EXP = []
+        cvq = [(k, t, 0) for k, t, _ in cvq]
+        addq = [(k, t, 0) for k, t, _ in addq]
+    dcost = COST["dma"] if dma_cost is None else dma_cost
     dgaps = DMA_GAPS if dma else []
-    pre = 64
+    salu = salu or {}
     ei = 0             # exponentials issued
     last_exp_line = -10
 
@@ -202,6 +222,9 @@ def gen_block(dt, U, dma, chain=None):
         has the 2048 subtracted.  The source base is the half-tile's row 0 (re-based once per block); lane offset register j
         holds the rows of piece j.  One SALU instruction per two pieces instead of four per piece."""
         nonlocal dma_j
+        if "nodma" in xf:
+            dma_j += 1
+            return
         pair, sub = divmod(dma_j, 2)
         isv, hi = pair & 1, pair >> 1
         base, ldsw, vo = (S_VB, S_VL, VOV) if isv else (S_KB, S_KL, VOK)
@@ -238,18 +261,20 @@ def gen_block(dt, U, dma, chain=None):
                 text = "\n".join(lines)
                 for hh in (0, 1):
                     for jj in range(4):
-                        assert f"{cv} {vr(P[hh] + 4 * k2 + jj)}," in text, (dt, U, "P not packed before PV", p)
+                        assert "novalu" in xf or "nocvt" in xf or f"{cv} {vr(P[hh] + 4 * k2 + jj)}," in text, (dt, U, "P not packed before PV", p)
                 wait_for(("V", p))
             if chain is not None and i == 30:
                 lines.extend(chain)
                 nk = ((U + 2) & 3) * HALF
-                lines.extend(f"ds_read_b128 {vr(KF + 4 * ks, 4)}, {vr(KA + ks)} offset:{nk}" for ks in range(AHEAD))
+                if "nolds" not in xf:
+                    lines.extend(f"ds_read_b128 {vr(KF + 4 * ks, 4)}, {vr(KA + ks)} offset:{nk}" for ks in range(AHEAD))
             lines.append(f"{mf} {ar(AO(h, d), 16)}, {vr(VF + 4 * (p % AHEAD), 4)}, {vr(P[h] + 4 * k2, 4)}, {ar(AO(h, d), 16)}")
             fixed = 0
             if h == 1 and p + AHEAD < 2 * DT:
                 v_read(p + AHEAD); fixed += 2 * COST["lds"]
+        lines.extend(salu.get(i, []))      # scalar bookkeeping of the loop riding in this gap (free beside an MFMA)
         if i in dgaps:
-            dma_piece(); fixed += COST["dma"]
+            dma_piece(); fixed += dcost
         usage.append(fixed + emit_slot(24 - fixed, i, final=(i == 31)))
     assert ei == len(EXP) and not cvq and not addq and not maxq and not tail, (dt, U, "vector work left over")
     assert dma_j == len(dgaps)
@@ -338,7 +363,15 @@ def rescale_decide():
     return L
 
 
-def gen_loop(dt, diag=False):
+def gen_loop_head0(t0, t1):
+    """K walker -> key 0 of the next kept block (S_BLK), K pieces to LDS slot 0.., V pieces to slot 3 (block 0's V(u+3))."""
+    return [f"s_mul_i32 {t0}, {sr(S_BLK)}, {sr(S_K128)}", f"s_mul_hi_u32 {t1}, {sr(S_BLK)}, {sr(S_K128)}",
+            f"s_mov_b64 {sr(S_KB, 2)}, %[kb]",
+            f"s_add_u32 {sr(S_KB)}, {sr(S_KB)}, {t0}", f"s_addc_u32 {sr(S_KB + 1)}, {sr(S_KB + 1)}, {t1}",
+            f"s_mov_b32 {sr(S_KL)}, %[ldsk]"]
+
+
+def gen_loop(dt, diag=False, xf=frozenset(), dma_cost=None, pre=64, tight=False):
     """The steady-state loop, one asm statement (see the file docstring).  Operands: cnt (kept blocks to process, >= 0),
     blk0 / blk1 (block index of the first one and of its successor), la (VGPR: LDS byte address of the list entry two blocks
     ahead), kb / vb (64-bit bases of this head's K / V), krow / vrow (bytes per key row), ldsk / ldsv (LDS address of the wave's
@@ -356,17 +389,20 @@ def gen_loop(dt, diag=False):
          f"s_add_u32 {sr(S_VB)}, {sr(S_VB)}, {t0}", f"s_addc_u32 {sr(S_VB + 1)}, {sr(S_VB + 1)}, {t1}",
          f"s_mul_i32 {t0}, %[vrow], 96",
          f"s_add_u32 {sr(S_VB)}, {sr(S_VB)}, {t0}", f"s_addc_u32 {sr(S_VB + 1)}, {sr(S_VB + 1)}, 0"]
+    if tight:      # the first iteration's K walker and V slot (every later one is set up in block 3's gaps)
+        L += gen_loop_head0(t0, t1) + [f"s_add_u32 {sr(S_VL)}, %[ldsv], {3 * HALF}"]
+
     def boundary(diag):
         """end of a sub-step: the pieces of two blocks ago have landed, every wave has finished its LDS reads"""
         if not diag:
-            return ["s_waitcnt vmcnt(16)", "s_barrier"]
+            return ([] if "novm" in xf else ["s_waitcnt vmcnt(16)"]) + ([] if "nobar" in xf else ["s_barrier"])
         tm, tt = sr(76, 2), sr(S_T2)
         return [f"s_memtime {tm}", "s_waitcnt lgkmcnt(0)", f"s_mov_b32 {tt}, s76", "s_waitcnt vmcnt(16)",
                 f"s_memtime {tm}", "s_waitcnt lgkmcnt(0)", f"s_sub_u32 {tt}, s76, {tt}", f"s_add_u32 s78, s78, {tt}",
                 f"s_mov_b32 {tt}, s76", "s_barrier",
                 f"s_memtime {tm}", "s_waitcnt lgkmcnt(0)", f"s_sub_u32 {tt}, s76, {tt}", f"s_add_u32 s79, s79, {tt}"]
     # entry: the boundary in front of the first block and its first K reads (slot 1: U = 0 reads K(u+1))
-    L += boundary(False) + [f"ds_read_b128 {vr(KF + 4 * ks, 4)}, {vr(KA + ks)} offset:{HALF}" for ks in range(AHEAD)]
+    L += ["s_waitcnt vmcnt(16)", "s_barrier"] + [f"ds_read_b128 {vr(KF + 4 * ks, 4)}, {vr(KA + ks)} offset:{HALF}" for ks in range(AHEAD)]
     if diag:
         L += ["s_mov_b32 s78, 0", "s_mov_b32 s79, 0"]
     L += [".Lk5w_loop_%=:"]
@@ -385,17 +421,42 @@ def gen_loop(dt, diag=False):
         tail = boundary(diag)
         if U == 1:     # list entry of the block after next: an LDS read older than every K read of block 2 (made scalar in block 3)
             tail = tail + ["ds_read_u16 %[lv], %[la]"]
-        blk = gen_block(dt, U, True, chain=tail)
-        # the DMA walkers step to the next half-tile (re-based at U = 0 / 1 above where a new kept block starts)
-        blk += [f"s_add_u32 {sr(S_KB)}, {sr(S_KB)}, {sr(S_KST)}", f"s_addc_u32 {sr(S_KB + 1)}, {sr(S_KB + 1)}, 0",
-                f"s_add_u32 {sr(S_VB)}, {sr(S_VB)}, {sr(S_VST)}", f"s_addc_u32 {sr(S_VB + 1)}, {sr(S_VB + 1)}, 0",
-                f"s_add_u32 {sr(S_KL)}, {sr(S_KL)}, {HALF}", f"s_add_u32 {sr(S_VL)}, {sr(S_VL)}, {HALF}"]
-        if U == 3:     # (read two blocks ago) -> the next iteration's block index; advance the list pointer
-            blk += [f"v_readfirstlane_b32 {sr(S_BLK)}, %[lv]", "v_add_u32 %[la], 2, %[la]"]
+        # the DMA walkers step to the next half-tile (re-based at U = 0 / 1 where a new kept block starts)
+        kstep = [f"s_add_u32 {sr(S_KB)}, {sr(S_KB)}, {sr(S_KST)}", f"s_addc_u32 {sr(S_KB + 1)}, {sr(S_KB + 1)}, 0",
+                 f"s_add_u32 {sr(S_KL)}, {sr(S_KL)}, {HALF}"]
+        vstep = [f"s_add_u32 {sr(S_VB)}, {sr(S_VB)}, {sr(S_VST)}", f"s_addc_u32 {sr(S_VB + 1)}, {sr(S_VB + 1)}, 0",
+                 f"s_add_u32 {sr(S_VL)}, {sr(S_VL)}, {HALF}"]
+        nxt = [f"v_readfirstlane_b32 {sr(S_BLK)}, %[lv]", "v_add_u32 %[la], 2, %[la]"]   # (read two blocks ago) -> the next iteration's block index
+        if not tight:
+            blk = gen_block(dt, U, True, chain=tail, xf=xf, dma_cost=dma_cost, pre=pre)
+            blk = head + blk + kstep[:2] + vstep[:2] + [kstep[2], vstep[2]] + (nxt if U == 3 else [])
+        else:
+            # the scalar bookkeeping rides in MFMA gaps (a scalar instruction beside an MFMA is free, between two blocks it is not:
+            # one wave per SIMD).  The wave's K pieces sit in gaps 1, 5, 17, 21, its V pieces in gaps 9, 13, 25, 29: the K walker
+            # steps (U = 3: is re-based on the next kept block) behind gap 21, the V walker steps behind gap 29 -- except in
+            # front of block 1, which re-bases it in its own gaps 2..4, ahead of its first V piece.
+            salu = {}
+            if U == 3:
+                k0 = [l for l in gen_loop_head0(t0, t1)]
+                salu[22] = nxt[:1] + k0[:2]
+                salu[23] = k0[2:5]
+                salu[24] = k0[5:] + nxt[1:]
+            else:
+                salu[22] = kstep
+            if U == 0:
+                pass                      # (block 1 re-bases the V walker itself)
+            else:
+                salu[30] = vstep
+            if U == 1:
+                salu[2] = head[:3]
+                salu[3] = head[3:]
+            blk = gen_block(dt, U, True, chain=tail, xf=xf, dma_cost=dma_cost, pre=pre, salu=salu)
         # deferred-rescale test on the scores the NEXT block consumes (S_nxt of this block)
         tst = ["v_cmp_gt_f32 vcc, %[mx0], %[th0]", f"v_cmp_gt_f32 {sr(S_T2, 2)}, %[mx1], %[th1]",
                f"s_or_b64 vcc, vcc, {sr(S_T2, 2)}", f"s_cbranch_vccnz .Lk5w_resc{U}_%="]
-        L += head + blk + tst + [f".Lk5w_back{U}_%=:"]
+        if "notest" in xf:
+            tst = []
+        L += blk + tst + [f".Lk5w_back{U}_%=:"]
     L += [f"s_sub_u32 {sr(S_CNT)}, {sr(S_CNT)}, 1", f"s_cmp_lg_u32 {sr(S_CNT)}, 0", "s_cbranch_scc1 .Lk5w_loop_%=",
           "s_waitcnt lgkmcnt(0)",       # (the K reads the last block issued for its successor: nothing may land behind the statement)
           "s_branch .Lk5w_done_%="]
@@ -410,6 +471,34 @@ def gen_loop(dt, diag=False):
     return L
 
 
+# A/B forms of the loop (librsa_hip_ab.so, tuning key "k5w_form"; rsa_attn_block64_forms.h).  Forms 1-6, 8 REMOVE work to price
+# it (their outputs are garbage); form 7 is a candidate schedule with valid results.
+FORMS = {
+    1: dict(xf={"nodma"}),                                          # no staging instructions
+    2: dict(xf={"nobar", "novm"}),                                  # no sub-step boundary (vmcnt wait + barrier)
+    3: dict(xf={"noexp"}),                                          # no exponentials
+    4: dict(xf={"novalu", "notest"}),                               # no vector work at all
+    5: dict(xf={"novalu", "notest", "nodma", "nobar", "novm"}),     # MFMAs + LDS operand reads
+    6: dict(xf={"novalu", "notest", "nodma", "nobar", "novm", "nolds"}),   # MFMAs
+    7: dict(xf=set(), dma_cost=4),                                  # the pieces priced at 4 cycles: vector work rides in their gaps
+    9: dict(xf=set(), pre=0),                                       # no vector work in front of a block's first MFMA
+    10: dict(xf=set(), tight=True),                                 # the loop's scalar bookkeeping inside MFMA gaps
+    11: dict(xf=set(), tight=True, pre=0),
+    12: dict(xf=set(), tight=True, pre=0, dma_cost=4),
+    13: dict(xf=set(), tight=True, pre=24),
+    8: dict(xf={"nodma", "nobar", "novm"}),                         # MFMAs + LDS reads + all vector work, no memory side
+}
+
+
+def gen_forms():
+    out = ["// GENERATED by gen_k5_block64.py forms -- A/B forms of the 64-row loop (NOT the product).", "#pragma once", ""]
+    for n, f in sorted(FORMS.items()):
+        out.append(f"#define RSA_K5W_LOOP_BF16_X{n} \\")
+        out.append(c_string(gen_loop("bf16", xf=frozenset(f["xf"]), dma_cost=f.get("dma_cost"), pre=f.get("pre", 64), tight=f.get("tight", False))))
+        out.append("")
+    print("\n".join(out))
+
+
 def c_string(lines):
     return " \\\n".join(f'    "{l}\\n\\t"' for l in lines)
 
@@ -422,10 +511,10 @@ def main():
             out.append(c_string(gen_block(dt, U, False)))
             out.append("")
         out.append(f"#define RSA_K5W_LOOP_{dt.upper()} \\")
-        out.append(c_string(gen_loop(dt)))
+        out.append(c_string(gen_loop(dt, pre=LOOP_PRE, tight=True)))
         out.append("")
         out.append(f"#define RSA_K5W_LOOP_{dt.upper()}_DIAG \\")
-        out.append(c_string(gen_loop(dt, diag=True)))
+        out.append(c_string(gen_loop(dt, diag=True, pre=LOOP_PRE, tight=True)))
         out.append("")
         out.append(f"#define RSA_K5W_QK0_{dt.upper()} \\")
         out.append(c_string(gen_qk0(dt)))
@@ -510,7 +599,9 @@ def main():
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "stats":
+    if len(sys.argv) > 1 and sys.argv[1] == "forms":
+        gen_forms()
+    elif len(sys.argv) > 1 and sys.argv[1] == "stats":
         STATS = []
         import contextlib
         import io

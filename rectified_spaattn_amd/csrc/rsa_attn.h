@@ -79,10 +79,75 @@ struct AttnArgs {
     float* tpart;                             // split-KV partials of the text query blocks, or null
     int tsplit, tper;                         // workgroups per text block, key blocks per workgroup
     float qk_scale;
+    unsigned* gsync;                          // 64-row kernel: start-alignment counters of this launch (rsa_attn_kernel64.hip), or null
+    int gsync_gen;                            // ... workgroups an XCD holds at a time (a generation)
 #ifdef RSA_K5_DIAG
     unsigned long long* dbg;                  // diagnostics build only (make diag): per-wave s_memtime sums, see tools/diag_k5.py
 #endif
 };
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Aligned starts of the sparse walks (all K5 kernels; host side: rsa_gsync_slot in rsa_attn.hip).
+// Workgroup b runs on XCD b & 7 and is the (b >> 3)-th workgroup that XCD receives; the XCD holds `gen` of them at a time
+// (its 32 CUs x the kernel's workgroups per CU, asked of the runtime by the launcher: 64 for the kernels at head dim 128),
+// so "generation" g = (b >> 3) / gen can only be resident once generation g - 1 has left.  Every workgroup announces itself in the counter of (g, XCD) when it starts and, in front of its first
+// staging instruction, waits until its whole generation has: the 64 walks of an XCD then start their ascending key lists
+// TOGETHER and meet in the XCD's L2 (4 MiB = the K, V of ~60 key blocks) instead of each finding the other 63 at unrelated
+// positions (HunyuanVideo R2, 10 % of the keys kept at random: L2 hit rate 15 % -> 41 %, 116 -> 79 GB over the fabric,
+// which is what bounded that launch: profiles/r04_k5_gsync.md).  Advisory only -- the results do not depend on it: a
+// bounded wait, switched off for the rest of the launch by the first workgroup that runs into the bound (word 0), so
+// kernels of other processes sharing the device cannot stall this one.  Walks that keep more than a fifth of the keys are
+// not held back: they meet in L2 by chance often enough, the wait would only cost them the spread of a generation's ends.
+constexpr unsigned RSA_GSYNC_MAXG = 4096;    // generations with a counter (x 8 XCDs x 64 workgroups: 2 M workgroups)
+constexpr int RSA_GSYNC_RING = 8;            // launches in flight with counters of their own
+constexpr size_t RSA_GSYNC_SLOT_WORDS = 8 + 8 * (size_t)RSA_GSYNC_MAXG;
+struct GsyncTicket { unsigned* cnt; unsigned expect; };
+
+__device__ __forceinline__ GsyncTicket rsa_gsync_announce(unsigned* gsync, int gen) {
+    GsyncTicket tk{nullptr, 0u};
+    if (gsync) {
+        const unsigned xcd = blockIdx.x & 7, n = blockIdx.x >> 3, g = n / (unsigned)gen;
+        if (g < RSA_GSYNC_MAXG) {
+            tk.cnt = gsync + 8 + g * 8 + xcd;
+            const unsigned nx = (gridDim.x - xcd + 7) >> 3, left = nx - (unsigned)gen * g;
+            tk.expect = left < (unsigned)gen ? left : (unsigned)gen;
+            if (threadIdx.x == 0) __hip_atomic_fetch_add(tk.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    return tk;
+}
+
+// (every thread of the workgroup calls it: ends in a workgroup barrier)
+__device__ __forceinline__ void rsa_gsync_wait(unsigned* gsync, GsyncTicket tk, int n_items, int nb_total) {
+    if (!tk.cnt) return;
+    if (threadIdx.x == 0 && 5 * n_items < nb_total &&
+        __hip_atomic_load(gsync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        const int bound = 32 + 3 * n_items;      // x (s_sleep 32 + one L2 round trip) ~ 2 us; a kept block takes ~3.4 us
+        int it = 0;
+        while (__hip_atomic_load(tk.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < tk.expect) {
+            __builtin_amdgcn_s_sleep(32);
+            if (++it > bound) { __hip_atomic_store(gsync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+    }
+    __syncthreads();
+}
+// host: the counters of one launch (cleared in stream order in front of it) or null.  which: 1 = the 64-row kernel (on by
+// default), 2 = the 32-row and the e4m3 kernels (off by default: with two waves per SIMD they gain nothing from it and lose the
+// wait, profiles/r04_k5_gsync.md) -- bits of the tuning key "k5_gsync"; wg_per_cu = what the runtime says fits
+// (hipOccupancyMaxActiveBlocksPerMultiprocessor); *gen = workgroups per XCD generation
+unsigned* rsa_gsync_slot(int which, unsigned grid, int wg_per_cu, hipStream_t s, int* gen);
+int rsa_wg_per_cu(const void* kernel, int block, size_t lds_bytes);   // cached hipOccupancyMaxActiveBlocksPerMultiprocessor; 0 = unknown
+// launch `kernel` with the launch's alignment counters filled into its argument struct (sparse lists only: dense walks share their keys anyway)
+#define RSA_LAUNCH_GSYNC(which, kernel, args, MODE_IS_SPARSE, grid, block, lds_bytes, stream) \
+    do { \
+        auto kfn_ = kernel; \
+        auto aa_ = args; \
+        aa_.gsync = nullptr; aa_.gsync_gen = 64; \
+        if (MODE_IS_SPARSE) \
+            aa_.gsync = rsa_gsync_slot(which, (grid).x, rsa_wg_per_cu(reinterpret_cast<const void*>(kfn_), block, lds_bytes), stream, \
+                                       &aa_.gsync_gen); \
+        kfn_<<<grid, block, lds_bytes, stream>>>(aa_); \
+    } while (0)
 
 // byte offset of 16-byte chunk `ch` of row `row` inside a [64][D] 2-byte tile.  The XOR keeps both the
 // ds_read_b128 row reads (K as MFMA A operand) and the ds_read_b64_tr_b16 transposing reads (V^T as A

@@ -2,6 +2,8 @@
 // rsa_block_sparse_fwd, rsa_dense_fwd and rsa_rectified_attention of include/rsa.h live here.
 #include <stdlib.h>
 
+#include <atomic>
+#include <mutex>
 #include "rsa_attn.h"
 
 // =====================================================================================================
@@ -9,8 +11,10 @@
 // =====================================================================================================
 static int g_k5_tsplit = 1;     // 1 = split-KV for the text query blocks when the partial buffer is given
 extern int g_rsa_k3_prefix;
+static int g_k5_gsync = 1;      // aligned starts of the sparse walks (rsa_attn.h): bit 0 = in the 64-row kernel, bit 1 = in the 32-row and e4m3 kernels
 #ifdef RSA_K5_FORMS
 extern int g_rsa_k5_form;
+extern int g_rsa_k5w_form;
 #endif
 #ifdef RSA_K5_DIAG
 static unsigned long long g_dbg_ptr = 0;   // diagnostics build: device buffer for K5's in-kernel time sums
@@ -32,6 +36,7 @@ extern "C" int rsa_set_tuning(const char* key, int value) {
     if (strcmp(key, "k3_prefix") == 0) { g_rsa_k3_prefix = value; return RSA_OK; }
 #ifdef RSA_K5_FORMS
     if (strcmp(key, "k5_form") == 0) { g_rsa_k5_form = value; return RSA_OK; }
+    if (strcmp(key, "k5w_form") == 0) { g_rsa_k5w_form = value; return RSA_OK; }
 #endif
 #ifdef RSA_K5_DIAG
     if (strcmp(key, "dbg_lo") == 0) { g_dbg_ptr = (g_dbg_ptr & 0xFFFFFFFF00000000ull) | (unsigned)value; return RSA_OK; }
@@ -39,6 +44,7 @@ extern "C" int rsa_set_tuning(const char* key, int value) {
 #endif
     if (strcmp(key, "k5_tsplit") == 0) { g_k5_tsplit = value; return RSA_OK; }
     if (strcmp(key, "k5_w64") == 0) { g_k5_w64 = value; return RSA_OK; }
+    if (strcmp(key, "k5_gsync") == 0) { g_k5_gsync = value; return RSA_OK; }
     if (strcmp(key, "fp8_variant") == 0) { rsa_set_fp8_variant(value); return RSA_OK; }
     if (strcmp(key, "fp8_smooth_k") == 0) { rsa_set_fp8_smooth_k(value); return RSA_OK; }
     return RSA_ERR_BAD_ARG;
@@ -106,8 +112,47 @@ static int launch_text_combine(const AttnArgs& a, int BH, int D, int dtype, hipS
                                    a.q_text_end, a.Sq, BH, dtype, s);
 }
 
+// Aligned starts (rsa_attn.h): the counters are a ring of slots in a __device__ array of the code object (no allocation, nothing
+// to free), one slot per launch, cleared in stream order in front of it; a slot shared by two launches in flight (more than
+// RING of them, on different streams) costs alignment, never correctness.  Grids of more than two generations only.
+__device__ unsigned g_rsa_gsync[RSA_GSYNC_RING][RSA_GSYNC_SLOT_WORDS];
+unsigned* rsa_gsync_slot(int which, unsigned grid, int wg_per_cu, hipStream_t s, int* gen) {
+    static std::atomic<unsigned*> base[64];
+    static std::atomic<unsigned> ticket{0};
+    *gen = 32 * (wg_per_cu > 0 ? wg_per_cu : 2);     // 32 CUs per XCD
+    if (!(g_k5_gsync & which) || wg_per_cu <= 0 || grid <= 16u * (unsigned)*gen) return nullptr;   // two generations or fewer: nothing to align
+    const unsigned gens = ((grid + 7) / 8 + *gen - 1) / *gen;
+    int dev = -1;
+    if (gens > RSA_GSYNC_MAXG || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    unsigned* b = base[dev].load();
+    if (!b) {
+        if (hipGetSymbolAddress(reinterpret_cast<void**>(&b), HIP_SYMBOL(g_rsa_gsync)) != hipSuccess) return nullptr;
+        base[dev].store(b);
+    }
+    unsigned* slot = b + (size_t)(ticket.fetch_add(1) % RSA_GSYNC_RING) * RSA_GSYNC_SLOT_WORDS;
+    return hipMemsetAsync(slot, 0, (8 + 8 * (size_t)gens) * sizeof(unsigned), s) == hipSuccess ? slot : nullptr;
+}
+int rsa_wg_per_cu(const void* kernel, int block, size_t lds_bytes) {
+    struct Entry { const void* k; size_t lds; int dev, n; };
+    static Entry cache[64];
+    static std::atomic<int> used{0};
+    static std::mutex mu;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    const int nu = used.load(std::memory_order_acquire);
+    for (int i = 0; i < nu; ++i)
+        if (cache[i].k == kernel && cache[i].lds == lds_bytes && cache[i].dev == dev) return cache[i].n;
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, block, lds_bytes) != hipSuccess) n = 0;
+    std::lock_guard<std::mutex> lk(mu);
+    const int at = used.load();
+    if (at < 64) { cache[at] = Entry{kernel, lds_bytes, dev, n}; used.store(at + 1, std::memory_order_release); }
+    return n;
+}
+
 static int launch_attn(AttnArgs& a, int BH, int D, int dtype, hipStream_t s) {
     const int ntq = a.NQB - a.NBv;
+    a.gsync = nullptr; a.gsync_gen = 64;
     // split-KV for the dense text rows: without it one workgroup walks every key block of a text query block (902 at the
     // HunyuanVideo shape = 10 kept lists) -- hidden among 21 600 sparse blocks on one GPU, the critical path when the
     // heads are sharded over 8

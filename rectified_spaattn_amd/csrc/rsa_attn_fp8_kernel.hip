@@ -54,6 +54,8 @@ struct Attn8Args {
     int out_fp16;
     float* tpart;        // split-KV partials of the text query blocks (layout of rsa_attn.hip's combine kernel) or null
     int tsplit, tper;
+    unsigned* gsync;     // aligned starts (rsa_attn.h): this launch's counters or null
+    int gsync_gen;
 };
 
 // rsa_attn.hip: merge of the split-KV partials of the text blocks, and the switch for the split
@@ -135,6 +137,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     unsigned char* lds_ones = lds + 2 * NSLOT * TILE8;  // 32 bytes of e4m3 1.0, then 32 bytes of 0
     unsigned* lds_list = reinterpret_cast<unsigned*>(lds + 2 * NSLOT * TILE8 + 64);
 
+    const GsyncTicket gs_tk = rsa_gsync_announce(a.gsync, a.gsync_gen);   // aligned starts (rsa_attn.h)
     // ---------------- work mapping (as rsa_attn_kernel.hip) ----------------
     int bh, qblk, tsp = 0;
     {
@@ -448,6 +451,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     };
 
     // ---------------- prologue + main loop ----------------
+    rsa_gsync_wait(a.gsync, gs_tk, n_items, a.NB_total);   // aligned starts: in front of the first staging instruction
     f32x16 SA[2], SB[2];
     float mxA = -INFINITY, mxB = -INFINITY;
     int key0 = 0;
@@ -594,13 +598,13 @@ int launch_attn8(Attn8Args& a, int BH, int D8, hipStream_t s) {
     if (a.NB_total > 8192) return RSA_ERR_UNSUPPORTED;
     const size_t lds_bytes = (size_t)2 * NSLOT * 64 * D8 + 64 + (((size_t)a.NB_total * 4 + 15) & ~(size_t)15);
     if (D8 == 64) {   // head dim 64: the product form and its compiled twin
-        if (g_fp8_variant == 1) bsfwd_fp8_kernel<6, 64><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a);
-        else bsfwd_fp8_kernel<7, 64><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a);
+        if (g_fp8_variant == 1) RSA_LAUNCH_GSYNC(2, (bsfwd_fp8_kernel<6, 64>), a, a.mode == MODE_SPARSE, dim3((unsigned)nblocks), 256, lds_bytes, s);
+        else RSA_LAUNCH_GSYNC(2, (bsfwd_fp8_kernel<7, 64>), a, a.mode == MODE_SPARSE, dim3((unsigned)nblocks), 256, lds_bytes, s);
     } else {
         switch (g_fp8_variant) {   // tuning key fp8_variant: 0 = product; 1, 2 = the two verification forms the tests compare it with
-            case 1: bsfwd_fp8_kernel<6><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a); break;   // product arithmetic, hipcc's schedule
-            case 2: bsfwd_fp8_kernel<3><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a); break;   // exact-exponential P, hand-placed
-            default: bsfwd_fp8_kernel<7><<<dim3((unsigned)nblocks), 256, lds_bytes, s>>>(a);
+            case 1: RSA_LAUNCH_GSYNC(2, (bsfwd_fp8_kernel<6>), a, a.mode == MODE_SPARSE, dim3((unsigned)nblocks), 256, lds_bytes, s); break;   // product arithmetic, hipcc's schedule
+            case 2: RSA_LAUNCH_GSYNC(2, (bsfwd_fp8_kernel<3>), a, a.mode == MODE_SPARSE, dim3((unsigned)nblocks), 256, lds_bytes, s); break;   // exact-exponential P, hand-placed
+            default: RSA_LAUNCH_GSYNC(2, (bsfwd_fp8_kernel<7>), a, a.mode == MODE_SPARSE, dim3((unsigned)nblocks), 256, lds_bytes, s);
         }
     }
     const int st = rsa_launch_status();

@@ -112,6 +112,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
     unsigned short* lds_list = reinterpret_cast<unsigned short*>(lds + 4 * TILE_BYTES);
 
     const int work = blockIdx.x;
+    const GsyncTicket gs_tk = rsa_gsync_announce(a.gsync, a.gsync_gen);   // aligned starts (rsa_attn.h)
     // ---------------- work mapping: dense text-row blocks first, then the sparse blocks chunked per XCD ----------------
     int bh, qblk, tsp = 0;   // tsp: which part of a text block's key range this workgroup walks
     if (work < a.n_heavy_pad) {
@@ -473,6 +474,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
     };
 
     // ---------------- prologue + main loop ----------------
+    rsa_gsync_wait(a.gsync, gs_tk, n_items, a.NB_total);   // aligned starts: in front of the first staging instruction
     f32x16 SA, SB;
     float mxA = -INFINITY, mxB = -INFINITY;
     int key0 = 0;
@@ -640,17 +642,17 @@ int rsa_launch_bsfwd(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int 
 #ifdef RSA_K5_FORMS
 #define RSA_K5(DD, TT) \
     do { \
-        if (!wide) bsfwd_kernel<DD, TT, false, k5_product_form(DD)><<<grid, 256, lds_bytes, s>>>(a); \
-        else if (g_rsa_k5_form == 0) bsfwd_kernel<DD, TT, true, 0><<<grid, 256, lds_bytes, s>>>(a); \
-        else if (g_rsa_k5_form == 1) bsfwd_kernel<DD, TT, true, 1><<<grid, 256, lds_bytes, s>>>(a); \
-        else if (g_rsa_k5_form == 2) bsfwd_kernel<DD, TT, true, 2><<<grid, 256, lds_bytes, s>>>(a); \
-        else bsfwd_kernel<DD, TT, true, k5_product_form(DD)><<<grid, 256, lds_bytes, s>>>(a); \
+        if (!wide) RSA_LAUNCH_GSYNC(2, (bsfwd_kernel<DD, TT, false, k5_product_form(DD)>), a, a.mode == MODE_SPARSE, grid, 256, lds_bytes, s); \
+        else if (g_rsa_k5_form == 0) RSA_LAUNCH_GSYNC(2, (bsfwd_kernel<DD, TT, true, 0>), a, a.mode == MODE_SPARSE, grid, 256, lds_bytes, s); \
+        else if (g_rsa_k5_form == 1) RSA_LAUNCH_GSYNC(2, (bsfwd_kernel<DD, TT, true, 1>), a, a.mode == MODE_SPARSE, grid, 256, lds_bytes, s); \
+        else if (g_rsa_k5_form == 2) RSA_LAUNCH_GSYNC(2, (bsfwd_kernel<DD, TT, true, 2>), a, a.mode == MODE_SPARSE, grid, 256, lds_bytes, s); \
+        else RSA_LAUNCH_GSYNC(2, (bsfwd_kernel<DD, TT, true, k5_product_form(DD)>), a, a.mode == MODE_SPARSE, grid, 256, lds_bytes, s); \
     } while (0)
 #else
 #define RSA_K5(DD, TT) \
     do { \
-        if (wide) bsfwd_kernel<DD, TT, true, k5_product_form(DD)><<<grid, 256, lds_bytes, s>>>(a); \
-        else bsfwd_kernel<DD, TT, false, k5_product_form(DD)><<<grid, 256, lds_bytes, s>>>(a); \
+        if (wide) RSA_LAUNCH_GSYNC(2, (bsfwd_kernel<DD, TT, true, k5_product_form(DD)>), a, a.mode == MODE_SPARSE, grid, 256, lds_bytes, s); \
+        else RSA_LAUNCH_GSYNC(2, (bsfwd_kernel<DD, TT, false, k5_product_form(DD)>), a, a.mode == MODE_SPARSE, grid, 256, lds_bytes, s); \
     } while (0)
 #endif
     if (D == 128) {

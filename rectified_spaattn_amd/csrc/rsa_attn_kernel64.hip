@@ -19,7 +19,11 @@
 //
 // LDS = [K ring: 4 x 8 KiB | V ring: 4 x 8 KiB | list (u16)]: half-tile x (32 keys) of the walk sits in slot x & 3.
 #include "rsa_attn.h"
+#include <atomic>
 #include "rsa_attn_block64.h"
+#ifdef RSA_K5_FORMS
+#include "rsa_attn_block64_forms.h"
+#endif
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -95,7 +99,8 @@ __device__ __forceinline__ bool k5w_map(const AttnArgs& a, int work, int& bh, in
 }
 
 // WIDE: 16-byte output stores after a permlane32_swap regroup (needs 16-byte aligned output rows), else 8-byte stores.
-template <typename Tag, bool WIDE>
+// XF (A/B build only, -DRSA_K5_FORMS): one of the loop forms of rsa_attn_block64_forms.h instead of the product's loop.
+template <typename Tag, bool WIDE, int XF = 0>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) void bsfwd64_kernel(AttnArgs a) {
     constexpr int D = 128;
     constexpr int NW = 2;                   // 2 waves x 64 query rows
@@ -106,6 +111,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     using E = Elem<Tag>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned short* lds_list = reinterpret_cast<unsigned short*>(lds + 8 * HALF);
+
+    const GsyncTicket gs_tk = rsa_gsync_announce(a.gsync, a.gsync_gen);   // aligned starts (rsa_attn.h)
 
     // ---------------- work mapping: dense text-row blocks first, then the sparse blocks chunked per XCD ----------------
     int bh, qblk, tsp;
@@ -349,6 +356,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     };
 
+    rsa_gsync_wait(a.gsync, gs_tk, n_items, a.NB_total);   // aligned starts: in front of the first staging instruction
+
     // ---------------- prologue: half-tiles K(0..3), V(0..2); scores of sub-step 0 ----------------
     if (n_sub > 0) {
 #pragma unroll
@@ -396,6 +405,13 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                          RSA_K5W_CLOBBER_LOOP_DIAG, "memory");
         tsum[3] = ((unsigned long long)d1 << 32) | d0;
 #else
+#ifdef RSA_K5_FORMS
+#define RSA_K5W_XFORM(N) else if constexpr (XF == N) \
+            asm volatile(RSA_K5W_LOOP_BF16_X##N RSA_K5W_OPS_LOOP : RSA_K5W_CLOBBER_TMP, RSA_K5W_CLOBBER_O, RSA_K5W_CLOBBER_LOOP, "memory");
+        if constexpr (false) {}
+        RSA_K5W_XFORM(1) RSA_K5W_XFORM(2) RSA_K5W_XFORM(3) RSA_K5W_XFORM(4) RSA_K5W_XFORM(5) RSA_K5W_XFORM(6) RSA_K5W_XFORM(7) RSA_K5W_XFORM(8) RSA_K5W_XFORM(9) RSA_K5W_XFORM(10) RSA_K5W_XFORM(11) RSA_K5W_XFORM(12) RSA_K5W_XFORM(13)
+        else
+#endif
         if constexpr (std::is_same<Tag, bf16_tag>::value)
             asm volatile(RSA_K5W_LOOP_BF16 RSA_K5W_OPS_LOOP : RSA_K5W_CLOBBER_TMP, RSA_K5W_CLOBBER_O, RSA_K5W_CLOBBER_LOOP, "memory");
         else
@@ -535,16 +551,23 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
 }
 
+#ifdef RSA_K5_FORMS
+int g_rsa_k5w_form = 0;   // A/B build: tuning key "k5w_form" (loop forms of rsa_attn_block64_forms.h)
+#endif
 // launch hook used by rsa_attn.hip::launch_attn (head dim 128 only)
 int rsa_launch_bsfwd64(const AttnArgs& a, dim3 grid, size_t lds_bytes, int dtype, hipStream_t s) {
     const bool wide = !(((uintptr_t)a.out & 15) || ((a.osb | a.osh | a.oss) & 7));
     lds_bytes += 16;   // the loop reads its list two entries ahead
+#ifdef RSA_K5_FORMS
+#define RSA_K5W_XLAUNCH(N) if (g_rsa_k5w_form == N && dtype == RSA_BF16 && wide) { RSA_LAUNCH_GSYNC(1, (bsfwd64_kernel<bf16_tag, true, N>), a, a.mode == MODE_SPARSE, grid, 128, lds_bytes, s); return rsa_launch_status(); }
+    RSA_K5W_XLAUNCH(1) RSA_K5W_XLAUNCH(2) RSA_K5W_XLAUNCH(3) RSA_K5W_XLAUNCH(4) RSA_K5W_XLAUNCH(5) RSA_K5W_XLAUNCH(6) RSA_K5W_XLAUNCH(7) RSA_K5W_XLAUNCH(8) RSA_K5W_XLAUNCH(9) RSA_K5W_XLAUNCH(10) RSA_K5W_XLAUNCH(11) RSA_K5W_XLAUNCH(12) RSA_K5W_XLAUNCH(13)
+#endif
     if (dtype == RSA_BF16) {
-        if (wide) bsfwd64_kernel<bf16_tag, true><<<grid, 128, lds_bytes, s>>>(a);
-        else bsfwd64_kernel<bf16_tag, false><<<grid, 128, lds_bytes, s>>>(a);
+        if (wide) RSA_LAUNCH_GSYNC(1, (bsfwd64_kernel<bf16_tag, true>), a, a.mode == MODE_SPARSE, grid, 128, lds_bytes, s);
+        else RSA_LAUNCH_GSYNC(1, (bsfwd64_kernel<bf16_tag, false>), a, a.mode == MODE_SPARSE, grid, 128, lds_bytes, s);
     } else {
-        if (wide) bsfwd64_kernel<fp16_tag, true><<<grid, 128, lds_bytes, s>>>(a);
-        else bsfwd64_kernel<fp16_tag, false><<<grid, 128, lds_bytes, s>>>(a);
+        if (wide) RSA_LAUNCH_GSYNC(1, (bsfwd64_kernel<fp16_tag, true>), a, a.mode == MODE_SPARSE, grid, 128, lds_bytes, s);
+        else RSA_LAUNCH_GSYNC(1, (bsfwd64_kernel<fp16_tag, false>), a, a.mode == MODE_SPARSE, grid, 128, lds_bytes, s);
     }
     return rsa_launch_status();
 }

@@ -1,0 +1,80 @@
+"""Aligned starts of the sparse walks (rsa_attn.h, tuning key k5_gsync; round 4).  The workgroups of an XCD wait for their
+generation before they stage their first tile, so that their ascending walks meet in the XCD's L2.  It is a scheduling aid:
+the arithmetic and its order are untouched, so every kernel must give the same BYTES with it on and off -- in the 64-row kernel
+(where it is on by default), in the 32-row kernel and in the e4m3 kernel (bit 1 of the key)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(H, nb, D, seed, dt):
+    g = torch.Generator(device="cuda:0").manual_seed(seed)
+    S = nb * 128
+    cent = torch.randn(H, nb, D, generator=g, device="cuda:0")
+
+    def mk():
+        return (cent.repeat_interleave(128, 1) + 0.7 * torch.randn(H, S, D, generator=g, device="cuda:0")).to(dt).view(1, H, S, D)
+    return mk(), mk(), torch.randn(1, H, S, D, generator=g, device="cuda:0").to(dt)
+
+
+@pytest.mark.parametrize("w64,D,dt", [(1, 128, torch.bfloat16), (1, 128, torch.float16), (0, 128, torch.bfloat16), (0, 64, torch.bfloat16)])
+def test_aligned_starts_do_not_change_a_byte(w64, D, dt):
+    from rectified_spaattn_amd import _core, _lib
+    H, nb, top_k = 8, 168, 14          # 1 344 workgroups (more than two generations of 8 x 64), 8 % of the keys kept: the walks wait
+    q, k, v = _inputs(H, nb, D, 11, dt)
+    spec = _core.LayoutSpec.wan(nb * 128, 0)
+    L = _lib.lib()
+    outs = []
+    try:
+        assert L.rsa_set_tuning(b"k5_w64", w64) == 0
+        for gs in (0, 3, 0, 3):
+            assert L.rsa_set_tuning(b"k5_gsync", gs) == 0
+            out = _core.rectified_attention(q, k, v, spec, top_k, 0.05, None)
+            torch.cuda.synchronize()
+            outs.append(out.view(torch.int16).cpu().numpy().copy())
+    finally:
+        L.rsa_set_tuning(b"k5_w64", 1)
+        L.rsa_set_tuning(b"k5_gsync", 1)
+    assert np.isfinite(out.float().cpu().numpy()).all()
+    for o in outs[1:]:
+        assert np.array_equal(o, outs[0])
+
+
+def test_aligned_starts_do_not_change_a_byte_of_the_e4m3_path():
+    from rectified_spaattn_amd import _core, _lib
+    H, nb, top_k = 8, 168, 14
+    q, k, v = _inputs(H, nb, 128, 12, torch.bfloat16)
+    spec = _core.LayoutSpec.wan(nb * 128, 0)
+    L = _lib.lib()
+    outs = []
+    try:
+        for gs in (0, 3, 0, 3):
+            assert L.rsa_set_tuning(b"k5_gsync", gs) == 0
+            out = _core.rectified_attention(q, k, v, spec, top_k, 0.05, None, qkv_fp8=True)
+            torch.cuda.synchronize()
+            outs.append(out.view(torch.int16).cpu().numpy().copy())
+    finally:
+        L.rsa_set_tuning(b"k5_gsync", 1)
+    for o in outs[1:]:
+        assert np.array_equal(o, outs[0])
+
+
+def test_a_walk_that_keeps_many_keys_and_a_small_grid_are_left_alone():
+    """More than a fifth of the keys kept, or two generations or fewer: no counters are taken / nobody waits; same bytes again."""
+    from rectified_spaattn_amd import _core, _lib
+    L = _lib.lib()
+    for H, nb, top_k in ((8, 168, 60), (2, 64, 6)):
+        q, k, v = _inputs(H, nb, 128, 13, torch.bfloat16)
+        spec = _core.LayoutSpec.wan(nb * 128, 0)
+        outs = []
+        try:
+            for gs in (0, 1):
+                assert L.rsa_set_tuning(b"k5_gsync", gs) == 0
+                out = _core.rectified_attention(q, k, v, spec, top_k, 0.05, None)
+                torch.cuda.synchronize()
+                outs.append(out.view(torch.int16).cpu().numpy().copy())
+        finally:
+            L.rsa_set_tuning(b"k5_gsync", 1)
+        assert np.array_equal(outs[0], outs[1])

@@ -5,6 +5,9 @@
 //   0: MFMAs only                         1: global_load_lds_dwordx4 (saddr + 32-bit lane offset), vmcnt(16) throttle
 //   2: global_load_dwordx4 -> VGPR ring   3: as 2 + ds_write_b128 of the piece loaded 16 iterations ago
 //   4: as 1 with contiguous lane offsets  5: as 2 into the ACCUMULATOR file, ds_write from there
+//   6: the piece as FOUR global_load_lds_dword (256 B = one key row each), one behind each MFMA
+//   7: ONE global_load_lds_dword per iteration (256 B)      8: TWO per iteration, behind MFMA 0 and MFMA 2
+//   9: four global_load_lds_dword back to back behind MFMA 1
 // build: hipcc --offload-arch=gfx950 -O3 -o dma_issue_probe dma_issue_probe.hip
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -20,6 +23,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
     // per-lane source offset: 4 rows x 16 chunks, row stride `stride` (a swizzled gather like K5's) or contiguous
     const unsigned vo = MODE == 4 ? lane * 16 : (lane >> 4) * stride + (lane & 15) * 16;
+    const unsigned v1a = lane * 4, v1b = stride + lane * 4, v1c = 2 * stride + lane * 4, v1d = 3 * stride + lane * 4;   // one 256-B row per instruction
     const unsigned char* base = src + ((size_t)(blockIdx.x * 4 + wv) * 65536);
     unsigned glo = __builtin_amdgcn_readfirstlane((unsigned)(size_t)base), ghi = __builtin_amdgcn_readfirstlane((unsigned)((size_t)base >> 32));
     unsigned ld = __builtin_amdgcn_readfirstlane(lds_base + wv * 16384);
@@ -31,7 +35,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         "s_memtime %[t0]\n\ts_waitcnt lgkmcnt(0)\n\t"
         ".Lp_%=:\n\t"
         "v_mfma_f32_32x32x16_bf16 v[0:15], v[32:35], v[32:35], v[0:15]\n\t"
+        ".if %c[mode] == 6 || %c[mode] == 7 || %c[mode] == 8\n\t"
+        "s_mov_b32 m0, s82\n\tglobal_load_lds_dword %[v1a], s[80:81]\n\t"
+        ".endif\n\t"
         "v_mfma_f32_32x32x16_bf16 v[16:31], v[32:35], v[32:35], v[16:31]\n\t"
+        ".if %c[mode] == 6\n\t"
+        "s_add_u32 m0, s82, 256\n\tglobal_load_lds_dword %[v1b], s[80:81]\n\t"
+        ".endif\n\t"
+        ".if %c[mode] == 9\n\t"
+        "s_mov_b32 m0, s82\n\tglobal_load_lds_dword %[v1a], s[80:81]\n\t"
+        "s_add_u32 m0, s82, 256\n\tglobal_load_lds_dword %[v1b], s[80:81]\n\t"
+        "s_add_u32 m0, s82, 512\n\tglobal_load_lds_dword %[v1c], s[80:81]\n\t"
+        "s_add_u32 m0, s82, 768\n\tglobal_load_lds_dword %[v1d], s[80:81]\n\t"
+        ".endif\n\t"
         ".if %c[mode] == 1 || %c[mode] == 4\n\t"
         "s_mov_b32 m0, s82\n\ts_add_u32 s84, s84, 1\n\tglobal_load_lds_dwordx4 %[vo], s[80:81]\n\t"
         ".endif\n\t"
@@ -45,6 +61,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         "s_add_u32 s80, s80, 0x6000\n\ts_addc_u32 s81, s81, 0\n\t"
         ".endif\n\t"
         "v_mfma_f32_32x32x16_bf16 v[0:15], v[32:35], v[32:35], v[0:15]\n\t"
+        ".if %c[mode] == 6 || %c[mode] == 8\n\t"
+        "s_add_u32 m0, s82, 512\n\tglobal_load_lds_dword %[v1c], s[80:81]\n\t"
+        ".endif\n\t"
         ".if %c[mode] == 3\n\t"
         "ds_write_b128 %[ldv], v[44:47]\n\t"
         ".endif\n\t"
@@ -52,8 +71,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         "ds_write_b128 %[ldv], a[44:47]\n\t"
         ".endif\n\t"
         "v_mfma_f32_32x32x16_bf16 v[16:31], v[32:35], v[32:35], v[16:31]\n\t"
-        ".if %c[mode] != 0\n\t"
+        ".if %c[mode] == 6\n\t"
+        "s_add_u32 m0, s82, 768\n\tglobal_load_lds_dword %[v1d], s[80:81]\n\t"
+        ".endif\n\t"
+        ".if %c[mode] == 6 || %c[mode] == 9\n\t"
+        "s_waitcnt vmcnt(48)\n\t"
+        ".endif\n\t"
+        ".if %c[mode] != 0 && %c[mode] != 6 && %c[mode] != 9\n\t"
         "s_waitcnt vmcnt(16)\n\t"
+        ".endif\n\t"
+        ".if %c[mode] != 0\n\t"
         "s_and_b32 s85, s83, 15\n\ts_cmp_eq_u32 s85, 0\n\ts_cbranch_scc0 .Lq_%=\n\t"
         "s_mov_b32 s80, %[glo]\n\ts_mov_b32 s81, %[ghi]\n\t"     // rewind every 16 pieces (a 384 KiB window per wave, 64 MiB in all: Infinity-Cache resident like one head of K, V)
         ".Lq_%=:\n\t"
@@ -62,7 +89,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
         "s_memtime %[t1]\n\ts_waitcnt lgkmcnt(0)\n\t"
         : [t0] "=&s"(t0), [t1] "=&s"(t1)
-        : [glo] "s"(glo), [ghi] "s"(ghi), [ld] "s"(ld), [it] "s"(iters), [vo] "v"(vo), [ldv] "v"(ldv), [mode] "i"(MODE)
+        : [glo] "s"(glo), [ghi] "s"(ghi), [ld] "s"(ld), [it] "s"(iters), [vo] "v"(vo), [ldv] "v"(ldv), [v1a] "v"(v1a), [v1b] "v"(v1b), [v1c] "v"(v1c), [v1d] "v"(v1d), [mode] "i"(MODE)
         : "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19",
           "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v40", "v41", "v42",
           "v43", "v44", "v45", "v46", "v47", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a255", "s80", "s81", "s82", "s83", "s84", "s85", "memory");
@@ -89,5 +116,6 @@ int main() {
     hipMalloc(&dout, 1024 * 8);
     const int iters = 4000;
     run<0>(src, dout, iters); run<1>(src, dout, iters); run<4>(src, dout, iters); run<2>(src, dout, iters); run<3>(src, dout, iters); run<5>(src, dout, iters);
+    run<7>(src, dout, iters); run<8>(src, dout, iters); run<6>(src, dout, iters); run<9>(src, dout, iters);
     return 0;
 }
