@@ -55,8 +55,8 @@ REGIMES = {
     "r1": ("iid", "gilbert", 0.05),        # algorithmic: cumulative-probability rule + true Gilbert neighbours
     "locality": ("spatial", "gilbert", 0.05),  # as r1 on spatially smooth centroids (overlapping kept lists)
 }
-K5_SOURCES = {False: ("rsa_attn_kernel64.hip", "gen_k5_block64.py", "rsa_attn_kernel.hip", "rsa_attn.h", "gen_k5_block.py"),
-              True: ("rsa_attn_fp8_kernel.hip", "rsa_attn.h", "gen_k5_block.py")}
+K5_SOURCES = {False: ("rsa_attn_kernel64.hip", "gen_k5_block64.py", "rsa_attn_kernel.hip", "rsa_attn.h", "rsa_attn.hip", "gen_k5_block.py"),
+              True: ("rsa_attn_fp8_kernel.hip", "rsa_attn.h", "rsa_attn.hip", "gen_k5_block.py")}
 
 
 def kernel_source_sha(fp8: bool = False) -> str:

@@ -299,7 +299,8 @@ int rsa_ipc_close(void* dev_ptr);
 int rsa_ipc_offset(const void* dev_ptr, int64_t* offset);                   /* dev_ptr - base of its allocation (a handle names the allocation) */
 
 /* Tuning / diagnostics hook, not part of the data path.  Keys: "k5_w64" (head dim 128: 1 = the 64-rows-per-wave K5, the
- * product; 0 = the 32-row kernel, for A/B), "k5_tsplit" (0/1: split-KV of the text query blocks),
+ * product; 0 = the 32-row kernel, for A/B), "k5_gsync" (aligned starts of the sparse walks: bit 0 the 64-row kernel -- default --,
+ * bit 1 the other K5 kernels, 0 off; a scheduling aid, outputs are byte-identical), "k5_text_last", "k5_tsplit" (0/1: split-KV of the text query blocks),
  * "k3_prefix" (0/1: sorted-head path of K3), "fp8_variant" (0: the product = hand-placed block, P through the e4m3 code map; 1: the same arithmetic as hipcc schedules it;
  * 2: P by v_exp_f32 + round-to-nearest e4m3 -- the two forms the tests compare the product with), "fp8_smooth_k"
  * (0: the fp8 producers take mu = 0 instead of the sampled K mean, for the same comparison).  The hook

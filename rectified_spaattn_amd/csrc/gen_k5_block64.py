@@ -29,10 +29,13 @@ single-issue instructions per v_mfma_f32_32x32x16 gap, costs summing to <= 24 cy
 packing of the first 16 keys (needed by PV MFMA 16), of the second 16 keys (MFMA 24), row sums, then the two row maxima
 interleaved with each other.  The wave's 8 DMA pieces (4 of K, 4 of V) take every fourth gap: they reach the CU's texture
 addresser spread over the sub-step instead of as a burst behind the barrier (the 32-row kernel's staging point costs each wave
-~450 cycles for 4 pieces: 8 waves x 4 pieces queue at one addresser, profiles/r03_k5_block.md).  A piece costs the wave ~39
-cycles of issue that no MFMA of its own overlaps (tools/probes/dma_issue_probe.hip), so nothing else rides with it: the
-source bases WALK in scalar registers -- a half-tile is 32 consecutive keys, a kept block 128 -- one step per block, re-based
-once per kept block; the rows of piece j come from lane-offset register j, the LDS destination from M0 + instruction offset.
+~450 cycles for 4 pieces: 8 waves x 4 pieces queue at one addresser, profiles/r03_k5_block.md; four pieces back to back cost
+this wave ~25 cycles each, one per four MFMAs ~2 when the lines are in the CU's own cache: tools/probes/dma_issue_probe2.hip --
+what a piece costs beyond that is the memory system pushing back, not the instruction).  The source bases WALK in scalar
+registers -- a half-tile is 32 consecutive keys, a kept block 128 -- one step per block, re-based once per kept block, all of it
+inside MFMA gaps (a scalar instruction beside an MFMA is free, between two blocks it is not: `tight` below); the rows of piece
+j come from lane-offset register j, the LDS destination from M0 + instruction offset.  Block alone (no staging, no boundary):
+1 131 .. 1 163 cycles per 32 MFMAs (tools/probes/k5w_block_probe.hip), in the loop with its staging ~1 330.
 
 Two products:
   * RSA_K5W_LOOP_*: the steady-state loop as ONE asm statement: per kept 128-key block four blocks (U = 0..3), each behind
@@ -50,7 +53,7 @@ usage: python3 gen_k5_block64.py > rsa_attn_block64.h        (python3 gen_k5_blo
 import sys
 
 AHEAD = 4
-COST = dict(exp=8, cvt=5, add=4, max=4, mov=4, swap=4, lds=4, wait=1, dma=24)   # (a piece measures 39: tools/probes/dma_issue_probe.hip)
+COST = dict(exp=8, cvt=5, add=4, max=4, mov=4, swap=4, lds=4, wait=1, dma=24)   # (dma: the piece keeps its gap to itself; pricing it at 4 changes nothing measurable: form 7)
 D, KS, DT = 128, 8, 4
 HALF = 32 * D * 2             # bytes of a 32-key half-tile
 VRING = 4 * HALF              # LDS offset of the V ring

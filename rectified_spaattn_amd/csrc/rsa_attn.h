@@ -78,6 +78,7 @@ struct AttnArgs {
     int n_heavy_pad, NBp, BH;                 // work mapping
     float* tpart;                             // split-KV partials of the text query blocks, or null
     int tsplit, tper;                         // workgroups per text block, key blocks per workgroup
+    int heavy_last;                           // 64-row kernel: the (split) text-row pieces are the LAST workgroups of the grid
     float qk_scale;
     unsigned* gsync;                          // 64-row kernel: start-alignment counters of this launch (rsa_attn_kernel64.hip), or null
     int gsync_gen;                            // ... workgroups an XCD holds at a time (a generation)

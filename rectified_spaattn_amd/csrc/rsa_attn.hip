@@ -11,6 +11,7 @@
 // =====================================================================================================
 static int g_k5_tsplit = 1;     // 1 = split-KV for the text query blocks when the partial buffer is given
 extern int g_rsa_k3_prefix;
+static int g_k5_text_last = 1;  // 64-row kernel: split text-row pieces at the end of the grid (rsa_attn_kernel64.hip::k5w_map)
 static int g_k5_gsync = 1;      // aligned starts of the sparse walks (rsa_attn.h): bit 0 = in the 64-row kernel, bit 1 = in the 32-row and e4m3 kernels
 #ifdef RSA_K5_FORMS
 extern int g_rsa_k5_form;
@@ -45,6 +46,7 @@ extern "C" int rsa_set_tuning(const char* key, int value) {
     if (strcmp(key, "k5_tsplit") == 0) { g_k5_tsplit = value; return RSA_OK; }
     if (strcmp(key, "k5_w64") == 0) { g_k5_w64 = value; return RSA_OK; }
     if (strcmp(key, "k5_gsync") == 0) { g_k5_gsync = value; return RSA_OK; }
+    if (strcmp(key, "k5_text_last") == 0) { g_k5_text_last = value; return RSA_OK; }
     if (strcmp(key, "fp8_variant") == 0) { rsa_set_fp8_variant(value); return RSA_OK; }
     if (strcmp(key, "fp8_smooth_k") == 0) { rsa_set_fp8_smooth_k(value); return RSA_OK; }
     return RSA_ERR_BAD_ARG;
@@ -164,6 +166,7 @@ static int launch_attn(AttnArgs& a, int BH, int D, int dtype, hipStream_t s) {
         a.tper = (n_txt_items + a.tsplit - 1) / a.tsplit;
     }
     const int n_heavy = ntq > 0 ? BH * ntq * a.tsplit : 0;
+    a.heavy_last = a.tsplit > 1 && g_k5_text_last;
     a.BH = BH;
     a.n_heavy_pad = (n_heavy + 7) & ~7;
     a.NBp = (a.NBv + 7) & ~7;

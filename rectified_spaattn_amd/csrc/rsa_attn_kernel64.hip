@@ -77,18 +77,26 @@ __device__ __forceinline__ f32x16 k5w_oread() {
 }
 
 // blockIdx -> (batch*head, query block, key-range part of a split text block); false = padding workgroup
+// Work mapping.  Sparse query blocks: workgroup v of a head's NBp (a multiple of 8) goes to XCD v & 7, which takes the
+// (v & 7)-th contiguous eighth of the head's query blocks.  The dense text-row blocks come FIRST when each is one long walk
+// over every key block (no split-KV buffer: the longest work first), and LAST when they are split into pieces shorter than a
+// sparse walk (tsplit > 1): with aligned starts the launch advances in generations of 8 x 64 workgroups, and the short
+// pieces then fill the slots the last, partial generation leaves idle instead of adding a generation of their own.
 __device__ __forceinline__ bool k5w_map(const AttnArgs& a, int work, int& bh, int& qblk, int& tsp) {
     tsp = 0;
-    if (work < a.n_heavy_pad) {
+    const int n_sparse = a.BH * a.NBp;
+    const bool heavy_last = a.heavy_last != 0;
+    const int wh = heavy_last ? work - n_sparse : work;                 // index among the text-row pieces
+    const int v = heavy_last ? work : work - a.n_heavy_pad;             // index among the sparse blocks
+    if (heavy_last ? work >= n_sparse : work < a.n_heavy_pad) {
         const int ntq = a.NQB - a.NBv;
         const int per_bh = ntq * a.tsplit;      // text blocks x key-range splits (tsplit = 1: no split)
-        if (ntq <= 0 || work >= a.BH * per_bh) return false;
-        bh = work / per_bh;
-        const int rem = work % per_bh;
+        if (ntq <= 0 || wh >= a.BH * per_bh) return false;
+        bh = wh / per_bh;
+        const int rem = wh % per_bh;
         qblk = a.NBv + rem / a.tsplit;
         tsp = rem % a.tsplit;
     } else {
-        const int v = work - a.n_heavy_pad;
         bh = v / a.NBp;
         const int j = v % a.NBp;
         const int chunk = a.NBp >> 3;

@@ -19,7 +19,7 @@ print("Collected with `tools/pmc_passes.sh` / `tools/pmc_select.sh` (separate `r
 print("`tools/pmc_summary.py` (mean per launch), formatted by `tools/pmc_md.py`.  SQ_ACTIVE_*/SQ_WAIT_*/SQ_WAVE_CYCLES count quad-cycles;")
 print("SQ_VALU_MFMA_BUSY_CYCLES counts cycles; GRBM_GUI_ACTIVE is summed over the 8 XCDs; FETCH_SIZE / WRITE_SIZE in KiB (FETCH_SIZE x2 on")
 print("gfx950 for wide streaming reads).  `grid=5750784` = the sparse K5 call (22 464 workgroups x 256 threads), `grid=786432` = the dense")
-print("16k call of the same kernel.  Per-regime memory-side traffic of K5: `profiles/r03_k5_traffic_{r2,r1,locality}.json`.\n")
+print("16k call of the same kernel.  Per-regime memory-side traffic of K5: `profiles/r04_k5_traffic_{r2,r1,locality}.json`.\n")
 for k, c in data.items():
     print(f"## `{k}`\n")
     print("| counter | per launch |\n|---|---|")
