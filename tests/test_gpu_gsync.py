@@ -78,3 +78,29 @@ def test_a_walk_that_keeps_many_keys_and_a_small_grid_are_left_alone():
         finally:
             L.rsa_set_tuning(b"k5_gsync", 1)
         assert np.array_equal(outs[0], outs[1])
+
+
+def test_aligned_starts_inside_a_captured_graph():
+    """The counters of a launch are cleared by a memset in stream order in front of it: captured, that is a memset node, and
+    every replay starts from cleared counters.  Capture (no warm-up call of this shape first), replay twice on new inputs."""
+    from rectified_spaattn_amd import _core
+    H, nb, top_k = 8, 168, 14
+    q, k, v = _inputs(H, nb, 128, 21, torch.bfloat16)
+    q2, k2, v2 = _inputs(H, nb, 128, 22, torch.bfloat16)
+    spec = _core.LayoutSpec.wan(nb * 128, 0)
+    call = _core.StagedCall(q, k, v, spec, top_k, 0.05, None)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        call.select()                    # (torch's capture needs the allocator warm; K5 itself is NOT run before the capture)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        call.select()
+        call.attend()
+    for _ in range(2):
+        q.copy_(q2); k.copy_(k2); v.copy_(v2)
+        g.replay()
+        torch.cuda.synchronize()
+        eager = _core.rectified_attention(q2, k2, v2, spec, top_k, 0.05, None)
+        assert torch.equal(call.out.reshape(eager.shape), eager)
