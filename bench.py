@@ -514,6 +514,53 @@ def load_traffic(name):
                                                f"hits; l2_hit_rate {d.get('l2_hit_rate')}")
 
 
+def measure_traffic_live(regime: str, fp8: bool, timeout_s: int = 150):
+    """The dominant kernel's memory-side bytes per launch, measured NOW: three rocprofv3 counter-only passes (child processes;
+    counters in passes of their own, no trace domains, the program itself behind `--`: MI355X_MICROARCH.md's recipe) over
+    `tools/perf_k5.py pmc` = three launches of the same call on the same synthetic inputs.  FETCH_SIZE x2 (gfx950: it counts 64 B
+    per 128-B request of a wide stream) + WRITE_SIZE, both KiB.  Returns (bytes, note) or (None, why)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    kern = "bsfwd_fp8" if fp8 else "bsfwd"
+    env = dict(os.environ, RSA_PERF_REGIME=regime, RSA_PERF_NODENSE="1", TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    if fp8:
+        env["RSA_PERF_FP8"] = "1"
+    acc = {}
+    t0 = time.time()
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        for n, counters in enumerate((("TCC_HIT_sum", "TCC_MISS_sum"), ("FETCH_SIZE",), ("WRITE_SIZE",))):
+            cmd = [exe, "--pmc", *counters, "--output-format", "csv", "-d", os.path.join(td, f"p{n}"), "--",
+                   sys.executable, os.path.join(ROOT, "tools", "perf_k5.py"), "pmc"]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s)
+            except (OSError, subprocess.TimeoutExpired) as e:
+                return None, f"rocprofv3 pass {n} did not finish: {e!r}"[:200]
+            if r.returncode != 0:
+                return None, f"rocprofv3 pass {n} exit {r.returncode}: {r.stderr.decode(errors='replace')[-160:]}"
+            for f in glob.glob(os.path.join(td, f"p{n}", "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if kern in row.get("Kernel_Name", ""):
+                        acc.setdefault(row["Counter_Name"], {}).setdefault(row["Dispatch_Id"], 0.0)
+                        acc[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
+    mean = {k: sum(v.values()) / len(v) for k, v in acc.items() if v}
+    if "FETCH_SIZE" not in mean or "WRITE_SIZE" not in mean:
+        return None, f"no counters for kernel '{kern}' in the rocprofv3 output ({sorted(mean)})"
+    tb = 2.0 * mean["FETCH_SIZE"] * 1024.0 + mean["WRITE_SIZE"] * 1024.0
+    hit = mean.get("TCC_HIT_sum", 0.0) / max(mean.get("TCC_HIT_sum", 0.0) + mean.get("TCC_MISS_sum", 0.0), 1.0)
+    n_l = len(acc["FETCH_SIZE"])
+    return tb, (f"measured in this run: rocprofv3 counter-only passes (TCC_HIT/MISS | FETCH_SIZE | WRITE_SIZE, child processes, "
+                f"{time.time() - t0:.0f} s) over {n_l} launches of the same call; L2 memory-side (fabric) bytes per launch = FETCH_SIZE x2 "
+                f"+ WRITE_SIZE; includes Infinity-Cache hits; l2_hit_rate {hit:.4f}")
+
+
 def dry_worker(args, comm):
     """Host logic only (gloo, no GPU): sharding, barriers, max-over-ranks timing, the JSON line."""
     from rectified_spaattn_amd import parallel
@@ -547,6 +594,8 @@ def main():
                     help="K5 on e4m3 images of Q/K/V (fp8 MFMA); the quantisation pass is inside the timed step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the headline regime (no r1/locality/api/sustained)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="roofline.traffic from the committed PMC json instead of three rocprofv3 counter passes in this run")
     ap.add_argument("--via-api", action="store_true", help="(kept for old command lines: the processor timing is on by default)")
     ap.add_argument("--no-processor", action="store_true", help="skip the processor __call__ timing of the api record")
     ap.add_argument("--gather-output", action="store_true",
@@ -708,6 +757,18 @@ def main():
     traffic, tnote = (None, "N > 1: traffic is collected at N = 1")
     if world == 1 and args.workload == "hunyuan_720p_128f":
         traffic, tnote = load_traffic(tname)
+        if not args.no_extras and not args.no_live_traffic and not comm.one_device:
+            torch.cuda.synchronize()
+            live, lnote = measure_traffic_live(main_regime, args.qkv_fp8)
+            if live is not None:
+                committed = traffic
+                traffic, tnote = live, lnote + (f"; committed profiles/{tname}: {committed:.4g}" if committed else "")
+                for rg, rr in (extras.get("regimes") or {}).items():      # the other regimes' launches, the same way
+                    lv, ln = measure_traffic_live(rg, args.qkv_fp8)
+                    if lv is not None:
+                        rr["traffic"], rr["traffic_note"] = lv, "measured in this run; " + ln.split("; ")[-1]
+            else:
+                tnote = f"live measurement failed ({lnote}); " + tnote
     per_rank_ms = [round(x, 3) for x in rec["per_rank_ms"]]
     res = {
         "metric": "attention-layer TFLOPs/sec (rectified block-sparse attention, HunyuanVideo seq~120k d=128 bf16)",
