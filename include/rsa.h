@@ -148,6 +148,21 @@ int rsa_dense_fwd(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q,
 int rsa_dense_causal_fwd(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
                          int q_split, int kv_split, rsa_out4 out, void* stream);
 
+/* Dense attention with an arbitrary mask: fullattn's "torch" / "vanilla" modes when attn_mask depends on the query row
+ * (attn.py:101-106: SDPA takes any mask broadcastable to [b, a, s, s1]; :134-147: boolean masks become -inf, float masks are
+ * added to the scores).  mask: DEVICE pointer; mask_kind: RSA_MASK_BOOL (1 byte per element, 0 = not attended),
+ * RSA_MASK_ADD_2BYTE (additive, in the dtype of q) or RSA_MASK_ADD_F32; mask_stride_*: ELEMENT strides of its [b, a, s, s1]
+ * view, 0 for a broadcast dimension.  A query row without any attended key gives NaN when empty_rows_nan != 0 (an explicit
+ * softmax over an all -inf row: the reference's "vanilla" mode) and zeros otherwise (torch's fused SDPA since 2.5: its "torch" mode).
+ * The plain kernel of the family (no pipeline of the reference builds such a mask; key masks go through rsa_dense_fwd's key
+ * limit): expect a fraction of rsa_dense_fwd's rate.  D = 64 or 128; out as rsa_dense_fwd. */
+#define RSA_MASK_BOOL 1
+#define RSA_MASK_ADD_2BYTE 2
+#define RSA_MASK_ADD_F32 3
+int rsa_dense_masked_fwd(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
+                         const void* mask, int mask_kind, int64_t mask_stride_b, int64_t mask_stride_h,
+                         int64_t mask_stride_q, int64_t mask_stride_k, int empty_rows_nan, rsa_out4 out, void* stream);
+
 /* Stand-alone GAPR for callers of estimate_pr_gain (gapr_mask.py:4): blocks are [BH, N, 128, D] contiguous
  * 2-byte elements, pools [BH, N, D] fp32, scores [BH, NQ, NK] fp32 -> mask [BH, NQ, NK] uint8 (1 = ~gapr_mask). */
 int rsa_estimate_pr_gain(int BH, int NQ, int NK, int D, int dtype, const void* q_blocks, const void* k_blocks,

@@ -393,6 +393,47 @@ def dense_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, q_split: 
     return out
 
 
+MASK_BOOL, MASK_ADD_2BYTE, MASK_ADD_F32 = 1, 2, 3
+
+
+def dense_attention_masked(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask: torch.Tensor,
+                           empty_rows_nan: bool = True) -> torch.Tensor:
+    """softmax(q k^T / sqrt(d) + mask) v on the device for a mask that depends on the query row (rsa_dense_masked_fwd).
+    q [B,H,Sq,D], k/v [B,H,Sk,D]; mask broadcastable to [B,H,Sq,Sk]: bool (False = not attended) or additive float (the dtype
+    of q, or float32) -> [B,Sq,H,D].  A row without attended keys is NaN (explicit softmax) or, with empty_rows_nan=False, zeros
+    (torch's fused SDPA)."""
+    _require_device(q, k, v)
+    L = _lib.lib()
+    B, H, Sq, D = q.shape
+    Sk = k.shape[2]
+    assert k.shape == v.shape and k.shape[0] == B and k.shape[1] == H and k.shape[3] == D
+    if D not in (64, 128):
+        raise NotImplementedError(f"device fullattn with a row-dependent mask: head dim {D} (64 and 128 are built)")
+    if mask.device != q.device:
+        raise RsaError("attn_mask must live on the device of q")
+    if mask.dtype == torch.bool:
+        kind = MASK_BOOL
+    elif mask.dtype == q.dtype:
+        kind = MASK_ADD_2BYTE
+    elif mask.dtype == torch.float32:
+        kind = MASK_ADD_F32
+    else:
+        raise NotImplementedError(f"attn_mask dtype {mask.dtype}: bool, {q.dtype} or float32")
+    m = mask
+    while m.dim() < 4:
+        m = m.unsqueeze(0)
+    if m.dim() != 4 or any(a != 1 and a != b for a, b in zip(m.shape, (B, H, Sq, Sk))):
+        raise ValueError(f"attn_mask of shape {tuple(mask.shape)} does not broadcast to {(B, H, Sq, Sk)}")
+    strides = [0 if m.shape[i] == 1 else m.stride(i) for i in range(4)]
+    q, k, v = _as_bhsd(q), _as_bhsd(k), _as_bhsd(v)
+    out = torch.empty((B, Sq, H, D), dtype=q.dtype, device=q.device)
+    o4 = RsaOut4(out.data_ptr(), out.stride(0), out.stride(2), out.stride(1))
+    with torch.cuda.device(q.device):
+        _lib.check(L.rsa_dense_masked_fwd(B, H, Sq, Sk, D, dtype_code(q.dtype), _t4(q), _t4(k), _t4(v), m.data_ptr(), kind,
+                                          *strides, int(bool(empty_rows_nan)), o4, _stream()), "rsa_dense_masked_fwd")
+    return out
+
+
 def unpack_bitmask(bitmask: torch.Tensor, n: int) -> torch.Tensor:
     """[..., NW] int32 words -> [..., n] bool (bit j%32 of word j//32)."""
     w = bitmask.to(torch.int64) & 0xFFFFFFFF

@@ -100,6 +100,7 @@ def lib():
     L.rsa_dense_fwd.argtypes = [i32] * 6 + [RsaTensor4, RsaTensor4, RsaTensor4, i32, i32, RsaOut4, vp]
     L.rsa_dense_causal_fwd.argtypes = L.rsa_dense_fwd.argtypes
     L.rsa_dense_causal_fwd.restype = i32
+    L.rsa_dense_masked_fwd.argtypes = [i32] * 6 + [RsaTensor4, RsaTensor4, RsaTensor4, vp, i32] + [ctypes.c_int64] * 4 + [i32, RsaOut4, vp]
     L.rsa_estimate_pr_gain.argtypes = [i32] * 5 + [vp] * 9
     L.rsa_fp8_operand_bytes.argtypes = [P(RsaLayout), P(sz * 4), P(sz)]
     L.rsa_carve_fp8_operands.argtypes = [P(RsaLayout), vp, sz, P(RsaFp8Operands)]
@@ -136,7 +137,7 @@ def lib():
         getattr(L, name).restype = i32
     for name in ("rsa_buffer_bytes", "rsa_carve_workspace", "rsa_pool_stats", "rsa_pooled_scores",
                  "rsa_select_mask", "rsa_compensation", "rsa_block_sparse_fwd", "rsa_rectified_attention",
-                 "rsa_dense_fwd", "rsa_estimate_pr_gain"):
+                 "rsa_dense_fwd", "rsa_dense_masked_fwd", "rsa_estimate_pr_gain"):
         getattr(L, name).restype = i32
     # kernel-variant switches for A/B runs and the variant tests; rsa_set_tuning works only under RSA_TUNING=1
     for key in ("k5_tsplit", "k3_prefix", "k5_w64", "k5_gsync", "k5_text_last"):
@@ -151,7 +152,7 @@ def lib():
 
 EXPORTED = ("rsa_version", "rsa_buffer_bytes", "rsa_carve_workspace", "rsa_pool_stats", "rsa_pooled_scores",
             "rsa_select_mask", "rsa_compensation", "rsa_block_sparse_fwd", "rsa_rectified_attention",
-            "rsa_dense_fwd", "rsa_dense_causal_fwd", "rsa_estimate_pr_gain", "rsa_status_string", "rsa_last_hip_error", "rsa_set_tuning", "rsa_gilbert_mapping",
+            "rsa_dense_fwd", "rsa_dense_causal_fwd", "rsa_dense_masked_fwd", "rsa_estimate_pr_gain", "rsa_status_string", "rsa_last_hip_error", "rsa_set_tuning", "rsa_gilbert_mapping",
             "rsa_gilbert_block_neighbors", "rsa_permute_tokens", "rsa_qk_norm_rope", "rsa_qk_layernorm_rope", "rsa_norm_rope_heads", "rsa_fp8_operand_bytes",
             "rsa_carve_fp8_operands", "rsa_quantize_fp8", "rsa_block_sparse_fwd_fp8", "rsa_rectified_attention_fp8",
             "rsa_pool_stats_fp8", "rsa_dense_fp8_bytes", "rsa_dense_fwd_fp8", "rsa_dense_causal_fwd_fp8", "rsa_rel_l1",

@@ -109,10 +109,10 @@ def _device_dense(q, k, v, splits, dense_fp8=None, causal=False):
 
 def _key_mask_rows(attn_mask, B, S1):
     """bool mask broadcastable to [b,a,s,s1] that only depends on the key index ([b,1,1,s1], what get_attn_mask builds)
-    -> ([b, s1] bool rows, valid key count per batch item, whether every row is a prefix); anything else is not supported."""
+    -> ([b, s1] bool rows, valid key count per batch item, whether every row is a prefix); None for any other mask."""
     m = attn_mask
     if m.dtype != torch.bool or m.dim() != 4 or m.shape[1] != 1 or m.shape[2] != 1 or m.shape[3] != S1:
-        raise NotImplementedError("device fullattn supports only boolean key masks [b,1,1,s1]")
+        return None          # not a key mask: the general-mask kernel serves it (_core.dense_attention_masked)
     m = m.reshape(m.shape[0], S1)
     counts = m.sum(-1)
     prefix = (m == (torch.arange(S1, device=m.device)[None, :] < counts[:, None])).all()
@@ -161,7 +161,18 @@ def fullattn(q, k, v, mode="flash", drop_rate=0, attn_mask=None, causal=False, c
             if attn_mask is None:
                 splits = [(S, S1)] * B
             else:
-                rows, counts, prefix = _key_mask_rows(attn_mask, B, S1)
+                km = _key_mask_rows(attn_mask, B, S1)
+                if km is None:
+                    # a mask that depends on the query row, or an additive one (attn.py:101-106, :134-147): the plain kernel
+                    if causal:
+                        raise NotImplementedError("device fullattn: causal together with a row-dependent attn_mask "
+                                                  "(torch's SDPA refuses the combination too)")
+                    if attn_mask.dtype != torch.bool:
+                        attn_mask = attn_mask.to(q.dtype)      # as the reference does before SDPA (attn.py:102-103)
+                    # a row without attended keys: NaN from "vanilla"'s explicit softmax (attn.py:148), zeros from the fused
+                    # SDPA of "torch" mode (torch >= 2.5)
+                    return _core.dense_attention_masked(q, k, v, attn_mask, empty_rows_nan=(mode == "vanilla")).transpose(1, 2)
+                rows, counts, prefix = km
                 if min(counts) == 0:
                     # (the reference's SDPA returns NaN for a row without keys: nothing a caller can use -- refuse clearly)
                     raise ValueError("fullattn: attn_mask leaves a batch item without any key")

@@ -1041,4 +1041,4 @@ extern "C" const char* rsa_status_string(int status) {
 int g_rsa_last_hip_error = 0;
 extern "C" const char* rsa_last_hip_error(void) { return hipGetErrorString((hipError_t)g_rsa_last_hip_error); }
 
-extern "C" int rsa_version(void) { return 310; }  // 0.3.1: block-scaled fp8 operands (rsa_fp8_operands.scales = E8M0 words + K mean), K1 writes the images, rsa_fp8_images gone; 0.3.0: rsa_buffers has 15 members, rsa_allgather_heads_p2p is stream-ordered (+ state buffers), rsa_ipc_offset
+extern "C" int rsa_version(void) { return 400; }  // 0.4.0: rsa_p2p_state_alloc / _free / _timeout (fine-grained exchange state), rsa_dense_masked_fwd; 0.3.1: block-scaled fp8 operands (rsa_fp8_operands.scales = E8M0 words + K mean), K1 writes the images, rsa_fp8_images gone; 0.3.0: rsa_buffers has 15 members, rsa_allgather_heads_p2p is stream-ordered (+ state buffers), rsa_ipc_offset

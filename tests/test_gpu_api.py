@@ -93,10 +93,12 @@ def test_fullattn_device_modes(mode):
         keep = holes.reshape(-1).cpu().numpy()
         qf, kf, vf = (x.float().cpu().numpy()[0, 0] for x in (q, k, v))
         assert np.abs(oh[0, 0] - orc.dense_attention(qf, kf[keep], vf[keep])).max() <= 2e-2
-        with pytest.raises(NotImplementedError):   # a mask that depends on the query row
-            attn.fullattn(q, k, v, mode=mode, attn_mask=torch.ones(1, 1, 1536, 1536, dtype=torch.bool, device=DEV))
-        with pytest.raises(NotImplementedError):   # an additive float mask
-            attn.fullattn(q, k, v, mode=mode, attn_mask=torch.zeros(1, 1, 1, 1536, device=DEV))
+        # masks that depend on the query row and additive float masks go to the general-mask kernel (tests/test_gpu_masked.py
+        # checks it against SDPA): all-True / all-zero ones must reproduce the unmasked call
+        o_rows = attn.fullattn(q, k, v, mode=mode, attn_mask=torch.ones(1, 1, 1536, 1536, dtype=torch.bool, device=DEV))
+        o_add = attn.fullattn(q, k, v, mode=mode, attn_mask=torch.zeros(1, 1, 1, 1536, device=DEV))
+        full = attn.fullattn(q, k, v, mode=mode).float()
+        assert (o_rows.float() - full).abs().max() <= 1e-2 and (o_add.float() - full).abs().max() <= 1e-2
     # causal=True (attn.py:60-73): the reference's own vector ("torch" == "vanilla" on CPU).  The reference's flash branch
     # never forwards `causal` to flash_attn_varlen_func (attn.py:107-116): there the same call is the NON-causal result.
     if mode == "flash":

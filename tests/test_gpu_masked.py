@@ -1,0 +1,91 @@
+"""fullattn with an attn_mask that depends on the query row, or an additive float one (reference attn.py:101-106 hands torch's
+SDPA any mask broadcastable to [b, a, s, s1]; :134-147 builds the same bias for "vanilla"): served on the device by
+rsa_dense_masked_fwd.  Checked against torch's own SDPA in float32 on the CPU, on the 2-byte-rounded inputs (a floating-point
+kernel: tolerance as for the other dense paths, 2e-2 on N(0,1) values)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _qkv(B, H, S, S1, D, dt, seed):
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randn(B, H, S, D, generator=g).to(dt)
+    k = torch.randn(B, H, S1, D, generator=g).to(dt)
+    v = torch.randn(B, H, S1, D, generator=g).to(dt)
+    return q, k, v
+
+
+def _ref(q, k, v, mask):
+    m = mask if mask.dtype == torch.bool else mask.float()
+    return F.scaled_dot_product_attention(q.float(), k.float(), v.float(), attn_mask=m)
+
+
+@pytest.mark.parametrize("mode", ["torch", "vanilla"])
+@pytest.mark.parametrize("D,dt", [(128, torch.bfloat16), (128, torch.float16), (64, torch.bfloat16)])
+def test_boolean_mask_that_depends_on_the_query_row(mode, D, dt):
+    from rectified_spaattn_amd import attn
+    B, H, S, S1 = 2, 3, 200, 333          # ragged: neither a multiple of the 128-row workgroup nor of the 32-key tile
+    q, k, v = _qkv(B, H, S, S1, D, dt, 1)
+    g = torch.Generator().manual_seed(2)
+    for shape in ((B, 1, S, S1), (1, H, S, S1), (B, H, S, S1), (1, 1, S, S1)):
+        mask = torch.rand(shape, generator=g) < 0.6
+        mask[..., 0] = True                                   # every row keeps a key
+        out = attn.fullattn(q.to(DEV), k.to(DEV), v.to(DEV), mode=mode, attn_mask=mask.to(DEV))
+        assert out.shape == (B, H, S, D) and out.dtype == dt
+        err = (out.float().cpu() - _ref(q, k, v, mask)).abs()
+        assert err.max() <= 2e-2, (shape, float(err.max()))
+
+
+@pytest.mark.parametrize("mode", ["torch", "vanilla"])
+def test_additive_float_mask(mode):
+    from rectified_spaattn_amd import attn
+    B, H, S, S1, D = 1, 4, 160, 257, 128
+    q, k, v = _qkv(B, H, S, S1, D, torch.bfloat16, 3)
+    g = torch.Generator().manual_seed(4)
+    for shape, mdt in (((B, H, S, S1), torch.bfloat16), ((1, 1, S, S1), torch.float32), ((B, 1, 1, S1), torch.bfloat16)):
+        bias = (2.0 * torch.randn(shape, generator=g)).to(mdt)
+        bias[..., 5] = float("-inf")                          # -inf entries = masked keys
+        out = attn.fullattn(q.to(DEV), k.to(DEV), v.to(DEV), mode=mode, attn_mask=bias.to(DEV))
+        # (the reference casts a float mask to the dtype of q before SDPA, attn.py:102-103: so does the device path)
+        err = (out.float().cpu() - _ref(q, k, v, bias.to(torch.bfloat16))).abs()
+        assert err.max() <= 2e-2, (shape, float(err.max()))
+
+
+def test_a_row_without_any_key():
+    """torch's fused SDPA ("torch" mode) returns zeros for such a row (torch >= 2.5), the explicit softmax of "vanilla" NaN: the
+    device path gives what the reference's own CPU expression of the mode gives here."""
+    from rectified_spaattn_amd import attn
+    q, k, v = _qkv(1, 2, 64, 96, 128, torch.bfloat16, 5)
+    mask = torch.ones(1, 1, 64, 96, dtype=torch.bool)
+    mask[0, 0, 7] = False
+    mask[0, 0, 40, 32:] = False                               # attended keys only in the first tile
+    keep = [i for i in range(64) if i != 7]
+    for mode in ("torch", "vanilla"):
+        ref = attn.fullattn(q.float(), k.float(), v.float(), mode=mode, attn_mask=mask)       # CPU tensors: the reference's expression
+        out = attn.fullattn(q.to(DEV), k.to(DEV), v.to(DEV), mode=mode, attn_mask=mask.to(DEV)).float().cpu()
+        assert torch.equal(torch.isnan(out[:, :, 7]), torch.isnan(ref[:, :, 7])), mode
+        if not torch.isnan(ref[:, :, 7]).any():
+            assert torch.equal(out[:, :, 7], ref[:, :, 7]), mode
+        assert (out[:, :, keep] - ref[:, :, keep]).abs().max() <= 2e-2, mode
+
+
+def test_c_abi_float32_masks_and_bad_arguments():
+    """The C entry also takes float32 masks as they are (hosts other than this Python wrapper), and refuses what it cannot serve."""
+    import ctypes
+    from rectified_spaattn_amd import _core, _lib
+    q, k, v = (x.to(DEV) for x in _qkv(1, 2, 100, 130, 128, torch.bfloat16, 6))
+    bias = torch.randn(1, 1, 100, 130, generator=torch.Generator().manual_seed(7))
+    out = _core.dense_attention_masked(q, k, v, bias.to(DEV))            # float32 kind
+    ref = _ref(q.cpu(), k.cpu(), v.cpu(), bias).transpose(1, 2)
+    assert (out.float().cpu() - ref).abs().max() <= 2e-2
+    L = _lib.lib()
+    o4 = _lib.RsaOut4(out.data_ptr(), out.stride(0), out.stride(2), out.stride(1))
+    args = lambda D, kind, mp: (1, 2, 100, 130, D, _core.dtype_code(q.dtype), _core._t4(q), _core._t4(k), _core._t4(v), mp, kind,  # noqa: E731
+                                0, 0, 130, 1, 1, o4, _core._stream())
+    assert L.rsa_dense_masked_fwd(*args(128, 3, None)) == -1            # no mask
+    assert L.rsa_dense_masked_fwd(*args(128, 9, bias.to(DEV).data_ptr())) == -1     # unknown kind
+    assert L.rsa_dense_masked_fwd(*args(32, 3, bias.to(DEV).data_ptr())) == -2      # head dim not built
