@@ -128,9 +128,17 @@ unsigned* rsa_gsync_slot(int which, unsigned grid, int wg_per_cu, hipStream_t s,
     if (gens > RSA_GSYNC_MAXG || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     unsigned* b = base[dev].load();
     if (!b) {
+        // the generation arithmetic is the full chip's: 8 XCDs x 32 CUs, workgroup b on XCD b & 7 (a partitioned device -- CPX,
+        // fewer CUs -- holds fewer workgroups than a generation expects: every first wait would run into its bound)
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus != 256) {
+            base[dev].store(reinterpret_cast<unsigned*>(1));
+            return nullptr;
+        }
         if (hipGetSymbolAddress(reinterpret_cast<void**>(&b), HIP_SYMBOL(g_rsa_gsync)) != hipSuccess) return nullptr;
         base[dev].store(b);
     }
+    if (b == reinterpret_cast<unsigned*>(1)) return nullptr;     // (not a full MI355X: see above)
     unsigned* slot = b + (size_t)(ticket.fetch_add(1) % RSA_GSYNC_RING) * RSA_GSYNC_SLOT_WORDS;
     return hipMemsetAsync(slot, 0, (8 + 8 * (size_t)gens) * sizeof(unsigned), s) == hipSuccess ? slot : nullptr;
 }
