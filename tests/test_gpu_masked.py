@@ -89,3 +89,14 @@ def test_c_abi_float32_masks_and_bad_arguments():
     assert L.rsa_dense_masked_fwd(*args(128, 3, None)) == -1            # no mask
     assert L.rsa_dense_masked_fwd(*args(128, 9, bias.to(DEV).data_ptr())) == -1     # unknown kind
     assert L.rsa_dense_masked_fwd(*args(32, 3, bias.to(DEV).data_ptr())) == -2      # head dim not built
+
+
+@pytest.mark.parametrize("S,S1", [(1, 1), (33, 31), (129, 32), (5, 700)])
+def test_tiny_and_ragged_shapes(S, S1):
+    from rectified_spaattn_amd import attn
+    q, k, v = _qkv(1, 2, S, S1, 64, torch.float16, 8)
+    g = torch.Generator().manual_seed(9)
+    mask = torch.rand(1, 2, S, S1, generator=g) < 0.5
+    mask[..., S1 - 1] = True
+    out = attn.fullattn(q.to(DEV), k.to(DEV), v.to(DEV), mode="torch", attn_mask=mask.to(DEV))
+    assert (out.float().cpu() - _ref(q, k, v, mask)).abs().max() <= 2e-2
