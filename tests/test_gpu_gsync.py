@@ -104,3 +104,41 @@ def test_aligned_starts_inside_a_captured_graph():
         torch.cuda.synchronize()
         eager = _core.rectified_attention(q2, k2, v2, spec, top_k, 0.05, None)
         assert torch.equal(call.out.reshape(eager.shape), eager)
+
+
+def test_text_rows_first_or_last_and_aligned_starts_on_a_layout_with_text():
+    """HunyuanVideo-like layout (visual blocks + a 256-token text tail, 200 valid): the split text-row pieces are the last
+    workgroups of the grid (tuning key k5_text_last; first = the order of rounds 1-3), the visual walks wait for their
+    generation: the work mapping and the waits change, no byte of the result does.  One head against the oracle as well."""
+    from oracle import oracle as orc
+    from rectified_spaattn_amd import _core, _lib
+    H, nbv, top_k = 6, 190, 16
+    S = (nbv + 2) * 128
+    num_true = S - 56
+    g = torch.Generator(device="cuda:0").manual_seed(31)
+    cent = torch.randn(H, nbv + 2, 128, generator=g, device="cuda:0")
+
+    def mk():
+        return (cent.repeat_interleave(128, 1) + 0.7 * torch.randn(H, S, 128, generator=g, device="cuda:0")).to(torch.bfloat16).view(1, H, S, 128)
+    q, k, v = mk(), mk(), torch.randn(1, H, S, 128, generator=g, device="cuda:0").to(torch.bfloat16)
+    spec = _core.LayoutSpec.hunyuan(S, num_true)
+    L = _lib.lib()
+    outs = []
+    try:
+        for gs, tl in ((0, 0), (1, 1), (1, 0), (0, 1)):
+            assert L.rsa_set_tuning(b"k5_gsync", gs) == 0 and L.rsa_set_tuning(b"k5_text_last", tl) == 0
+            out = _core.rectified_attention(q, k, v, spec, top_k, 0.05, None, shape_xfuse=True)
+            torch.cuda.synchronize()
+            outs.append(out.view(torch.int16).cpu().numpy().copy())
+    finally:
+        L.rsa_set_tuning(b"k5_gsync", 1)
+        L.rsa_set_tuning(b"k5_text_last", 1)
+    for o in outs[1:]:
+        assert np.array_equal(o, outs[0])
+    lay = orc.layout_hunyuan(S, num_true)
+    hd = 3
+    qf, kf, vf = (x[0, hd].float().cpu().numpy() for x in (q, k, v))
+    ref = orc.rectified_attention(qf[None, None], kf[None, None], vf[None, None], lay, top_k, 0.05, None)
+    got = out[0, :, hd].float().cpu().numpy()
+    err = np.abs(got - ref.reshape(got.shape))
+    assert err.max() <= 2e-2 and err.mean() <= 1.5e-3
