@@ -83,12 +83,16 @@ typedef struct rsa_buffers {
     uint32_t* bitmask;/* [BH, NBv, ceil(NB_total/32)]  kept blocks, bit j%32 of word j/32 */
     int32_t* cols;    /* [BH, NBv, NB_total] kept block indices ascending (first counts[] entries valid) */
     int32_t* counts;  /* [BH, NBv]                                              */
-    /* split-KV partials of the dense TEXT query blocks (K5 splits each text block's key range over up to RSA_TEXT_SPLIT
-     * workgroups and a small combine kernel merges them; may be NULL: then one workgroup walks all keys of a text block): */
-    float* tpart;     /* [BH, NB_total - NBv, RSA_TEXT_SPLIT, 128, D + 2]  unnormalised O, then (m, l) per query row  */
+    /* split-KV partials (may be NULL: then nothing is split).  First region: the dense TEXT query blocks -- K5 splits each
+     * text block's key range over up to RSA_TEXT_SPLIT workgroups and a small combine kernel merges them (NULL: one workgroup
+     * walks all keys of a text block).  Second region, RSA_TAIL_PIECES more [128, D + 2] blocks behind it (since 0.4.0): the
+     * walks of the LAST, partial generation of sparse query blocks, split over the workgroup slots that generation would
+     * leave idle (head dim 128; merged, rectified and stored by a second combine kernel): */
+    float* tpart;     /* [BH * (NB_total - NBv) * RSA_TEXT_SPLIT + RSA_TAIL_PIECES, 128, D + 2]  unnormalised O, then (m, l) per query row */
 } rsa_buffers;
 #define RSA_NUM_BUFFERS 15
 #define RSA_TEXT_SPLIT 16
+#define RSA_TAIL_PIECES 512
 
 /* Library identification: returns 10000*major + 100*minor + patch. */
 int rsa_version(void);
@@ -315,7 +319,8 @@ int rsa_ipc_offset(const void* dev_ptr, int64_t* offset);                   /* d
 
 /* Tuning / diagnostics hook, not part of the data path.  Keys: "k5_w64" (head dim 128: 1 = the 64-rows-per-wave K5, the
  * product; 0 = the 32-row kernel, for A/B), "k5_gsync" (aligned starts of the sparse walks: bit 0 the 64-row kernel -- default --,
- * bit 1 the other K5 kernels, 0 off; a scheduling aid, outputs are byte-identical), "k5_text_last", "k5_tsplit" (0/1: split-KV of the text query blocks),
+ * bit 1 the other K5 kernels, 0 off; a scheduling aid, outputs are byte-identical), "k5_text_last", "k5_tail_split" (0: the
+ * walks of the last partial generation stay whole -- byte-identical results whatever the grid), "k5_tsplit" (0/1: split-KV of the text query blocks),
  * "k3_prefix" (0/1: sorted-head path of K3), "fp8_variant" (0: the product = hand-placed block, P through the e4m3 code map; 1: the same arithmetic as hipcc schedules it;
  * 2: P by v_exp_f32 + round-to-nearest e4m3 -- the two forms the tests compare the product with), "fp8_smooth_k"
  * (0: the fp8 producers take mu = 0 instead of the sampled K mean, for the same comparison).  The hook

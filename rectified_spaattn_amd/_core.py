@@ -156,7 +156,7 @@ def buffer_shapes(spec: LayoutSpec, B: int, H: int, D: int) -> Dict[str, tuple]:
     return dict(qbar=(BH, NBv, D), aq=(BH, NBv, D), kbar=(BH, NBv, D), ak=(BH, NBv, D), vbar=(BH, NB, D),
                 scores=(BH, NBv, NS), unrel=(BH, NBv, NBv), probs=(BH, NBv, L), w=(BH, NBv, L), R=(BH, NBv),
                 comp=(BH, NBv, D), bitmask=(BH, NBv, NW), cols=(BH, NBv, NB), counts=(BH, NBv),
-                tpart=(BH, NB - NBv, _lib.TEXT_SPLIT, BLOCK, D + 2))
+                tpart=(BH * (NB - NBv) * _lib.TEXT_SPLIT + _lib.TAIL_PIECES, BLOCK, D + 2))
 
 
 def alloc_buffers(spec: LayoutSpec, B: int, H: int, D: int, device) -> Dict[str, torch.Tensor]:

@@ -79,6 +79,11 @@ struct AttnArgs {
     float* tpart;                             // split-KV partials of the text query blocks, or null
     int tsplit, tper;                         // workgroups per text block, key blocks per workgroup
     int heavy_last;                           // 64-row kernel: the (split) text-row pieces are the LAST workgroups of the grid
+    // 64-row kernel, tail split: sparse workgroups [0, tail_first) walk their whole list; the tail_n x tail_p workgroups behind them
+    // are the pieces of the tail_n sparse blocks tail_first .. (piece i = block tail_first + i / tail_p, part i % tail_p of its
+    // list), partials to tail_part; the text pieces follow.  tail_n = 0: no split
+    int tail_first, tail_n, tail_p;
+    float* tail_part;
     float qk_scale;
     unsigned* gsync;                          // 64-row kernel: start-alignment counters of this launch (rsa_attn_kernel64.hip), or null
     int gsync_gen;                            // ... workgroups an XCD holds at a time (a generation)

@@ -11,6 +11,7 @@
 // =====================================================================================================
 static int g_k5_tsplit = 1;     // 1 = split-KV for the text query blocks when the partial buffer is given
 extern int g_rsa_k3_prefix;
+static int g_k5_tail_split = 1; // 64-row kernel: the last, partial generation's walks split over its idle slots (k5w_map)
 static int g_k5_text_last = 1;  // 64-row kernel: split text-row pieces at the end of the grid (rsa_attn_kernel64.hip::k5w_map)
 static int g_k5_gsync = 1;      // aligned starts of the sparse walks (rsa_attn.h): bit 0 = in the 64-row kernel, bit 1 = in the 32-row and e4m3 kernels
 #ifdef RSA_K5_FORMS
@@ -47,6 +48,7 @@ extern "C" int rsa_set_tuning(const char* key, int value) {
     if (strcmp(key, "k5_w64") == 0) { g_k5_w64 = value; return RSA_OK; }
     if (strcmp(key, "k5_gsync") == 0) { g_k5_gsync = value; return RSA_OK; }
     if (strcmp(key, "k5_text_last") == 0) { g_k5_text_last = value; return RSA_OK; }
+    if (strcmp(key, "k5_tail_split") == 0) { g_k5_tail_split = value; return RSA_OK; }
     if (strcmp(key, "fp8_variant") == 0) { rsa_set_fp8_variant(value); return RSA_OK; }
     if (strcmp(key, "fp8_smooth_k") == 0) { rsa_set_fp8_smooth_k(value); return RSA_OK; }
     return RSA_ERR_BAD_ARG;
@@ -108,6 +110,58 @@ int rsa_launch_text_combine(const float* tpart, unsigned short* out, long osb, l
     return rsa_launch_status();
 }
 int rsa_text_split_enabled() { return g_k5_tsplit; }
+
+// Tail split of the 64-row kernel (rsa_attn_kernel64.hip::k5w_map): merge the tail_p partials of every tail block, then what the
+// kernel's own epilogue does -- normalise, rectify (O . R / l + comp as one fma rounded to fp32), convert, store.  One wave per
+// query row, lane = d and d + 64.
+template <typename Tag>
+__global__ __launch_bounds__(256) void tail_combine_kernel(const float* __restrict__ part, unsigned short* out, long osb, long osh,
+                                                           long oss, int H, int NBv, int NBp, int tail_first, int tail_n, int tail_p,
+                                                           const float* __restrict__ R, const float* __restrict__ comp, int Sq) {
+    constexpr int D = 128;
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long)tail_n * RSA_BLOCK) return;
+    const int t = (int)(row / RSA_BLOCK), r = (int)(row % RSA_BLOCK);
+    const int v = tail_first + t, bh = v / NBp, j = v % NBp;
+    const int qblk = (j & 7) * (NBp >> 3) + (j >> 3);
+    const int grow = qblk * RSA_BLOCK + r;
+    if (qblk >= NBv || grow >= Sq) return;
+    const float* base = part + ((long)t * tail_p * RSA_BLOCK + r) * (long)(D + 2);
+    const long pstride = (long)RSA_BLOCK * (D + 2);
+    float M = -INFINITY;
+    for (int p = 0; p < tail_p; ++p) M = fmaxf(M, base[p * pstride + D]);
+    float L = 0.0f, acc[2] = {0.0f, 0.0f};
+    for (int p = 0; p < tail_p; ++p) {
+        const float m = base[p * pstride + D], l = base[p * pstride + D + 1];
+        const float wgt = (m == -INFINITY) ? 0.0f : __builtin_amdgcn_exp2f(m - M);
+        L += l * wgt;
+        acc[0] += base[p * pstride + lane] * wgt;
+        acc[1] += base[p * pstride + lane + 64] * wgt;
+    }
+    const long rowi = (long)bh * NBv + qblk;
+    const float sc = (L > 0.0f ? 1.0f / L : 0.0f) * (R ? R[rowi] : 1.0f);
+    unsigned short* op = out + (long)(bh / H) * osb + (long)(bh % H) * osh + (long)grow * oss;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int d = lane + 64 * e;
+        float x = __builtin_fmaf(acc[e], sc, comp ? comp[rowi * D + d] : 0.0f);
+        asm volatile("" : "+v"(x));     // (fma, THEN the conversion: as the kernel's epilogue)
+        op[d] = Elem<Tag>::from_f32(x);
+    }
+}
+
+static int launch_tail_combine(const AttnArgs& a, int dtype, hipStream_t s) {
+    const long rows = (long)a.tail_n * RSA_BLOCK;
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    if (dtype == RSA_BF16)
+        tail_combine_kernel<bf16_tag><<<grid, 256, 0, s>>>(a.tail_part, a.out, a.osb, a.osh, a.oss, a.H, a.NBv, a.NBp, a.tail_first,
+                                                         a.tail_n, a.tail_p, a.R, a.comp, a.Sq);
+    else
+        tail_combine_kernel<fp16_tag><<<grid, 256, 0, s>>>(a.tail_part, a.out, a.osb, a.osh, a.oss, a.H, a.NBv, a.NBp, a.tail_first,
+                                                         a.tail_n, a.tail_p, a.R, a.comp, a.Sq);
+    return rsa_launch_status();
+}
 
 static int launch_text_combine(const AttnArgs& a, int BH, int D, int dtype, hipStream_t s) {
     return rsa_launch_text_combine(a.tpart, a.out, a.osb, a.osh, a.oss, D, a.H, a.NBv, a.NQB - a.NBv, a.tsplit,
@@ -178,14 +232,41 @@ static int launch_attn(AttnArgs& a, int BH, int D, int dtype, hipStream_t s) {
     a.BH = BH;
     a.n_heavy_pad = (n_heavy + 7) & ~7;
     a.NBp = (a.NBv + 7) & ~7;
-    const long nblocks = (long)a.n_heavy_pad + (long)BH * a.NBp;
+    long nblocks = (long)a.n_heavy_pad + (long)BH * a.NBp;
+    // Tail split (64-row kernel, sparse lists): 512 workgroups run at a time (2 per CU), each for about as long as the others, so
+    // a launch costs ceil(workgroups / 512) lives; when the last generation of sparse blocks is less than half full, its blocks'
+    // walks are split over the idle slots (tail_p pieces each, partials behind the text region of tpart) and merged by a combine
+    // pass.  Which blocks are split depends on the grid: a sharded and an unsharded run then agree on those blocks within
+    // rounding, not byte for byte (tuning key k5_tail_split = 0 keeps every walk whole).
+    a.tail_first = a.tail_n = a.tail_p = 0; a.tail_part = nullptr;
+    const bool w64 = D == 128 && (g_k5_w64 & 1);
+    if (w64 && g_k5_tail_split && a.mode == MODE_SPARSE && a.tpart && (a.heavy_last || n_heavy == 0)) {
+        const long n_sparse = (long)BH * a.NBp;
+        const long full = n_sparse / 512, T = n_sparse % 512;
+        // the pieces AND the text-row pieces behind them must fit the 512 slots together: otherwise whatever starts late (0.6 of a
+        // life for a text piece) ends the launch as late as the unsplit tail did (measured: 3 heads of the headline shape, 456
+        // pieces + 96 text pieces: 1.92 ms against 1.88 unsplit)
+        const long room = 512 - (long)a.n_heavy_pad;
+        const long P = T > 0 ? (room / T < 4 ? room / T : 4) : 0;
+        if (full >= 1 && T > 0 && P >= 2) {
+            a.tail_first = (int)(full * 512); a.tail_n = (int)T;
+            a.tail_p = (int)P;                                           // T x tail_p <= 512 = RSA_TAIL_PIECES
+            a.tail_part = a.tpart + (long)BH * ntq * RSA_TEXT_SPLIT * RSA_BLOCK * (D + 2);
+            nblocks = (long)a.tail_first + (long)a.tail_n * a.tail_p + a.n_heavy_pad;
+        }
+    }
     if (nblocks <= 0) return RSA_OK;
     if (nblocks > 0x7FFFFFFF) return RSA_ERR_UNSUPPORTED;
     if (a.NB_total > 8192) return RSA_ERR_UNSUPPORTED;  // kept list lives in LDS as u16, 16 KiB max
     const size_t lds_bytes = (size_t)4 * 64 * D * 2 + (((size_t)a.NB_total * 2 + 15) & ~(size_t)15);
     const int st = (D == 128 && (g_k5_w64 & 1)) ? rsa_launch_bsfwd64(a, dim3((unsigned)nblocks), lds_bytes, dtype, s)
                                           : rsa_launch_bsfwd(a, dim3((unsigned)nblocks), lds_bytes, D, dtype, s);
-    if (st != RSA_OK || a.tsplit <= 1) return st;
+    if (st != RSA_OK) return st;
+    if (a.tail_n > 0) {
+        const int st2 = launch_tail_combine(a, dtype, s);
+        if (st2 != RSA_OK) return st2;
+    }
+    if (a.tsplit <= 1) return st;
     return launch_text_combine(a, BH, D, dtype, s);
 }
 

@@ -82,13 +82,28 @@ __device__ __forceinline__ f32x16 k5w_oread() {
 // over every key block (no split-KV buffer: the longest work first), and LAST when they are split into pieces shorter than a
 // sparse walk (tsplit > 1): with aligned starts the launch advances in generations of 8 x 64 workgroups, and the short
 // pieces then fill the slots the last, partial generation leaves idle instead of adding a generation of their own.
-__device__ __forceinline__ bool k5w_map(const AttnArgs& a, int work, int& bh, int& qblk, int& tsp) {
+// Tail split (a.tail_n > 0; sparse blocks first): the sparse blocks from index tail_first on -- the last, partial generation --
+// are walked by tail_p workgroups each (piece i of the region = block tail_first + i / tail_p, part i % tail_p of its kept
+// list), which together fill the slots that generation would leave idle; tail >= 0 tells the caller (the piece's index).
+__device__ __forceinline__ bool k5w_map(const AttnArgs& a, int work, int& bh, int& qblk, int& tsp, int& tail) {
     tsp = 0;
+    tail = -1;
     const int n_sparse = a.BH * a.NBp;
     const bool heavy_last = a.heavy_last != 0;
-    const int wh = heavy_last ? work - n_sparse : work;                 // index among the text-row pieces
-    const int v = heavy_last ? work : work - a.n_heavy_pad;             // index among the sparse blocks
-    if (heavy_last ? work >= n_sparse : work < a.n_heavy_pad) {
+    int wh = heavy_last ? work - n_sparse : work;                 // index among the text-row pieces
+    int v = heavy_last ? work : work - a.n_heavy_pad;             // index among the sparse blocks
+    bool text = heavy_last ? work >= n_sparse : work < a.n_heavy_pad;
+    if (a.tail_n > 0) {
+        const int tail_end = a.tail_first + a.tail_n * a.tail_p;
+        text = work >= tail_end;
+        wh = work - tail_end;
+        if (work >= a.tail_first && !text) {
+            tail = work - a.tail_first;
+            v = a.tail_first + tail / a.tail_p;
+            tsp = tail % a.tail_p;
+        }
+    }
+    if (text) {
         const int ntq = a.NQB - a.NBv;
         const int per_bh = ntq * a.tsplit;      // text blocks x key-range splits (tsplit = 1: no split)
         if (ntq <= 0 || wh >= a.BH * per_bh) return false;
@@ -123,8 +138,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const GsyncTicket gs_tk = rsa_gsync_announce(a.gsync, a.gsync_gen);   // aligned starts (rsa_attn.h)
 
     // ---------------- work mapping: dense text-row blocks first, then the sparse blocks chunked per XCD ----------------
-    int bh, qblk, tsp;
-    if (!k5w_map(a, blockIdx.x, bh, qblk, tsp)) return;
+    int bh, qblk, tsp, tail;
+    if (!k5w_map(a, blockIdx.x, bh, qblk, tsp, tail)) return;
     const int b = bh / a.H, h = bh % a.H;
     const int t = threadIdx.x, lane = t & 63;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -142,6 +157,12 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const long rowi = (long)bh * a.NBv + qblk;
             list = a.cols + rowi * a.NB_total;
             n_items = a.counts[rowi];
+            if (tail >= 0) {   // this workgroup's part of the kept list (tail split)
+                const int per = (n_items + a.tail_p - 1) / a.tail_p, first = tsp * per;
+                const int left = n_items - first;
+                list += first;
+                n_items = left < 0 ? 0 : (left < per ? left : per);
+            }
             lo_max = 0; hi_min = hi_max = a.kv_valid;
             hi_r[0] = hi_r[1] = a.kv_valid;
         } else {
@@ -438,15 +459,15 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const AttnArgs* ep = (const AttnArgs*)(const void*)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(ep));
     const AttnArgs& e = *ep;
-    int bh2, qblk2, tsp2;
+    int bh2, qblk2, tsp2, tail2;
     {
         int work2 = blockIdx.x;
         asm volatile("" : "+s"(work2));
-        k5w_map(e, work2, bh2, qblk2, tsp2);
+        k5w_map(e, work2, bh2, qblk2, tsp2, tail2);
     }
     const int b2 = bh2 / e.H, h2 = bh2 % e.H;
-    const bool partial = e.mode == MODE_SPARSE && e.tsplit > 1 && qblk2 >= e.NBv;
-    const bool rectify = e.mode == MODE_SPARSE && qblk2 < e.NBv && e.R != nullptr;
+    const bool partial = (e.mode == MODE_SPARSE && e.tsplit > 1 && qblk2 >= e.NBv) || tail2 >= 0;
+    const bool rectify = e.mode == MODE_SPARSE && qblk2 < e.NBv && e.R != nullptr && tail2 < 0;   // (a tail piece is rectified by its combine pass)
     // the compensation row of this query block, the 64 values this lane adds (d = 32 dt + 8 g + 4 hh + 0..3), and R: ALL loads
     // issued here, back to back, one wait -- per (dt, g) inside the store loop each load's latency (L2 / HBM: 1-2 k cycles)
     // is exposed in turn: 30 k of a wave's 535 k cycles with nothing else on the SIMD to cover it (stamps: profiles/r04_k5_w64.md)
@@ -472,11 +493,12 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const auto swl = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run[x]), __float_as_uint(l_run[x]), false, false);
         const float l_tot = __uint_as_float(swl[0]) + __uint_as_float(swl[1]);
         if (partial) {
-            // split-KV partial of a text block: unnormalised O (fp32), m (log2 domain) and l per row (merged by
-            // text_combine_kernel, rsa_attn.hip)
+            // split-KV partial of a text block or of a tail piece: unnormalised O (fp32), m (log2 domain) and l per row (merged by
+            // text_combine_kernel / tail_combine_kernel, rsa_attn.hip)
             const int ntq = e.NQB - e.NBv;
             const int rowb = 64 * wv + 32 * x + r;
-            float* pp = e.tpart + ((((long)bh2 * ntq + (qblk2 - e.NBv)) * e.tsplit + tsp2) * RSA_BLOCK + rowb) * (D + 2);
+            float* pp = tail2 >= 0 ? e.tail_part + ((long)tail2 * RSA_BLOCK + rowb) * (D + 2)
+                                   : e.tpart + ((((long)bh2 * ntq + (qblk2 - e.NBv)) * e.tsplit + tsp2) * RSA_BLOCK + rowb) * (D + 2);
             auto put = [&](int dt, const f32x16& o) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {

@@ -814,7 +814,7 @@ extern "C" int rsa_buffer_bytes(const rsa_layout* l, size_t sizes[RSA_NUM_BUFFER
         BH * NBv * D * 4, BH * NBv * D * 4, BH * NBv * D * 4, BH * NBv * D * 4, BH * NB * D * 4,
         BH * NBv * NS * 4, BH * NBv * NBv,  BH * NBv * L * 4, BH * NBv * L * 4, BH * NBv * 4,
         BH * NBv * D * 4,  BH * NBv * NW * 4, BH * NBv * NB * 4, BH * NBv * 4,
-        BH * (NB - NBv) * RSA_TEXT_SPLIT * 128 * (D + 2) * 4};
+        (BH * (NB - NBv) * RSA_TEXT_SPLIT + RSA_TAIL_PIECES) * 128 * (D + 2) * 4};
     size_t tot = 0;
     for (int i = 0; i < RSA_NUM_BUFFERS; ++i) {
         sizes[i] = s[i];

@@ -125,6 +125,9 @@ def test_text_rows_first_or_last_and_aligned_starts_on_a_layout_with_text():
     L = _lib.lib()
     outs = []
     try:
+        # (the tail split -- tests/test_gpu_tail_split.py -- needs the text pieces last and changes the split blocks' rounding:
+        # off here, where the claim is byte identity across the scheduling switches)
+        assert L.rsa_set_tuning(b"k5_tail_split", 0) == 0
         for gs, tl in ((0, 0), (1, 1), (1, 0), (0, 1)):
             assert L.rsa_set_tuning(b"k5_gsync", gs) == 0 and L.rsa_set_tuning(b"k5_text_last", tl) == 0
             out = _core.rectified_attention(q, k, v, spec, top_k, 0.05, None, shape_xfuse=True)
@@ -133,8 +136,10 @@ def test_text_rows_first_or_last_and_aligned_starts_on_a_layout_with_text():
     finally:
         L.rsa_set_tuning(b"k5_gsync", 1)
         L.rsa_set_tuning(b"k5_text_last", 1)
+        L.rsa_set_tuning(b"k5_tail_split", 1)
     for o in outs[1:]:
         assert np.array_equal(o, outs[0])
+    out = _core.rectified_attention(q, k, v, spec, top_k, 0.05, None, shape_xfuse=True)    # the product's defaults (tail split on)
     lay = orc.layout_hunyuan(S, num_true)
     hd = 3
     qf, kf, vf = (x[0, hd].float().cpu().numpy() for x in (q, k, v))

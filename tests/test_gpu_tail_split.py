@@ -1,0 +1,90 @@
+"""Tail split of the 64-row K5 (rsa_attn.hip::launch_attn, tuning key k5_tail_split; round 4): when the last generation of 512
+workgroups is less than half full, the walks of its query blocks are split over the idle slots (split-KV partials + a combine pass
+that also rectifies).  The split blocks' accumulation order changes, so they agree with the unsplit kernel within rounding, not
+byte for byte; every other block stays byte-identical; everything agrees with the oracle within the operator's tolerance."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _qkv(H, S, seed, dt=torch.bfloat16):
+    g = torch.Generator(device="cuda:0").manual_seed(seed)
+    nb = (S + 127) // 128
+    cent = torch.randn(H, nb, 128, generator=g, device="cuda:0")
+
+    def mk():
+        return (cent.repeat_interleave(128, 1)[:, :S] + 0.7 * torch.randn(H, S, 128, generator=g, device="cuda:0")).to(dt).view(1, H, S, 128)
+    return mk(), mk(), torch.randn(1, H, S, 128, generator=g, device="cuda:0").to(dt)
+
+
+def _run(q, k, v, spec, top_k, split):
+    from rectified_spaattn_amd import _core, _lib
+    L = _lib.lib()
+    try:
+        assert L.rsa_set_tuning(b"k5_tail_split", split) == 0
+        out = _core.rectified_attention(q, k, v, spec, top_k, 0.05, None, shape_xfuse=True)
+        torch.cuda.synchronize()
+        return out
+    finally:
+        L.rsa_set_tuning(b"k5_tail_split", 1)
+
+
+@pytest.mark.parametrize("layout,H,nbv,dt", [("wan", 8, 72, torch.bfloat16), ("wan", 9, 70, torch.float16),
+                                             ("hunyuan", 6, 102, torch.bfloat16), ("wan", 4, 140, torch.bfloat16)])
+def test_split_tail_against_the_unsplit_kernel_and_the_oracle(layout, H, nbv, dt):
+    """wan 8 x 72 = 576 workgroups: one full generation + 64 blocks split 4 ways; 9 x 72 (70 blocks padded to 72) = 648: 136 blocks
+    3 ways (with the padding workgroups of the mapping inside the tail); hunyuan 6 x 104 = 624: 112 blocks 4 ways with the text
+    pieces behind them; 4 x 144 = 576 again with longer lists."""
+    from oracle import oracle as orc
+    from rectified_spaattn_amd import _core
+    if layout == "wan":
+        S = nbv * 128 - 37
+        spec, lay = _core.LayoutSpec.wan(S, 2), orc.layout_wan(S, 2)
+    else:
+        S = (nbv + 2) * 128
+        spec, lay = _core.LayoutSpec.hunyuan(S, S - 56), orc.layout_hunyuan(S, S - 56)
+    top_k = 12
+    q, k, v = _qkv(H, S, 41 + nbv, dt)
+    whole = _run(q, k, v, spec, top_k, 0)
+    split = _run(q, k, v, spec, top_k, 1)
+    again = _run(q, k, v, spec, top_k, 1)
+    assert torch.equal(split, again)                                    # deterministic
+    assert torch.isfinite(split.float()).all()
+    diff = (split.float() - whole.float()).abs()
+    ulp = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10
+    assert diff.max() <= 2 * ulp * max(1.0, float(whole.float().abs().max()))
+    # which blocks may differ at all: the sparse blocks behind the last full generation (work index = head * NBp + j, query
+    # block (j & 7) * NBp / 8 + (j >> 3))
+    NBp = (spec.NBv + 7) // 8 * 8
+    n_sparse = H * NBp
+    first = (n_sparse // 512) * 512
+    assert 0 < n_sparse - first <= 256, "the case does not have a tail to split"
+    touched = torch.zeros(H, spec.NB_total, dtype=torch.bool)
+    for vv in range(first, n_sparse):
+        h, j = divmod(vv, NBp)
+        qb = (j & 7) * (NBp // 8) + (j >> 3)
+        if qb < spec.NBv:
+            touched[h, qb] = True
+    blk_diff = diff[0].reshape(-1, 128, H, 128).amax(dim=(1, 3)).t().cpu() if S % 128 == 0 else None
+    if blk_diff is not None:
+        assert (blk_diff[~touched[:, :blk_diff.shape[1]]] == 0).all(), "a block outside the tail changed"
+    assert int(touched.sum()) > 0
+    # the oracle, one head that has split blocks
+    hd = int(torch.nonzero(touched.any(1))[-1])
+    qf, kf, vf = (x[0, hd].float().cpu().numpy() for x in (q, k, v))
+    ref = orc.rectified_attention(qf[None, None], kf[None, None], vf[None, None], lay, top_k, 0.05, None)
+    got = split[0, :, hd].float().cpu().numpy()
+    err = np.abs(got - ref.reshape(got.shape))
+    mx, mean = (2e-2, 2e-3) if dt == torch.bfloat16 else (2e-3, 2e-4)
+    assert err.max() <= mx and err.mean() <= mean
+
+
+def test_without_the_partial_buffer_or_with_a_full_last_generation_nothing_is_split():
+    """8 x 64 = 512 workgroups exactly, and 8 x 80 = 640 with 128 < 256 in the tail but no tpart (the C entry with buffers that lack
+    it): same bytes with the switch on and off."""
+    from rectified_spaattn_amd import _core
+    q, k, v = _qkv(8, 64 * 128, 51)
+    spec = _core.LayoutSpec.wan(64 * 128, 0)
+    assert torch.equal(_run(q, k, v, spec, 10, 0), _run(q, k, v, spec, 10, 1))

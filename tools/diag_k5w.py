@@ -28,7 +28,7 @@ def main():
     call = _core.StagedCall(q, k, v, spec, wl["top_k"], p, make_neighbors(wl, spec, nbr_kind))
     call.select()
     torch.cuda.synchronize()
-    nwg = 8 + H * 2 * 16 + H * ((spec.NBv + 7) // 8 * 8) + 64
+    nwg = 8 + H * 2 * 16 + H * ((spec.NBv + 7) // 8 * 8) + 64 + 1024   # (+ the pieces of a split tail)
     dbg = torch.zeros(nwg * 4 * 8, dtype=torch.int64, device=dev)
     ptr = dbg.data_ptr()
     assert L.rsa_set_tuning(b"k5_w64", 1) == 0
