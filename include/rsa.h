@@ -91,7 +91,7 @@ typedef struct rsa_buffers {
     float* tpart;     /* [BH * (NB_total - NBv) * RSA_TEXT_SPLIT + RSA_TAIL_PIECES, 128, D + 2]  unnormalised O, then (m, l) per query row */
 } rsa_buffers;
 #define RSA_NUM_BUFFERS 15
-#define RSA_TEXT_SPLIT 16
+#define RSA_TEXT_SPLIT 32
 #define RSA_TAIL_PIECES 512
 
 /* Library identification: returns 10000*major + 100*minor + patch. */

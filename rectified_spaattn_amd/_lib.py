@@ -41,7 +41,7 @@ class RsaOut4(ctypes.Structure):
 
 BUFFER_NAMES = ("qbar", "aq", "kbar", "ak", "vbar", "scores", "unrel", "probs", "w", "R", "comp", "bitmask",
                 "cols", "counts", "tpart")
-TEXT_SPLIT = 16
+TEXT_SPLIT = 32
 TAIL_PIECES = 512
 NUM_BUFFERS = len(BUFFER_NAMES)
 

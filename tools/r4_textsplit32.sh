@@ -1,0 +1,7 @@
+export RSA_TUNING=1
+L=rectified_spaattn_amd/librsa_hip.so
+for H in 24 3 4; do
+  RSA_PERF_H=$H timeout 600 python tools/ab_libs.py whole=$L::k5_w64=1,k5_tail_split=0 split=$L::k5_w64=1,k5_tail_split=1 --rounds 8 2>&1 | grep -E "sparse median" | cut -c1-110 | sed "s/^/heads $H /"
+done
+RSA_PERF_H=24 timeout 600 python tools/ab_libs.py x=$L --rounds 6 --fp8 2>&1 | grep -E "sparse median" | cut -c1-110
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_fp8.py tests/test_gpu_tail_split.py -x -q -m gpu 2>&1 | grep -E "passed|failed"
