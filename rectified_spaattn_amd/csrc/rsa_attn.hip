@@ -224,7 +224,11 @@ static int launch_attn(AttnArgs& a, int BH, int D, int dtype, hipStream_t s) {
     a.tsplit = 1; a.tper = n_txt_items;
     if (a.mode == MODE_SPARSE && ntq > 0 && a.tpart && g_k5_tsplit && n_txt_items >= 32) {
         int sp = n_txt_items / 16;
-        a.tsplit = sp > RSA_TEXT_SPLIT ? RSA_TEXT_SPLIT : sp;
+        // 16 pieces per text block; 32 (RSA_TEXT_SPLIT, what tpart is sized for) on grids of fewer than 8 generations, where the
+        // pieces of 0.6 of a sparse walk's life would be the last to finish behind a split tail (and the combine pass that
+        // doubles with them is still small)
+        const int cap = (long)BH * ((a.NBv + 7) & ~7) < 8 * 512 ? RSA_TEXT_SPLIT : 16;
+        a.tsplit = sp > cap ? cap : sp;
         a.tper = (n_txt_items + a.tsplit - 1) / a.tsplit;
     }
     const int n_heavy = ntq > 0 ? BH * ntq * a.tsplit : 0;

@@ -585,7 +585,7 @@ int launch_attn8(Attn8Args& a, int BH, int D8, hipStream_t s) {
     a.tsplit = 1; a.tper = n_txt_items;
     if (a.mode == MODE_SPARSE && ntq > 0 && a.tpart && rsa_text_split_enabled() && n_txt_items >= 32) {
         const int sp = n_txt_items / 16;
-        a.tsplit = sp > RSA_TEXT_SPLIT ? RSA_TEXT_SPLIT : sp;
+        a.tsplit = sp > 16 ? 16 : sp;        // (tpart has room for RSA_TEXT_SPLIT = 32; the 2-byte kernel uses them on short grids)
         a.tper = (n_txt_items + a.tsplit - 1) / a.tsplit;
     }
     const int n_heavy = ntq > 0 ? BH * ntq * a.tsplit : 0;

@@ -5,7 +5,7 @@ import csv
 import sys
 
 OURS = ("bsfwd_kernel", "bsfwd64_kernel", "select_mask_kernel", "compensation_kernel", "pool_stats_kernel", "pooled_scores_kernel",
-        "gapr_compare_kernel", "bsfwd_fp8_kernel", "fp8_blocks_kernel", "kmean_sample_kernel", "text_combine",
+        "gapr_compare_kernel", "bsfwd_fp8_kernel", "fp8_blocks_kernel", "kmean_sample_kernel", "text_combine", "tail_combine", "dense_masked_kernel",
         "permute_tokens_kernel", "qk_norm_rope_kernel", "norm_rope_heads", "rel_l1_", "p2p_")
 rows = list(csv.DictReader(open(sys.argv[1])))
 title = sys.argv[2] if len(sys.argv) > 2 else sys.argv[1]
