@@ -110,6 +110,7 @@ int rsa_launch_text_combine(const float* tpart, unsigned short* out, long osb, l
     return rsa_launch_status();
 }
 int rsa_text_split_enabled() { return g_k5_tsplit; }
+int rsa_text_last_enabled() { return g_k5_text_last; }
 
 // Tail split of the 64-row kernel (rsa_attn_kernel64.hip::k5w_map): merge the tail_p partials of every tail block, then what the
 // kernel's own epilogue does -- normalise, rectify (O . R / l + comp as one fma rounded to fp32), convert, store.  One wave per

@@ -56,12 +56,14 @@ struct Attn8Args {
     int tsplit, tper;
     unsigned* gsync;     // aligned starts (rsa_attn.h): this launch's counters or null
     int gsync_gen;
+    int heavy_last;      // the split text-row pieces behind the sparse blocks in the grid
 };
 
 // rsa_attn.hip: merge of the split-KV partials of the text blocks, and the switch for the split
 int rsa_launch_text_combine(const float* tpart, unsigned short* out, long osb, long osh, long oss, int D, int H, int NBv,
                             int ntq, int tsplit, int q_text_end, int Sq, int BH, int dtype, hipStream_t s);
 int rsa_text_split_enabled();
+int rsa_text_last_enabled();
 
 namespace {
 
@@ -141,8 +143,12 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     // ---------------- work mapping (as rsa_attn_kernel.hip) ----------------
     int bh, qblk, tsp = 0;
     {
-        const int bid = blockIdx.x;
-        if (bid < a.n_heavy_pad) {
+        // (the split text-row pieces are the LAST workgroups of the grid -- heavy_last, as in rsa_attn_kernel64.hip: they fill the
+        // slots the last generation of sparse blocks leaves idle; an unsplit text row, one long walk, still comes first)
+        const int n_sparse = a.BH * a.NBp;
+        const bool text = a.heavy_last ? (int)blockIdx.x >= n_sparse : (int)blockIdx.x < a.n_heavy_pad;
+        const int bid = a.heavy_last ? (int)blockIdx.x - n_sparse : (int)blockIdx.x;        // index among the text pieces
+        if (text) {
             const int ntq = a.NQB - a.NBv;
             const int per_bh = ntq * a.tsplit;
             if (ntq <= 0 || bid >= a.BH * per_bh) return;
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
             qblk = a.NBv + rem / a.tsplit;
             tsp = rem % a.tsplit;
         } else {
-            const int v = bid - a.n_heavy_pad;
+            const int v = a.heavy_last ? (int)blockIdx.x : (int)blockIdx.x - a.n_heavy_pad;
             bh = v / a.NBp;
             const int j = v % a.NBp;
             const int chunk = a.NBp >> 3;
@@ -589,6 +595,7 @@ int launch_attn8(Attn8Args& a, int BH, int D8, hipStream_t s) {
         a.tper = (n_txt_items + a.tsplit - 1) / a.tsplit;
     }
     const int n_heavy = ntq > 0 ? BH * ntq * a.tsplit : 0;
+    a.heavy_last = a.tsplit > 1 && rsa_text_last_enabled();
     a.BH = BH;
     a.n_heavy_pad = (n_heavy + 7) & ~7;
     a.NBp = (a.NBv + 7) & ~7;

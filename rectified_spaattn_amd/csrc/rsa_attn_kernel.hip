@@ -115,16 +115,20 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
     const GsyncTicket gs_tk = rsa_gsync_announce(a.gsync, a.gsync_gen);   // aligned starts (rsa_attn.h)
     // ---------------- work mapping: dense text-row blocks first, then the sparse blocks chunked per XCD ----------------
     int bh, qblk, tsp = 0;   // tsp: which part of a text block's key range this workgroup walks
-    if (work < a.n_heavy_pad) {
+    // (the split text-row pieces are the LAST workgroups of the grid -- a.heavy_last, as in rsa_attn_kernel64.hip)
+    const int n_sparse = a.BH * a.NBp;
+    const bool text = a.heavy_last ? work >= n_sparse : work < a.n_heavy_pad;
+    if (text) {
+        const int wh = a.heavy_last ? work - n_sparse : work;
         const int ntq = a.NQB - a.NBv;
         const int per_bh = ntq * a.tsplit;      // text blocks x key-range splits (tsplit = 1: no split)
-        if (ntq <= 0 || work >= a.BH * per_bh) return;
-        bh = work / per_bh;
-        const int rem = work % per_bh;
+        if (ntq <= 0 || wh >= a.BH * per_bh) return;
+        bh = wh / per_bh;
+        const int rem = wh % per_bh;
         qblk = a.NBv + rem / a.tsplit;
         tsp = rem % a.tsplit;
     } else {
-        const int v = work - a.n_heavy_pad;
+        const int v = a.heavy_last ? work : work - a.n_heavy_pad;
         bh = v / a.NBp;
         const int j = v % a.NBp;
         const int chunk = a.NBp >> 3;
