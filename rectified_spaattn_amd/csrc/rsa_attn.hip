@@ -152,16 +152,32 @@ __global__ __launch_bounds__(256) void tail_combine_kernel(const float* __restri
     }
 }
 
-static int launch_tail_combine(const AttnArgs& a, int dtype, hipStream_t s) {
-    const long rows = (long)a.tail_n * RSA_BLOCK;
+// (also used by the e4m3 kernel's host side, rsa_attn_fp8_kernel.hip)
+int rsa_launch_tail_combine(const float* part, unsigned short* out, long osb, long osh, long oss, int H, int NBv, int NBp,
+                            int tail_first, int tail_n, int tail_p, const float* R, const float* comp, int Sq, int dtype,
+                            hipStream_t s) {
+    const long rows = (long)tail_n * RSA_BLOCK;
     const dim3 grid((unsigned)((rows + 3) / 4));
     if (dtype == RSA_BF16)
-        tail_combine_kernel<bf16_tag><<<grid, 256, 0, s>>>(a.tail_part, a.out, a.osb, a.osh, a.oss, a.H, a.NBv, a.NBp, a.tail_first,
-                                                         a.tail_n, a.tail_p, a.R, a.comp, a.Sq);
+        tail_combine_kernel<bf16_tag><<<grid, 256, 0, s>>>(part, out, osb, osh, oss, H, NBv, NBp, tail_first, tail_n, tail_p, R, comp, Sq);
     else
-        tail_combine_kernel<fp16_tag><<<grid, 256, 0, s>>>(a.tail_part, a.out, a.osb, a.osh, a.oss, a.H, a.NBv, a.NBp, a.tail_first,
-                                                         a.tail_n, a.tail_p, a.R, a.comp, a.Sq);
+        tail_combine_kernel<fp16_tag><<<grid, 256, 0, s>>>(part, out, osb, osh, oss, H, NBv, NBp, tail_first, tail_n, tail_p, R, comp, Sq);
     return rsa_launch_status();
+}
+// the plan of a tail split (see launch_attn): n_sparse = BH x NBp sparse workgroups, n_heavy_pad text pieces behind them
+int rsa_plan_tail_split(long n_sparse, long n_heavy_pad, int* tail_first, int* tail_n, int* tail_p) {
+    *tail_first = *tail_n = *tail_p = 0;
+    if (!g_k5_tail_split) return 0;
+    const long full = n_sparse / 512, T = n_sparse % 512;
+    const long room = 512 - n_heavy_pad;
+    const long P = T > 0 ? (room / T < 4 ? room / T : 4) : 0;
+    if (full < 1 || T <= 0 || P < 2) return 0;
+    *tail_first = (int)(full * 512); *tail_n = (int)T; *tail_p = (int)P;       // T x P <= 512 = RSA_TAIL_PIECES
+    return 1;
+}
+static int launch_tail_combine(const AttnArgs& a, int dtype, hipStream_t s) {
+    return rsa_launch_tail_combine(a.tail_part, a.out, a.osb, a.osh, a.oss, a.H, a.NBv, a.NBp, a.tail_first, a.tail_n, a.tail_p, a.R,
+                                   a.comp, a.Sq, dtype, s);
 }
 
 static int launch_text_combine(const AttnArgs& a, int BH, int D, int dtype, hipStream_t s) {
@@ -245,17 +261,11 @@ static int launch_attn(AttnArgs& a, int BH, int D, int dtype, hipStream_t s) {
     // rounding, not byte for byte (tuning key k5_tail_split = 0 keeps every walk whole).
     a.tail_first = a.tail_n = a.tail_p = 0; a.tail_part = nullptr;
     const bool w64 = D == 128 && (g_k5_w64 & 1);
-    if (w64 && g_k5_tail_split && a.mode == MODE_SPARSE && a.tpart && (a.heavy_last || n_heavy == 0)) {
-        const long n_sparse = (long)BH * a.NBp;
-        const long full = n_sparse / 512, T = n_sparse % 512;
+    if (w64 && a.mode == MODE_SPARSE && a.tpart && (a.heavy_last || n_heavy == 0)) {
         // the pieces AND the text-row pieces behind them must fit the 512 slots together: otherwise whatever starts late (0.6 of a
         // life for a text piece) ends the launch as late as the unsplit tail did (measured: 3 heads of the headline shape, 456
         // pieces + 96 text pieces: 1.92 ms against 1.88 unsplit)
-        const long room = 512 - (long)a.n_heavy_pad;
-        const long P = T > 0 ? (room / T < 4 ? room / T : 4) : 0;
-        if (full >= 1 && T > 0 && P >= 2) {
-            a.tail_first = (int)(full * 512); a.tail_n = (int)T;
-            a.tail_p = (int)P;                                           // T x tail_p <= 512 = RSA_TAIL_PIECES
+        if (rsa_plan_tail_split((long)BH * a.NBp, a.n_heavy_pad, &a.tail_first, &a.tail_n, &a.tail_p)) {
             a.tail_part = a.tpart + (long)BH * ntq * RSA_TEXT_SPLIT * RSA_BLOCK * (D + 2);
             nblocks = (long)a.tail_first + (long)a.tail_n * a.tail_p + a.n_heavy_pad;
         }

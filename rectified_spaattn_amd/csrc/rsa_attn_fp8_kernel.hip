@@ -57,6 +57,8 @@ struct Attn8Args {
     unsigned* gsync;     // aligned starts (rsa_attn.h): this launch's counters or null
     int gsync_gen;
     int heavy_last;      // the split text-row pieces behind the sparse blocks in the grid
+    int tail_first, tail_n, tail_p;   // tail split (rsa_attn.hip::launch_attn, rsa_attn_kernel64.hip::k5w_map): head dim 128 only
+    float* tail_part;
 };
 
 // rsa_attn.hip: merge of the split-KV partials of the text blocks, and the switch for the split
@@ -64,6 +66,10 @@ int rsa_launch_text_combine(const float* tpart, unsigned short* out, long osb, l
                             int ntq, int tsplit, int q_text_end, int Sq, int BH, int dtype, hipStream_t s);
 int rsa_text_split_enabled();
 int rsa_text_last_enabled();
+int rsa_plan_tail_split(long n_sparse, long n_heavy_pad, int* tail_first, int* tail_n, int* tail_p);
+int rsa_launch_tail_combine(const float* part, unsigned short* out, long osb, long osh, long oss, int H, int NBv, int NBp,
+                            int tail_first, int tail_n, int tail_p, const float* R, const float* comp, int Sq, int dtype,
+                            hipStream_t s);
 
 namespace {
 
@@ -141,13 +147,24 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
 
     const GsyncTicket gs_tk = rsa_gsync_announce(a.gsync, a.gsync_gen);   // aligned starts (rsa_attn.h)
     // ---------------- work mapping (as rsa_attn_kernel.hip) ----------------
-    int bh, qblk, tsp = 0;
+    int bh, qblk, tsp = 0, tail = -1;
     {
         // (the split text-row pieces are the LAST workgroups of the grid -- heavy_last, as in rsa_attn_kernel64.hip: they fill the
         // slots the last generation of sparse blocks leaves idle; an unsplit text row, one long walk, still comes first)
         const int n_sparse = a.BH * a.NBp;
-        const bool text = a.heavy_last ? (int)blockIdx.x >= n_sparse : (int)blockIdx.x < a.n_heavy_pad;
-        const int bid = a.heavy_last ? (int)blockIdx.x - n_sparse : (int)blockIdx.x;        // index among the text pieces
+        bool text = a.heavy_last ? (int)blockIdx.x >= n_sparse : (int)blockIdx.x < a.n_heavy_pad;
+        int bid = a.heavy_last ? (int)blockIdx.x - n_sparse : (int)blockIdx.x;        // index among the text pieces
+        int vtail = -1;
+        if (a.tail_n > 0) {    // (sparse blocks first: the tail's pieces sit between the whole walks and the text pieces)
+            const int tail_end = a.tail_first + a.tail_n * a.tail_p;
+            text = (int)blockIdx.x >= tail_end;
+            bid = (int)blockIdx.x - tail_end;
+            if ((int)blockIdx.x >= a.tail_first && !text) {
+                tail = (int)blockIdx.x - a.tail_first;
+                vtail = a.tail_first + tail / a.tail_p;
+                tsp = tail % a.tail_p;
+            }
+        }
         if (text) {
             const int ntq = a.NQB - a.NBv;
             const int per_bh = ntq * a.tsplit;
@@ -157,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
             qblk = a.NBv + rem / a.tsplit;
             tsp = rem % a.tsplit;
         } else {
-            const int v = a.heavy_last ? (int)blockIdx.x : (int)blockIdx.x - a.n_heavy_pad;
+            const int v = vtail >= 0 ? vtail : (a.heavy_last ? (int)blockIdx.x : (int)blockIdx.x - a.n_heavy_pad);
             bh = v / a.NBp;
             const int j = v % a.NBp;
             const int chunk = a.NBp >> 3;
@@ -182,6 +199,12 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
             const long rowi = (long)bh * a.NBv + qblk;
             list = a.cols + rowi * a.NB_total;
             n_items = a.counts[rowi];
+            if (tail >= 0) {   // this workgroup's part of the kept list (tail split)
+                const int per = (n_items + a.tail_p - 1) / a.tail_p, first = tsp * per;
+                const int left = n_items - first;
+                list += first;
+                n_items = left < 0 ? 0 : (left < per ? left : per);
+            }
             lo_max = 0; hi_min = hi_max = a.kv_valid;
             rectify = a.R != nullptr;
             hi_r = a.kv_valid; store_r = grow < a.Sq;
@@ -457,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     };
 
     // ---------------- prologue + main loop ----------------
-    rsa_gsync_wait(a.gsync, gs_tk, n_items, a.NB_total);   // aligned starts: in front of the first staging instruction
+    if (tail < 0 && qblk < a.NBv) rsa_gsync_wait(a.gsync, gs_tk, n_items, a.NB_total);   // aligned starts (off by default here)
     f32x16 SA[2], SB[2];
     float mxA = -INFINITY, mxB = -INFINITY;
     int key0 = 0;
@@ -520,11 +543,12 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     // ---------------- epilogue ----------------
     asm volatile("s_nop 15\n\ts_nop 5" ::: "memory");   // (the last block's last MFMA -> the reads of O / l below)
     const float l_tot = lacc[0];
-    if (a.mode == MODE_SPARSE && a.tsplit > 1 && qblk >= a.NBv) {
-        // split-KV partial of a text block (merged by rsa_attn.hip's combine kernel): O in V's units, m, l
+    if ((a.mode == MODE_SPARSE && a.tsplit > 1 && qblk >= a.NBv) || tail >= 0) {
+        // split-KV partial of a text block or of a tail piece (merged by rsa_attn.hip's combine kernels): O in V's units, m, l
         const int ntq = a.NQB - a.NBv;
         const int rowb = 32 * wv + r;
-        float* pp = a.tpart + ((((long)bh * ntq + (qblk - a.NBv)) * a.tsplit + tsp) * RSA_BLOCK + rowb) * (D8 + 2);
+        float* pp = tail >= 0 ? a.tail_part + ((long)tail * RSA_BLOCK + rowb) * (D8 + 2)
+                              : a.tpart + ((((long)bh * ntq + (qblk - a.NBv)) * a.tsplit + tsp) * RSA_BLOCK + rowb) * (D8 + 2);
 #pragma unroll
         for (int dt = 0; dt < DT8; ++dt)
 #pragma unroll
@@ -599,7 +623,16 @@ int launch_attn8(Attn8Args& a, int BH, int D8, hipStream_t s) {
     a.BH = BH;
     a.n_heavy_pad = (n_heavy + 7) & ~7;
     a.NBp = (a.NBv + 7) & ~7;
-    const long nblocks = (long)a.n_heavy_pad + (long)BH * a.NBp;
+    long nblocks = (long)a.n_heavy_pad + (long)BH * a.NBp;
+    a.tail_first = a.tail_n = a.tail_p = 0; a.tail_part = nullptr;
+    // (as rsa_attn.hip::launch_attn, but only for layouts without text rows: with this kernel's shorter lives and two waves per
+    // SIMD the split measured +1.6 % on Wan2.2-TI2V and -2.3 % at 3 heads of the HunyuanVideo shape, where the text pieces end the
+    // launch either way: profiles/r04_k5_tail_split.txt)
+    if (D8 == 128 && a.mode == MODE_SPARSE && a.tpart && n_heavy == 0 &&
+        rsa_plan_tail_split((long)BH * a.NBp, a.n_heavy_pad, &a.tail_first, &a.tail_n, &a.tail_p)) {
+        a.tail_part = a.tpart + (long)BH * ntq * RSA_TEXT_SPLIT * RSA_BLOCK * (D8 + 2);
+        nblocks = (long)a.tail_first + (long)a.tail_n * a.tail_p + a.n_heavy_pad;
+    }
     if (nblocks <= 0) return RSA_OK;
     if (nblocks > 0x7FFFFFFF) return RSA_ERR_UNSUPPORTED;
     if (a.NB_total > 8192) return RSA_ERR_UNSUPPORTED;
@@ -615,7 +648,13 @@ int launch_attn8(Attn8Args& a, int BH, int D8, hipStream_t s) {
         }
     }
     const int st = rsa_launch_status();
-    if (st != RSA_OK || a.tsplit <= 1) return st;
+    if (st != RSA_OK) return st;
+    if (a.tail_n > 0) {
+        const int st2 = rsa_launch_tail_combine(a.tail_part, a.out, a.osb, a.osh, a.oss, a.H, a.NBv, a.NBp, a.tail_first, a.tail_n,
+                                                a.tail_p, a.R, a.comp, a.Sq, a.out_fp16 ? RSA_FP16 : RSA_BF16, s);
+        if (st2 != RSA_OK) return st2;
+    }
+    if (a.tsplit <= 1) return st;
     return rsa_launch_text_combine(a.tpart, a.out, a.osb, a.osh, a.oss, D8, a.H, a.NBv, ntq, a.tsplit, a.q_text_end, a.Sq,
                                    BH, a.out_fp16 ? RSA_FP16 : RSA_BF16, s);
 }

@@ -88,3 +88,37 @@ def test_without_the_partial_buffer_or_with_a_full_last_generation_nothing_is_sp
     q, k, v = _qkv(8, 64 * 128, 51)
     spec = _core.LayoutSpec.wan(64 * 128, 0)
     assert torch.equal(_run(q, k, v, spec, 10, 0), _run(q, k, v, spec, 10, 1))
+
+
+def test_split_tail_in_the_e4m3_kernel():
+    """The same split in the e4m3 K5 (head dim 128): split and whole walks agree within the rounding of a different summation
+    order, blocks outside the tail byte for byte, and the result is deterministic."""
+    from rectified_spaattn_amd import _core, _lib
+    H, nbv, top_k = 8, 72, 12
+    S = nbv * 128
+    q, k, v = _qkv(H, S, 77)
+    spec = _core.LayoutSpec.wan(S, 2)
+    L = _lib.lib()
+    outs = {}
+    try:
+        for split in (0, 1, 1):
+            assert L.rsa_set_tuning(b"k5_tail_split", split) == 0
+            o = _core.rectified_attention(q, k, v, spec, top_k, 0.05, None, shape_xfuse=True, qkv_fp8=True)
+            torch.cuda.synchronize()
+            outs.setdefault(split, []).append(o)
+    finally:
+        L.rsa_set_tuning(b"k5_tail_split", 1)
+    whole, split = outs[0][0], outs[1][0]
+    assert torch.equal(split, outs[1][1])
+    diff = (split.float() - whole.float()).abs()
+    assert 0 < float(diff.max()) <= 2 * 2.0 ** -7 * max(1.0, float(whole.float().abs().max()))
+    NBp = (spec.NBv + 7) // 8 * 8
+    first = (H * NBp // 512) * 512
+    touched = torch.zeros(H, spec.NB_total, dtype=torch.bool)
+    for vv in range(first, H * NBp):
+        h, j = divmod(vv, NBp)
+        qb = (j & 7) * (NBp // 8) + (j >> 3)
+        if qb < spec.NBv:
+            touched[h, qb] = True
+    blk_diff = diff[0].reshape(-1, 128, H, 128).amax(dim=(1, 3)).t().cpu()
+    assert (blk_diff[~touched] == 0).all() and (blk_diff[touched] > 0).any()
