@@ -122,3 +122,27 @@ def test_split_tail_in_the_e4m3_kernel():
             touched[h, qb] = True
     blk_diff = diff[0].reshape(-1, 128, H, 128).amax(dim=(1, 3)).t().cpu()
     assert (blk_diff[~touched] == 0).all() and (blk_diff[touched] > 0).any()
+
+
+@pytest.mark.parametrize("layout,H,nbv,top_k", [("wan", 5, 130, 9), ("wan", 3, 200, 20), ("wan", 11, 56, 6), ("flux", 5, 116, 10),
+                                                ("hunyuan", 3, 190, 12), ("wan", 7, 100, 50), ("wan", 2, 300, 8)])
+def test_split_plans_of_every_shape(layout, H, nbv, top_k):
+    """Different tail sizes and piece counts (2, 3, 4 pieces; tails with and without text pieces behind them; lists shorter than
+    the piece count would like; a case the planner must leave alone): split == whole within rounding, finite, deterministic."""
+    from rectified_spaattn_amd import _core
+    if layout == "wan":
+        S = nbv * 128 - 5
+        spec = _core.LayoutSpec.wan(S, 1)
+    elif layout == "flux":
+        S = (nbv + 4) * 128
+        spec = _core.LayoutSpec.flux(S, 512)
+    else:
+        S = (nbv + 2) * 128
+        spec = _core.LayoutSpec.hunyuan(S, S - 100)
+    q, k, v = _qkv(H, S, 100 + H + nbv)
+    whole = _run(q, k, v, spec, top_k, 0)
+    split = _run(q, k, v, spec, top_k, 1)
+    assert torch.isfinite(split.float()).all()
+    assert torch.equal(split, _run(q, k, v, spec, top_k, 1))
+    diff = (split.float() - whole.float()).abs()
+    assert diff.max() <= 2 * 2.0 ** -7 * max(1.0, float(whole.float().abs().max()))
