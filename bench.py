@@ -36,7 +36,10 @@ MFMA_FP8_PEAK_TFLOPS = 5000.0   # MI355X dense fp8 (same table)
 SEED = 20251212                 # seed + global head index
 
 WORKLOADS = {
-    "hunyuan_720p_128f": dict(H=24, S_vis=115200, text=256, text_valid=200, top_k=90, variant="hunyuan",
+    # top_k 90 = the north star's "10 % kept blocks"; script_top_k = what scripts/main_hunyuan.py ships (sa_drop_rate 0.8:
+    # int(0.2 * 900), :219, :251-254).  The other workloads' top_k ARE their scripts' (main_upflux.py:274 0.9, main_wan21t2v.py:218
+    # / main_wan22ti2v.py:236 / main_cogvideox.py:313 0.75).
+    "hunyuan_720p_128f": dict(H=24, S_vis=115200, text=256, text_valid=200, top_k=90, script_top_k=180, variant="hunyuan",
                               latent=(32, 45, 80)),
     "flux_4096": dict(H=24, S_vis=65536, text=512, text_valid=512, top_k=51, variant="flux", latent=(1, 256, 256)),
     "wan21_720p_81f": dict(H=40, S_vis=75600, text=0, text_valid=0, top_k=147, variant="wan", ffb=28,
@@ -54,7 +57,14 @@ REGIMES = {
     "r2": ("iid", "none", 0.0),            # controlled: exactly top_k kept visual blocks per row (+ text blocks)
     "r1": ("iid", "gilbert", 0.05),        # algorithmic: cumulative-probability rule + true Gilbert neighbours
     "locality": ("spatial", "gilbert", 0.05),  # as r1 on spatially smooth centroids (overlapping kept lists)
+    # the reference scripts' shipped operating point: top_k = script_top_k of the workload, p_remain_rates 0.3 (every script's
+    # default, e.g. main_hunyuan.py:220), true Gilbert neighbours (:245-246), spatially smooth centroids
+    "script": ("spatial", "gilbert", 0.3),
 }
+
+
+def regime_top_k(wl, regime):
+    return wl.get("script_top_k", wl["top_k"]) if regime == "script" else wl["top_k"]
 K5_SOURCES = {False: ("rsa_attn_kernel64.hip", "gen_k5_block64.py", "rsa_attn_kernel.hip", "rsa_attn.h", "rsa_attn.hip", "gen_k5_block.py"),
               True: ("rsa_attn_fp8_kernel.hip", "rsa_attn.h", "rsa_attn.hip", "gen_k5_block.py")}
 
@@ -334,7 +344,7 @@ def run_regime(comm, args, wl, regime, q, k, v, spec, steps, warmup, want_call=F
     if args.p_remain is not None and regime == "r2":
         p = args.p_remain
     nbr = make_neighbors(wl, spec, nbr_kind)
-    call = _core.StagedCall(q, k, v, spec, wl["top_k"], p, nbr, qkv_fp8=args.qkv_fp8)
+    call = _core.StagedCall(q, k, v, spec, regime_top_k(wl, regime), p, nbr, qkv_fp8=args.qkv_fp8)
 
     def step(ev):
         call.select()
@@ -353,7 +363,7 @@ def run_regime(comm, args, wl, regime, q, k, v, spec, steps, warmup, want_call=F
     el_max, fl_sum, pairs_sum, k5_max, per_rank = parallel.reduce_step_stats(elapsed, local_flops, counts, k5_ms,
                                                                             comm.stat_dev, busy_s=busy)
     H = wl["H"]
-    rec = dict(regime=regime, neighbors=nbr_kind, p_remain=p,
+    rec = dict(regime=regime, neighbors=nbr_kind, p_remain=p, top_k=regime_top_k(wl, regime),
                ms_per_step=el_max / steps * 1e3, value=fl_sum / (el_max / steps) / 1e12,
                kept_block_fraction=pairs_sum / (H * spec.NBv * spec.NB_total),
                k5_ms=k5_ms, k5_tflops=local_flops / (k5_ms * 1e-3) / 1e12,
@@ -456,11 +466,15 @@ def fp8_records(comm, args, call_bf16, q, k, v, spec, wl, dev):
     import torch
     from rectified_spaattn_amd import _core
     out = {}
-    call_bf16.select(); call_bf16.attend()
-    torch.cuda.synchronize()
-    ref = call_bf16.out.float()
+    del call_bf16          # (the last regime's call: may be another operating point than the locality one compared here)
     _, nbr_kind, p = REGIMES["locality"]
-    c8 = _core.StagedCall(q, k, v, spec, wl["top_k"], p, make_neighbors(wl, spec, nbr_kind), qkv_fp8=True)
+    nbr = make_neighbors(wl, spec, nbr_kind)
+    cb = _core.StagedCall(q, k, v, spec, wl["top_k"], p, nbr)
+    cb.select(); cb.attend()
+    torch.cuda.synchronize()
+    ref = cb.out.float()
+    del cb
+    c8 = _core.StagedCall(q, k, v, spec, wl["top_k"], p, nbr, qkv_fp8=True)
 
     def st8(_):
         c8.select()
@@ -514,7 +528,15 @@ def load_traffic(name):
                                                f"hits; l2_hit_rate {d.get('l2_hit_rate')}")
 
 
-def measure_traffic_live(regime: str, fp8: bool, timeout_s: int = 150):
+def profiler_attached() -> bool:
+    """True when this process runs under rocprofv3 / rocprofiler (tools/prof_quick.sh, the kernel-stats runs): children started
+    from here would inherit the outer tool's LD_PRELOAD and ROCP_* variables."""
+    if any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ):
+        return True
+    return any(("rocprof" in os.environ.get(k, "")) for k in ("LD_PRELOAD", "HSA_TOOLS_LIB"))
+
+
+def measure_traffic_live(regime: str, fp8: bool, timeout_s: int = 150, workload: str = "hunyuan_720p_128f"):
     """The dominant kernel's memory-side bytes per launch, measured NOW: three rocprofv3 counter-only passes (child processes;
     counters in passes of their own, no trace domains, the program itself behind `--`: MI355X_MICROARCH.md's recipe) over
     `tools/perf_k5.py pmc` = three launches of the same call on the same synthetic inputs.  FETCH_SIZE x2 (gfx950: it counts 64 B
@@ -527,13 +549,16 @@ def measure_traffic_live(regime: str, fp8: bool, timeout_s: int = 150):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
-    kern = "bsfwd_fp8" if fp8 else "bsfwd"
-    env = dict(os.environ, RSA_PERF_REGIME=regime, RSA_PERF_NODENSE="1", TMPDIR="/tmp")
+    # K5 = the walk kernel AND the combine passes that read the split-KV partials back (text rows, split tail)
+    kerns = ("bsfwd_fp8" if fp8 else "bsfwd", "text_combine_kernel", "tail_combine_kernel")
+    if profiler_attached():
+        return None, "this process already runs under a profiler (rocprofv3 children would inherit its preload): not nested"
+    env = dict(os.environ, RSA_PERF_REGIME=regime, RSA_PERF_NODENSE="1", TMPDIR="/tmp", RSA_PERF_WORKLOAD=workload)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     if fp8:
         env["RSA_PERF_FP8"] = "1"
-    acc = {}
+    acc, walks = {}, {}
     t0 = time.time()
     with tempfile.TemporaryDirectory(dir="/tmp") as td:
         for n, counters in enumerate((("TCC_HIT_sum", "TCC_MISS_sum"), ("FETCH_SIZE",), ("WRITE_SIZE",))):
@@ -547,18 +572,25 @@ def measure_traffic_live(regime: str, fp8: bool, timeout_s: int = 150):
                 return None, f"rocprofv3 pass {n} exit {r.returncode}: {r.stderr.decode(errors='replace')[-160:]}"
             for f in glob.glob(os.path.join(td, f"p{n}", "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if kern in row.get("Kernel_Name", ""):
-                        acc.setdefault(row["Counter_Name"], {}).setdefault(row["Dispatch_Id"], 0.0)
-                        acc[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
-    mean = {k: sum(v.values()) / len(v) for k, v in acc.items() if v}
+                    name = row.get("Kernel_Name", "")
+                    which = next((i for i, kn in enumerate(kerns) if kn in name), None)
+                    if which is None:
+                        continue
+                    # per counter: the walk kernel's dispatches, and the combine passes' totals (folded into the per-launch mean)
+                    acc.setdefault(row["Counter_Name"], {}).setdefault(row["Dispatch_Id"], 0.0)
+                    acc[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
+                    if which == 0:
+                        walks.setdefault(row["Counter_Name"], set()).add(row["Dispatch_Id"])
+    # bytes per K5 launch = everything the walk kernel and its combine passes moved / number of walk launches
+    mean = {k: sum(v.values()) / max(1, len(walks.get(k, ()))) for k, v in acc.items() if v}
     if "FETCH_SIZE" not in mean or "WRITE_SIZE" not in mean:
-        return None, f"no counters for kernel '{kern}' in the rocprofv3 output ({sorted(mean)})"
+        return None, f"no counters for kernels {kerns} in the rocprofv3 output ({sorted(mean)})"
     tb = 2.0 * mean["FETCH_SIZE"] * 1024.0 + mean["WRITE_SIZE"] * 1024.0
     hit = mean.get("TCC_HIT_sum", 0.0) / max(mean.get("TCC_HIT_sum", 0.0) + mean.get("TCC_MISS_sum", 0.0), 1.0)
-    n_l = len(acc["FETCH_SIZE"])
+    n_l = len(walks.get("FETCH_SIZE", ()))
     return tb, (f"measured in this run: rocprofv3 counter-only passes (TCC_HIT/MISS | FETCH_SIZE | WRITE_SIZE, child processes, "
-                f"{time.time() - t0:.0f} s) over {n_l} launches of the same call; L2 memory-side (fabric) bytes per launch = FETCH_SIZE x2 "
-                f"+ WRITE_SIZE; includes Infinity-Cache hits; l2_hit_rate {hit:.4f}")
+                f"{time.time() - t0:.0f} s) over {n_l} launches of the same call (the walk kernel + its text / tail combine passes); L2 "
+                f"memory-side (fabric) bytes per launch = FETCH_SIZE x2 + WRITE_SIZE; includes Infinity-Cache hits; l2_hit_rate {hit:.4f}")
 
 
 def dry_worker(args, comm):
@@ -638,10 +670,24 @@ def main():
     extras = {}
     gather = None
     if world > 1:  # the optional exchange step at the layer boundary: all-gather of O along the head axis
+        # Self-check of every exchange (the first real N-GPU run is the driver's, with no one watching): each rank publishes
+        # per-head fingerprints of its LOCAL O (fp64 sum, sum of squares, 8 whole rows: parallel.head_checksums); after each
+        # transport's timed steps every rank recomputes them from the buffer that transport gathered; a transport whose buffer
+        # does not reproduce them on EVERY rank is reported as {"error": ...}, never as a time.
+        call.select(); call.attend()
+        comm.local_sync()
+        want = parallel.exchange_checksums(parallel.head_checksums(call.out, D), comm.stat_dev)
+        last = {}
+
+        def verified(full):
+            msg = parallel.verify_gathered(full, want, D)
+            ok = comm.all_ok(msg is None)
+            return ok, (msg or ("the gathered buffer is wrong on another rank" if not ok else None))
+
         def gstep(_):
             call.select()
             call.attend()
-            parallel.gather_heads(call.out)
+            last["torch"] = parallel.gather_heads(call.out)
         # (a failure inside a collective cannot be caught rank by rank -- the peers would hang in it --, so these timed
         # stages run unguarded: an exception takes the job down through torch.distributed.run.  What CAN fail on one rank
         # alone, the set-up of the library's own transports below, is agreed on across ranks before anyone enters it.)
@@ -655,6 +701,12 @@ def main():
                       value=round(rec["flops"] / (elg / args.steps) / 1e12, 3),
                       bytes_per_rank=int(call.out.numel() * call.out.element_size()),
                       transport="torch.distributed all_gather (RCCL)")
+        comm.local_sync()
+        ok_t, why_t = verified(last.pop("torch"))
+        gather["verified"] = ok_t
+        if not ok_t:
+            gather = dict(ranks=world, rccl_version=rccl_ver, error=f"torch.distributed all_gather: {why_t}",
+                          bytes_per_rank=gather["bytes_per_rank"], transport=gather["transport"], verified=False)
         for tr in [t for t in args.gather_transports.split(",") if t]:
             B_, S_, Hl_, D_ = call.out.shape
             hg, err = None, None
@@ -671,7 +723,7 @@ def main():
             def hstep(_):
                 call.select()
                 call.attend()
-                hg.gather(call.out)
+                last[tr] = hg.gather(call.out)
             elh = timed_steps(comm, hstep, args.steps, max(1, args.warmup))
             elh, _, _, _, _ = parallel.reduce_step_stats(elh, 0.0, 0.0, 0.0, comm.stat_dev)
             # a p2p wait that gave up (a peer's slab did not arrive within 4 s) leaves stale data behind a valid-looking time:
@@ -682,8 +734,19 @@ def main():
             except Exception as e:  # noqa: BLE001
                 terr = repr(e)[:200]
             if comm.all_ok(terr is None):
-                gather[tr] = dict(ms_per_step=round(elh / args.steps * 1e3, 4),
-                                  value=round(rec["flops"] / (elh / args.steps) / 1e12, 3))
+                ok_h, why_h = verified(last.pop(tr))       # (synchronised by hg.check() / the closing barrier of timed_steps)
+                if ok_h:
+                    gather[tr] = dict(ms_per_step=round(elh / args.steps * 1e3, 4),
+                                      value=round(rec["flops"] / (elh / args.steps) / 1e12, 3), verified=True)
+                    cr = None
+                    try:
+                        cr = hg.comm_ranks()
+                    except Exception:  # noqa: BLE001  (an RCCL without ncclCommCount: the record just lacks the field)
+                        pass
+                    if cr is not None:
+                        gather[tr]["comm_ranks"] = cr
+                else:
+                    gather[tr] = {"error": why_h, "verified": False}
             else:
                 gather[tr] = {"error": terr or "a wait timed out on another rank"}
             hg.close()
@@ -721,10 +784,12 @@ def main():
             extras["api"] = api_record(comm, wl, spec, q, k, v, args.steps, args.warmup, rec["ms_per_step"],
                                        not args.no_processor)
         regs = {}
+        cur_cent = REGIMES[main_regime][0]     # which centroid model q, k, v currently hold
         for rg in REGIMES:
             if rg == main_regime:
                 continue
-            if REGIMES[rg][0] != REGIMES[main_regime][0]:
+            if REGIMES[rg][0] != cur_cent:
+                cur_cent = REGIMES[rg][0]
                 del call
                 q = k = v = None
                 torch.cuda.empty_cache()
@@ -733,16 +798,16 @@ def main():
             else:
                 r2 = run_regime(comm, args, wl, rg, q, k, v, spec, max(5, args.steps // 2), 2)
             peak_ = MFMA_FP8_PEAK_TFLOPS if args.qkv_fp8 else MFMA_BF16_PEAK_TFLOPS
-            regs[rg] = dict(neighbors=r2["neighbors"], p_remain=r2["p_remain"],
+            regs[rg] = dict(neighbors=r2["neighbors"], p_remain=r2["p_remain"], top_k=r2["top_k"],
                             kept_block_fraction=round(r2["kept_block_fraction"], 4),
                             ms_per_step=round(r2["ms_per_step"], 4), value=round(r2["value"], 3),
                             k5_ms=round(r2["k5_ms"], 4), k5_tflops=round(r2["k5_tflops"], 2),
                             k5_frac=round(r2["k5_tflops"] / peak_, 4), select_pass_ms=round(r2["select_pass_ms"], 4))
-            tb, _ = load_traffic(f"r04_k5_traffic_{rg}{'_fp8' if args.qkv_fp8 else ''}.json")
+            tb, _ = load_traffic(f"r05_k5_traffic_{rg}{'_fp8' if args.qkv_fp8 else ''}.json")
             regs[rg]["traffic"] = tb
         extras["regimes"] = regs
         if not args.qkv_fp8 and args.workload == "hunyuan_720p_128f":
-            # (`call`, q, k, v now hold the locality regime: the last one of REGIMES)
+            # (q, k, v now hold the spatially smooth inputs of the last regimes; fp8_records builds its own locality call)
             try:
                 extras["fp8"] = fp8_records(comm, args, call, q, k, v, spec, wl, dev)
             except Exception as e:  # noqa: BLE001
@@ -753,20 +818,21 @@ def main():
         return
 
     peak = MFMA_FP8_PEAK_TFLOPS if args.qkv_fp8 else MFMA_BF16_PEAK_TFLOPS
-    tname = f"r04_k5_traffic_{main_regime}{'_fp8' if args.qkv_fp8 else ''}.json"
+    tname = f"r05_k5_traffic_{main_regime}{'_fp8' if args.qkv_fp8 else ''}.json"
     traffic, tnote = (None, "N > 1: traffic is collected at N = 1")
-    if world == 1 and args.workload == "hunyuan_720p_128f":
-        traffic, tnote = load_traffic(tname)
+    if world == 1:
+        traffic, tnote = load_traffic(tname) if args.workload == "hunyuan_720p_128f" else (None, "no committed traffic json for this workload")
         if not args.no_extras and not args.no_live_traffic and not comm.one_device:
             torch.cuda.synchronize()
-            live, lnote = measure_traffic_live(main_regime, args.qkv_fp8)
+            live, lnote = measure_traffic_live(main_regime, args.qkv_fp8, workload=args.workload)
             if live is not None:
                 committed = traffic
                 traffic, tnote = live, lnote + (f"; committed profiles/{tname}: {committed:.4g}" if committed else "")
                 for rg, rr in (extras.get("regimes") or {}).items():      # the other regimes' launches, the same way
-                    lv, ln = measure_traffic_live(rg, args.qkv_fp8)
+                    lv, ln = measure_traffic_live(rg, args.qkv_fp8, workload=args.workload)
                     if lv is not None:
                         rr["traffic"], rr["traffic_note"] = lv, "measured in this run; " + ln.split("; ")[-1]
+                        rr["l2_hit_rate"] = float(ln.rsplit("l2_hit_rate ", 1)[-1])
             else:
                 tnote = f"live measurement failed ({lnote}); " + tnote
     per_rank_ms = [round(x, 3) for x in rec["per_rank_ms"]]
@@ -781,7 +847,8 @@ def main():
                                f"(p_remain={rec['p_remain']}, neighbors={rec['neighbors']})",
                    "kept_block_fraction": round(rec["kept_block_fraction"], 4), "heads_per_gpu": H_local,
                    "dense_equivalent_tflops": round(4.0 * S * S * D * H / (rec["elapsed"] / args.steps) / 1e12, 1),
-                   "parallelism": f"head-shard x{world}", "per_rank_ms": per_rank_ms,
+                   "parallelism": f"head-shard x{world}", "world_size": (comm.dist.get_world_size() if comm.dist is not None else 1),
+                   "per_rank_ms": per_rank_ms,
                    "imbalance": round(max(per_rank_ms) / (sum(per_rank_ms) / len(per_rank_ms)), 4),
                    "gather_output": gather},
         "roofline": {"kernel": "bsfwd_fp8_kernel (K5 block_sparse_fwd_fp8)" if args.qkv_fp8 else

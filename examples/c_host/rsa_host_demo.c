@@ -28,7 +28,7 @@ int main(int argc, char** argv) {
     const size_t n = (size_t)B * H * S * D, bytes = n * 2;
 
     rsa_layout lay;
-    if (rsa_version() < 310) {   /* this host was built against the 0.3.1 header (rsa_buffers: 15 members; block-scaled fp8 operands) */
+    if (rsa_version() < 500) {   /* this host was built against the 0.5.0 header (rsa_buffers: 15 members + tpart_bytes) */
         fprintf(stderr, "librsa_hip %d is older than the header this demo was built with\n", rsa_version());
         return 1;
     }

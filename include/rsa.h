@@ -89,6 +89,11 @@ typedef struct rsa_buffers {
      * walks of the LAST, partial generation of sparse query blocks, split over the workgroup slots that generation would
      * leave idle (head dim 128; merged, rectified and stored by a second combine kernel): */
     float* tpart;     /* [BH * (NB_total - NBv) * RSA_TEXT_SPLIT + RSA_TAIL_PIECES, 128, D + 2]  unnormalised O, then (m, l) per query row */
+    /* (since 0.5.0; not a buffer: RSA_NUM_BUFFERS stays 15) bytes the caller allocated behind tpart.  rsa_carve_workspace
+     * fills it; a host that sets tpart by hand must set it too: K5 clamps the text split and the tail split to what fits,
+     * and a non-NULL tpart with tpart_bytes == 0 is refused (RSA_ERR_WORKSPACE) instead of trusted -- the formula above grew
+     * in 0.4.0, and a buffer sized by an older header would otherwise be overrun. */
+    size_t tpart_bytes;
 } rsa_buffers;
 #define RSA_NUM_BUFFERS 15
 #define RSA_TEXT_SPLIT 32
@@ -96,6 +101,14 @@ typedef struct rsa_buffers {
 
 /* Library identification: returns 10000*major + 100*minor + patch. */
 int rsa_version(void);
+
+/* Process-global switch (default 0).  K5 plans two things from the SIZE OF THE LAUNCH: how many pieces the dense text rows
+ * are split into (32 on grids of fewer than 8 generations, else 16) and whether the walks of the last, partial generation are
+ * split over its idle slots.  Both change the summation order of the rows they touch, so a head-sharded run (3 heads per
+ * rank) and the unsharded one (24 heads) agree on those rows within rounding, not byte for byte.  on != 0 plans both per
+ * head (16 text pieces, no tail split): every rank then produces exactly the bytes the unsharded call produces for its
+ * heads, at 3-5 % of K5 on short grids.  Returns the previous value. */
+int rsa_set_shard_invariant(int on);
 
 /* Bytes needed for each rsa_buffers member, written in member order into sizes[RSA_NUM_BUFFERS], and their sum
  * (each rounded up to 256 B) into *total.  Lets a caller carve one workspace.  Replaces the ~25 temporaries
@@ -289,6 +302,9 @@ int rsa_dense_causal_fwd_fp8(int B, int H, int Sq, int Sk, int D, int dtype, rsa
 int rsa_comm_unique_id(void* id128);
 int rsa_comm_create(int world, int rank, const void* id128, void** comm);
 int rsa_comm_destroy(void* comm);
+/* The rank count the communicator itself reports (ncclCommCount): lets a launcher record that the collective really spans the
+ * ranks it believes it does (since 0.5.0). */
+int rsa_comm_count(void* comm, int* ranks);
 
 /* All-gather of O along the head axis: local [rows][local_row_bytes] on every rank -> full [rows][world*local_row_bytes]
  * on every rank (rank r's bytes at column offset r*local_row_bytes) = ncclAllGather into `staging`

@@ -201,7 +201,9 @@ def clear_buffer_cache() -> None:
 
 
 def _c_buffers(bufs: Dict[str, torch.Tensor]) -> RsaBuffers:
-    return RsaBuffers(*[bufs[n].data_ptr() if bufs[n].numel() else None for n in BUFFER_NAMES])
+    tp = bufs["tpart"]
+    return RsaBuffers(*[bufs[n].data_ptr() if bufs[n].numel() else None for n in BUFFER_NAMES],
+                      tp.numel() * tp.element_size())
 
 
 def neighbor_on_device(block_neighbor_list, NBv: int, device) -> Optional[torch.Tensor]:

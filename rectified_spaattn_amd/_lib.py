@@ -47,7 +47,8 @@ NUM_BUFFERS = len(BUFFER_NAMES)
 
 
 class RsaBuffers(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_void_p) for n in BUFFER_NAMES]
+    # the 15 buffers, then the capacity of the last one in bytes (rsa.h 0.5.0: a non-NULL tpart must declare it)
+    _fields_ = [(n, ctypes.c_void_p) for n in BUFFER_NAMES] + [("tpart_bytes", ctypes.c_size_t)]
 
 
 class RsaFp8Operands(ctypes.Structure):
@@ -89,6 +90,8 @@ def lib():
     L.rsa_rel_l1.restype = i32
     L.rsa_set_tuning.argtypes = [ctypes.c_char_p, i32]
     L.rsa_set_tuning.restype = i32
+    L.rsa_set_shard_invariant.argtypes = [i32]
+    L.rsa_set_shard_invariant.restype = i32
     L.rsa_buffer_bytes.argtypes = [P(RsaLayout), P(sz * NUM_BUFFERS), P(sz)]
     L.rsa_carve_workspace.argtypes = [P(RsaLayout), vp, sz, P(RsaBuffers)]
     L.rsa_pool_stats.argtypes = [P(RsaLayout), RsaTensor4, RsaTensor4, RsaTensor4, P(RsaBuffers), vp]
@@ -118,6 +121,7 @@ def lib():
     L.rsa_comm_unique_id.argtypes = [vp]
     L.rsa_comm_create.argtypes = [i32, i32, vp, P(vp)]
     L.rsa_comm_destroy.argtypes = [vp]
+    L.rsa_comm_count.argtypes = [vp, P(i32)]
     L.rsa_allgather_heads.argtypes = [vp, i32, vp, vp, vp, i64, i64, vp]
     L.rsa_allgather_heads_p2p.argtypes = [i32, i32, vp, P(vp), P(vp), i64, i64, vp]
     L.rsa_p2p_state_bytes.restype = i32
@@ -128,7 +132,7 @@ def lib():
     L.rsa_ipc_export.argtypes = [vp, vp]
     L.rsa_ipc_open.argtypes = [vp, i32, P(vp)]
     L.rsa_ipc_close.argtypes = [vp]
-    for name in ("rsa_comm_unique_id", "rsa_comm_create", "rsa_comm_destroy", "rsa_allgather_heads",
+    for name in ("rsa_comm_unique_id", "rsa_comm_create", "rsa_comm_destroy", "rsa_comm_count", "rsa_allgather_heads",
                  "rsa_allgather_heads_p2p", "rsa_ipc_export", "rsa_ipc_open", "rsa_ipc_close", "rsa_ipc_offset",
                  "rsa_p2p_state_alloc", "rsa_p2p_state_free", "rsa_p2p_state_timeout"):
         getattr(L, name).restype = i32
@@ -141,7 +145,7 @@ def lib():
                  "rsa_dense_fwd", "rsa_dense_masked_fwd", "rsa_estimate_pr_gain"):
         getattr(L, name).restype = i32
     # kernel-variant switches for A/B runs and the variant tests; rsa_set_tuning works only under RSA_TUNING=1
-    for key in ("k5_tsplit", "k3_prefix", "k5_w64", "k5_gsync", "k5_text_last", "k5_tail_split"):
+    for key in ("k5_tsplit", "k3_prefix", "k5_w64", "k5_gsync", "k5_gsync_ratio", "k5_text_last", "k5_tail_split"):
         val = os.environ.get("RSA_" + key.upper())
         if val is not None:
             check_rc = L.rsa_set_tuning(key.encode(), int(val))
@@ -153,11 +157,11 @@ def lib():
 
 EXPORTED = ("rsa_version", "rsa_buffer_bytes", "rsa_carve_workspace", "rsa_pool_stats", "rsa_pooled_scores",
             "rsa_select_mask", "rsa_compensation", "rsa_block_sparse_fwd", "rsa_rectified_attention",
-            "rsa_dense_fwd", "rsa_dense_causal_fwd", "rsa_dense_masked_fwd", "rsa_estimate_pr_gain", "rsa_status_string", "rsa_last_hip_error", "rsa_set_tuning", "rsa_gilbert_mapping",
+            "rsa_dense_fwd", "rsa_dense_causal_fwd", "rsa_dense_masked_fwd", "rsa_estimate_pr_gain", "rsa_status_string", "rsa_last_hip_error", "rsa_set_tuning", "rsa_set_shard_invariant", "rsa_gilbert_mapping",
             "rsa_gilbert_block_neighbors", "rsa_permute_tokens", "rsa_qk_norm_rope", "rsa_qk_layernorm_rope", "rsa_norm_rope_heads", "rsa_fp8_operand_bytes",
             "rsa_carve_fp8_operands", "rsa_quantize_fp8", "rsa_block_sparse_fwd_fp8", "rsa_rectified_attention_fp8",
             "rsa_pool_stats_fp8", "rsa_dense_fp8_bytes", "rsa_dense_fwd_fp8", "rsa_dense_causal_fwd_fp8", "rsa_rel_l1",
-            "rsa_comm_unique_id", "rsa_comm_create", "rsa_comm_destroy", "rsa_allgather_heads",
+            "rsa_comm_unique_id", "rsa_comm_create", "rsa_comm_destroy", "rsa_comm_count", "rsa_allgather_heads",
             "rsa_allgather_heads_p2p", "rsa_p2p_state_bytes", "rsa_p2p_state_alloc", "rsa_p2p_state_free", "rsa_p2p_state_timeout", "rsa_ipc_export", "rsa_ipc_open", "rsa_ipc_close",
             "rsa_ipc_offset")
 

@@ -87,6 +87,7 @@ struct AttnArgs {
     float qk_scale;
     unsigned* gsync;                          // 64-row kernel: start-alignment counters of this launch (rsa_attn_kernel64.hip), or null
     int gsync_gen;                            // ... workgroups an XCD holds at a time (a generation)
+    int gsync_ratio;                          // ... walks that keep 1 / gsync_ratio of the keys or more are not held (default 5)
 #ifdef RSA_K5_DIAG
     unsigned long long* dbg;                  // diagnostics build only (make diag): per-wave s_memtime sums, see tools/diag_k5.py
 #endif
@@ -124,9 +125,9 @@ __device__ __forceinline__ GsyncTicket rsa_gsync_announce(unsigned* gsync, int g
 }
 
 // (every thread of the workgroup calls it: ends in a workgroup barrier)
-__device__ __forceinline__ void rsa_gsync_wait(unsigned* gsync, GsyncTicket tk, int n_items, int nb_total) {
+__device__ __forceinline__ void rsa_gsync_wait(unsigned* gsync, GsyncTicket tk, int n_items, int nb_total, int ratio = 5) {
     if (!tk.cnt) return;
-    if (threadIdx.x == 0 && 5 * n_items < nb_total &&
+    if (threadIdx.x == 0 && ratio * n_items < nb_total &&
         __hip_atomic_load(gsync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
         const int bound = 32 + 3 * n_items;      // x (s_sleep 32 + one L2 round trip) ~ 2 us; a kept block takes ~3.4 us
         int it = 0;
@@ -142,13 +143,14 @@ __device__ __forceinline__ void rsa_gsync_wait(unsigned* gsync, GsyncTicket tk, 
 // wait, profiles/r04_k5_gsync.md) -- bits of the tuning key "k5_gsync"; wg_per_cu = what the runtime says fits
 // (hipOccupancyMaxActiveBlocksPerMultiprocessor); *gen = workgroups per XCD generation
 unsigned* rsa_gsync_slot(int which, unsigned grid, int wg_per_cu, hipStream_t s, int* gen);
+int rsa_gsync_ratio();    // tuning key "k5_gsync_ratio" (default 5: walks keeping a fifth of the keys or more are not held)
 int rsa_wg_per_cu(const void* kernel, int block, size_t lds_bytes);   // cached hipOccupancyMaxActiveBlocksPerMultiprocessor; 0 = unknown
 // launch `kernel` with the launch's alignment counters filled into its argument struct (sparse lists only: dense walks share their keys anyway)
 #define RSA_LAUNCH_GSYNC(which, kernel, args, MODE_IS_SPARSE, grid, block, lds_bytes, stream) \
     do { \
         auto kfn_ = kernel; \
         auto aa_ = args; \
-        aa_.gsync = nullptr; aa_.gsync_gen = 64; \
+        aa_.gsync = nullptr; aa_.gsync_gen = 64; aa_.gsync_ratio = rsa_gsync_ratio(); \
         if (MODE_IS_SPARSE) \
             aa_.gsync = rsa_gsync_slot(which, (grid).x, rsa_wg_per_cu(reinterpret_cast<const void*>(kfn_), block, lds_bytes), stream, \
                                        &aa_.gsync_gen); \

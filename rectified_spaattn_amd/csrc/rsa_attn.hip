@@ -13,6 +13,9 @@ static int g_k5_tsplit = 1;     // 1 = split-KV for the text query blocks when t
 extern int g_rsa_k3_prefix;
 static int g_k5_tail_split = 1; // 64-row kernel: the last, partial generation's walks split over its idle slots (k5w_map)
 static int g_k5_text_last = 1;  // 64-row kernel: split text-row pieces at the end of the grid (rsa_attn_kernel64.hip::k5w_map)
+static int g_shard_invariant = 0; // rsa_set_shard_invariant: nothing about a row's arithmetic may depend on the size of the launch
+static int g_k5_gsync_ratio = 5; // aligned starts: walks that keep 1 / ratio of the keys or more are not held back
+int rsa_gsync_ratio() { return g_k5_gsync_ratio; }
 static int g_k5_gsync = 1;      // aligned starts of the sparse walks (rsa_attn.h): bit 0 = in the 64-row kernel, bit 1 = in the 32-row and e4m3 kernels
 #ifdef RSA_K5_FORMS
 extern int g_rsa_k5_form;
@@ -47,6 +50,7 @@ extern "C" int rsa_set_tuning(const char* key, int value) {
     if (strcmp(key, "k5_tsplit") == 0) { g_k5_tsplit = value; return RSA_OK; }
     if (strcmp(key, "k5_w64") == 0) { g_k5_w64 = value; return RSA_OK; }
     if (strcmp(key, "k5_gsync") == 0) { g_k5_gsync = value; return RSA_OK; }
+    if (strcmp(key, "k5_gsync_ratio") == 0) { g_k5_gsync_ratio = value; return RSA_OK; }
     if (strcmp(key, "k5_text_last") == 0) { g_k5_text_last = value; return RSA_OK; }
     if (strcmp(key, "k5_tail_split") == 0) { g_k5_tail_split = value; return RSA_OK; }
     if (strcmp(key, "fp8_variant") == 0) { rsa_set_fp8_variant(value); return RSA_OK; }
@@ -110,6 +114,23 @@ int rsa_launch_text_combine(const float* tpart, unsigned short* out, long osb, l
     return rsa_launch_status();
 }
 int rsa_text_split_enabled() { return g_k5_tsplit; }
+int rsa_shard_invariant() { return g_shard_invariant; }
+extern "C" int rsa_set_shard_invariant(int on) {
+    const int prev = g_shard_invariant;
+    g_shard_invariant = on != 0;
+    return prev;
+}
+// How many pieces the partial buffer has room for per text block (capacity in bytes declared by the caller, rsa_buffers.tpart_bytes)
+int rsa_text_split_capacity(size_t tpart_bytes, int BH, int ntq, int D) {
+    const size_t per = (size_t)BH * (size_t)(ntq > 0 ? ntq : 1) * RSA_BLOCK * (size_t)(D + 2) * sizeof(float);
+    const size_t n = tpart_bytes / per;
+    return n > (size_t)RSA_TEXT_SPLIT ? RSA_TEXT_SPLIT : (int)n;
+}
+// Room for the tail pieces behind the text region (which always starts RSA_TEXT_SPLIT pieces per text block in)
+bool rsa_tail_fits(size_t tpart_bytes, int BH, int ntq, int D, int tail_n, int tail_p) {
+    const size_t blk = (size_t)RSA_BLOCK * (size_t)(D + 2) * sizeof(float);
+    return ((size_t)BH * (size_t)ntq * RSA_TEXT_SPLIT + (size_t)tail_n * (size_t)tail_p) * blk <= tpart_bytes;
+}
 int rsa_text_last_enabled() { return g_k5_text_last; }
 
 // Tail split of the 64-row kernel (rsa_attn_kernel64.hip::k5w_map): merge the tail_p partials of every tail block, then what the
@@ -167,7 +188,7 @@ int rsa_launch_tail_combine(const float* part, unsigned short* out, long osb, lo
 // the plan of a tail split (see launch_attn): n_sparse = BH x NBp sparse workgroups, n_heavy_pad text pieces behind them
 int rsa_plan_tail_split(long n_sparse, long n_heavy_pad, int* tail_first, int* tail_n, int* tail_p) {
     *tail_first = *tail_n = *tail_p = 0;
-    if (!g_k5_tail_split) return 0;
+    if (!g_k5_tail_split || g_shard_invariant) return 0;
     const long full = n_sparse / 512, T = n_sparse % 512;
     const long room = 512 - n_heavy_pad;
     const long P = T > 0 ? (room / T < 4 ? room / T : 4) : 0;
@@ -231,9 +252,10 @@ int rsa_wg_per_cu(const void* kernel, int block, size_t lds_bytes) {
     return n;
 }
 
-static int launch_attn(AttnArgs& a, int BH, int D, int dtype, hipStream_t s) {
+static int launch_attn(AttnArgs& a, int BH, int D, int dtype, size_t tpart_bytes, hipStream_t s) {
     const int ntq = a.NQB - a.NBv;
-    a.gsync = nullptr; a.gsync_gen = 64;
+    if (a.tpart && tpart_bytes == 0) return RSA_ERR_WORKSPACE;   // capacity not declared (rsa_buffers.tpart_bytes, 0.5.0)
+    a.gsync = nullptr; a.gsync_gen = 64; a.gsync_ratio = 5;
     // split-KV for the dense text rows: without it one workgroup walks every key block of a text query block (902 at the
     // HunyuanVideo shape = 10 kept lists) -- hidden among 21 600 sparse blocks on one GPU, the critical path when the
     // heads are sharded over 8
@@ -244,8 +266,11 @@ static int launch_attn(AttnArgs& a, int BH, int D, int dtype, hipStream_t s) {
         // 16 pieces per text block; 32 (RSA_TEXT_SPLIT, what tpart is sized for) on grids of fewer than 8 generations, where the
         // pieces of 0.6 of a sparse walk's life would be the last to finish behind a split tail (and the combine pass that
         // doubles with them is still small)
-        const int cap = (long)BH * ((a.NBv + 7) & ~7) < 8 * 512 ? RSA_TEXT_SPLIT : 16;
+        int cap = ((long)BH * ((a.NBv + 7) & ~7) < 8 * 512 && !g_shard_invariant) ? RSA_TEXT_SPLIT : 16;
+        const int room = rsa_text_split_capacity(tpart_bytes, BH, ntq, D);   // what the caller's buffer holds
+        if (cap > room) cap = room;
         a.tsplit = sp > cap ? cap : sp;
+        if (a.tsplit < 2) a.tsplit = 1;
         a.tper = (n_txt_items + a.tsplit - 1) / a.tsplit;
     }
     const int n_heavy = ntq > 0 ? BH * ntq * a.tsplit : 0;
@@ -265,7 +290,10 @@ static int launch_attn(AttnArgs& a, int BH, int D, int dtype, hipStream_t s) {
         // the pieces AND the text-row pieces behind them must fit the 512 slots together: otherwise whatever starts late (0.6 of a
         // life for a text piece) ends the launch as late as the unsplit tail did (measured: 3 heads of the headline shape, 456
         // pieces + 96 text pieces: 1.92 ms against 1.88 unsplit)
-        if (rsa_plan_tail_split((long)BH * a.NBp, a.n_heavy_pad, &a.tail_first, &a.tail_n, &a.tail_p)) {
+        if (rsa_plan_tail_split((long)BH * a.NBp, a.n_heavy_pad, &a.tail_first, &a.tail_n, &a.tail_p) &&
+            !rsa_tail_fits(tpart_bytes, BH, ntq, D, a.tail_n, a.tail_p))
+            a.tail_first = a.tail_n = a.tail_p = 0;
+        if (a.tail_n > 0) {
             a.tail_part = a.tpart + (long)BH * ntq * RSA_TEXT_SPLIT * RSA_BLOCK * (D + 2);
             nblocks = (long)a.tail_first + (long)a.tail_n * a.tail_p + a.n_heavy_pad;
         }
@@ -321,7 +349,7 @@ extern "C" int rsa_block_sparse_fwd(const rsa_layout* l, rsa_tensor4 q, rsa_tens
 #ifdef RSA_K5_DIAG
     a.dbg = reinterpret_cast<unsigned long long*>(g_dbg_ptr);
 #endif
-    return launch_attn(a, l->B * l->H, l->D, l->dtype, static_cast<hipStream_t>(stream));
+    return launch_attn(a, l->B * l->H, l->D, l->dtype, buf->tpart_bytes, static_cast<hipStream_t>(stream));
 }
 
 static int dense_fwd(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
@@ -347,7 +375,7 @@ static int dense_fwd(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4
 #ifdef RSA_K5_DIAG
     a.dbg = nullptr;
 #endif
-    return launch_attn(a, B * H, D, dtype, static_cast<hipStream_t>(stream));
+    return launch_attn(a, B * H, D, dtype, 0, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int rsa_dense_fwd(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k,

@@ -55,7 +55,7 @@ struct Attn8Args {
     float* tpart;        // split-KV partials of the text query blocks (layout of rsa_attn.hip's combine kernel) or null
     int tsplit, tper;
     unsigned* gsync;     // aligned starts (rsa_attn.h): this launch's counters or null
-    int gsync_gen;
+    int gsync_gen, gsync_ratio;
     int heavy_last;      // the split text-row pieces behind the sparse blocks in the grid
     int tail_first, tail_n, tail_p;   // tail split (rsa_attn.hip::launch_attn, rsa_attn_kernel64.hip::k5w_map): head dim 128 only
     float* tail_part;
@@ -66,6 +66,8 @@ int rsa_launch_text_combine(const float* tpart, unsigned short* out, long osb, l
                             int ntq, int tsplit, int q_text_end, int Sq, int BH, int dtype, hipStream_t s);
 int rsa_text_split_enabled();
 int rsa_text_last_enabled();
+int rsa_text_split_capacity(size_t tpart_bytes, int BH, int ntq, int D);
+bool rsa_tail_fits(size_t tpart_bytes, int BH, int ntq, int D, int tail_n, int tail_p);
 int rsa_plan_tail_split(long n_sparse, long n_heavy_pad, int* tail_first, int* tail_n, int* tail_p);
 int rsa_launch_tail_combine(const float* part, unsigned short* out, long osb, long osh, long oss, int H, int NBv, int NBp,
                             int tail_first, int tail_n, int tail_p, const float* R, const float* comp, int Sq, int dtype,
@@ -480,7 +482,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     };
 
     // ---------------- prologue + main loop ----------------
-    if (tail < 0 && qblk < a.NBv) rsa_gsync_wait(a.gsync, gs_tk, n_items, a.NB_total);   // aligned starts (off by default here)
+    if (tail < 0 && qblk < a.NBv) rsa_gsync_wait(a.gsync, gs_tk, n_items, a.NB_total, a.gsync_ratio);   // aligned starts (off by default here)
     f32x16 SA[2], SB[2];
     float mxA = -INFINITY, mxB = -INFINITY;
     int key0 = 0;
@@ -609,13 +611,17 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
 }
 
 int g_fp8_variant = 0;
-int launch_attn8(Attn8Args& a, int BH, int D8, hipStream_t s) {
+int launch_attn8(Attn8Args& a, int BH, int D8, size_t tpart_bytes, hipStream_t s) {
     const int ntq = a.NQB - a.NBv;
+    if (a.tpart && tpart_bytes == 0) return RSA_ERR_WORKSPACE;   // capacity not declared (rsa_buffers.tpart_bytes, 0.5.0)
     const int n_txt_items = (a.kv_text_valid + RSA_BLOCK - 1) / RSA_BLOCK;
     a.tsplit = 1; a.tper = n_txt_items;
     if (a.mode == MODE_SPARSE && ntq > 0 && a.tpart && rsa_text_split_enabled() && n_txt_items >= 32) {
         const int sp = n_txt_items / 16;
-        a.tsplit = sp > 16 ? 16 : sp;        // (tpart has room for RSA_TEXT_SPLIT = 32; the 2-byte kernel uses them on short grids)
+        int cap = rsa_text_split_capacity(tpart_bytes, BH, ntq, D8);   // (sized for RSA_TEXT_SPLIT = 32 by rsa_buffer_bytes; the 2-byte kernel uses them on short grids)
+        if (cap > 16) cap = 16;
+        a.tsplit = sp > cap ? cap : sp;
+        if (a.tsplit < 2) a.tsplit = 1;
         a.tper = (n_txt_items + a.tsplit - 1) / a.tsplit;
     }
     const int n_heavy = ntq > 0 ? BH * ntq * a.tsplit : 0;
@@ -629,7 +635,10 @@ int launch_attn8(Attn8Args& a, int BH, int D8, hipStream_t s) {
     // SIMD the split measured +1.6 % on Wan2.2-TI2V and -2.3 % at 3 heads of the HunyuanVideo shape, where the text pieces end the
     // launch either way: profiles/r04_k5_tail_split.txt)
     if (D8 == 128 && a.mode == MODE_SPARSE && a.tpart && n_heavy == 0 &&
-        rsa_plan_tail_split((long)BH * a.NBp, a.n_heavy_pad, &a.tail_first, &a.tail_n, &a.tail_p)) {
+        rsa_plan_tail_split((long)BH * a.NBp, a.n_heavy_pad, &a.tail_first, &a.tail_n, &a.tail_p) &&
+        !rsa_tail_fits(tpart_bytes, BH, ntq, D8, a.tail_n, a.tail_p))
+        a.tail_first = a.tail_n = a.tail_p = 0;
+    if (a.tail_n > 0) {
         a.tail_part = a.tpart + (long)BH * ntq * RSA_TEXT_SPLIT * RSA_BLOCK * (D8 + 2);
         nblocks = (long)a.tail_first + (long)a.tail_n * a.tail_p + a.n_heavy_pad;
     }
@@ -689,7 +698,7 @@ extern "C" int rsa_block_sparse_fwd_fp8(const rsa_layout* l, const rsa_fp8_opera
     a.q_text_end = l->NBv * RSA_BLOCK + l->q_text_valid;
     a.q_split = 0; a.kv_split = 0; a.causal = 0;
     a.out_fp16 = l->dtype == RSA_FP16;
-    return launch_attn8(a, l->B * l->H, l->D, static_cast<hipStream_t>(stream));
+    return launch_attn8(a, l->B * l->H, l->D, buf->tpart_bytes, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int rsa_rectified_attention_fp8(const rsa_layout* l, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
@@ -738,7 +747,7 @@ static int dense_fwd_fp8(int B, int H, int Sq, int Sk, int D, int dtype, rsa_ten
     a.kv_valid = Sk; a.kv_text_valid = Sk; a.q_text_end = 0;
     a.q_split = q_split; a.kv_split = kv_split; a.causal = causal;
     a.out_fp16 = dtype == RSA_FP16;
-    return launch_attn8(a, B * H, D, s);
+    return launch_attn8(a, B * H, D, 0, s);
 }
 
 extern "C" int rsa_dense_fwd_fp8(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k,

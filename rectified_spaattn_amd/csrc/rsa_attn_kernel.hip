@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
     };
 
     // ---------------- prologue + main loop ----------------
-    rsa_gsync_wait(a.gsync, gs_tk, n_items, a.NB_total);   // aligned starts: in front of the first staging instruction
+    if (qblk < a.NBv || a.mode != MODE_SPARSE) rsa_gsync_wait(a.gsync, gs_tk, n_items, a.NB_total, a.gsync_ratio);   // aligned starts: in front of the first staging instruction (text-row pieces do not wait, as in the 64-row and e4m3 kernels)
     f32x16 SA, SB;
     float mxA = -INFINITY, mxB = -INFINITY;
     int key0 = 0;

@@ -387,7 +387,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // aligned starts: in front of the first staging instruction (the pieces of a split tail and of the text rows do not wait:
     // short walks over different parts of the key range, the last workgroups of the launch)
-    if (tail < 0 && qblk < a.NBv) rsa_gsync_wait(a.gsync, gs_tk, n_items, a.NB_total);
+    if (tail < 0 && qblk < a.NBv) rsa_gsync_wait(a.gsync, gs_tk, n_items, a.NB_total, a.gsync_ratio);
 
     // ---------------- prologue: half-tiles K(0..3), V(0..2); scores of sub-step 0 ----------------
     if (n_sub > 0) {

@@ -28,6 +28,7 @@ typedef int (*fn_get_id)(rsa_nccl_id*);
 typedef int (*fn_init_rank)(void**, int, rsa_nccl_id, int);
 typedef int (*fn_destroy)(void*);
 typedef int (*fn_allgather)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef int (*fn_count)(void*, int*);
 
 struct Rccl {
     void* h = nullptr;
@@ -35,6 +36,7 @@ struct Rccl {
     fn_init_rank init_rank = nullptr;
     fn_destroy destroy = nullptr;
     fn_allgather allgather = nullptr;
+    fn_count count = nullptr;
     bool tried = false;
 };
 Rccl g_rccl;
@@ -53,6 +55,7 @@ bool load_rccl() {
     g_rccl.init_rank = (fn_init_rank)dlsym(g_rccl.h, "ncclCommInitRank");
     g_rccl.destroy = (fn_destroy)dlsym(g_rccl.h, "ncclCommDestroy");
     g_rccl.allgather = (fn_allgather)dlsym(g_rccl.h, "ncclAllGather");
+    g_rccl.count = (fn_count)dlsym(g_rccl.h, "ncclCommCount");
     if (!g_rccl.get_id || !g_rccl.init_rank || !g_rccl.destroy || !g_rccl.allgather) g_rccl.allgather = nullptr;
     return g_rccl.allgather != nullptr;
 }
@@ -95,6 +98,12 @@ extern "C" int rsa_comm_create(int world, int rank, const void* id128, void** co
     if (g_rccl.init_rank(&c, world, id, rank) != 0) return RSA_ERR_LAUNCH;
     *comm = c;
     return RSA_OK;
+}
+
+extern "C" int rsa_comm_count(void* comm, int* ranks) {
+    if (!comm || !ranks) return RSA_ERR_BAD_ARG;
+    if (!load_rccl() || !g_rccl.count) return RSA_ERR_UNSUPPORTED;
+    return g_rccl.count(comm, ranks) == 0 ? RSA_OK : RSA_ERR_LAUNCH;
 }
 
 extern "C" int rsa_comm_destroy(void* comm) {

@@ -840,7 +840,8 @@ extern "C" int rsa_carve_workspace(const rsa_layout* l, void* ws, size_t ws_byte
     out->vbar = (float*)ptrs[4]; out->scores = (float*)ptrs[5]; out->unrel = (uint8_t*)ptrs[6];
     out->probs = (float*)ptrs[7]; out->w = (float*)ptrs[8]; out->R = (float*)ptrs[9]; out->comp = (float*)ptrs[10];
     out->bitmask = (uint32_t*)ptrs[11]; out->cols = (int32_t*)ptrs[12]; out->counts = (int32_t*)ptrs[13];
-    out->tpart = (l->NB_total > l->NBv) ? (float*)ptrs[14] : nullptr;
+    out->tpart = (float*)ptrs[14];   // every layout has the tail region (layouts without text rows too: Wan)
+    out->tpart_bytes = sizes[14];
     return RSA_OK;
 }
 
@@ -1041,4 +1042,4 @@ extern "C" const char* rsa_status_string(int status) {
 int g_rsa_last_hip_error = 0;
 extern "C" const char* rsa_last_hip_error(void) { return hipGetErrorString((hipError_t)g_rsa_last_hip_error); }
 
-extern "C" int rsa_version(void) { return 400; }  // 0.4.0: rsa_p2p_state_alloc / _free / _timeout (fine-grained exchange state), rsa_dense_masked_fwd; 0.3.1: block-scaled fp8 operands (rsa_fp8_operands.scales = E8M0 words + K mean), K1 writes the images, rsa_fp8_images gone; 0.3.0: rsa_buffers has 15 members, rsa_allgather_heads_p2p is stream-ordered (+ state buffers), rsa_ipc_offset
+extern "C" int rsa_version(void) { return 500; }  // 0.5.0: rsa_buffers.tpart_bytes (declared capacity of the partial buffer; carve_workspace hands tpart out for every layout), rsa_set_shard_invariant; 0.4.0: rsa_p2p_state_alloc / _free / _timeout (fine-grained exchange state), rsa_dense_masked_fwd; 0.3.1: block-scaled fp8 operands (rsa_fp8_operands.scales = E8M0 words + K mean), K1 writes the images, rsa_fp8_images gone; 0.3.0: rsa_buffers has 15 members, rsa_allgather_heads_p2p is stream-ordered (+ state buffers), rsa_ipc_offset

@@ -20,6 +20,16 @@ def head_shard(num_heads: int, world_size: int, rank: int) -> Tuple[int, int]:
     return rank * per, per
 
 
+def set_shard_invariant(on: bool = True) -> bool:
+    """Process-global (rsa_set_shard_invariant, include/rsa.h).  K5 plans the split of the dense text rows (32 pieces on short
+    grids, else 16) and the split of the last, partial generation's walks from the SIZE OF THE LAUNCH, so a rank that holds 3
+    heads and the unsharded 24-head call sum the rows those plans touch in different orders: equal within rounding, not byte
+    for byte.  With the switch on both are planned per head and every rank produces exactly the unsharded call's bytes for its
+    heads (3-5 % of K5 on short grids).  Returns the previous setting."""
+    from . import _lib
+    return bool(_lib.lib().rsa_set_shard_invariant(1 if on else 0))
+
+
 def gather_heads(out_local: torch.Tensor, group=None) -> torch.Tensor:
     """out_local [B, S, H_local, D] (or [B, S, H_local*D]) on every rank -> [B, S, H*D] on every rank, heads
     in rank order (== the unsharded layout of the reference's output, hunyuan :383-387)."""
@@ -31,6 +41,51 @@ def gather_heads(out_local: torch.Tensor, group=None) -> torch.Tensor:
     parts: List[torch.Tensor] = [torch.empty_like(flat) for _ in range(world)]
     dist.all_gather(parts, flat, group=group)
     return torch.cat(parts, dim=-1)
+
+
+CHECK_ROWS = 8   # sampled rows per head in head_checksums
+
+
+def head_checksums(o: torch.Tensor, D: int) -> torch.Tensor:
+    """Per-head fingerprints of an attention output, fp64 [H, 2 + CHECK_ROWS * D]: sum, sum of squares and CHECK_ROWS whole
+    rows (positions spread over the sequence, the same for every head).  o: [B, S, H, D] or [B, S, H*D].  What a rank computes
+    from its LOCAL heads must reappear in every rank's gathered buffer: sums within 1e-9 relative (the reduction order of the
+    two layouts may differ), the sampled rows exactly."""
+    B, S = o.shape[:2]
+    x = o.reshape(B, S, -1, D)
+    H = x.shape[2]
+    xf = x.to(torch.float64)
+    rows = torch.tensor([(S * (2 * i + 1)) // (2 * CHECK_ROWS) for i in range(CHECK_ROWS)], device=o.device)
+    samp = xf[B - 1].index_select(0, rows).permute(1, 0, 2).reshape(H, CHECK_ROWS * D)
+    return torch.cat([xf.sum(dim=(0, 1, 3))[:, None], (xf * xf).sum(dim=(0, 1, 3))[:, None], samp], dim=1)
+
+
+def exchange_checksums(local: torch.Tensor, stat_device, group=None) -> torch.Tensor:
+    """[H_local, C] on every rank -> [H, C] on every rank, heads in rank order (a small all_gather on the control plane)."""
+    t = local.to(stat_device)
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return t
+    parts = [torch.empty_like(t) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(parts, t, group=group)
+    return torch.cat(parts, dim=0)
+
+
+def verify_gathered(full: torch.Tensor, want: torch.Tensor, D: int) -> Optional[str]:
+    """Checks a gathered [B, S, H*D] buffer against the fingerprints every rank published for its heads.  Returns None if every
+    head matches, else a short description of the first mismatch (which head -- i.e. which source rank's slab -- and how)."""
+    got = head_checksums(full, D).to(want.device)
+    if got.shape != want.shape:
+        return f"gathered buffer has {got.shape[0]} heads, expected {want.shape[0]}"
+    scale = want[:, :2].abs().clamp_min(1e-30)
+    bad_sum = ((got[:, :2] - want[:, :2]).abs() / scale > 1e-9).any(dim=1)
+    bad_row = (got[:, 2:] != want[:, 2:]).any(dim=1)
+    bad = bad_sum | bad_row | ~torch.isfinite(got).all(dim=1)
+    if not bool(bad.any()):
+        return None
+    h = int(torch.nonzero(bad)[0])
+    return (f"head {h} of the gathered buffer differs from what its rank computed (sum {got[h, 0].item():.6e} vs "
+            f"{want[h, 0].item():.6e}, sampled rows {'differ' if bool(bad_row[h]) else 'equal'}); "
+            f"{int(bad.sum())} of {bad.numel()} heads wrong")
 
 
 def reduce_step_stats(elapsed_s: float, flops: float, pairs: float, k5_ms: float, device, group=None,
@@ -199,6 +254,14 @@ class HeadGather:
                                                            st), "rsa_allgather_heads_p2p")
                 self.full = self._fulls[par]
         return self.full
+
+    def comm_ranks(self) -> Optional[int]:
+        """rccl transport: the rank count the RCCL communicator itself reports (ncclCommCount); None for p2p."""
+        if self.transport != "rccl" or not self.comm:
+            return None
+        n = ctypes.c_int32(0)
+        self._check(self.L.rsa_comm_count(self.comm, ctypes.byref(n)), "rsa_comm_count")
+        return int(n.value)
 
     def check(self) -> None:
         """p2p: raises if a wait inside an exchange gave up (a peer did not deliver within 4 s).  Synchronises."""

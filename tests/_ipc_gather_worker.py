@@ -40,6 +40,17 @@ def main():
     for step, out in enumerate(outs):
         want = (full_ref.to(dev) + step).reshape(B, S, world * Hl * D)
         assert torch.equal(out, want), f"rank {rank} step {step}: gathered rows differ"
+    # the self-check of bench.py --gpus N on the same exchange: fingerprints of the local heads over the control plane (gloo),
+    # recomputed from the gathered buffer on every rank; a buffer missing a peer's slab must fail it
+    sums = parallel.exchange_checksums(parallel.head_checksums(mine + 5, D), torch.device("cpu"))
+    assert sums.shape == (world * Hl, 2 + parallel.CHECK_ROWS * D)
+    assert parallel.verify_gathered(outs[5], sums, D) is None
+    msg = parallel.verify_gathered(outs[4], sums, D)          # the previous gather's buffer: every slab is stale by 1.0
+    assert isinstance(msg, str) and "head 0" in msg, msg
+    broken = outs[5].clone()
+    broken.view(B, S, world * Hl, D)[:, :, (1 - rank) * Hl:(2 - rank) * Hl] = 0      # the peer's slab never arrived
+    msg = parallel.verify_gathered(broken, sums, D)
+    assert isinstance(msg, str) and f"head {(1 - rank) * Hl}" in msg, msg
     hg.close()
     dist.barrier()
     if rank == 0:

@@ -1,6 +1,11 @@
-"""Head sharding: a rank that holds heads [h0, h0+n) computes, for those heads, exactly the bytes the
-unsharded call computes -- bitmask, kept lists, R, compensation and O.  (No statistic crosses heads: softmax, sort and
-the cumulative rule are per (b, h, query block); top_k, p and the neighbour matrix are head-independent.)"""
+"""Head sharding: a rank that holds heads [h0, h0+n) computes, for those heads, exactly the unsharded call's
+bitmask, kept lists, R and compensation -- always (no statistic crosses heads: softmax, sort and the cumulative rule are per
+(b, h, query block); top_k, p and the neighbour matrix are head-independent) -- and exactly its O wherever K5 planned the row's
+walk the same way in both launches.  Two plans depend on the size of the launch (rsa_attn.hip::launch_attn): the tail split
+(which query blocks of the last, partial generation are walked in pieces) and the piece count of the dense text rows (32 on
+short grids, 16 otherwise); the rows they touch agree within rounding.  `parallel.set_shard_invariant(True)` (C:
+rsa_set_shard_invariant) plans both per head: byte-identical O everywhere, which the second test pins at a shape where one
+side splits.  The first test's shape (8 x 48 = 384 workgroups) is below one generation: nothing is ever split there."""
 import pytest
 import torch
 
@@ -32,6 +37,62 @@ def test_head_shard_equals_full_run(layout):
         cnt = pb["counts"]
         valid = torch.arange(spec.NB_total, device=dev)[None, None, :] < cnt[..., None]
         assert torch.equal(torch.where(valid, pb["cols"], -1), torch.where(valid, fb["cols"][h0:h0 + hl], -1))
+
+
+def _tail_blocks(H, spec):
+    """[H, NBv] bool: the query blocks a launch of H heads walks in pieces (the plan of rsa_plan_tail_split)."""
+    NBp = (spec.NBv + 7) // 8 * 8
+    n_sparse = H * NBp
+    full, T = divmod(n_sparse, 512)
+    touched = torch.zeros(H, spec.NBv, dtype=torch.bool)
+    if full < 1 or T == 0 or min(512 // T, 4) < 2:
+        return touched
+    for vv in range(full * 512, n_sparse):
+        h, j = divmod(vv, NBp)
+        qb = (j & 7) * (NBp // 8) + (j >> 3)
+        if qb < spec.NBv:
+            touched[h, qb] = True
+    return touched
+
+
+def test_head_shard_where_one_side_splits_its_tail():
+    """8 heads x 72 query blocks = 576 workgroups: the unsharded launch splits the 64 walks of its second generation 4 ways;
+    a rank with 4 heads (288 workgroups, less than a generation) splits nothing.  Default: the selection results and every
+    block neither launch split are byte-identical, the split blocks agree within two output ulps.  With
+    set_shard_invariant(True): byte-identical everywhere (the invariant the first test documents, at a production-like
+    shape)."""
+    from bench import gen_qkv
+    from rectified_spaattn_amd import _core, parallel
+    H, D, world, nbv = 8, 128, 2, 72
+    S = nbv * 128
+    dev = torch.device(DEV)
+    q, k, v = gen_qkv(H, 0, S, S, D, dev, seed=23)
+    spec = _core.LayoutSpec.wan(S, 2)
+    touched_full = _tail_blocks(H, spec)
+    assert int(touched_full.sum()) == 64 and int(_tail_blocks(H // world, spec).sum()) == 0
+    for invariant in (False, True):
+        prev = parallel.set_shard_invariant(invariant)
+        try:
+            full, fb = _core.rectified_attention(q, k, v, spec, 12, 0.05, None, return_parts=True, shape_xfuse=True)
+            for rank in range(world):
+                h0, hl = parallel.head_shard(H, world, rank)
+                part, pb = _core.rectified_attention(q[:, h0:h0 + hl], k[:, h0:h0 + hl], v[:, h0:h0 + hl], spec, 12, 0.05,
+                                                     None, return_parts=True, shape_xfuse=True)
+                torch.cuda.synchronize()
+                for name in ("bitmask", "counts", "R", "comp"):
+                    assert torch.equal(pb[name], fb[name][h0:h0 + hl]), f"rank {rank}: {name} differs"
+                want = full[:, :, h0:h0 + hl]
+                if invariant:
+                    assert torch.equal(part, want), f"rank {rank}: O differs with shard invariance on"
+                    continue
+                diff = (part.float() - want.float()).abs()[0].reshape(nbv, 128, hl, D).amax(dim=(1, 3)).t().cpu()   # [hl, NBv]
+                tf = touched_full[h0:h0 + hl]
+                assert (diff[~tf] == 0).all(), f"rank {rank}: a block neither launch split differs"
+                assert float(diff.max()) <= 2 * 2.0 ** -7 * max(1.0, float(want.float().abs().max()))
+                if tf.any():
+                    assert (diff[tf] > 0).any(), "the split blocks came out byte-identical: is the tail split still planned?"
+        finally:
+            parallel.set_shard_invariant(prev)
 
 
 @pytest.mark.parametrize("transport", ["rccl", "p2p"])
@@ -73,6 +134,9 @@ def test_bench_two_ranks_on_one_device():
     assert rec["value"] > 0 and "one_device_test" in rec["config"]
     g = rec["config"]["gather_output"]
     assert g is not None and "p2p" in g and "ms_per_step" in g["p2p"], g
+    # every exchange checked itself: the fingerprints each rank published for its heads reappear in the gathered buffers
+    assert g.get("verified") is True and g["p2p"].get("verified") is True, g
+    assert rec["config"]["world_size"] == 2
 
 
 def test_p2p_gather_two_processes_one_device():

@@ -88,6 +88,50 @@ def test_without_the_partial_buffer_or_with_a_full_last_generation_nothing_is_sp
     q, k, v = _qkv(8, 64 * 128, 51)
     spec = _core.LayoutSpec.wan(64 * 128, 0)
     assert torch.equal(_run(q, k, v, spec, 10, 0), _run(q, k, v, spec, 10, 1))
+    # 8 x 80 = 640 workgroups: 128 walks in the tail -- split 3 ways when the buffers carry tpart, whole when they do not
+    q, k, v = _qkv(8, 80 * 128, 52)
+    spec = _core.LayoutSpec.wan(80 * 128, 0)
+    whole = _run(q, k, v, spec, 10, 0)
+    assert not torch.equal(whole, _run(q, k, v, spec, 10, 1)), "the case has no tail to split"
+
+    def staged(tpart, nbytes):
+        c = _core.StagedCall(q, k, v, spec, 10, 0.05)
+        c.cb.tpart, c.cb.tpart_bytes = tpart(c), nbytes(c)
+        c.select()
+        o = c.attend()
+        torch.cuda.synchronize()
+        return o
+    full_bytes = lambda c: c.bufs["tpart"].numel() * 4            # noqa: E731
+    assert torch.equal(staged(lambda c: None, lambda c: 0), whole), "without tpart every walk must stay whole"
+    # a partial buffer too small for the 128 x 3 pieces: the split is dropped, not overrun (rsa_buffers.tpart_bytes, 0.5.0)
+    assert torch.equal(staged(lambda c: c.bufs["tpart"].data_ptr(), lambda c: 100 * 128 * 130 * 4), whole)
+    assert not torch.equal(staged(lambda c: c.bufs["tpart"].data_ptr(), full_bytes), whole)
+    # ... and a non-NULL tpart whose capacity is not declared is refused
+    from rectified_spaattn_amd import _lib
+    with pytest.raises(_lib.RsaError, match="workspace"):
+        staged(lambda c: c.bufs["tpart"].data_ptr(), lambda c: 0)
+
+
+def test_text_split_is_clamped_to_the_declared_capacity():
+    """Hunyuan layout, 3 heads, 72 key blocks (4 text pieces by default: 72 / 16): with room for only 2 pieces per text block
+    the text rows are split 2 ways instead -- same result within rounding, nothing written past the declared bytes (the region
+    behind them stays untouched)."""
+    from rectified_spaattn_amd import _core
+    H, nbv = 3, 70
+    S = (nbv + 2) * 128
+    q, k, v = _qkv(H, S, 61)
+    spec = _core.LayoutSpec.hunyuan(S, S - 56)
+    ref = _core.rectified_attention(q, k, v, spec, 8, 0.05, None, shape_xfuse=True)
+    c = _core.StagedCall(q, k, v, spec, 8, 0.05)
+    per_piece = 128 * 130 * 4
+    cap = H * 2 * 2 * per_piece                   # 2 pieces per text block
+    c.bufs["tpart"].fill_(-7.0)
+    c.cb.tpart_bytes = cap
+    c.select()
+    o = c.attend()
+    torch.cuda.synchronize()
+    assert (c.bufs["tpart"].view(-1)[cap // 4:] == -7.0).all(), "K5 wrote past the declared capacity of tpart"
+    assert float((o.float() - ref.float()).abs().max()) <= 2 * 2.0 ** -7 * max(1.0, float(ref.float().abs().max()))
 
 
 def test_split_tail_in_the_e4m3_kernel():

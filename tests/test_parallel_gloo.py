@@ -21,8 +21,21 @@ def _worker(rank, world, port, q):
         local = full[:, :, h0:h0 + hl].contiguous()
         got = parallel.gather_heads(local)
         ok_gather = torch.equal(got, full.reshape(B, S, H * D))
+        # the self-check bench.py --gpus N runs on every exchange: fingerprints of the LOCAL heads, published over the control
+        # plane, must reappear in the gathered buffer -- and a buffer with a stale / swapped / partly written slab must not pass
+        g = torch.Generator().manual_seed(3)
+        big = torch.randn(2, 64, H, 8, generator=g).to(torch.bfloat16)
+        mine = big[:, :, h0:h0 + hl].contiguous()
+        want = parallel.exchange_checksums(parallel.head_checksums(mine, 8), "cpu")
+        gathered = parallel.gather_heads(mine)
+        ok_chk = parallel.verify_gathered(gathered, want, 8) is None
+        swapped = gathered.view(2, 64, H, 8)[:, :, [3, 4, 5, 0, 1, 2]].reshape(2, 64, H * 8)      # the ranks' slabs exchanged
+        stale = gathered.clone(); stale.view(2, 64, H, 8)[1, 40:, 4] = 0                          # the tail of one head's rows missing
+        onebit = gathered.clone().view(torch.int16); onebit[0, 7, 5 * 8 + 3] ^= 1                   # one flipped bit outside the sampled rows
+        ok_neg = all(isinstance(parallel.verify_gathered(x, want, 8), str)
+                     for x in (swapped, stale, onebit.view(torch.bfloat16), gathered[:, :, :-8]))
         el, fl, pr, k5, per = parallel.reduce_step_stats(1.0 + rank, 10.0 * (rank + 1), 3.0, 0.5 + rank, "cpu")
-        q.put((rank, ok_gather, el, fl, pr, k5, per))
+        q.put((rank, ok_gather and ok_chk and ok_neg, el, fl, pr, k5, per))
     finally:
         dist.destroy_process_group()
 

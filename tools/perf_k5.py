@@ -12,7 +12,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from bench import REGIMES, WORKLOADS, gen_inputs, gen_qkv, make_neighbors, make_spec  # noqa: E402
+from bench import REGIMES, WORKLOADS, gen_inputs, gen_qkv, make_neighbors, make_spec, regime_top_k  # noqa: E402
 from rectified_spaattn_amd import _core  # noqa: E402
 
 
@@ -31,12 +31,13 @@ def timeit(fn, n=5, warm=2):
 
 
 def regime_call(regime, H, dev, fp8=False):
-    """StagedCall of the Hunyuan bench workload in one of bench.REGIMES (inputs generated on the device)."""
-    wl = WORKLOADS["hunyuan_720p_128f"]
+    """StagedCall of a bench workload (RSA_PERF_WORKLOAD, default the Hunyuan one) in one of bench.REGIMES (inputs generated on
+    the device)."""
+    wl = WORKLOADS[os.environ.get("RSA_PERF_WORKLOAD", "hunyuan_720p_128f")]
     spec = make_spec(wl)
     cent, nbr_kind, p = REGIMES[regime]
-    q, k, v = gen_inputs(wl, H, 0, dev, cent)
-    call = _core.StagedCall(q, k, v, spec, wl["top_k"], p, make_neighbors(wl, spec, nbr_kind), qkv_fp8=fp8)
+    q, k, v = gen_inputs(wl, H if H else wl["H"], 0, dev, cent, D=wl.get("D", 128))
+    call = _core.StagedCall(q, k, v, spec, regime_top_k(wl, regime), p, make_neighbors(wl, spec, nbr_kind), qkv_fp8=fp8)
     return call, spec
 
 
@@ -87,13 +88,13 @@ def main():
         print(f"select pass: {msel:.3f} ms")
         del q, k, v, call
     if "pmcsel" in what:  # mask-selection pass only, for rocprofv3 --pmc passes over K1..K4
-        call, spec = regime_call(os.environ.get("RSA_PERF_REGIME", "r2"), 24, dev)
+        call, spec = regime_call(os.environ.get("RSA_PERF_REGIME", "r2"), int(os.environ.get("RSA_PERF_H", "0")), dev)
         for _ in range(3):
             call.select()
         torch.cuda.synchronize()
         return
     if "pmc" in what:  # few launches, for rocprofv3 --pmc passes (env RSA_PERF_REGIME selects the regime)
-        H = 24
+        H = int(os.environ.get("RSA_PERF_H", "0"))   # 0 = the workload's head count
         fp8 = os.environ.get("RSA_PERF_FP8", "0") == "1"
         call, spec = regime_call(os.environ.get("RSA_PERF_REGIME", "r2"), H, dev, fp8=fp8)
         if os.environ.get("RSA_PERF_NODENSE", "0") == "1":
@@ -109,7 +110,7 @@ def main():
             torch.cuda.synchronize()
             return
         Sd = 16384
-        qd = torch.randn(1, H, Sd, D, device=dev).to(torch.bfloat16)
+        qd = torch.randn(1, 24, Sd, D, device=dev).to(torch.bfloat16)
         for _ in range(2):
             _core.dense_attention(qd, qd, qd)
         torch.cuda.synchronize()
