@@ -25,6 +25,7 @@ import types
 
 os.environ["TRITON_INTERPRET"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+FIRST_SEED = 20251212   # the op_* cases try FIRST_SEED, FIRST_SEED + 1, ...: a fixture whose meta says seed == FIRST_SEED had no rejected seed
 sys.path.insert(0, ROOT)
 REF = "/root/reference"
 
@@ -110,7 +111,7 @@ def main():
     torch.set_num_threads(8)
     outdir = os.path.dirname(os.path.abspath(__file__))
 
-    def run_case(name, variant, B, H, S, D, top_k, p, nb_width, seed, smooth=0.0, **kw):
+    def run_case(name, variant, B, H, S, D, top_k, p, nb_width, seed, smooth=0.0, rejected=None, **kw):
         """Runs the reference builder + whole operator; returns dict of arrays or None if oracle disagrees."""
         q, k, v = synth.structured_qkv(seed, B, H, S, D, smooth=smooth)
         tq, tk, tv = (torch.from_numpy(x.copy()) for x in (q, k, v))
@@ -186,9 +187,28 @@ def main():
         print(f"{name}: seed {seed} mask/gapr equal={ok} max|dprobs|={max(margin):.2e} max|dO|={err_o:.2e} "
               f"kept={one_hot.mean():.3f} unrel={nogapr.mean():.3f}")
         if not ok:
-            return None
+            # a seed on which reference and oracle disagree is NOT silently skipped: the rows that differ and how close their
+            # decisions were go into the accepted fixture's meta (the op_* fixtures were made by trying seeds;
+            # every committed one was accepted at the FIRST seed, tests/test_oracle_golden.py pins that)
+            rows = []
+            for b in range(B):
+                for h in range(H):
+                    sel = parts[b * H + h]
+                    bad = np.nonzero((sel["kept"] != one_hot[b, h]).any(1) | (sel["unrel"] != nogapr[b, h]).any(1))[0]
+                    for i in bad[:8]:
+                        pr = np.sort(probs[b, h, i].astype(np.float64))[::-1]
+                        cs = np.cumsum(pr.astype(np.float32), dtype=np.float32)
+                        n = int(sel["n_needed"][i]) if "n_needed" in sel else 0
+                        rows.append(dict(b=b, h=h, row=int(i),
+                                         kept_bits_differ=int((sel["kept"][i] != one_hot[b, h, i]).sum()),
+                                         gapr_bits_differ=int((sel["unrel"][i] != nogapr[b, h, i]).sum()),
+                                         cumsum_minus_p_around_n=[float(cs[j] - p) for j in range(max(0, n - 2), min(len(cs), n + 1))],
+                                         adjacent_sorted_prob_gaps_around_n=[float(pr[j] - pr[j + 1]) for j in
+                                                                             range(max(0, n - 2), min(len(pr) - 1, n + 1))],
+                                         max_dprobs=float(np.abs(sel["probs"][i] - probs[b, h, i]).max())))
+            return dict(rejected=dict(seed=seed, rows=rows))
         meta = dict(variant=variant, B=B, H=H, S=S, D=D, top_k=top_k, p=p, nb_width=nb_width, seed=seed,
-                    smooth=smooth, **kw)
+                    smooth=smooth, rejected_seeds=list(rejected or []), **kw)
         out_store = out.astype(np.float16) if S > 8192 else out.astype(np.float32)   # big cases: fp16 storage
         return dict(meta=np.array(repr(meta)), one_hot=np.packbits(one_hot, axis=-1), probs=probs,
                     nogapr=np.packbits(nogapr, axis=-1), out=out_store,
@@ -227,9 +247,10 @@ def main():
     for name, variant, B, H, S, D, top_k, p, nbw, kw in cases:
         kw = dict(kw)
         smooth = kw.pop("smooth", 0.0)
-        for seed in range(20251212, 20251212 + 20):
+        rejected = []
+        for seed in range(FIRST_SEED, FIRST_SEED + 20):
             try:
-                res = run_case(name, variant, B, H, S, D, top_k, p, nbw, seed, smooth=smooth, **kw)
+                res = run_case(name, variant, B, H, S, D, top_k, p, nbw, seed, smooth=smooth, rejected=rejected, **kw)
             except (TypeError, RuntimeError, ValueError) as e:
                 if B == 1:
                     raise
@@ -238,9 +259,11 @@ def main():
                 print(f"{name}: the reference cannot run this layout with B={B}: {type(e).__name__}: {str(e)[:100]}")
                 res = "unsupported"
                 break
-            if res is not None:
-                np.savez_compressed(os.path.join(outdir, f"op_{name}.npz"), **res)
-                break
+            if "rejected" in res:
+                rejected.append(res["rejected"])
+                continue
+            np.savez_compressed(os.path.join(outdir, f"op_{name}.npz"), **res)
+            break
         else:
             raise SystemExit(f"no agreeing seed for {name}")
         if isinstance(res, str):

@@ -102,6 +102,48 @@ def test_flux_4096_full_size():
     _check_config("flux", _core.LayoutSpec.flux(S, 512), orc.layout_flux(S, 512), 4, 51, 0.3, None, [3, 511])
 
 
+def test_flux_4096_whole_head_output_against_the_oracles_mask():
+    """at full size O was only checked on 2-3 sampled query blocks.  Here EVERY row of one whole head of BASELINE
+    configs[1] (Flux 4096 x 4096: 512 visual + 4 text blocks) is compared with a dense-masked fp32 reference computed on the
+    device with plain torch ops from the ORACLE's mask, R and comp (the C oracle's select_head on the same inputs; the device's
+    own mask is compared with it bit for bit first): softmax over the kept keys per query block, x R + comp; text rows attend
+    every valid key.  Tolerances = the operator's (bf16: max 2e-2, mean 2e-3)."""
+    from rectified_spaattn_amd import _core
+    S, H, D, top_k, p = 66048, 2, 128, 51, 0.3
+    spec, lay = _core.LayoutSpec.flux(S, 512), orc.layout_flux(S, 512)
+    q, k, v = _gen(H, S, D, 91)
+    out, bufs = _core.rectified_attention(q, k, v, spec, top_k, p, None, return_parts=True, shape_xfuse=True)
+    torch.cuda.synchronize()
+    bh = 1
+    qh, kh, vh = (x[0, bh].float().cpu().numpy() for x in (q, k, v))
+    full = orc.select_head(qh, kh, vh, lay, top_k, p, None)
+    kept = full["kept"].astype(bool)                                   # [NBv, NB_total], the ORACLE's
+    assert np.array_equal(_core.unpack_bitmask(bufs["bitmask"], lay.NB_total)[bh].cpu().numpy(), kept)
+    qf, kf, vf = (x[0, bh].float() for x in (q, k, v))                 # fp32 copies of the 2-byte inputs, on the device
+    scale = float(D) ** -0.5
+    Rv = torch.from_numpy(full["R"]).to(DEV)
+    comp = torch.from_numpy(full["comp"]).to(DEV)
+    ref = torch.zeros(S, D, device=DEV)
+    kb, vb = kf.view(lay.NB_total, 128, D), vf.view(lay.NB_total, 128, D)
+    keptd = torch.from_numpy(kept).to(DEV)
+    for i in range(lay.NBv):
+        sel = torch.nonzero(keptd[i])[:, 0]
+        ks, vs = kb[sel].reshape(-1, D), vb[sel].reshape(-1, D)
+        sc = (qf[i * 128:(i + 1) * 128] @ ks.t()) * scale
+        key_idx = (sel[:, None] * 128 + torch.arange(128, device=DEV)[None]).reshape(-1)
+        sc = sc.masked_fill(key_idx[None, :] >= lay.kv_valid, float("-inf"))
+        ref[i * 128:(i + 1) * 128] = torch.softmax(sc, dim=-1) @ vs * Rv[i] + comp[i][None, :]
+    r0 = lay.NBv * 128                                                 # text rows: exact attention over the valid keys
+    sc = (qf[r0:r0 + lay.q_text_valid] @ kf[:lay.kv_text_valid].t()) * scale
+    ref[r0:r0 + lay.q_text_valid] = torch.softmax(sc, dim=-1) @ vf[:lay.kv_text_valid]
+    got = out[0, :, bh].float()
+    err = (got - ref).abs()
+    assert float(err.max()) <= 2e-2 and float(err.mean()) <= 2e-3, f"whole head: max {float(err.max()):.3e} mean {float(err.mean()):.3e}"
+    # per query block too: no block hides inside the head's mean
+    blk_mean = err.view(lay.NB_total, 128 * D).mean(1)
+    assert float(blk_mean.max()) <= 4e-3, f"worst query block mean error {float(blk_mean.max()):.3e} at block {int(blk_mean.argmax())}"
+
+
 def test_wan21_720p_full_size():
     """BASELINE configs[2]: Wan2.1-T2V 81f 720p, S = 75 600 (padded to 591 blocks), top_k = 147, ffb = 28."""
     from rectified_spaattn_amd import _core

@@ -133,3 +133,26 @@ def test_bit_packing_roundtrip():
     rng = np.random.default_rng(0)
     m = (rng.random((3, 5, 77)) < 0.3).astype(np.uint8)
     assert np.array_equal(orc.unpack_bits(orc.pack_bits(m), 77), m)
+
+
+def test_no_operator_fixture_was_made_by_rejecting_seeds():
+    """make_golden.py tries seeds FIRST_SEED, FIRST_SEED + 1, ... until the oracle and the reference agree on every mask bit.
+    Every committed op_* fixture carries the FIRST seed of that sequence: none was produced by skipping a seed on which the two
+    disagreed (a fixture regenerated after a rejection stores the rejected seeds with the failing rows' margins in its meta, and
+    this test then demands that record)."""
+    import ast
+    import glob
+    import re
+    src = open(os.path.join(GOLDEN, "make_golden.py")).read()
+    first = int(re.search(r"^FIRST_SEED = (\d+)", src, re.M).group(1))
+    files = sorted(glob.glob(os.path.join(GOLDEN, "op_*.npz")))
+    assert len(files) >= 17
+    for f in files:
+        meta = ast.literal_eval(str(np.load(f)["meta"]))
+        skipped = meta["seed"] - first
+        assert skipped >= 0
+        rej = meta.get("rejected_seeds", [])
+        assert len(rej) == skipped, f"{os.path.basename(f)}: seed {meta['seed']} but {len(rej)} rejected seeds recorded"
+        assert [r["seed"] for r in rej] == list(range(first, meta["seed"]))
+        for r in rej:
+            assert r["rows"], "a rejected seed must name the rows that differed and their margins"
