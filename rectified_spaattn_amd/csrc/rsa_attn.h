@@ -87,7 +87,7 @@ struct AttnArgs {
     float qk_scale;
     unsigned* gsync;                          // 64-row kernel: start-alignment counters of this launch (rsa_attn_kernel64.hip), or null
     int gsync_gen;                            // ... workgroups an XCD holds at a time (a generation)
-    int gsync_ratio;                          // ... walks that keep 1 / gsync_ratio of the keys or more are not held (default 5)
+    int gsync_ratio;                          // ... walks that keep 1 / gsync_ratio of the keys or more are not held (default 2)
 #ifdef RSA_K5_DIAG
     unsigned long long* dbg;                  // diagnostics build only (make diag): per-wave s_memtime sums, see tools/diag_k5.py
 #endif
@@ -103,8 +103,9 @@ struct AttnArgs {
 // positions (HunyuanVideo R2, 10 % of the keys kept at random: L2 hit rate 15 % -> 41 %, 116 -> 79 GB over the fabric,
 // which is what bounded that launch: profiles/r04_k5_gsync.md).  Advisory only -- the results do not depend on it: a
 // bounded wait, switched off for the rest of the launch by the first workgroup that runs into the bound (word 0), so
-// kernels of other processes sharing the device cannot stall this one.  Walks that keep more than a fifth of the keys are
-// not held back: they meet in L2 by chance often enough, the wait would only cost them the spread of a generation's ends.
+// kernels of other processes sharing the device cannot stall this one.  Walks that keep half of the keys or more are not held
+// back (round 4 drew that line at a fifth; measured at the reference scripts' operating points in round 5 --
+// profiles/r05_k5_gsync_ratio.txt -- walks of 20 % of the keys gain 2.6 % from the wait, walks of 25 % on Wan2.1's 40 heads 8 %).
 constexpr unsigned RSA_GSYNC_MAXG = 4096;    // generations with a counter (x 8 XCDs x 64 workgroups: 2 M workgroups)
 constexpr int RSA_GSYNC_RING = 8;            // launches in flight with counters of their own
 constexpr size_t RSA_GSYNC_SLOT_WORDS = 8 + 8 * (size_t)RSA_GSYNC_MAXG;
@@ -125,7 +126,7 @@ __device__ __forceinline__ GsyncTicket rsa_gsync_announce(unsigned* gsync, int g
 }
 
 // (every thread of the workgroup calls it: ends in a workgroup barrier)
-__device__ __forceinline__ void rsa_gsync_wait(unsigned* gsync, GsyncTicket tk, int n_items, int nb_total, int ratio = 5) {
+__device__ __forceinline__ void rsa_gsync_wait(unsigned* gsync, GsyncTicket tk, int n_items, int nb_total, int ratio = 2) {
     if (!tk.cnt) return;
     if (threadIdx.x == 0 && ratio * n_items < nb_total &&
         __hip_atomic_load(gsync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
@@ -143,7 +144,7 @@ __device__ __forceinline__ void rsa_gsync_wait(unsigned* gsync, GsyncTicket tk, 
 // wait, profiles/r04_k5_gsync.md) -- bits of the tuning key "k5_gsync"; wg_per_cu = what the runtime says fits
 // (hipOccupancyMaxActiveBlocksPerMultiprocessor); *gen = workgroups per XCD generation
 unsigned* rsa_gsync_slot(int which, unsigned grid, int wg_per_cu, hipStream_t s, int* gen);
-int rsa_gsync_ratio();    // tuning key "k5_gsync_ratio" (default 5: walks keeping a fifth of the keys or more are not held)
+int rsa_gsync_ratio();    // tuning key "k5_gsync_ratio" (default 2: walks keeping half of the keys or more are not held)
 int rsa_wg_per_cu(const void* kernel, int block, size_t lds_bytes);   // cached hipOccupancyMaxActiveBlocksPerMultiprocessor; 0 = unknown
 // launch `kernel` with the launch's alignment counters filled into its argument struct (sparse lists only: dense walks share their keys anyway)
 #define RSA_LAUNCH_GSYNC(which, kernel, args, MODE_IS_SPARSE, grid, block, lds_bytes, stream) \

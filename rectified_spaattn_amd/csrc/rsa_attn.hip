@@ -11,10 +11,13 @@
 // =====================================================================================================
 static int g_k5_tsplit = 1;     // 1 = split-KV for the text query blocks when the partial buffer is given
 extern int g_rsa_k3_prefix;
+extern int g_rsa_k2_v2;
+extern int g_rsa_k2_split;
+extern int g_k2_form;
 static int g_k5_tail_split = 1; // 64-row kernel: the last, partial generation's walks split over its idle slots (k5w_map)
 static int g_k5_text_last = 1;  // 64-row kernel: split text-row pieces at the end of the grid (rsa_attn_kernel64.hip::k5w_map)
 static int g_shard_invariant = 0; // rsa_set_shard_invariant: nothing about a row's arithmetic may depend on the size of the launch
-static int g_k5_gsync_ratio = 5; // aligned starts: walks that keep 1 / ratio of the keys or more are not held back
+static int g_k5_gsync_ratio = 2; // aligned starts: walks that keep 1 / ratio of the keys or more are not held back
 int rsa_gsync_ratio() { return g_k5_gsync_ratio; }
 static int g_k5_gsync = 1;      // aligned starts of the sparse walks (rsa_attn.h): bit 0 = in the 64-row kernel, bit 1 = in the 32-row and e4m3 kernels
 #ifdef RSA_K5_FORMS
@@ -39,6 +42,9 @@ extern "C" int rsa_set_tuning(const char* key, int value) {
     if (!key) return RSA_ERR_BAD_ARG;
     if (!enabled) return RSA_ERR_UNSUPPORTED;
     if (strcmp(key, "k3_prefix") == 0) { g_rsa_k3_prefix = value; return RSA_OK; }
+    if (strcmp(key, "k2_v2") == 0) { g_rsa_k2_v2 = value; return RSA_OK; }
+    if (strcmp(key, "k2_split") == 0) { g_rsa_k2_split = value; return RSA_OK; }
+    if (strcmp(key, "k2_form") == 0) { g_k2_form = value; return RSA_OK; }
 #ifdef RSA_K5_FORMS
     if (strcmp(key, "k5_form") == 0) { g_rsa_k5_form = value; return RSA_OK; }
     if (strcmp(key, "k5w_form") == 0) { g_rsa_k5w_form = value; return RSA_OK; }
@@ -255,7 +261,7 @@ int rsa_wg_per_cu(const void* kernel, int block, size_t lds_bytes) {
 static int launch_attn(AttnArgs& a, int BH, int D, int dtype, size_t tpart_bytes, hipStream_t s) {
     const int ntq = a.NQB - a.NBv;
     if (a.tpart && tpart_bytes == 0) return RSA_ERR_WORKSPACE;   // capacity not declared (rsa_buffers.tpart_bytes, 0.5.0)
-    a.gsync = nullptr; a.gsync_gen = 64; a.gsync_ratio = 5;
+    a.gsync = nullptr; a.gsync_gen = 64; a.gsync_ratio = 2;
     // split-KV for the dense text rows: without it one workgroup walks every key block of a text query block (902 at the
     // HunyuanVideo shape = 10 kept lists) -- hidden among 21 600 sparse blocks on one GPU, the critical path when the
     // heads are sharded over 8

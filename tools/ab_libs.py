@@ -19,7 +19,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from bench import REGIMES, WORKLOADS, gen_inputs, make_neighbors, make_spec  # noqa: E402
+from bench import REGIMES, WORKLOADS, gen_inputs, make_neighbors, make_spec, regime_top_k  # noqa: E402
 from rectified_spaattn_amd import _core, _lib  # noqa: E402
 from rectified_spaattn_amd._lib import RsaLayout, RsaOut4, RsaTensor4  # noqa: E402
 
@@ -28,7 +28,8 @@ FIRST14 = ("qbar", "aq", "kbar", "ak", "vbar", "scores", "unrel", "probs", "w", 
 
 def load(path, nbuf):
     L = ctypes.CDLL(os.path.abspath(path))
-    fields = [(n, ctypes.c_void_p) for n in FIRST14] + [(f"x{i}", ctypes.c_void_p) for i in range(nbuf - 14)]
+    # (builds since 0.5.0 read the capacity of tpart behind the 15 pointers; older builds never look there)
+    fields = [(n, ctypes.c_void_p) for n in FIRST14] + [(f"x{i}", ctypes.c_void_p) for i in range(nbuf - 14)] + [("tpart_bytes", ctypes.c_size_t)]
     Buf = type(f"Buf{nbuf}", (ctypes.Structure,), {"_fields_": fields})
     P = ctypes.POINTER
     L.rsa_block_sparse_fwd.argtypes = [P(RsaLayout), RsaTensor4, RsaTensor4, RsaTensor4, P(Buf), RsaOut4, ctypes.c_void_p]
@@ -49,11 +50,14 @@ def main():
     fp8 = "--fp8" in sys.argv      # K5 on the e4m3 images (rsa_block_sparse_fwd_fp8); builds with the current rsa_fp8_operands only
     dev = torch.device("cuda:0")
     H = int(os.environ.get("RSA_PERF_H", "24"))
-    wl = WORKLOADS["hunyuan_720p_128f"]
+    wl = WORKLOADS[os.environ.get("RSA_PERF_WORKLOAD", "hunyuan_720p_128f")]
+    if "RSA_PERF_H" not in os.environ:
+        H = wl["H"]
     spec = make_spec(wl)
-    cent, nbr_kind, p = REGIMES[os.environ.get("RSA_PERF_REGIME", "r2")]
+    regime = os.environ.get("RSA_PERF_REGIME", "r2")
+    cent, nbr_kind, p = REGIMES[regime]
     q, k, v = gen_inputs(wl, H, 0, dev, cent)
-    call = _core.StagedCall(q, k, v, spec, wl["top_k"], p, make_neighbors(wl, spec, nbr_kind), qkv_fp8=fp8)
+    call = _core.StagedCall(q, k, v, spec, regime_top_k(wl, regime), p, make_neighbors(wl, spec, nbr_kind), qkv_fp8=fp8)
     call.select()
     torch.cuda.synchronize()
     pairs = call.bufs["counts"].sum().item()
@@ -70,7 +74,7 @@ def main():
         extra = [None] * (nbuf - 14)
         if nbuf > 14 and "nots" not in flags:
             extra[-1] = call.bufs["tpart"].data_ptr()
-        cb = Buf(*(ptrs + extra))
+        cb = Buf(*(ptrs + extra + [call.bufs["tpart"].numel() * 4 if extra and extra[-1] else 0]))
         if "o8" in flags:
             raw = torch.empty(call.out.numel() + 4, dtype=call.out.dtype, device=dev)
             out = raw[4:].view(call.out.shape)
