@@ -4,7 +4,6 @@
 // bit for bit.  All of this is HBM/LDS-bound integer-and-fp32 work; no MFMA on purpose.
 #include "rsa_common.h"
 #include "rsa_fp8_emit.h"
-#include "rsa_scores2.h"
 
 // =====================================================================================================
 // K1: pool_stats -- block means (and mean |x - mean|) of Q, K, V in one launch.
@@ -169,62 +168,8 @@ struct ScoreArgs {
 typedef float k2_f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ int ncols_of(const ScoreArgs& a, int mode) { return mode == 0 ? a.NBv : a.n_txt; }
 
-// ---- the GAPR error terms from the 2-byte matrix pipe (SPLIT = true, round 5) ---------------------------------------
-// The contract fixes s = qbar . kbar bit for bit, but of the two error terms only the BYTE !(|s| > |aq . kbar| + |qbar . ak|).
-// With x = hi + lo + rest (hi = bf16(x), lo = bf16(x - hi), |rest| <= 2^-16 |x|) the terms come from three
-// v_mfma_f32_32x32x16_bf16 per 16 k (hi hi + hi lo + lo hi: 192 matrix cycles where the fp32 chain takes 512) with
-//   |e~ - e_chain| <= c_E ||a|| ||b||, c_E = 2^-12: 2^-17 (the fp32 chain's own D roundings) + 3 * 2^-16 (dropped terms of the
-//   split) + 3 D accumulation steps inside the MFMAs at <= 2^-22 each (twice what truncating every step would cost), all relative
-//   to sum |a_k b_k| <= ||a|| ||b||: together < 2^-12.7.
-// The byte is DECIDED when ||s| - t~| exceeds E = c_E (||aq_i|| ||kbar_j|| + ||qbar_i|| ||ak_j||) + the rounding of t~; the few
-// elements inside the band (0.3 % on the bench's inputs) are queued by the wave that met them and recomputed with the exact
-// scalar chains, so the stored bytes are the contract's on every input (vanishing or non-finite operands make the bound NaN:
-// they take the exact path).  tests/test_gpu_select_paths.py compares both forms element by element.
-typedef __bf16 k2_bf16x8 __attribute__((ext_vector_type(8)));
-#define RSA_K2_FIXCAP 128    // queued undecided elements per wave
-
-// k = 16 mm + 8 h + 0..7 of a staged row ([16 even k | 16 odd k]) in k order
-__device__ __forceinline__ void k2_image8(const float* rowp, int mm, int h, float (&x)[8]) {
-    const float4 ev = *reinterpret_cast<const float4*>(rowp + 8 * mm + 4 * h);
-    const float4 od = *reinterpret_cast<const float4*>(rowp + 16 + 8 * mm + 4 * h);
-    x[0] = ev.x; x[1] = od.x; x[2] = ev.y; x[3] = od.y; x[4] = ev.z; x[5] = od.z; x[6] = ev.w; x[7] = od.w;
-}
-__device__ __forceinline__ float k2_split8(const float (&x)[8], k2_bf16x8& hi, k2_bf16x8& lo) {
-    float n2 = 0.0f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const __bf16 hb = (__bf16)x[e];
-        hi[e] = hb;
-        lo[e] = (__bf16)(x[e] - (float)hb);
-        n2 += x[e] * x[e];
-    }
-    return n2;
-}
-// the queued elements of one wave, 64 at a time: both error terms as the contract's k-ordered fmaf chains, the byte from them
-__device__ __noinline__ void k2_flush(const ScoreArgs& a, int bh, int n, const unsigned* fix_idx, const float* fix_s) {
-    const int lane = threadIdx.x & 63, D = a.D;
-    for (int idx = lane; idx < n; idx += 64) {
-        const unsigned u = fix_idx[idx];
-        const int i = (int)(u >> 16), j = (int)(u & 0xFFFF);
-        const float4* pa = reinterpret_cast<const float4*>(a.aq + ((long)bh * a.NBv + i) * D);
-        const float4* pq = reinterpret_cast<const float4*>(a.qbar + ((long)bh * a.NBv + i) * D);
-        const float4* pk = reinterpret_cast<const float4*>(a.kbar + ((long)bh * a.NBv + j) * D);
-        const float4* pb = reinterpret_cast<const float4*>(a.ak + ((long)bh * a.NBv + j) * D);
-        float eq = 0.0f, ek = 0.0f;
-        for (int d4 = 0; d4 < D / 4; ++d4) {
-            const float4 a4 = pa[d4], q4 = pq[d4], k4 = pk[d4], b4 = pb[d4];
-            eq = __builtin_fmaf(a4.x, k4.x, eq); eq = __builtin_fmaf(a4.y, k4.y, eq);
-            eq = __builtin_fmaf(a4.z, k4.z, eq); eq = __builtin_fmaf(a4.w, k4.w, eq);
-            ek = __builtin_fmaf(q4.x, b4.x, ek); ek = __builtin_fmaf(q4.y, b4.y, ek);
-            ek = __builtin_fmaf(q4.z, b4.z, ek); ek = __builtin_fmaf(q4.w, b4.w, ek);
-        }
-        a.unrel[((long)bh * a.NBv + i) * a.NBv + j] = !(fabsf(fix_s[idx]) > (fabsf(eq) + fabsf(ek)));
-    }
-}
-
-template <int MODE, typename Tag, bool SPLIT = false>
-__device__ __forceinline__ void pooled_scores_tile(const ScoreArgs& a, int bh, int i0, int j0, float (*tile)[64 * 36],
-                                                   unsigned* fix_idx = nullptr, float* fix_s = nullptr) {
+template <int MODE, typename Tag>
+__device__ __forceinline__ void pooled_scores_tile(const ScoreArgs& a, int bh, int i0, int j0, float (*tile)[64 * 36]) {
     constexpr int DK = 32, LD = 36, NOP = MODE == 0 ? 4 : 2;   // operands: q, k (, aq, ak)
     const int t = threadIdx.x, lane = t & 63;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -290,7 +235,6 @@ __device__ __forceinline__ void pooled_scores_tile(const ScoreArgs& a, int bh, i
     k2_f32x16 s, eq, ek;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { s[i] = 0.0f; eq[i] = 0.0f; ek[i] = 0.0f; }
-    float nrm[4] = {0.0f, 0.0f, 0.0f, 0.0f};    // SPLIT: squared norms of this lane's half of (qbar_i, aq_i, kbar_j, ak_j)
 
     fetch(0);
     if (!live) {   // this wave's 32 x 32 outputs lie outside the matrix: it only helps staging (same barriers)
@@ -311,34 +255,6 @@ __device__ __forceinline__ void pooled_scores_tile(const ScoreArgs& a, int bh, i
         put();
         __syncthreads();
         if (d0 + DK < D) fetch(d0 + DK);
-        if constexpr (MODE == 0 && SPLIT) {
-            // s on the fp32 pipe (the contract's chain), the two error terms from the bf16 pieces of the same LDS rows
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const float4 q4 = *reinterpret_cast<const float4*>(pa + 4 * m);
-                const float4 k4 = *reinterpret_cast<const float4*>(pb + 4 * m);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.x, k4.x, s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.y, k4.y, s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.z, k4.z, s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.w, k4.w, s, 0, 0, 0);
-            }
-#pragma unroll
-            for (int mm = 0; mm < 2; ++mm) {
-                float x[8];
-                k2_bf16x8 qhi, qlo, ahi, alo, khi, klo, bhi, blo;
-                k2_image8(pa - 16 * h, mm, h, x); nrm[0] += k2_split8(x, qhi, qlo);
-                k2_image8(paa - 16 * h, mm, h, x); nrm[1] += k2_split8(x, ahi, alo);
-                k2_image8(pb - 16 * h, mm, h, x); nrm[2] += k2_split8(x, khi, klo);
-                k2_image8(pba - 16 * h, mm, h, x); nrm[3] += k2_split8(x, bhi, blo);
-                eq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, khi, eq, 0, 0, 0);
-                ek = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qhi, bhi, ek, 0, 0, 0);
-                eq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, klo, eq, 0, 0, 0);
-                ek = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qhi, blo, ek, 0, 0, 0);
-                eq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, khi, eq, 0, 0, 0);
-                ek = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qlo, bhi, ek, 0, 0, 0);
-            }
-            continue;
-        }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const float4 q4 = *reinterpret_cast<const float4*>(pa + 4 * m);
@@ -362,60 +278,6 @@ __device__ __forceinline__ void pooled_scores_tile(const ScoreArgs& a, int bh, i
             }
         }
     }
-    if constexpr (MODE == 0 && SPLIT) {
-        // norms: the two lane halves hold disjoint k; rows of the tile through the wave's own LDS rows (the operand tiles are
-        // dead for this wave only after its last read above; rown lives in the queue's head room instead)
-#pragma unroll
-        for (int x = 0; x < 4; ++x) nrm[x] += __shfl_xor(nrm[x], 32, 64);
-        const bool rbad = !(fminf(nrm[0], nrm[1]) >= 1e-30f) || !(fmaxf(nrm[0], nrm[1]) < 1e30f);
-        const bool cbad = !(fminf(nrm[2], nrm[3]) >= 1e-30f) || !(fmaxf(nrm[2], nrm[3]) < 1e30f);
-        // (a vanishing or non-finite norm becomes NaN: every comparison against the bound is then false -> exact path)
-        const float rq = rbad ? NAN : __builtin_sqrtf(nrm[0]), ra = rbad ? NAN : __builtin_sqrtf(nrm[1]);
-        const float ck = cbad ? NAN : 2.4658203125e-4f * __builtin_sqrtf(nrm[2]);     // 1.01 * 2^-12 ||kbar_j||
-        const float cb = cbad ? NAN : 2.4658203125e-4f * __builtin_sqrtf(nrm[3]);
-        const int j = j0 + 32 * wj + r;
-        const bool jok = j < ncols;
-        int nfix = 0;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int il = (e & 3) + 8 * (e >> 2) + 4 * h;      // row of the wave tile: its norms sit in lane il (either half)
-            const int i = i0 + 32 * wi + il;
-            const bool ok = jok && i < a.NBv;
-            const float sv = s[e];
-            const float t = fabsf(eq[e]) + fabsf(ek[e]);
-            const float mg = fabsf(sv) - t;
-            const float rqi = __shfl(rq, il, 64), rai = __shfl(ra, il, 64);
-            // E = c_E (||aq_i|| ||kbar_j|| + ||qbar_i|| ||ak_j||) + the rounding of t itself (2^-21 t)
-            const float E = __builtin_fmaf(4.76837158203125e-7f, t, __builtin_fmaf(rqi, cb, rai * ck));
-            const bool decided = fabsf(mg) > E;
-            if (ok) {
-                a.scores[((long)bh * a.NBv + i) * a.NS + j] = sv;
-                if (decided) a.unrel[((long)bh * a.NBv + i) * a.NBv + j] = !(fabsf(sv) > t);
-            }
-            const bool und = ok && !decided;
-            const unsigned long long mk = __ballot(und);
-            if (mk != 0ull) {     // wave-uniform
-                const int cnt = __popcll(mk);
-                if (nfix + cnt > RSA_K2_FIXCAP) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    k2_flush(a, bh, nfix, fix_idx, fix_s);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    nfix = 0;
-                }
-                if (und) {
-                    const int pos = nfix + __popcll(mk & ((1ull << lane) - 1ull));
-                    fix_idx[pos] = ((unsigned)i << 16) | (unsigned)j;
-                    fix_s[pos] = sv;
-                }
-                nfix += cnt;
-            }
-        }
-        if (nfix > 0) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            k2_flush(a, bh, nfix, fix_idx, fix_s);
-        }
-        return;
-    }
     // accumulator element e of lane (r, h): row (e & 3) + 8 (e >> 2) + 4 h, column r of the wave tile
     const int colbase = MODE == 0 ? 0 : a.NBv;
     const int j = j0 + 32 * wj + r;
@@ -433,11 +295,9 @@ __device__ __forceinline__ void pooled_scores_tile(const ScoreArgs& a, int bh, i
 // One launch for both column kinds.  1-D grid, XCD-aware: workgroup ids go round-robin over the 8 XCDs, so XCD c takes the
 // c-th contiguous eighth of the (bh, i-tile, j-tile) space -- whole heads per XCD, whose pooled operands (1.8 MB per head)
 // then stay in that L2.  Within a head's row of tiles the visual column tiles come first, then the text-token tiles.
-template <typename Tag, bool SPLIT>
+template <typename Tag>
 __global__ __launch_bounds__(256) void pooled_scores_kernel(ScoreArgs a) {
     __shared__ __attribute__((aligned(16))) float tile[4][64 * 36];
-    __shared__ unsigned fix_idx[SPLIT ? 4 : 1][RSA_K2_FIXCAP];   // per wave: undecided elements (row << 16 | column) ...
-    __shared__ float fix_s[SPLIT ? 4 : 1][RSA_K2_FIXCAP];        // ... and their s
     const int nti = (a.NBv + 63) / 64, ntj0 = (a.NBv + 63) / 64, ntj1 = (a.n_txt + 63) / 64, ntj = ntj0 + ntj1;
     const int per = (int)(gridDim.x >> 3);          // the grid is a multiple of 8
     const int wid = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
@@ -445,8 +305,7 @@ __global__ __launch_bounds__(256) void pooled_scores_kernel(ScoreArgs a) {
     const int bh = wid / (nti * ntj);
     const int rem = wid % (nti * ntj);
     const int i0 = (rem / ntj) * 64, tj = rem % ntj;
-    const int wv_ = SPLIT ? (int)(threadIdx.x >> 6) : 0;
-    if (tj < ntj0) pooled_scores_tile<0, Tag, SPLIT>(a, bh, i0, tj * 64, tile, fix_idx[wv_], fix_s[wv_]);
+    if (tj < ntj0) pooled_scores_tile<0, Tag>(a, bh, i0, tj * 64, tile);
     else pooled_scores_tile<1, Tag>(a, bh, i0, (tj - ntj0) * 64, tile);
 }
 
@@ -474,8 +333,6 @@ struct SelectArgs {
     float thr, scale;
 };
 int g_rsa_k3_prefix = 1;
-int g_rsa_k2_v2 = 0;     // K2: 1 = the barrier-free experiment of round 5 (rsa_scores2.hip: same bits, slower), 0 = pooled_scores_kernel below (tuning key "k2_v2")
-int g_rsa_k2_split = 1;  // pooled_scores_kernel: 1 = GAPR error terms from split-bf16 MFMAs + exact fix-up (round 5), 0 = all three chains on the fp32 pipe (tuning key "k2_split")
 
 __device__ __forceinline__ float wave_tree4(const float (&part)[4]) {
     float u[4];
@@ -1053,24 +910,11 @@ extern "C" int rsa_pooled_scores(const rsa_layout* l, rsa_tensor4 k, const rsa_b
     a.NBv = l->NBv; a.n_txt = l->n_txt; a.NS = l->NBv + l->n_txt; a.D = l->D; a.H = l->H;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int BH = l->B * l->H;
-    if (g_rsa_k2_v2) {   // the form of round 5 (rsa_scores2.hip): same bits, 2/3 of the matrix work on the 2-byte pipe
-        Score2Args a2;
-        a2.qbar = buf->qbar; a2.aq = buf->aq; a2.kbar = buf->kbar; a2.ak = buf->ak;
-        a2.ktxt = a.ktxt; a2.ksb = a.ksb; a2.ksh = a.ksh; a2.kss = a.kss;
-        a2.scores = buf->scores; a2.unrel = buf->unrel;
-        a2.NBv = l->NBv; a2.n_txt = l->n_txt; a2.NS = a.NS; a2.H = l->H; a2.BH = BH;
-        return rsa_launch_pooled_scores2(a2, l->D, l->dtype, s);
-    }
     const unsigned nti = (unsigned)((l->NBv + 63) / 64);
     a.BH = BH;
     dim3 g0((nti * (nti + (unsigned)((l->n_txt + 63) / 64)) * BH + 7) / 8 * 8);
-    if (g_rsa_k2_split && l->NBv <= 65535) {   // rows / columns are queued as 16-bit indices
-        if (l->dtype == RSA_BF16) pooled_scores_kernel<bf16_tag, true><<<g0, 256, 0, s>>>(a);
-        else pooled_scores_kernel<fp16_tag, true><<<g0, 256, 0, s>>>(a);
-    } else {
-        if (l->dtype == RSA_BF16) pooled_scores_kernel<bf16_tag, false><<<g0, 256, 0, s>>>(a);
-        else pooled_scores_kernel<fp16_tag, false><<<g0, 256, 0, s>>>(a);
-    }
+    if (l->dtype == RSA_BF16) pooled_scores_kernel<bf16_tag><<<g0, 256, 0, s>>>(a);
+    else pooled_scores_kernel<fp16_tag><<<g0, 256, 0, s>>>(a);
     return rsa_launch_status();
 }
 
@@ -1198,4 +1042,4 @@ extern "C" const char* rsa_status_string(int status) {
 int g_rsa_last_hip_error = 0;
 extern "C" const char* rsa_last_hip_error(void) { return hipGetErrorString((hipError_t)g_rsa_last_hip_error); }
 
-extern "C" int rsa_version(void) { return 500; }  // 0.5.0: rsa_buffers.tpart_bytes (declared capacity of the partial buffer; carve_workspace hands tpart out for every layout), rsa_set_shard_invariant; 0.4.0: rsa_p2p_state_alloc / _free / _timeout (fine-grained exchange state), rsa_dense_masked_fwd; 0.3.1: block-scaled fp8 operands (rsa_fp8_operands.scales = E8M0 words + K mean), K1 writes the images, rsa_fp8_images gone; 0.3.0: rsa_buffers has 15 members, rsa_allgather_heads_p2p is stream-ordered (+ state buffers), rsa_ipc_offset
+extern "C" int rsa_version(void) { return 500; }  // 0.5.0: rsa_buffers.tpart_bytes (declared capacity of the partial buffer; carve_workspace hands tpart out for every layout), rsa_set_shard_invariant, rsa_comm_count; 0.4.0: rsa_p2p_state_alloc / _free / _timeout (fine-grained exchange state), rsa_dense_masked_fwd; 0.3.1: block-scaled fp8 operands (rsa_fp8_operands.scales = E8M0 words + K mean), K1 writes the images, rsa_fp8_images gone; 0.3.0: rsa_buffers has 15 members, rsa_allgather_heads_p2p is stream-ordered (+ state buffers), rsa_ipc_offset

@@ -156,88 +156,3 @@ def test_k5_32row_kernel_still_serves_head_dim_128(name, dt):
     ulp = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10
     assert np.abs(outs[0] - outs[1]).max() <= ulp * max(1.0, np.abs(ref).max())
 
-
-# ----------------------------------------------------------------------------------------------------------------------
-# K2's forms: "chains" (k2_split = 0: all three products as fp32 MFMA chains, rounds 2-4), "split" (k2_split = 1, the product
-# since round 5: the two GAPR error terms from split-bf16 MFMAs first, the elements inside the error band recomputed with the
-# contract's exact chains) and "v2" (k2_v2 = 1: the barrier-free experiment of rsa_scores2.hip, same arithmetic as "split").
-# Scores and GAPR bytes must equal the all-chains form's (and hence the oracle's, which the parity tests pin) on EVERY element,
-# on any input.
-def _scores(q, k, v, spec, form):
-    from rectified_spaattn_amd import _core, _lib
-    keys = {"chains": (0, 0), "split": (0, 1), "v2": (1, 1)}[form]
-    L = _lib.lib()
-    assert L.rsa_set_tuning(b"k2_v2", keys[0]) == 0 and L.rsa_set_tuning(b"k2_split", keys[1]) == 0
-    try:
-        call = _core.StagedCall(q, k, v, spec, 4, 0.1, None)
-        call.bufs["unrel"].fill_(7)                      # a byte K2 fails to write shows
-        call.bufs["scores"].fill_(float("nan"))
-        call.select_pool()
-        tk = call.t[1]
-        import ctypes
-        _lib.check(call.L.rsa_pooled_scores(ctypes.byref(call.lay), tk, ctypes.byref(call.cb), _core._stream()), "rsa_pooled_scores")
-        torch.cuda.synchronize()
-    finally:
-        L.rsa_set_tuning(b"k2_v2", 0)
-        L.rsa_set_tuning(b"k2_split", 1)
-    return call.bufs["scores"].clone(), call.bufs["unrel"].clone()
-
-
-K2_CASES = [
-    # (layout, H, S, D, dtype, data)
-    ("hunyuan", 3, 37 * 128 + 256, 128, torch.bfloat16, "structured"),
-    ("hunyuan", 2, 115456, 128, torch.bfloat16, "structured"),          # the headline row length: 29 i tiles x 36 j sub-tiles
-    ("wan", 2, 75600, 128, torch.bfloat16, "structured"),               # ragged last block
-    ("wan", 5, 33 * 128 - 19, 128, torch.float16, "iid"),
-    ("cogvideo", 3, 42466, 64, torch.bfloat16, "structured"),           # head dim 64, 226 text tokens
-    ("flux", 2, 20 * 128 + 512, 128, torch.bfloat16, "iid"),
-    ("wan", 2, 9 * 128, 128, torch.bfloat16, "zeros"),                  # every norm vanishes: every element takes the exact path
-    ("wan", 2, 40 * 128, 128, torch.bfloat16, "constant_blocks"),       # aq = ak = 0 exactly, s != 0
-    ("hunyuan", 2, 20 * 128 + 256, 128, torch.bfloat16, "near_ties"),   # |s| engineered close to |eq| + |ek|
-    ("wan", 2, 30 * 128, 128, torch.float16, "huge"),                   # fp16 maxima: sums near overflow in the products
-    ("wan", 1, 3 * 128 - 100, 128, torch.bfloat16, "iid"),              # fewer rows than one tile
-]
-
-
-@pytest.mark.parametrize("case", K2_CASES, ids=[f"{c[0]}-{c[2]}-{c[5]}" for c in K2_CASES])
-def test_k2_forms_agree_on_every_element(case):
-    from bench import gen_qkv
-    from rectified_spaattn_amd import _core
-    layout, H, S, D, dt, data = case
-    dev = torch.device(DEV)
-    g = torch.Generator(device=dev).manual_seed(17)
-    if data == "structured":
-        q, k, v = gen_qkv(H, 0, S, S, D, dev, seed=9)
-        q, k, v = q.to(dt), k.to(dt), v.to(dt)
-    elif data == "iid":
-        q, k, v = (torch.randn(1, H, S, D, generator=g, device=dev).to(dt) for _ in range(3))
-    elif data == "zeros":
-        q = torch.zeros(1, H, S, D, device=dev, dtype=dt); k = torch.zeros_like(q); v = torch.ones_like(q)
-    elif data == "constant_blocks":
-        nb = S // 128
-        cq = torch.randn(1, H, nb, 1, D, generator=g, device=dev).expand(1, H, nb, 128, D).reshape(1, H, S, D)
-        ck = torch.randn(1, H, nb, 1, D, generator=g, device=dev).expand(1, H, nb, 128, D).reshape(1, H, S, D)
-        q, k, v = cq.to(dt).contiguous(), ck.to(dt).contiguous(), torch.randn(1, H, S, D, generator=g, device=dev).to(dt)
-    elif data == "near_ties":
-        # small block means, deviations of matching size: |qbar . kbar| lands in the neighbourhood of the error terms
-        q = (0.25 * torch.randn(1, H, S // 128, 1, D, generator=g, device=dev) + 0.35 * torch.randn(1, H, S // 128, 128, D, generator=g, device=dev)).reshape(1, H, S, D).to(dt)
-        k = (0.25 * torch.randn(1, H, S // 128, 1, D, generator=g, device=dev) + 0.35 * torch.randn(1, H, S // 128, 128, D, generator=g, device=dev)).reshape(1, H, S, D).to(dt)
-        v = torch.randn(1, H, S, D, generator=g, device=dev).to(dt)
-    else:  # huge
-        q = (torch.randn(1, H, S, D, generator=g, device=dev) * 3.0e4).clamp(-65000, 65000).to(dt)
-        k = (torch.randn(1, H, S, D, generator=g, device=dev) * 3.0e4).clamp(-65000, 65000).to(dt)
-        v = torch.randn(1, H, S, D, generator=g, device=dev).to(dt)
-    if layout == "hunyuan":
-        spec = _core.LayoutSpec.hunyuan(S, S - 56)
-    elif layout == "flux":
-        spec = _core.LayoutSpec.flux(S, 512)
-    elif layout == "cogvideo":
-        spec = _core.LayoutSpec.cogvideo(S, 226)
-    else:
-        spec = _core.LayoutSpec.wan(S, 2)
-    s0, u0 = _scores(q, k, v, spec, "chains")
-    assert int(u0.max()) <= 1
-    for form in ("split", "v2"):
-        s1, u1 = _scores(q, k, v, spec, form)
-        assert torch.equal(s0.view(torch.int32), s1.view(torch.int32)), f"pooled scores differ between K2's forms (chains vs {form})"
-        assert torch.equal(u0, u1), f"GAPR bytes differ on {(u0 != u1).sum().item()} elements (chains vs {form})"
