@@ -11,6 +11,7 @@
 // =====================================================================================================
 static int g_k5_tsplit = 1;     // 1 = split-KV for the text query blocks when the partial buffer is given
 extern int g_rsa_k3_prefix;
+extern int g_rsa_k3_long;
 static int g_k5_tail_split = 1; // 64-row kernel: the last, partial generation's walks split over its idle slots (k5w_map)
 static int g_k5_text_last = 1;  // 64-row kernel: split text-row pieces at the end of the grid (rsa_attn_kernel64.hip::k5w_map)
 static int g_shard_invariant = 0; // rsa_set_shard_invariant: nothing about a row's arithmetic may depend on the size of the launch
@@ -39,6 +40,7 @@ extern "C" int rsa_set_tuning(const char* key, int value) {
     if (!key) return RSA_ERR_BAD_ARG;
     if (!enabled) return RSA_ERR_UNSUPPORTED;
     if (strcmp(key, "k3_prefix") == 0) { g_rsa_k3_prefix = value; return RSA_OK; }
+    if (strcmp(key, "k3_long") == 0) { g_rsa_k3_long = value; return RSA_OK; }
 #ifdef RSA_K5_FORMS
     if (strcmp(key, "k5_form") == 0) { g_rsa_k5_form = value; return RSA_OK; }
     if (strcmp(key, "k5w_form") == 0) { g_rsa_k5w_form = value; return RSA_OK; }

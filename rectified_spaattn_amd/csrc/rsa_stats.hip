@@ -333,6 +333,7 @@ struct SelectArgs {
     float thr, scale;
 };
 int g_rsa_k3_prefix = 1;
+int g_rsa_k3_long = 0;    // 1 = the workgroup-per-row kernel for every row length (tuning key "k3_long": the tests compare the two)
 
 __device__ __forceinline__ float wave_tree4(const float (&part)[4]) {
     float u[4];
@@ -698,6 +699,146 @@ __global__ __launch_bounds__(256) void select_mask_kernel(SelectArgs a) {
 }
 
 // =====================================================================================================
+// K3 for LONG rows (round 5): one 256-thread WORKGROUP per (bh, q-block) row, the row in LDS instead of registers.
+// The one-wave-per-row kernel above keeps a row's probabilities, text exponentials and keep bytes in 16 KB of LDS per wave and
+// its keys in registers: rows beyond ~2 860 visual blocks (a 257-frame 720p video) did not fit and were refused (rounds 2-4).
+// This form serves them up to L = 8 192 sorted entries (the walk of K5 holds its kept list as u16 in LDS: 8 192 key blocks is
+// the path's limit anyway).  Same contract C5..C8, formulated as the oracle formulates it: thread t owns the elements
+// j = t (mod 256) in ascending j -- which IS the contract's 256 strided partial sums --, block_tree_sum is its pairwise tree;
+// the total order (probability desc, index asc) comes from a full bitonic sort of the 64-bit keys in LDS (no sorted-head
+// shortcut: 91 passes of 16 compare-exchanges per thread at 8 192 keys, ~12 us per row -- 1 % of what K5 spends on such a row's
+// kept blocks); the sequential cumulative sum runs on one thread and stops at the first sum above the threshold.
+// dynamic LDS: float xs[NS] | u64 keys[N2] | u8 kept[NB_total]  (<= 36 + 64 + 8 KB)
+// =====================================================================================================
+__global__ __launch_bounds__(256) void select_mask_long_kernel(SelectArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ float red[4];
+    __shared__ int sh_n;
+    __shared__ int sh_scan[256];
+    const int t = threadIdx.x;
+    const long row = blockIdx.x;
+    const int qblk = (int)(row % a.NBv);
+    float* xs = reinterpret_cast<float*>(smem);
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem + (((size_t)a.NS * 4 + 15) & ~(size_t)15));
+    uint8_t* kept = reinterpret_cast<uint8_t*>(keys + a.N2);
+    const float* sc = a.scores + row * a.NS;
+    const bool has_txt = a.n_txt > 0;
+
+    // scaled scores, row maximum
+    float mx = -INFINITY;
+    for (int j = t; j < a.NS; j += 256) {
+        const float x = sc[j] * a.scale;
+        xs[j] = x;
+        mx = fmaxf(mx, x);
+    }
+    mx = block_max(mx, red);
+    // exp and denominator (C6: partial t takes the elements j = t mod 256, ascending)
+    float part = 0.0f;
+    for (int j = t; j < a.NS; j += 256) {
+        const float e = rsa_exp(xs[j] - mx);
+        xs[j] = e;
+        part = part + e;
+    }
+    const float Z = block_tree_sum(part, red);
+    for (int j = t; j < a.NS; j += 256) xs[j] = xs[j] / Z;
+    if (has_txt) {   // IPAR: the text tokens' probabilities collapse into one entry (column NBv)
+        __syncthreads();      // (text entry u is divided by thread (NBv + u) mod 256 and summed by thread u mod 256)
+        float pn = 0.0f, pt = 0.0f;
+        for (int j = t; j < a.NBv; j += 256) pn = pn + xs[j];
+        for (int u = t; u < a.n_txt; u += 256) pt = pt + xs[a.NBv + u];
+        const float normal_sum = block_tree_sum(pn, red);
+        const float text_sum = block_tree_sum(pt, red);      // (its barriers sit behind every thread's reads of the text entries)
+        const float denom = normal_sum * 128.0f + text_sum;
+        __syncthreads();
+        for (int j = t; j < a.NBv; j += 256) xs[j] = (xs[j] * 128.0f) / denom;
+        if (t == 0) xs[a.NBv] = text_sum / denom;
+    }
+    __syncthreads();
+    for (int j = t; j < a.L; j += 256) a.probs[row * a.L + j] = xs[j];
+    // keys (probability bits << 32 | ~index), padded with zeros to the power of two; full bitonic sort, descending
+    for (int idx = t; idx < a.N2; idx += 256)
+        keys[idx] = idx < a.L ? (((unsigned long long)__float_as_uint(xs[idx]) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)idx)) : 0ull;
+    for (int k = 2; k <= a.N2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            __syncthreads();
+            for (int i = t; i < (a.N2 >> 1); i += 256) {
+                const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1)), hi = lo | j;
+                const bool desc = (lo & k) == 0;
+                const unsigned long long ka = keys[lo], kb = keys[hi];
+                if ((ka < kb) == desc) { keys[lo] = kb; keys[hi] = ka; }
+            }
+        }
+    }
+    __syncthreads();
+    // C8: sequential fp32 sum in sorted order; the sums never decrease, so the count ends at the first one above thr
+    if (t == 0) {
+        int count = 0;
+        float c = 0.0f;
+        for (int k = 0; k < a.L; ++k) {
+            c = c + __uint_as_float((unsigned)(keys[k] >> 32));
+            if (c <= a.thr) ++count; else break;
+        }
+        int n = count + 1;
+        if (n < a.top_k) n = a.top_k;
+        if (n > a.L) n = a.L;
+        sh_n = n;
+    }
+    for (int j = t; j < a.NB_total; j += 256) kept[j] = 0;
+    __syncthreads();
+    const int n = sh_n;
+    for (int k = t; k < n; k += 256) kept[0xFFFFFFFFu - (unsigned)(keys[k] & 0xFFFFFFFFull)] = 1;   // column NBv = text block NBv
+    __syncthreads();
+    for (int j = t; j < a.NB_total; j += 256) {
+        uint8_t kj = kept[j];
+        if (j < a.NBv) {
+            if (a.neighbor && a.neighbor[(long)qblk * a.NBv + j] != 0) kj = 1;
+        } else if (has_txt && j < a.text_end_block) {
+            kj = 1;
+        }
+        if (qblk < a.ffb && j < a.ffb) kj = 1;
+        kept[j] = kj;
+    }
+    __syncthreads();
+    // rectification factor and compensation weights (C6 partials again)
+    float pr = 0.0f;
+    for (int j = t; j < a.L; j += 256) {
+        bool mm = kept[j] != 0;
+        if (j < a.NBv) mm = mm || (a.unrel[row * a.NBv + j] != 0);
+        const float pj = xs[j];
+        pr = pr + (mm ? pj : 0.0f);
+        a.w[row * a.L + j] = mm ? 0.0f : pj;
+    }
+    const float Rv = block_tree_sum(pr, red);
+    if (t == 0) a.R[row] = Rv;
+    // bitmask words
+    for (int wi = t; wi < a.NW; wi += 256) {
+        unsigned wd = 0;
+        for (int b = 0; b < 32; ++b) {
+            const int j = 32 * wi + b;
+            if (j < a.NB_total && kept[j]) wd |= 1u << b;
+        }
+        a.bitmask[row * a.NW + wi] = wd;
+    }
+    // ascending list: thread t owns blocks [t * ch, (t + 1) * ch); exclusive scan of the per-thread counts
+    const int ch = (a.NB_total + 255) / 256;
+    const int b0 = t * ch, b1 = min(b0 + ch, a.NB_total);
+    int mine = 0;
+    for (int j = b0; j < b1; ++j) mine += kept[j] != 0;
+    sh_scan[t] = mine;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const int v = t >= d ? sh_scan[t - d] : 0;
+        __syncthreads();
+        sh_scan[t] += v;
+        __syncthreads();
+    }
+    int off = sh_scan[t] - mine;
+    for (int j = b0; j < b1; ++j)
+        if (kept[j]) a.cols[row * a.NB_total + off++] = j;
+    if (t == 255) a.counts[row] = sh_scan[255];
+}
+
+// =====================================================================================================
 // K4: comp[i, :] = sum_j w[i, j] * vbar[j, :]   (tolerance-only quantity; fp32, j ascending) on the fp32 matrix pipe,
 // same chain form as K2: v_mfma_f32_32x32x2_f32 over j = 0,1 | 2,3 | ...
 // Workgroup = D/32 waves = 32 query-block rows x D; wave = one 32 x 32 tile of comp (16 accumulator registers), all waves
@@ -945,9 +1086,19 @@ extern "C" int rsa_select_mask(const rsa_layout* l, const uint8_t* neighbor, int
                             ~(size_t)15;
     a.lds_per_wave = (int)per_wave;
     const size_t lds = per_wave * 4;
-    if (lds > 64 * 1024 || n2 > 4096 || a.NB_total > n2 + 63) return RSA_ERR_UNSUPPORTED;
-    dim3 grid((unsigned)((a.rows_total + 3) / 4));
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (g_rsa_k3_long || lds > 64 * 1024 || n2 > 4096 || a.NB_total > n2 + 63) {
+        // rows too long for the one-wave-per-row kernel (more than ~2 860 visual blocks): the workgroup-per-row form, up to
+        // 8 192 sorted entries / key blocks (K5's own limit)
+        if (n2 > 8192 || a.NB_total > 8192) return RSA_ERR_UNSUPPORTED;
+        const size_t lds_long = (((size_t)a.NS * 4 + 15) & ~(size_t)15) + (size_t)n2 * 8 + (((size_t)a.NB_total + 15) & ~(size_t)15);
+        if (lds_long > 150 * 1024) return RSA_ERR_UNSUPPORTED;     // (more than 8 192 + ~5 000 individually scored text tokens)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(select_mask_long_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_long);
+        (void)hipGetLastError();
+        select_mask_long_kernel<<<dim3((unsigned)a.rows_total), 256, lds_long, s>>>(a);
+        return rsa_launch_status();
+    }
+    dim3 grid((unsigned)((a.rows_total + 3) / 4));
     // rows longer than the sorted head (256 keys) take the two-pass form when the head can hold top_k
     const int need = top_k > RSA_SEL_CAP / 2 ? top_k : RSA_SEL_CAP / 2;
     const bool two_pass = a.use_prefix && n2 / 64 > RSA_SEL_CAP / 64 && need <= RSA_SEL_CAP && a.L > RSA_SEL_CAP;

@@ -91,37 +91,108 @@ def test_text_rows_split_kv_matches_single_workgroup_form(fp8):
     assert float(a[:, nv + spec.q_text_valid:].abs().max()) == 0.0 and float(a[:, nv:nv + spec.q_text_valid].abs().max()) > 0
 
 
-def test_longest_rows_the_operator_serves_and_the_refusal_beyond():
-    """K3 keeps a row's probabilities, text exponentials and keep bytes in LDS, 16 KB per wave: 2 816 visual blocks (360k
-    tokens) are served -- mask and lists of sampled rows against the oracle --, 3 000 are refused with the library's
-    'unsupported' status (AssertionError, as the reference's own shape asserts), not computed wrongly."""
-    from rectified_spaattn_amd import _core, synth
+def _long_rows_case(nb, text, D=64, top_k=20, p=0.02, rows=None):
+    from rectified_spaattn_amd import _core
     from oracle import oracle as orc
-    D, top_k, p = 64, 20, 0.02
-    nb = 2816
-    S = nb * 128
-    g = torch.Generator(device=DEV).manual_seed(5)
-    cent = torch.randn(nb, D, generator=g, device=DEV) * 1.5
+    S = (nb + (2 if text else 0)) * 128
+    g = torch.Generator(device=DEV).manual_seed(5 + nb)
+    cent = torch.randn(S // 128, D, generator=g, device=DEV) * 1.5
+
     def mk():
         return (cent.repeat_interleave(128, 0) + 0.5 * torch.randn(S, D, generator=g, device=DEV)).to(torch.bfloat16).view(1, 1, S, D)
     q, k = mk(), mk()
     v = torch.randn(1, 1, S, D, generator=g, device=DEV).to(torch.bfloat16)
-    out, parts = _core.rectified_attention(q, k, v, _core.LayoutSpec.wan(S, 0), top_k, p, None, return_parts=True)
+    spec = _core.LayoutSpec.hunyuan(S, S - 56) if text else _core.LayoutSpec.wan(S, 3)
+    lay = orc.layout_hunyuan(S, S - 56) if text else orc.layout_wan(S, 3)
+    out, parts = _core.rectified_attention(q, k, v, spec, top_k, p, None, return_parts=True)
     assert torch.isfinite(out.float()).all()
-    lay = orc.layout_wan(S, 0)
     qf, kf, vf = (x[0, 0].float().cpu().numpy() for x in (q, k, v))
-    rows = [0, 1407, nb - 1]
+    if lay.pool_valid < lay.S:
+        kf[lay.pool_valid:] = 0
+        vf[lay.pool_valid:] = 0
+    rows = rows or [0, nb // 2 - 1, nb - 1]
     sel = orc.select_head(qf, kf, vf, lay, top_k, p, None, rows=rows)
     kept = _core.unpack_bitmask(parts["bitmask"], lay.NB_total).cpu().numpy()
-    for a, i in enumerate(rows):
-        assert np.array_equal(kept[0, i], sel["kept"][a].astype(bool)), i
+    for a_, i in enumerate(rows):
+        assert np.array_equal(kept[0, i], sel["kept"][a_].astype(bool)), i
         n = int(parts["counts"][0, i])
-        assert np.array_equal(parts["cols"][0, i, :n].cpu().numpy(), np.nonzero(sel["kept"][a])[0])
-    del q, k, v, out, parts
-    S2 = 3000 * 128
+        assert n == int(sel["kept"][a_].sum())
+        assert np.array_equal(parts["cols"][0, i, :n].cpu().numpy(), np.nonzero(sel["kept"][a_])[0])
+        assert np.array_equal(parts["probs"][0, i].cpu().numpy(), sel["probs"][a_])
+        assert parts["R"][0, i].item() == sel["R"][a_]
+        assert np.array_equal(parts["w"][0, i].cpu().numpy(), sel["w"][a_])
+    # whole-result properties: lists and bitmask agree on every row, every row keeps at least top_k entries
+    cnt = parts["counts"][0].cpu().numpy()
+    assert np.array_equal(kept[0].sum(-1), cnt) and (cnt >= top_k).all()
+    # the sampled query blocks of O against the oracle
+    ref = orc.sparse_attention_head(qf, kf, vf, lay, sel["kept"], rows)
+    ref = ref * sel["R"][:, None, None] + sel["comp"][:, None, :]
+    o = out.view(1, lay.S, 1, D)
+    for a_, i in enumerate(rows):
+        err = np.abs(o[0, i * 128:(i + 1) * 128, 0].float().cpu().numpy() - ref[a_])
+        assert err.max() <= 2e-2 and err.mean() <= 2e-3
+
+
+def test_longest_rows_of_the_one_wave_kernel():
+    """K3's one-wave-per-row kernel keeps a row's probabilities, text exponentials and keep bytes in 16 KB of LDS per wave:
+    2 816 visual blocks (360k tokens) -- mask, lists, probabilities, R, w and O of sampled rows against the oracle."""
+    _long_rows_case(2816, text=False)
+
+
+@pytest.mark.parametrize("nb,text", [(3000, False), (4100, False), (3200, True)])
+def test_rows_beyond_it_take_the_workgroup_per_row_kernel(nb, text):
+    """Round 5: rows the one-wave kernel cannot hold (refused with 'unsupported' in rounds 2-4; the reference has no limit,
+    rectified_hunyuan_attn.py:226-262) run select_mask_long_kernel: 3 000 blocks (a 4 096-key sort), 4 100 blocks = 525k tokens
+    (an 8 192-key sort), and a text-carrying layout (IPAR, the collapsed text entry) -- bit for bit against the oracle on
+    sampled rows, O within the operator's tolerance."""
+    _long_rows_case(nb, text)
+
+
+def test_refusal_beyond_8192_key_blocks():
+    """K5 holds a walk's kept list as u16 entries in 16 KB of LDS: 8 192 key blocks (1 M tokens) is the path's limit; beyond it
+    the library answers 'unsupported' (AssertionError, as the reference's own shape asserts) instead of computing wrongly."""
+    from rectified_spaattn_amd import _core
+    D = 64
+    S2 = 8200 * 128
     z = torch.zeros(1, 1, S2, D, dtype=torch.bfloat16, device=DEV)
     with pytest.raises(AssertionError):
-        _core.rectified_attention(z, z, z, _core.LayoutSpec.wan(S2, 0), top_k, p, None)
+        _core.rectified_attention(z, z, z, _core.LayoutSpec.wan(S2, 0), 20, 0.02, None)
+
+
+@pytest.mark.parametrize("cfg", [("hunyuan", 2, 37 * 128 + 256, 9, 0.3, "structured"), ("wan", 3, 33 * 128 - 19, 5, 0.05, "iid"),
+                                 ("flux", 2, 20 * 128 + 512, 4, 0.9, "iid"), ("hunyuan", 1, 40 * 128 + 256, 6, 0.3, "zeros"),
+                                 ("hunyuan", 2, 115456, 90, 0.05, "structured")])
+def test_workgroup_per_row_kernel_equals_the_one_wave_kernel(cfg):
+    """The long-row kernel forced onto shapes the one-wave kernel serves (tuning key k3_long): every output of the selection --
+    bitmask, lists, counts, R, w, probabilities -- identical on every row, including plateaus of equal probabilities (zeros),
+    thresholds the sum only passes late (p = 0.9), neighbours, text entries and the headline row length."""
+    from bench import gen_qkv
+    from rectified_spaattn_amd import _core, _lib, synth
+    layout, H, S, top_k, p, data = cfg
+    D = 128
+    dev = torch.device(DEV)
+    if data == "structured":
+        q, k, v = gen_qkv(H, 0, S, S, D, dev, seed=5)
+    elif data == "iid":
+        g = torch.Generator(device=dev).manual_seed(3)
+        q, k, v = (torch.randn(1, H, S, D, generator=g, device=dev).to(torch.bfloat16) for _ in range(3))
+    else:
+        q = torch.zeros(1, H, S, D, device=dev, dtype=torch.bfloat16)
+        k = torch.ones_like(q)
+        v = torch.ones_like(q)
+    spec = {"hunyuan": lambda: _core.LayoutSpec.hunyuan(S, S - 56), "flux": lambda: _core.LayoutSpec.flux(S, 512),
+            "wan": lambda: _core.LayoutSpec.wan(S, 2)}[layout]()
+    nbr = torch.from_numpy(synth.banded_neighbors(spec.NBv, 1)) if S < 100000 else None
+    L = _lib.lib()
+    res = []
+    for flag in (0, 1):
+        assert L.rsa_set_tuning(b"k3_long", flag) == 0
+        try:
+            res.append(_select(q, k, v, spec, top_k, p, nbr, 1))
+        finally:
+            L.rsa_set_tuning(b"k3_long", 0)
+    for name in res[0]:
+        assert torch.equal(res[0][name], res[1][name]), f"{cfg}: {name} differs between the one-wave and the workgroup-per-row kernel"
 
 
 @pytest.mark.parametrize("name", ["hunyuan_1280", "wan_pad_1450", "flux_1536"])
