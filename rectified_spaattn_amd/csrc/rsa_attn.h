@@ -106,6 +106,9 @@ struct AttnArgs {
 // kernels of other processes sharing the device cannot stall this one.  Walks that keep half of the keys or more are not held
 // back (round 4 drew that line at a fifth; measured at the reference scripts' operating points in round 5 --
 // profiles/r05_k5_gsync_ratio.txt -- walks of 20 % of the keys gain 2.6 % from the wait, walks of 25 % on Wan2.1's 40 heads 8 %).
+// ... nor are the walks of a head whose K, V mostly fit the L2 anyway (fewer than 256 key blocks = 16 MB: Wan2.2-TI2V's 214 blocks,
+// 24.8 % kept, lost 2 % to the wait; measured with the guard above at 1/2, profiles/r05_k5_gsync_ratio.txt)
+constexpr int RSA_GSYNC_MIN_BLOCKS = 256;
 constexpr unsigned RSA_GSYNC_MAXG = 4096;    // generations with a counter (x 8 XCDs x 64 workgroups: 2 M workgroups)
 constexpr int RSA_GSYNC_RING = 8;            // launches in flight with counters of their own
 constexpr size_t RSA_GSYNC_SLOT_WORDS = 8 + 8 * (size_t)RSA_GSYNC_MAXG;
@@ -128,7 +131,7 @@ __device__ __forceinline__ GsyncTicket rsa_gsync_announce(unsigned* gsync, int g
 // (every thread of the workgroup calls it: ends in a workgroup barrier)
 __device__ __forceinline__ void rsa_gsync_wait(unsigned* gsync, GsyncTicket tk, int n_items, int nb_total, int ratio = 2) {
     if (!tk.cnt) return;
-    if (threadIdx.x == 0 && ratio * n_items < nb_total &&
+    if (threadIdx.x == 0 && ratio * n_items < nb_total && nb_total >= RSA_GSYNC_MIN_BLOCKS &&
         __hip_atomic_load(gsync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
         const int bound = 32 + 3 * n_items;      // x (s_sleep 32 + one L2 round trip) ~ 2 us; a kept block takes ~3.4 us
         int it = 0;
