@@ -180,6 +180,17 @@ int rsa_dense_masked_fwd(int B, int H, int Sq, int Sk, int D, int dtype, rsa_ten
                          const void* mask, int mask_kind, int64_t mask_stride_b, int64_t mask_stride_h,
                          int64_t mask_stride_q, int64_t mask_stride_k, int empty_rows_nan, rsa_out4 out, void* stream);
 
+/* The same kernel with DROPOUT on the attention weights (fullattn's drop_rate: attn.py:104-106 hands it to SDPA as dropout_p,
+ * :148 applies torch.dropout to the softmax's output): every weight is kept with probability 1 - drop_rate and scaled by
+ * 1 / (1 - drop_rate), the softmax's denominator keeps all of them.  The keep decisions are a counter-based hash of (seed, batch *
+ * head, query row, key): reproducible for a seed, not torch's Philox stream (which cannot be reproduced from outside) -- what the
+ * reference's semantics fix is the distribution.  mask may be NULL with mask_kind = 0; causal != 0: key j is attended by row i
+ * only if j <= i (the reference's "torch" / "vanilla" triangle).  drop_rate in [0, 1].  Since 0.5.0. */
+int rsa_dense_dropout_fwd(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
+                          const void* mask, int mask_kind, int64_t mask_stride_b, int64_t mask_stride_h,
+                          int64_t mask_stride_q, int64_t mask_stride_k, int causal, int empty_rows_nan, float drop_rate,
+                          uint64_t seed, rsa_out4 out, void* stream);
+
 /* Stand-alone GAPR for callers of estimate_pr_gain (gapr_mask.py:4): blocks are [BH, N, 128, D] contiguous
  * 2-byte elements, pools [BH, N, D] fp32, scores [BH, NQ, NK] fp32 -> mask [BH, NQ, NK] uint8 (1 = ~gapr_mask). */
 int rsa_estimate_pr_gain(int BH, int NQ, int NK, int D, int dtype, const void* q_blocks, const void* k_blocks,

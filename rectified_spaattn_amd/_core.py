@@ -436,6 +436,42 @@ def dense_attention_masked(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, ma
     return out
 
 
+def dense_attention_dropout(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, drop_rate: float, seed: int,
+                            mask: Optional[torch.Tensor] = None, causal: bool = False, empty_rows_nan: bool = True) -> torch.Tensor:
+    """softmax(q k^T / sqrt(d) [+ mask] [causal]) with dropout on the attention weights, times v (rsa_dense_dropout_fwd): every
+    weight is kept with probability 1 - drop_rate and scaled by 1 / (1 - drop_rate) (torch.dropout / SDPA's dropout_p); the keep
+    decisions are a counter-based hash of (seed, head, row, key).  Shapes and mask forms as dense_attention_masked; -> [B,Sq,H,D]."""
+    _require_device(q, k, v)
+    L = _lib.lib()
+    B, H, Sq, D = q.shape
+    Sk = k.shape[2]
+    assert k.shape == v.shape and k.shape[0] == B and k.shape[1] == H and k.shape[3] == D
+    if D not in (64, 128):
+        raise NotImplementedError(f"device fullattn with dropout: head dim {D} (64 and 128 are built)")
+    kind, mptr, strides = 0, None, [0, 0, 0, 0]
+    if mask is not None:
+        if mask.device != q.device:
+            raise _lib.RsaError("attn_mask must live on the device of q")
+        kind = MASK_BOOL if mask.dtype == torch.bool else (MASK_ADD_2BYTE if mask.dtype == q.dtype else MASK_ADD_F32)
+        if kind == MASK_ADD_F32 and mask.dtype != torch.float32:
+            raise NotImplementedError(f"attn_mask dtype {mask.dtype}: bool, {q.dtype} or float32")
+        m = mask
+        while m.dim() < 4:
+            m = m.unsqueeze(0)
+        if m.dim() != 4 or any(a_ != 1 and a_ != b_ for a_, b_ in zip(m.shape, (B, H, Sq, Sk))):
+            raise ValueError(f"attn_mask of shape {tuple(mask.shape)} does not broadcast to {(B, H, Sq, Sk)}")
+        strides = [0 if m.shape[i] == 1 else m.stride(i) for i in range(4)]
+        mptr = m.data_ptr()
+    q, k, v = _as_bhsd(q), _as_bhsd(k), _as_bhsd(v)
+    out = torch.empty((B, Sq, H, D), dtype=q.dtype, device=q.device)
+    o4 = RsaOut4(out.data_ptr(), out.stride(0), out.stride(2), out.stride(1))
+    with torch.cuda.device(q.device):
+        _lib.check(L.rsa_dense_dropout_fwd(B, H, Sq, Sk, D, dtype_code(q.dtype), _t4(q), _t4(k), _t4(v), mptr, kind, *strides,
+                                           int(bool(causal)), int(bool(empty_rows_nan)), float(drop_rate),
+                                           int(seed) & 0xFFFFFFFFFFFFFFFF, o4, _stream()), "rsa_dense_dropout_fwd")
+    return out
+
+
 def unpack_bitmask(bitmask: torch.Tensor, n: int) -> torch.Tensor:
     """[..., NW] int32 words -> [..., n] bool (bit j%32 of word j//32)."""
     w = bitmask.to(torch.int64) & 0xFFFFFFFF

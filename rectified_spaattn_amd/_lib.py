@@ -105,6 +105,9 @@ def lib():
     L.rsa_dense_causal_fwd.argtypes = L.rsa_dense_fwd.argtypes
     L.rsa_dense_causal_fwd.restype = i32
     L.rsa_dense_masked_fwd.argtypes = [i32] * 6 + [RsaTensor4, RsaTensor4, RsaTensor4, vp, i32] + [ctypes.c_int64] * 4 + [i32, RsaOut4, vp]
+    L.rsa_dense_dropout_fwd.argtypes = ([i32] * 6 + [RsaTensor4, RsaTensor4, RsaTensor4, vp, i32] + [ctypes.c_int64] * 4 +
+                                        [i32, i32, f32, ctypes.c_uint64, RsaOut4, vp])
+    L.rsa_dense_dropout_fwd.restype = i32
     L.rsa_estimate_pr_gain.argtypes = [i32] * 5 + [vp] * 9
     L.rsa_fp8_operand_bytes.argtypes = [P(RsaLayout), P(sz * 4), P(sz)]
     L.rsa_carve_fp8_operands.argtypes = [P(RsaLayout), vp, sz, P(RsaFp8Operands)]
@@ -157,7 +160,7 @@ def lib():
 
 EXPORTED = ("rsa_version", "rsa_buffer_bytes", "rsa_carve_workspace", "rsa_pool_stats", "rsa_pooled_scores",
             "rsa_select_mask", "rsa_compensation", "rsa_block_sparse_fwd", "rsa_rectified_attention",
-            "rsa_dense_fwd", "rsa_dense_causal_fwd", "rsa_dense_masked_fwd", "rsa_estimate_pr_gain", "rsa_status_string", "rsa_last_hip_error", "rsa_set_tuning", "rsa_set_shard_invariant", "rsa_gilbert_mapping",
+            "rsa_dense_fwd", "rsa_dense_causal_fwd", "rsa_dense_masked_fwd", "rsa_dense_dropout_fwd", "rsa_estimate_pr_gain", "rsa_status_string", "rsa_last_hip_error", "rsa_set_tuning", "rsa_set_shard_invariant", "rsa_gilbert_mapping",
             "rsa_gilbert_block_neighbors", "rsa_permute_tokens", "rsa_qk_norm_rope", "rsa_qk_layernorm_rope", "rsa_norm_rope_heads", "rsa_fp8_operand_bytes",
             "rsa_carve_fp8_operands", "rsa_quantize_fp8", "rsa_block_sparse_fwd_fp8", "rsa_rectified_attention_fp8",
             "rsa_pool_stats_fp8", "rsa_dense_fp8_bytes", "rsa_dense_fwd_fp8", "rsa_dense_causal_fwd_fp8", "rsa_rel_l1",

@@ -145,8 +145,24 @@ def fullattn(q, k, v, mode="flash", drop_rate=0, attn_mask=None, causal=False, c
     B, _, S, D = q.shape
     S1 = k.shape[2]
     if q.is_cuda:
-        if drop_rate:
-            raise NotImplementedError("dropout is not implemented in the HIP attention path")
+        if drop_rate and mode != "flash":
+            # attn.py:104-106 (SDPA's dropout_p) / :148 (torch.dropout on the softmax's output): the plain device kernel with a
+            # counter-based keep mask, seeded from torch's generator -- reproducible under torch.manual_seed, not torch's own stream
+            if not 0.0 <= float(drop_rate) <= 1.0:
+                raise ValueError(f"dropout probability has to be between 0 and 1, but got {drop_rate}")
+            if causal and attn_mask is not None:
+                if mode == "vanilla":
+                    raise AssertionError("Causal mask and attn_mask cannot be used together")      # attn.py:127-129
+                raise NotImplementedError("device fullattn: causal together with an attn_mask (torch's SDPA refuses the combination too)")
+            if causal and S != S1 and mode == "vanilla":
+                raise NotImplementedError("device fullattn: vanilla's causal triangle is s x s (attn.py:130): needs s == s1")
+            m = attn_mask
+            if m is not None and m.dtype != torch.bool:
+                m = m.to(q.dtype)
+            seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+            return _core.dense_attention_dropout(q, k, v, float(drop_rate), seed, m, causal=bool(causal),
+                                                 empty_rows_nan=(mode == "vanilla")).transpose(1, 2)
+        # (mode "flash" does not forward drop_rate: attn.py:107-116 calls flash_attn_varlen_func without it)
         if causal and mode != "flash" and (attn_mask is not None or S != S1):
             # "torch" / "vanilla" put the causal triangle top-left (attn.py:105, :129-133; vanilla asserts no mask); the
             # kernel's segments are bottom-right aligned like flash-attn: the two agree only for s == s1 without padding

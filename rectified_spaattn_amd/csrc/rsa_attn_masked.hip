@@ -26,7 +26,22 @@ struct MaskedArgs {
     int H, Sq, Sk;
     int empty_nan;                // a row without attended keys: 1 = NaN, 0 = zeros
     float scale_log2;             // log2(e) / sqrt(D)
+    int causal;                   // key j attended by row i only if j <= i (the top-left triangle of attn.py:105, :129-133)
+    unsigned drop_thresh;         // dropout: an attention weight is dropped when its 24-bit hash < drop_thresh (0 = no dropout)
+    float keep_scale;             // 1 / (1 - drop_rate)
+    unsigned long long seed;
 };
+
+// one uniform 24-bit number per (seed, batch*head, query row, key): SplitMix64's finaliser over the packed coordinates.  The
+// stream is this library's own (torch's Philox offsets are not reproducible from outside); what the contract of
+// torch.dropout / SDPA's dropout_p fixes is the distribution: independent Bernoulli(1 - p) keeps, kept weights x 1 / (1 - p).
+__device__ __forceinline__ unsigned drop_hash(unsigned long long seed, int bh, int row, int key) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * ((((unsigned long long)(unsigned)bh) << 42) ^ (((unsigned long long)(unsigned)row) << 21) ^ (unsigned long long)(unsigned)key);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (unsigned)(z >> 40);
+}
 
 template <typename Tag, int D>
 __global__ __launch_bounds__(256) void dense_masked_kernel(MaskedArgs a) {
@@ -93,8 +108,9 @@ __global__ __launch_bounds__(256) void dense_masked_kernel(MaskedArgs a) {
         for (int i = 0; i < 16; ++i) {
             const int key = key0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
             float x = S[i] * a.scale_log2;
-            if (key >= a.Sk) {
+            if (key >= a.Sk || (a.causal && key > qrow)) {
                 x = -INFINITY;
+            } else if (a.mask_kind == 0) {
             } else if (a.mask_kind == RSA_MASK_BOOL) {
                 if (!reinterpret_cast<const unsigned char*>(mrow)[moff + (long)key * a.msk]) x = -INFINITY;
             } else if (a.mask_kind == RSA_MASK_ADD_2BYTE) {
@@ -117,6 +133,13 @@ __global__ __launch_bounds__(256) void dense_masked_kernel(MaskedArgs a) {
         }
         l_run = l_run * alpha + psum;
         m_run = m_new;
+        if (a.drop_thresh != 0u) {      // dropout acts on the softmax's OUTPUT (attn.py:148 / SDPA's dropout_p): the row sum keeps every weight
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = key0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                p[i] = drop_hash(a.seed, bh, qrow, key) < a.drop_thresh ? 0.0f : p[i] * a.keep_scale;
+            }
+        }
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -156,14 +179,17 @@ __global__ __launch_bounds__(256) void dense_masked_kernel(MaskedArgs a) {
 
 }  // namespace
 
-extern "C" int rsa_dense_masked_fwd(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
-                                    const void* mask, int mask_kind, int64_t mask_stride_b, int64_t mask_stride_h,
-                                    int64_t mask_stride_q, int64_t mask_stride_k, int empty_rows_nan, rsa_out4 out, void* stream) {
-    if (B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0 || !mask) return RSA_ERR_BAD_ARG;
+static int dense_masked_launch(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
+                               const void* mask, int mask_kind, int64_t mask_stride_b, int64_t mask_stride_h,
+                               int64_t mask_stride_q, int64_t mask_stride_k, int causal, int empty_rows_nan, float drop_rate,
+                               unsigned long long seed, rsa_out4 out, void* stream) {
+    if (B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0) return RSA_ERR_BAD_ARG;
     if (D != 64 && D != 128) return RSA_ERR_UNSUPPORTED;
     if (dtype != RSA_BF16 && dtype != RSA_FP16) return RSA_ERR_UNSUPPORTED;
-    if (mask_kind != RSA_MASK_BOOL && mask_kind != RSA_MASK_ADD_2BYTE && mask_kind != RSA_MASK_ADD_F32) return RSA_ERR_BAD_ARG;
+    if (mask_kind != 0 && mask_kind != RSA_MASK_BOOL && mask_kind != RSA_MASK_ADD_2BYTE && mask_kind != RSA_MASK_ADD_F32) return RSA_ERR_BAD_ARG;
+    if ((mask_kind != 0) != (mask != nullptr)) return RSA_ERR_BAD_ARG;
     if (mask_stride_b < 0 || mask_stride_h < 0 || mask_stride_q < 0 || mask_stride_k < 0) return RSA_ERR_BAD_ARG;
+    if (!(drop_rate >= 0.0f) || drop_rate > 1.0f) return RSA_ERR_BAD_ARG;
     int st;
     if ((st = rsa_check_tensor(q)) || (st = rsa_check_tensor(k)) || (st = rsa_check_tensor(v))) return st;
     if (!out.ptr || (reinterpret_cast<uintptr_t>(out.ptr) & 7) || (out.stride_b % 4) || (out.stride_h % 4) || (out.stride_s % 4))
@@ -181,6 +207,12 @@ extern "C" int rsa_dense_masked_fwd(int B, int H, int Sq, int Sk, int D, int dty
     a.H = H; a.Sq = Sq; a.Sk = Sk;
     a.empty_nan = empty_rows_nan != 0;
     a.scale_log2 = (float)((1.0 / sqrt((double)D)) * 1.44269504);
+    a.causal = causal != 0;
+    // drop_rate = 1 drops everything (torch.dropout(p = 1) returns zeros): threshold 2^24 is above every 24-bit hash
+    a.drop_thresh = drop_rate > 0.0f ? (unsigned)((double)drop_rate * 16777216.0 + 0.5) : 0u;
+    if (drop_rate > 0.0f && a.drop_thresh == 0u) a.drop_thresh = 1u;
+    a.keep_scale = drop_rate < 1.0f ? 1.0f / (1.0f - drop_rate) : 0.0f;
+    a.seed = seed;
     const dim3 grid((unsigned)((Sq + 127) / 128), (unsigned)(B * H));
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (D == 128) {
@@ -191,4 +223,20 @@ extern "C" int rsa_dense_masked_fwd(int B, int H, int Sq, int Sk, int D, int dty
         else dense_masked_kernel<fp16_tag, 64><<<grid, 256, 0, s>>>(a);
     }
     return rsa_launch_status();
+}
+
+extern "C" int rsa_dense_masked_fwd(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
+                                    const void* mask, int mask_kind, int64_t mask_stride_b, int64_t mask_stride_h,
+                                    int64_t mask_stride_q, int64_t mask_stride_k, int empty_rows_nan, rsa_out4 out, void* stream) {
+    if (!mask) return RSA_ERR_BAD_ARG;
+    return dense_masked_launch(B, H, Sq, Sk, D, dtype, q, k, v, mask, mask_kind, mask_stride_b, mask_stride_h, mask_stride_q,
+                               mask_stride_k, 0, empty_rows_nan, 0.0f, 0ull, out, stream);
+}
+
+extern "C" int rsa_dense_dropout_fwd(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
+                                     const void* mask, int mask_kind, int64_t mask_stride_b, int64_t mask_stride_h,
+                                     int64_t mask_stride_q, int64_t mask_stride_k, int causal, int empty_rows_nan, float drop_rate,
+                                     uint64_t seed, rsa_out4 out, void* stream) {
+    return dense_masked_launch(B, H, Sq, Sk, D, dtype, q, k, v, mask, mask_kind, mask_stride_b, mask_stride_h, mask_stride_q,
+                               mask_stride_k, causal, empty_rows_nan, drop_rate, (unsigned long long)seed, out, stream);
 }

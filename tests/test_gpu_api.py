@@ -112,8 +112,13 @@ def test_fullattn_device_modes(mode):
         am = torch.ones(1, 1, 1, 1536, dtype=torch.bool, device=DEV)
         with pytest.raises(NotImplementedError):
             attn.fullattn(q, k, v, mode=mode, attn_mask=am, causal=True)
-    with pytest.raises(NotImplementedError):
-        attn.fullattn(q, k, v, mode=mode, drop_rate=0.1)
+    # drop_rate: "torch" / "vanilla" apply dropout to the attention weights (served since round 5: tests/test_gpu_masked.py);
+    # the reference's flash branch never forwards it (attn.py:107-116): same call, same result
+    od = attn.fullattn(q, k, v, mode=mode, drop_rate=0.1)
+    if mode == "flash":
+        assert torch.equal(od, out)
+    else:
+        assert od.shape == out.shape and torch.isfinite(od.float()).all() and not torch.equal(od, attn.fullattn(q, k, v, mode=mode))
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])

@@ -100,3 +100,71 @@ def test_tiny_and_ragged_shapes(S, S1):
     mask[..., S1 - 1] = True
     out = attn.fullattn(q.to(DEV), k.to(DEV), v.to(DEV), mode="torch", attn_mask=mask.to(DEV))
     assert (out.float().cpu() - _ref(q, k, v, mask)).abs().max() <= 2e-2
+
+
+# ---- dropout (round 5): fullattn(drop_rate=...) on the device, attn.py:104-106 / :148 -----------------------------------------
+def test_dropout_zero_rate_and_full_rate_edges():
+    """drop_rate = 0 through the dropout entry point equals the same kernel without dropout; drop_rate = 1 drops every weight
+    (torch.dropout(p = 1) returns zeros)."""
+    from rectified_spaattn_amd import _core
+    q, k, v = (x.to(DEV) for x in _qkv(1, 2, 150, 201, 128, torch.bfloat16, 5))
+    mask = (torch.rand(1, 1, 150, 201, generator=torch.Generator().manual_seed(6)) < 0.7)
+    mask[..., 0] = True
+    base = _core.dense_attention_masked(q, k, v, mask.to(DEV))
+    assert torch.equal(_core.dense_attention_dropout(q, k, v, 0.0, 123, mask.to(DEV)), base)
+    assert float(_core.dense_attention_dropout(q, k, v, 1.0, 123, mask.to(DEV)).abs().max()) == 0.0
+    # no mask at all, causal: against torch on the CPU
+    o = _core.dense_attention_dropout(q[:, :, :150], k[:, :, :150], v[:, :, :150], 0.0, 1, None, causal=True).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(q[:, :, :150].float().cpu(), k[:, :, :150].float().cpu(), v[:, :, :150].float().cpu(), is_causal=True)
+    assert float((o.float().cpu() - ref).abs().max()) <= 2e-2
+
+
+@pytest.mark.parametrize("mode", ["torch", "vanilla"])
+def test_dropout_is_reproducible_unbiased_and_drops_the_stated_share(mode):
+    """The distribution the reference's semantics fix (independent keeps with probability 1 - p, kept weights x 1 / (1 - p)):
+    (i) same torch seed -> same bytes, another seed -> other bytes; (ii) with V = 1 every output row is sum of kept weights /
+    (1 - p): its mean over rows and heads is 1 and the share of dropped weights, read off uniform attention, is p; (iii) the
+    mean over 48 seeds approaches the dropout-free output."""
+    from rectified_spaattn_amd import attn
+    B, H, S, S1, D, p = 1, 4, 256, 512, 128, 0.3
+    q, k, v = _qkv(B, H, S, S1, D, torch.bfloat16, 9)
+    dq, dk, dv = q.to(DEV), k.to(DEV), v.to(DEV)
+    torch.manual_seed(77)
+    a = attn.fullattn(dq, dk, dv, mode=mode, drop_rate=p)
+    torch.manual_seed(77)
+    b = attn.fullattn(dq, dk, dv, mode=mode, drop_rate=p)
+    c = attn.fullattn(dq, dk, dv, mode=mode, drop_rate=p)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    # uniform attention (q = 0), V = 1: out = (#kept / S1) / (1 - p)
+    ones = torch.ones_like(dv)
+    u = attn.fullattn(torch.zeros_like(dq), dk, ones, mode=mode, drop_rate=p).float()
+    kept_share = u[..., 0] * (1 - p)                         # per (head, row): share of the 512 keys kept
+    assert abs(float(kept_share.mean()) - (1 - p)) < 0.01
+    assert abs(float(kept_share.std()) - (p * (1 - p) / S1) ** 0.5) < 0.006      # binomial spread: keeps are independent
+    assert float((u - u[..., :1]).abs().max()) == 0.0
+    # unbiased: the mean over seeds tends to the dropout-free result
+    base = attn.fullattn(dq, dk, dv, mode=mode).float()
+    acc = torch.zeros_like(base)
+    n = 48
+    for _ in range(n):
+        acc += attn.fullattn(dq, dk, dv, mode=mode, drop_rate=p).float()
+    err = (acc / n - base).abs()
+    assert float(err.mean()) < 0.03 and float(err.max()) < 0.25, (float(err.mean()), float(err.max()))
+
+
+def test_dropout_with_masks_and_causal():
+    """A boolean row mask and causal attention under dropout: dropped weights never resurrect masked keys (V = one-hot over the
+    keys shows which keys contribute), rows keep summing to ~1 on average."""
+    from rectified_spaattn_amd import attn
+    B, H, S, D = 1, 2, 128, 128
+    q, k, _ = _qkv(B, H, S, S, D, torch.bfloat16, 11)
+    v = torch.zeros(B, H, S, D, dtype=torch.bfloat16)
+    v[..., torch.arange(S), torch.arange(S) % D] = 1.0          # key j writes into channel j (S == D here)
+    out = attn.fullattn(q.to(DEV), k.to(DEV), v.to(DEV), mode="torch", drop_rate=0.25, causal=True).float().cpu()
+    upper = torch.triu(torch.ones(S, S, dtype=torch.bool), diagonal=1)
+    assert float(out[0, 0][upper].abs().max()) == 0.0, "a key above the diagonal contributed"
+    mask = torch.rand(B, 1, S, S, generator=torch.Generator().manual_seed(3)) < 0.5
+    mask[..., 0] = True
+    out = attn.fullattn(q.to(DEV), k.to(DEV), v.to(DEV), mode="vanilla", drop_rate=0.25, attn_mask=mask.to(DEV)).float().cpu()
+    assert float(out[0, 1][~mask[0, 0]].abs().max()) == 0.0, "a masked key contributed"
+    assert abs(float(out.sum(-1).mean()) - 1.0) < 0.05
