@@ -474,26 +474,29 @@ def fp8_records(comm, args, call_bf16, q, k, v, spec, wl, dev):
     torch.cuda.synchronize()
     ref = cb.out.float()
     del cb
-    c8 = _core.StagedCall(q, k, v, spec, wl["top_k"], p, nbr, qkv_fp8=True)
+    for mode, key, what in ((True, "fp8_vs_bf16", "K5 on e4m3 Q/K/V/P"),
+                            ("pv", "pv_vs_bf16", "the pv form: Q.K^T on the bf16 operands, only P.V on e4m3")):
+        c8 = _core.StagedCall(q, k, v, spec, wl["top_k"], p, nbr, qkv_fp8=mode)
 
-    def st8(_):
-        c8.select()
-        c8.attend()
-    el = timed_steps(comm, st8, 5, 2)
-    d = (c8.out.float() - ref).abs()
-    pairs = float(c8.bufs["counts"].sum().item())
-    fl = 4.0 * 128 * 128 * 128 * pairs + 4.0 * 128 * spec.q_text_valid * spec.kv_text_valid * q.shape[1]
-    out["fp8_vs_bf16"] = dict(what="HunyuanVideo 720p layer, locality regime: K5 on e4m3 Q/K/V/P vs K5 on the bf16 operands, same kept lists",
-                              rel_l1=round(float(d.sum() / ref.abs().sum()), 5), max_abs=round(float(d.max()), 4),
-                              mean_abs=round(float(d.mean()), 5), out_rms=round(float(ref.pow(2).mean().sqrt()), 4),
-                              fp8_layer_ms=round(el / 5 * 1e3, 4), fp8_layer_tflops=round(fl / (el / 5) / 1e12, 1))
-    del c8, d, ref
+        def st8(_):
+            c8.select()
+            c8.attend()
+        el = timed_steps(comm, st8, 5, 2)
+        d = (c8.out.float() - ref).abs()
+        pairs = float(c8.bufs["counts"].sum().item())
+        fl = 4.0 * 128 * 128 * 128 * pairs + 4.0 * 128 * spec.q_text_valid * spec.kv_text_valid * q.shape[1]
+        out[key] = dict(what=f"HunyuanVideo 720p layer, locality regime: {what} vs K5 on the bf16 operands, same kept lists",
+                        rel_l1=round(float(d.sum() / ref.abs().sum()), 5), max_abs=round(float(d.max()), 4),
+                        mean_abs=round(float(d.mean()), 5), out_rms=round(float(ref.pow(2).mean().sqrt()), 4),
+                        fp8_layer_ms=round(el / 5 * 1e3, 4), fp8_layer_tflops=round(fl / (el / 5) / 1e12, 1))
+        del c8, d
+    del ref
     torch.cuda.empty_cache()
     w5 = WORKLOADS["wan22_ti2v_720p_121f"]
     s5 = make_spec(w5)
     q5, k5, v5 = gen_inputs(w5, w5["H"], 0, dev, "iid")
     rec5 = {}
-    for f8 in (False, True):
+    for f8 in (False, "pv", True):
         c5 = _core.StagedCall(q5, k5, v5, s5, w5["top_k"], 0.0, None, qkv_fp8=f8)
 
         def st5(_):
@@ -502,7 +505,7 @@ def fp8_records(comm, args, call_bf16, q, k, v, spec, wl, dev):
         el5 = timed_steps(comm, st5, 10, 3)
         pr5 = float(c5.bufs["counts"].sum().item())
         fl5 = 4.0 * 128 * 128 * 128 * pr5
-        rec5["e4m3" if f8 else "bf16"] = dict(ms_per_layer=round(el5 / 10 * 1e3, 4), tflops=round(fl5 / (el5 / 10) / 1e12, 1))
+        rec5["pv" if f8 == "pv" else ("e4m3" if f8 else "bf16")] = dict(ms_per_layer=round(el5 / 10 * 1e3, 4), tflops=round(fl5 / (el5 / 10) / 1e12, 1))
         del c5
     rec5["what"] = "BASELINE config 5: Wan2.2-TI2V 720p 121f, S = 27 280, 24 heads, top_k 53 (regime r2), whole layer (select + K5)"
     out["config5_wan22_ti2v"] = rec5

@@ -272,7 +272,8 @@ int rsa_quantize_fp8(const rsa_layout* lay, rsa_tensor4 q, rsa_tensor4 k, rsa_te
 /* The same fused into the mask-selection pass: K1 (rsa_pool_stats) writes the images of every block it pools in the pass
  * that pools it (Q and K visual blocks, every V block: the tensors are read from HBM once), a small launch covers the
  * text-tail blocks of Q and K.  buf gets K1's statistics as rsa_pool_stats would write them; ops is bit-identical to
- * rsa_quantize_fp8's. */
+ * rsa_quantize_fp8's.  With ops->q8 == ops->k8 == NULL only the V image and the V bytes of the exponent words are written (the
+ * operands of rsa_block_sparse_fwd_fp8pv; since 0.5.0). */
 int rsa_pool_stats_fp8(const rsa_layout* lay, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v, const rsa_buffers* buf,
                        const rsa_fp8_operands* ops, void* stream);
 
@@ -280,6 +281,13 @@ int rsa_pool_stats_fp8(const rsa_layout* lay, rsa_tensor4 q, rsa_tensor4 k, rsa_
  * lay->dtype selects the OUTPUT element type. */
 int rsa_block_sparse_fwd_fp8(const rsa_layout* lay, const rsa_fp8_operands* ops, const rsa_buffers* buf,
                              rsa_out4 out, void* stream);
+
+/* The "pv" form (since 0.5.0): Q . K^T on the 2-byte q and k themselves (v_mfma_f32_32x32x16), e4m3 only for P and V
+ * (ops->v8t and the V bytes of ops->scales; q8 / k8 are not read).  The scores are then the 2-byte path's -- the e4m3 rounding of
+ * Q and K is nine tenths of rsa_block_sparse_fwd_fp8's error -- while P . V still runs at the fp8 rate: 800 matrix cycles per 64
+ * keys and 32 rows against 1 024 (2-byte) and 544 (e4m3).  Head dim 128. */
+int rsa_block_sparse_fwd_fp8pv(const rsa_layout* lay, rsa_tensor4 q, rsa_tensor4 k, const rsa_fp8_operands* ops,
+                               const rsa_buffers* buf, rsa_out4 out, void* stream);
 
 /* The whole operator with fp8 K5: K1..K4 on the 2-byte inputs (the mask is the bf16 path's, bit for bit; K1 in its
  * rsa_pool_stats_fp8 form, which leaves the images behind), then rsa_block_sparse_fwd_fp8. */

@@ -631,14 +631,18 @@ def dense_rows_pcode(qr, k, v, kv_valid: int, row0: int):
 
 
 def rectified_attention_fp8(q, k, v, lay: Layout, top_k: int, p: float, neighbor=None, want_parts: bool = False,
-                            smooth_k: bool = True, p_form: str = "exact"):
+                            smooth_k: bool = True, p_form: str = "exact", qk: str = "e4m3"):
     """Operator with fp8 K5 operands: mask statistics, R and comp from the 2-byte inputs (unchanged contract), the
     sparse / text-row attention itself on the dequantised e4m3 values.  p_form = "exact": P kept in fp64 (what the e4m3
     rounding of P is measured against: the stated fp8 tolerance); "code": P exactly as the kernel forms it (code map and
-    deferred reference above) -- the kernel then differs only by fp32 accumulation and by codes on a rounding boundary."""
-    assert p_form in ("exact", "code")
+    deferred reference above) -- the kernel then differs only by fp32 accumulation and by codes on a rounding boundary.
+    qk = "2byte": the pv form's scores (q, k as given; its kernel additionally rounds q * sm_scale * log2(e) * 8 to the 2-byte type,
+    as the 2-byte kernels round their scaled q)."""
+    assert p_form in ("exact", "code") and qk in ("e4m3", "2byte")
     B, H, S, D = q.shape
     q8, k8, v8, ops = fp8_dequantized_qkv(q, k, v, lay, smooth_k)
+    if qk == "2byte":      # the "pv" form (rsa_block_sparse_fwd_fp8pv): the scores from the 2-byte q and k themselves, e4m3 only P and V
+        q8, k8 = q, k
     out = np.zeros((B, S, H, D), np.float32)
     parts = []
     nvis_tok = lay.NBv * BLOCK

@@ -16,12 +16,14 @@ reference's own code paths: fullattn(mode="torch" | "vanilla") on CPU tensors (B
 teacache.rel_l1_distance for CPU tensors / small fp32 inputs such as timestep embeddings (bf16 / fp16 device tensors take
 the one-pass HIP reduction rsa_rel_l1).
 """
-__version__ = "0.3.1"
+__version__ = "0.5.0"
 
 
-def set_qkv_fp8(enabled: bool) -> bool:
-    """Run the block-sparse kernel of every sparse operator / processor call on e4m3 images of Q, K, V (fp8 MFMA,
-    head_dim 128); returns the previous setting.  Default off = the reference's input-dtype behaviour."""
+def set_qkv_fp8(enabled):
+    """Run the block-sparse kernel of every sparse operator / processor call on e4m3 operands (fp8 MFMA): True = e4m3 images of
+    Q, K, V (head dim 64 / 128; relative L1 distance 0.12 of the layer output from the 2-byte path), "pv" = Q . K^T on the 2-byte
+    inputs and only P . V on e4m3 (head dim 128; relative L1 0.04, within SURVEY 8(d)'s 8e-2 of the bf16 oracle); returns the
+    previous setting.  Default off = the reference's input-dtype behaviour."""
     from . import _operator
     return _operator.set_qkv_fp8(enabled)
 

@@ -231,12 +231,16 @@ def neighbor_on_device(block_neighbor_list, NBv: int, device) -> Optional[torch.
     return hit
 
 
-def alloc_fp8_operands(spec: LayoutSpec, B: int, H: int, D: int, device) -> Dict[str, torch.Tensor]:
+def alloc_fp8_operands(spec: LayoutSpec, B: int, H: int, D: int, device, v_only: bool = False) -> Dict[str, torch.Tensor]:
     """e4m3 images of Q, K, V for the fp8 K5 (include/rsa.h::rsa_fp8_operands).  `scales` is ONE int32 buffer:
     [BH, NB_total] block-exponent words (byte 0 / 1 / 2 = E8M0 of the Q / K / V block) followed by the K mean, [BH, D]
     fp32 bit patterns (fp8_exps / fp8_kmean view it)."""
     assert D in (64, 128), "the fp8 block-sparse kernels are built for head_dim 64 and 128"
     BH, SP = B * H, spec.NB_total * BLOCK
+    if v_only:     # the pv form reads the V image and the V exponents only
+        return dict(q8=torch.empty((0,), dtype=torch.uint8, device=device), k8=torch.empty((0,), dtype=torch.uint8, device=device),
+                    v8t=torch.empty((BH, SP // 64, D, 64), dtype=torch.uint8, device=device),
+                    scales=torch.zeros((BH * (spec.NB_total + D),), dtype=torch.int32, device=device))
     return dict(q8=torch.empty((BH, SP, D), dtype=torch.uint8, device=device),
                 k8=torch.empty((BH, SP, D), dtype=torch.uint8, device=device),
                 v8t=torch.empty((BH, SP // 64, D, 64), dtype=torch.uint8, device=device),
@@ -279,9 +283,15 @@ class StagedCall:
         self.nbr = neighbor_on_device(block_neighbor_list, spec.NBv, q.device)
         self.t = (_t4(self.q), _t4(self.k), _t4(self.v))
         self.fp8 = None
+        # qkv_fp8: False | True (e4m3 Q, K, V and P) | "pv" (2-byte Q . K^T, e4m3 P . V: head dim 128)
+        self.fp8_pv = isinstance(qkv_fp8, str) and qkv_fp8 == "pv"
+        if isinstance(qkv_fp8, str) and not self.fp8_pv:
+            raise ValueError(f"qkv_fp8 must be False, True or 'pv', got {qkv_fp8!r}")
+        if self.fp8_pv and D != 128:
+            raise NotImplementedError("qkv_fp8='pv' (2-byte Q.K^T + e4m3 P.V) is built for head dim 128")
         if qkv_fp8:
-            self.fp8 = alloc_fp8_operands(spec, B, H, D, q.device)
-            self.cf = RsaFp8Operands(*[self.fp8[n].data_ptr() for n in ("q8", "k8", "v8t", "scales")])
+            self.fp8 = alloc_fp8_operands(spec, B, H, D, q.device, v_only=self.fp8_pv)
+            self.cf = RsaFp8Operands(*[self.fp8[n].data_ptr() if self.fp8[n].numel() else None for n in ("q8", "k8", "v8t", "scales")])
 
     def quantize(self):
         """The stand-alone producer of the e4m3 images (rsa_quantize_fp8: one pass over Q, K, V).  select() does not need
@@ -317,6 +327,12 @@ class StagedCall:
 
     def attend(self):
         tq, tk, tv = self.t
+        if self.fp8 is not None and self.fp8_pv:
+            with torch.cuda.device(self.q.device):
+                _lib.check(self.L.rsa_block_sparse_fwd_fp8pv(ctypes.byref(self.lay), tq, tk, ctypes.byref(self.cf),
+                                                             ctypes.byref(self.cb), self.o4, _stream()),
+                           "rsa_block_sparse_fwd_fp8pv")
+            return self.out
         if self.fp8 is not None:
             with torch.cuda.device(self.q.device):
                 _lib.check(self.L.rsa_block_sparse_fwd_fp8(ctypes.byref(self.lay), ctypes.byref(self.cf),
@@ -490,6 +506,8 @@ def rectified_attention_onecall(q: torch.Tensor, k: torch.Tensor, v: torch.Tenso
         o, workspace = rectified_attention_onecall(*pad_small_head_dim(q, k, v), spec, top_k, p_remain, block_neighbor_list,
                                                    workspace, qkv_fp8)
         return o.view(B, S, H, -1)[..., :D].reshape(B, S, H * D), workspace
+    if isinstance(qkv_fp8, str):    # the pv form has no one-call C entry of its own: the staged calls, same kernels
+        return rectified_attention(q, k, v, spec, top_k, p_remain, block_neighbor_list, qkv_fp8=qkv_fp8), workspace
     L = _lib.lib()
     B, H, S, D = q.shape
     q, k, v = _as_bhsd(q), _as_bhsd(k), _as_bhsd(v)

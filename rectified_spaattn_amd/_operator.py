@@ -34,11 +34,14 @@ def _check_blocks(bm: int, bn: int):
 QKV_FP8 = False
 
 
-def set_qkv_fp8(enabled: bool) -> bool:
-    """Switch the sparse operator (and therefore every processor's sparse steps) to fp8 K5 operands.  Returns the
-    previous setting."""
+def set_qkv_fp8(enabled):
+    """Switch the sparse operator (and therefore every processor's sparse steps) to fp8 K5 operands: True = e4m3 Q, K, V and P;
+    "pv" = Q . K^T on the 2-byte inputs, e4m3 only for P . V (relative L1 0.04 of the layer output instead of 0.12, at 0.8 of the
+    2-byte kernel's matrix work; head dim 128, other head dims keep the 2-byte kernel); False = off.  Returns the previous setting."""
     global QKV_FP8
-    old, QKV_FP8 = QKV_FP8, bool(enabled)
+    if isinstance(enabled, str) and enabled != "pv":
+        raise ValueError(f"set_qkv_fp8: False, True or 'pv', got {enabled!r}")
+    old, QKV_FP8 = QKV_FP8, (enabled if isinstance(enabled, str) else bool(enabled))
     return old
 
 
@@ -51,6 +54,15 @@ def set_dense_fp8(enabled: bool) -> bool:
     global DENSE_FP8
     old, DENSE_FP8 = DENSE_FP8, bool(enabled)
     return old
+
+
+def _fp8_mode(choice, D: int):
+    """False | True | "pv" for head dim D (head dims without the chosen kernel keep the 2-byte one)."""
+    if isinstance(choice, str):
+        if choice != "pv":
+            raise ValueError(f"qkv_fp8: False, True or 'pv', got {choice!r}")
+        return "pv" if D == 128 else False
+    return bool(choice) and D in (64, 128)
 
 
 def run(variant: str, query, key, value, top_k, prob_threshold, block_neighbor_list, shape_xfuse,
@@ -71,7 +83,7 @@ def run(variant: str, query, key, value, top_k, prob_threshold, block_neighbor_l
         raise ValueError(variant)
     return _core.rectified_attention(query, key, value, spec, int(top_k), float(prob_threshold),
                                      block_neighbor_list, shape_xfuse=shape_xfuse,
-                                     qkv_fp8=(QKV_FP8 if qkv_fp8 is None else bool(qkv_fp8)) and D in (64, 128))
+                                     qkv_fp8=_fp8_mode(QKV_FP8 if qkv_fp8 is None else qkv_fp8, D))
 
 
 # ---- small helpers shared by the processors ---------------------------------------------------------

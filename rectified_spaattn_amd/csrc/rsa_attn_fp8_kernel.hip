@@ -59,6 +59,10 @@ struct Attn8Args {
     int heavy_last;      // the split text-row pieces behind the sparse blocks in the grid
     int tail_first, tail_n, tail_p;   // tail split (rsa_attn.hip::launch_attn, rsa_attn_kernel64.hip::k5w_map): head dim 128 only
     float* tail_part;
+    // "pv" form (round 5, HYB instances): Q . K^T on the 2-byte operands as they are, only P . V on e4m3
+    const unsigned short *q16, *k16;
+    long qsb, qsh, qss, ksb, ksh, kss;
+    float qk_scale;                   // sm_scale * log2(e) * PMap::U, folded into Q
 };
 
 // rsa_attn.hip: merge of the split-KV partials of the text blocks, and the switch for the split
@@ -133,9 +137,18 @@ __device__ __forceinline__ void k5f8_block(f32x16 (&o)[D8 / 32], const i32x8 (&q
 // PIPE_OPT bit 0: the hand-placed block (clear: the block as hipcc schedules it, same arithmetic, for A/B);
 // bit 1: s_setprio around the compiled block; bit 2: the code-map form of P (PMap above).  Product = 7.
 // D8: head dim = bytes per Q / K row (128; 64 = the CogVideoX shape, hand-placed code-map form only).
-template <int PIPE_OPT, int D8 = 128>
+// HYB (round 5, "pv" form): 0 = e4m3 everywhere; 1 / 2 = Q . K^T on the bf16 / fp16 inputs themselves (K tiles of 64 keys x 256
+// bytes staged like the 2-byte kernels' -- rsa_attn_kernel.hip -- and multiplied by v_mfma_f32_32x32x16), e4m3 only for P and V.
+// The scores are then the 2-byte path's (the e4m3 rounding of Q and K is 90 % of the fp8 path's error: DESIGN 4b), P . V runs at
+// the fp8 rate: 800 instead of 1 024 (2-byte) or 544 (e4m3) matrix cycles per 64 keys and 32 rows.  Three-slot rings (K 3 x 16
+// KiB, V 3 x 8 KiB: two workgroups per CU), the compiled block only.
+template <int PIPE_OPT, int D8 = 128, int HYB = 0>
 __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
+    static_assert(HYB == 0 || (D8 == 128 && (PIPE_OPT & 1) == 0), "the pv form: head dim 128, compiled block");
     constexpr int TILE8 = 64 * D8;        // bytes of one K tile (64 keys x D8) and of one V tile (D8 rows x 64 keys)
+    constexpr int TILEK = HYB ? 64 * 2 * D8 : TILE8;     // K tile: e4m3 rows, or the 2-byte rows themselves
+    constexpr int NSK = HYB ? 3 : NSLOT, NSV = HYB ? 3 : NSLOT;
+    constexpr int VBASE = NSK * TILEK, ONES = VBASE + NSV * TILE8;
     constexpr int KS8 = D8 / 64;          // QK^T MFMAs per 32-key half (k = 64 each)
     constexpr int DT8 = D8 / 32;          // 32-row d tiles of O^T
     constexpr int NPC8 = TILE8 / 4096;    // 1-KiB LDS-DMA pieces per wave and tile operand
@@ -144,8 +157,8 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     constexpr float P_BASE = PM::U * PM::OFFSET + PM::BIAS;   // accumulator value of a score equal to the reference m
     constexpr float P_GROW = PM::U * PM::THRESH + P_BASE;     // above it the reference moves
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    unsigned char* lds_ones = lds + 2 * NSLOT * TILE8;  // 32 bytes of e4m3 1.0, then 32 bytes of 0
-    unsigned* lds_list = reinterpret_cast<unsigned*>(lds + 2 * NSLOT * TILE8 + 64);
+    unsigned char* lds_ones = lds + ONES;  // 32 bytes of e4m3 1.0, then 32 bytes of 0
+    unsigned* lds_list = reinterpret_cast<unsigned*>(lds + ONES + 64);
 
     const GsyncTicket gs_tk = rsa_gsync_announce(a.gsync, a.gsync_gen);   // aligned starts (rsa_attn.h)
     // ---------------- work mapping (as rsa_attn_kernel.hip) ----------------
@@ -294,6 +307,26 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
         }
     }
 
+    // "pv" form: the 2-byte Q fragments (B operand of v_mfma_f32_32x32x16: lane (r, hh) holds k = 16 ks + 8 hh .. + 7), scaled
+    using HT = typename std::conditional<HYB == 2, fp16_tag, bf16_tag>::type;
+    s16x8 qh[HYB ? 8 : 1];
+    if constexpr (HYB != 0) {
+        const unsigned short* qp16 = a.q16 + (long)b * a.qsb + (long)h * a.qsh + (long)grow * a.qss + 8 * hh;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            uint4 raw = make_uint4(0, 0, 0, 0);
+            if (grow < a.Sq) raw = *reinterpret_cast<const uint4*>(qp16 + 16 * ks);
+            const unsigned w4[4] = {raw.x, raw.y, raw.z, raw.w};
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f[2 * e] = rsa_to_f32<HT>((unsigned short)(w4[e] & 0xFFFF)) * a.qk_scale;
+                f[2 * e + 1] = rsa_to_f32<HT>((unsigned short)(w4[e] >> 16)) * a.qk_scale;
+            }
+            qh[ks] = Elem<HT>::cvt8(f);
+        }
+    }
+
     // ---------------- LDS-DMA staging ----------------
     // K tile [64 keys][128 B]: 1-KiB piece pc = rows 8pc..8pc+7; wave w moves pieces w and w+4 (same swizzle phase).
     // V tile [128 d][64 B]:    1-KiB piece pc = rows 16pc..16pc+15; wave w moves pieces w and w+4.
@@ -312,9 +345,29 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
                          : "memory");
         }
     };
-    auto dma_k = [&](int key0, int slot) { dma2(kbase + (long)key0 * D8, lds_base + slot * TILE8, voffk); };
+    // "pv" form: the 64-key K tile from the 2-byte tensor, image and swizzle of rsa_attn_kernel.hip (groups of 16 rows = 4 pieces
+    // of 4 rows, wave w moves piece w of every group; source chunk XOR-swizzled, rows past the last valid key clamped)
+    const int kv_limit_h = hi_max < a.Sk ? hi_max : a.Sk;
+    const int rsub_h = lane >> 4, cl_h = lane & 15, rowl_h = wv * 4 + rsub_h;
+    const int gsw_h = cl_h ^ (((rowl_h & 3) << 2) | ((rowl_h >> 2) & 3));
+    auto dma_k = [&](int key0, int slot) {
+        if constexpr (HYB == 0) {
+            dma2(kbase + (long)key0 * D8, lds_base + slot * TILE8, voffk);
+        } else {
+            const unsigned char* kb16 = reinterpret_cast<const unsigned char*>(a.k16 + (long)b * a.ksb + (long)h * a.ksh);
+            const unsigned ld0 = lds_base + slot * TILEK + wv * 1024;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int krow = key0 + 16 * j + rowl_h;
+                krow = krow < kv_limit_h ? krow : kv_limit_h - 1;
+                const unsigned vo = (unsigned)(((long)krow * a.kss + gsw_h * 8) * 2);
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                             :: "v"(vo), "s"(kb16), "s"(ld0 + j * 4096) : "memory");
+            }
+        }
+    };
     auto dma_v = [&](int key0, int slot) {
-        dma2(vbase + (long)(key0 >> 6) * TILE8, lds_base + (NSLOT + slot) * TILE8, voffv);
+        dma2(vbase + (long)(key0 >> 6) * TILE8, lds_base + VBASE + slot * TILE8, voffv);
     };
 
     // ---------------- state ----------------
@@ -358,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
         for (int c2 = 0; c2 < 2; ++c2) ka[2 * ks + c2] = (int)lds_base + koff[0][ks][c2];
     va[0] = (int)lds_base + voff_rd[0];
     va[1] = (int)lds_base + voff_rd[1];
-    const int ona = (int)lds_base + 2 * NSLOT * TILE8 + ones_off;
+    const int ona = (int)lds_base + ONES + ones_off;
 
     auto ld32 = [&](const unsigned char* p0, const unsigned char* p1) -> i32x8 {
         const i32x4 lo = *reinterpret_cast<const i32x4*>(p0);
@@ -367,6 +420,20 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     };
     // S^T (two 32-key halves) of the tile in K slot `slot`
     auto qk_tile = [&](int slot, f32x16 (&S)[2], int sc_k) {
+        if constexpr (HYB != 0) {
+            const unsigned char* kt16 = lds + slot * TILEK;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                f32x16 acc = mblk;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const s16x8 kf = *reinterpret_cast<const s16x8*>(kt16 + tile_off<128>(32 * sub + r, 2 * ks + hh));
+                    acc = Elem<HT>::mfma(kf, qh[ks], acc);
+                }
+                S[sub] = acc;
+            }
+            return;
+        }
         const unsigned char* kt_ = lds + slot * TILE8;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
@@ -403,15 +470,19 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     auto step = [&](auto TS, int tile, int key0, f32x16 (&S_cur)[2], float& mx_cur, f32x16 (&S_nxt)[2], float& mx_nxt) {
         const int ts = TS;  // integral_constant (static LDS addresses) or the runtime tile & 3
         const int sc_a = (int)((sw1 & 0xFFu) | (sw0 & 0xFF00u));   // K(tile + 1) in byte 0, V(tile) in byte 1
-        if (tile + 2 < n_tiles) {   // (the newest tile's pieces may stay in flight: 2 NPC8 per wave)
-            if constexpr (NPC8 == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (tile + 2 < n_tiles) {   // (the newest tile's pieces may stay in flight: 2 NPC8 per wave; pv form: 4 of K + 2 of V)
+            if constexpr (HYB != 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if constexpr (NPC8 == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
-        if (tile + 3 < n_tiles) dma_k(kq3, (ts + 3) & (NSLOT - 1));
-        if (tile + 2 < n_tiles) dma_v(kq2, (ts + 2) & (NSLOT - 1));
+        // ring slots: tile & 3 of four (ts), or tile mod 3 of three in the pv form
+        const int ks_dma = HYB ? tile % 3 : (ts + 3) & (NSLOT - 1), vs_dma = HYB ? (tile + 2) % 3 : (ts + 2) & (NSLOT - 1);
+        const int ks_nxt = HYB ? (tile + 1) % 3 : (ts + 1) & (NSLOT - 1), vs_cur = HYB ? tile % 3 : ts;
+        if (tile + 3 < n_tiles) dma_k(kq3, ks_dma);
+        if (tile + 2 < n_tiles) dma_v(kq2, vs_dma);
         // ---- head (rare branches): boundary mask, deferred rescale ----
         if (key0 < lo_max || key0 + 64 > hi_min) {
             apply_mask(S_cur, key0);
@@ -450,7 +521,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
             return;
         }
         if constexpr (PIPE_OPT & 2) __builtin_amdgcn_s_setprio(2);
-        qk_tile((ts + 1) & (NSLOT - 1), S_nxt, sc_a);
+        qk_tile(ks_nxt, S_nxt, sc_a);
         i32x8 pb;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
@@ -473,7 +544,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
             }
         lacc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ld32(lds_ones + ones_off, lds_ones + ones_off + 16), pb,
                                                                 lacc, 0, 0, 0, 0, 0, 0);
-        const unsigned char* vt_ = lds + (NSLOT + ts) * TILE8;
+        const unsigned char* vt_ = lds + VBASE + vs_cur * TILE8;
 #pragma unroll
         for (int dt = 0; dt < DT8; ++dt)
             o[dt] = mfma8s1(ld32(vt_ + dt * 2048 + voff_rd[0], vt_ + dt * 2048 + voff_rd[1]), pb, o[dt], sc_a, sc_b);
@@ -611,7 +682,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
 }
 
 int g_fp8_variant = 0;
-int launch_attn8(Attn8Args& a, int BH, int D8, size_t tpart_bytes, hipStream_t s) {
+int launch_attn8(Attn8Args& a, int BH, int D8, size_t tpart_bytes, hipStream_t s, int hyb = 0) {
     const int ntq = a.NQB - a.NBv;
     if (a.tpart && tpart_bytes == 0) return RSA_ERR_WORKSPACE;   // capacity not declared (rsa_buffers.tpart_bytes, 0.5.0)
     const int n_txt_items = (a.kv_text_valid + RSA_BLOCK - 1) / RSA_BLOCK;
@@ -646,6 +717,12 @@ int launch_attn8(Attn8Args& a, int BH, int D8, size_t tpart_bytes, hipStream_t s
     if (nblocks > 0x7FFFFFFF) return RSA_ERR_UNSUPPORTED;
     if (a.NB_total > 8192) return RSA_ERR_UNSUPPORTED;
     const size_t lds_bytes = (size_t)2 * NSLOT * 64 * D8 + 64 + (((size_t)a.NB_total * 4 + 15) & ~(size_t)15);
+    if (hyb != 0) {   // the pv form: 2-byte Q . K^T, e4m3 P . V (three-slot rings: K 3 x 16 KiB, V 3 x 8 KiB)
+        if (D8 != 128) return RSA_ERR_UNSUPPORTED;
+        const size_t lds_h = (size_t)3 * 16384 + (size_t)3 * 8192 + 64 + (((size_t)a.NB_total * 4 + 15) & ~(size_t)15);
+        if (hyb == 2) RSA_LAUNCH_GSYNC(2, (bsfwd_fp8_kernel<6, 128, 2>), a, a.mode == MODE_SPARSE, dim3((unsigned)nblocks), 256, lds_h, s);
+        else RSA_LAUNCH_GSYNC(2, (bsfwd_fp8_kernel<6, 128, 1>), a, a.mode == MODE_SPARSE, dim3((unsigned)nblocks), 256, lds_h, s);
+    } else
     if (D8 == 64) {   // head dim 64: the product form and its compiled twin
         if (g_fp8_variant == 1) RSA_LAUNCH_GSYNC(2, (bsfwd_fp8_kernel<6, 64>), a, a.mode == MODE_SPARSE, dim3((unsigned)nblocks), 256, lds_bytes, s);
         else RSA_LAUNCH_GSYNC(2, (bsfwd_fp8_kernel<7, 64>), a, a.mode == MODE_SPARSE, dim3((unsigned)nblocks), 256, lds_bytes, s);
@@ -698,7 +775,36 @@ extern "C" int rsa_block_sparse_fwd_fp8(const rsa_layout* l, const rsa_fp8_opera
     a.q_text_end = l->NBv * RSA_BLOCK + l->q_text_valid;
     a.q_split = 0; a.kv_split = 0; a.causal = 0;
     a.out_fp16 = l->dtype == RSA_FP16;
+    a.q16 = a.k16 = nullptr; a.qsb = a.qsh = a.qss = a.ksb = a.ksh = a.kss = 0; a.qk_scale = 0.0f;
     return launch_attn8(a, l->B * l->H, l->D, buf->tpart_bytes, static_cast<hipStream_t>(stream));
+}
+
+// The "pv" form (round 5): Q . K^T on the 2-byte q and k themselves, e4m3 only for P and V (ops->v8t and the V bytes of
+// ops->scales are read; q8 / k8 may be NULL).
+extern "C" int rsa_block_sparse_fwd_fp8pv(const rsa_layout* l, rsa_tensor4 q, rsa_tensor4 k, const rsa_fp8_operands* ops,
+                                          const rsa_buffers* buf, rsa_out4 out, void* stream) {
+    int st = rsa_check_layout(l);
+    if (st != RSA_OK) return st;
+    if (l->D != 128) return RSA_ERR_UNSUPPORTED;
+    if (!ops || !ops->v8t || !ops->scales) return RSA_ERR_BAD_ARG;
+    if ((st = rsa_check_tensor(q)) || (st = rsa_check_tensor(k)) || (st = check_out8(out))) return st;
+    if (!buf || (l->NBv > 0 && (!buf->cols || !buf->counts))) return RSA_ERR_BAD_ARG;
+    if ((buf->R == nullptr) != (buf->comp == nullptr)) return RSA_ERR_BAD_ARG;
+    Attn8Args a;
+    a.q8 = ops->q8; a.k8 = ops->k8; a.v8t = ops->v8t; a.exps = ops->scales; a.exps_stride = l->NB_total;
+    a.out = static_cast<unsigned short*>(out.ptr); a.osb = out.stride_b; a.osh = out.stride_h; a.oss = out.stride_s;
+    a.cols = buf->cols; a.counts = buf->counts; a.R = buf->R; a.comp = buf->comp; a.tpart = buf->tpart;
+    a.mode = MODE_SPARSE; a.H = l->H; a.Sq = l->S; a.Sk = l->S;
+    a.Sq_pad = a.Sk_pad = l->NB_total * RSA_BLOCK;
+    a.NBv = l->NBv; a.NQB = l->NB_total; a.NB_total = l->NB_total;
+    a.kv_valid = l->kv_valid; a.kv_text_valid = l->kv_text_valid;
+    a.q_text_end = l->NBv * RSA_BLOCK + l->q_text_valid;
+    a.q_split = 0; a.kv_split = 0; a.causal = 0;
+    a.out_fp16 = l->dtype == RSA_FP16;
+    a.q16 = static_cast<const unsigned short*>(q.ptr); a.qsb = q.stride_b; a.qsh = q.stride_h; a.qss = q.stride_s;
+    a.k16 = static_cast<const unsigned short*>(k.ptr); a.ksb = k.stride_b; a.ksh = k.stride_h; a.kss = k.stride_s;
+    a.qk_scale = (float)((1.0 / sqrt((double)l->D)) * 1.44269504 * 8.0);      // sm_scale * log2(e) * PMap<true>::U
+    return launch_attn8(a, l->B * l->H, l->D, buf->tpart_bytes, static_cast<hipStream_t>(stream), l->dtype == RSA_FP16 ? 2 : 1);
 }
 
 extern "C" int rsa_rectified_attention_fp8(const rsa_layout* l, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
@@ -747,6 +853,7 @@ static int dense_fwd_fp8(int B, int H, int Sq, int Sk, int D, int dtype, rsa_ten
     a.kv_valid = Sk; a.kv_text_valid = Sk; a.q_text_end = 0;
     a.q_split = q_split; a.kv_split = kv_split; a.causal = causal;
     a.out_fp16 = dtype == RSA_FP16;
+    a.q16 = a.k16 = nullptr; a.qsb = a.qsh = a.qss = a.ksb = a.ksh = a.kss = 0; a.qk_scale = 0.0f;
     return launch_attn8(a, B * H, D, 0, s);
 }
 

@@ -162,11 +162,12 @@ void launch_blocks(BlocksArgs& a, int D, int dtype, int BH, int ntensors, hipStr
 }
 
 int fill_args(const rsa_layout* l, const rsa_tensor4& q, const rsa_tensor4& k, const rsa_tensor4& v,
-              const rsa_fp8_operands* ops, BlocksArgs& a) {
+              const rsa_fp8_operands* ops, BlocksArgs& a, bool v_only = false) {
     int st = rsa_check_layout(l);
     if (st != RSA_OK) return st;
     if (l->D != 128 && l->D != 64) return RSA_ERR_UNSUPPORTED;
-    if (!ops || !ops->q8 || !ops->k8 || !ops->v8t || !ops->scales) return RSA_ERR_BAD_ARG;
+    if (!ops || !ops->v8t || !ops->scales) return RSA_ERR_BAD_ARG;
+    if (!v_only && (!ops->q8 || !ops->k8)) return RSA_ERR_BAD_ARG;
     if ((st = rsa_check_tensor(q)) || (st = rsa_check_tensor(k)) || (st = rsa_check_tensor(v))) return st;
     // every key K5 may read unmasked must be a row the images hold
     if (l->pool_valid < l->kv_valid || l->pool_valid < l->kv_text_valid) return RSA_ERR_BAD_ARG;
@@ -206,9 +207,13 @@ extern "C" int rsa_quantize_fp8(const rsa_layout* l, rsa_tensor4 q, rsa_tensor4 
 extern "C" int rsa_pool_stats_fp8(const rsa_layout* l, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
                                   const rsa_buffers* buf, const rsa_fp8_operands* ops, void* stream) {
     BlocksArgs a;
-    int st = fill_args(l, q, k, v, ops, a);
+    // ops->q8 == ops->k8 == NULL: only the V image and the V exponents (what rsa_block_sparse_fwd_fp8pv reads): the Q and K blocks
+    // are pooled without being quantised, no K mean, no text-tail pass
+    const bool v_only = ops && !ops->q8 && !ops->k8;
+    int st = fill_args(l, q, k, v, ops, a, v_only);
     if (st != RSA_OK) return st;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (v_only) return rsa_pool_stats_f8(l, q, k, v, buf, &a.f8, stream);
     launch_kmean(l->D, l->dtype, k, l->B * l->H, l->H, l->pool_valid, const_cast<float*>(a.f8.kmean), s);
     if ((st = rsa_pool_stats_f8(l, q, k, v, buf, &a.f8, stream))) return st;
     a.blk0[0] = a.blk0[1] = l->NBv;   // q and k blocks K1 does not pool

@@ -46,6 +46,7 @@ template <int D, typename Tag>
 __device__ __forceinline__ void fp8_emit_block(const float (&x)[8][8], const Fp8Emit& f, int which, int blk, int bh,
                                                unsigned char* lds) {
     constexpr int CH = D / 8, NW = (2 * D) / 64, RSA_F8_LROW = rsa_f8_lrow(D);
+    if (which < 2 && (which == 0 ? f.q8 : f.k8) == nullptr) return;      // V-only producer (the pv form of K5): uniform per block
     const int t = threadIdx.x, c = t % CH, g = t / CH;
     const int valid = f.valid[which];
     float mu[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};

@@ -412,3 +412,68 @@ def test_fp8_dense_kernel_causal(Sq, Sk, qs, ks, D):
         assert rel.max() <= 0.2 and np.median(rel) <= 0.05, (rel.max(), np.median(rel))   # rows with 1-2 keys reproduce V
     d16 = (out.float() - ref16.float()).abs()
     assert d16.mean() <= FP8_MEAN_VS_BF16
+
+
+# ---- the "pv" form (round 5): 2-byte Q . K^T, e4m3 only for P . V (rsa_block_sparse_fwd_fp8pv) --------------------------------
+PV_MAX_VS_ORACLE, PV_MEAN_VS_ORACLE = 3e-2, 1e-3       # oracle with the kernel's own P map and the 2-byte scores; the kernel also
+                                                       # rounds its scaled q to the 2-byte type, as the 2-byte kernels do
+PV_MAX_VS_BF16, PV_MEAN_VS_BF16, PV_REL_L1 = 8e-2, 8e-3, 0.06   # SURVEY 8(d)'s bound for fp8 operands: this form meets it
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if len(c) == 7], ids=lambda c: c[0])
+def test_fp8_pv_form(case):
+    """Scores from the 2-byte q and k, e4m3 P and V: the selection pass and the V image are the fp8 path's (byte for byte), the
+    output is the oracle's with the same two choices (P by the code map: p_form="code", qk="2byte") within fp32 accumulation
+    and the 2-byte rounding of the scaled q, and sits within SURVEY 8(d)'s 8e-2 of the bf16 oracle -- which the all-e4m3 form
+    does not (1.4e-1)."""
+    from rectified_spaattn_amd import _core, synth
+    name, mk, H, top_k, p, nbw, dt = case
+    lay = mk()
+    q, k, v = synth.structured_qkv(4242 + len(name), 1, H, lay.S, 128, smooth=0.0)
+    nbr = synth.banded_neighbors(lay.NBv, nbw) if nbw >= 0 else None
+    tq, tk, tv = (torch.from_numpy(x).to(DEV, dt) for x in (q, k, v))
+    q, k, v = (x.float().cpu().numpy() for x in (tq, tk, tv))
+    tn = torch.from_numpy(nbr) if nbr is not None else None
+    out, parts = _core.rectified_attention(tq, tk, tv, _spec(lay), top_k, p, tn, return_parts=True, qkv_fp8="pv")
+    out8, parts8 = _core.rectified_attention(tq, tk, tv, _spec(lay), top_k, p, tn, return_parts=True, qkv_fp8=True)
+    for n in ("bitmask", "counts", "R", "comp", "v8t"):
+        assert torch.equal(parts[n], parts8[n]), n
+    # the pv form's producer writes the V image and the V exponents only (no Q / K images, no K mean)
+    assert torch.equal((parts["exps"] >> 16) & 0xFF, (parts8["exps"] >> 16) & 0xFF) and parts["q8"].numel() == 0 and parts["k8"].numel() == 0
+    o = out.float().cpu().numpy()
+    assert np.isfinite(o).all()
+    refc = orc.rectified_attention_fp8(q, k, v, lay, top_k, p, nbr, p_form="code", qk="2byte")
+    ec = np.abs(o - refc)
+    ref16 = orc.rectified_attention(q, k, v, lay, top_k, p, nbr)
+    e16 = np.abs(o - ref16)
+    e8 = np.abs(out8.float().cpu().numpy() - ref16)
+    rel = e16.sum() / np.abs(ref16).sum()
+    print(f"{name}: pv vs its oracle {ec.max():.3e} / {ec.mean():.3e}; vs bf16 oracle {e16.max():.3e} / {e16.mean():.3e} rel-L1 {rel:.4f} "
+          f"(all-e4m3: {e8.max():.3e} / {e8.mean():.3e} rel-L1 {e8.sum() / np.abs(ref16).sum():.4f})")
+    assert ec.max() <= PV_MAX_VS_ORACLE and ec.mean() <= PV_MEAN_VS_ORACLE, f"vs pv oracle: {ec.max():.3e} {ec.mean():.3e}"
+    assert e16.max() <= PV_MAX_VS_BF16 and e16.mean() <= PV_MEAN_VS_BF16 and rel <= PV_REL_L1, (e16.max(), e16.mean(), rel)
+    if name not in ("wan_keep_all", "wan_tiny"):
+        assert e16.mean() < 0.6 * e8.mean(), "the pv form is meant to be clearly closer to the bf16 oracle than the all-e4m3 form"
+
+
+def test_fp8_pv_form_public_switch_and_head_dim_64():
+    """set_qkv_fp8("pv") reaches the operators; head dim 64 has no pv kernel: the operator keeps the 2-byte kernel there (as the
+    e4m3 switch does for head dims without an fp8 kernel), a StagedCall refuses."""
+    import rectified_spaattn_amd as rsa
+    from rectified_spaattn_amd import _core, rectified_wan21_attn as rw, synth
+    S = 6 * 128
+    q, k, v = synth.structured_qkv(5, 1, 2, S, 128, smooth=0.0)
+    tq, tk, tv = (torch.from_numpy(x).to(DEV, torch.bfloat16) for x in (q, k, v))
+    spec = _core.LayoutSpec.wan(S, 1)
+    want = _core.rectified_attention(tq, tk, tv, spec, 2, 0.3, None, qkv_fp8="pv")
+    old = rsa.set_qkv_fp8("pv")
+    try:
+        got = rw.rectified_block_sparse_attention(tq, tk, tv, None, 2, block_neighbor_list=None, p_remain_rates=0.3, first_frame_blocks=1)
+    finally:
+        rsa.set_qkv_fp8(old)
+    assert torch.equal(got.reshape(want.shape), want)
+    q6, k6, v6 = (torch.randn(1, 2, S, 64, device=DEV).to(torch.bfloat16) for _ in range(3))
+    with pytest.raises(NotImplementedError):
+        _core.StagedCall(q6, k6, v6, spec, 2, 0.3, None, qkv_fp8="pv")
+    with pytest.raises(ValueError):
+        rsa.set_qkv_fp8("qk")
