@@ -214,6 +214,7 @@ def main():
                        f"SB v[{m.SB}:{m.SB + 15}], " + (f"-m v[{m.NM}:{m.NM + 15}], " if negm else "")
                        + f"temporaries v[{m.tmp0}:{m.tmp1 - 1}], K addresses v[{m.KA}:{m.KA + m.KS - 1}], V addresses v[{m.VA}:{m.end - 1}]")
     main8(out)
+    main8h(out)
     print("\n".join(out))
 
 
@@ -398,6 +399,182 @@ def main8(out):
     out.append(f"// e4m3 kernel: O v[0:63], Q v[{m.Q}:{m.SA - 1}], SA v[{m.SA}:{m.SB - 1}], SB v[{m.SB}:{m.MB - 1}], 4 - m v[{m.MB}:{m.LACC - 1}], "
                f"l v[{m.LACC}:{m.LACC + 3}], temporaries v[{m.tmp0}:{m.tmp1 - 1}], scales v[{m.SC}:{m.SC + 1}], "
                f"K / V / ones addresses v[{m.KA}:{m.end - 1}]")
+
+
+# =====================================================================================================================
+# the "pv" form of the e4m3 kernel (round 5; rsa_attn_fp8_kernel.hip, HYB instances): one block = one 64-key tile of one wave
+#     S_nxt^T (two 32-key halves) = K(tile+1) . Q^T + MB     16 x v_mfma_f32_32x32x16 on the 2-BYTE K rows (A = one ds_read_b128 per
+#                                                            k-step from the 16 KiB K tile, image of rsa_attn_kernel.hip) and the
+#                                                            2-byte Q fragments (32 registers; Q carries sm_scale log2e 8)
+#     P codes, row sum, O^T += V8^T . P, mx                  exactly the e4m3 block above (code map form)
+# Rings of THREE slots (K 3 x 16 KiB at LDS 0, V 3 x 8 KiB behind it): K(tile+1) sits in slot (tile + 1) % 3, V(tile) in
+# tile % 3, S_cur is SA on even tiles -> six variants, T = tile % 6.  The V read addresses carry the V ring's base (49 152 is
+# beyond what the 16-bit offset field could add to a K address with slot and d-tile offsets on top).
+# The LDS operand registers are a pool of eight 4-register slots (QK^T fragments take one, the 8-register operands of the row
+# sum and of P . V two, aligned): a read may re-target a slot once the MFMA AFTER its last consumer has been issued (the rule
+# of the e4m3 block's ring); QK^T fragments are read six MFMAs ahead (a 2-byte MFMA is half as long as an e4m3 one), the rest three.
+# =====================================================================================================================
+class Map8H:
+    def __init__(self):
+        r = 0
+        self.O = r; r += 64
+        self.Q = r; r += 32
+        self.SA = r; r += 32
+        self.SB = r; r += 32
+        self.MB = r; r += 16
+        self.LACC = r; r += 4
+        self.tmp0 = r
+        self.OP = r; r += 4 * NSLOT8H
+        self.T0 = r; r += 1
+        self.T1 = r; r += 1
+        self.tmp1 = r
+        r = (r + 1) & ~1
+        self.SC = r; r += 2
+        self.VA = r; r += 2          # V read addresses [chunk], V ring base included (an even-aligned pair)
+        self.KB = r; r += 1          # K read address of k-step 0 (row r of slot 0); k-step ks = this ^ (ks << 5) (the tile's XOR
+                                     # swizzle), built in T0 / T1 just before the reads; 32-key half and ring slot are immediates
+        r = (r + 1) & ~1
+        self.ONES = r; r += 8        # A operand of the row-sum product (e4m3 1.0 or 0 in all 32 bytes: a constant of the lane)
+        self.end = r
+
+
+NSLOT8H = 6      # 4-register operand slots (256 registers per wave at two waves per SIMD: the block pins 212 of them)
+
+
+def gen_block8h(T6, dt):
+    m = Map8H()
+    mf = "v_mfma_f32_32x32x16_bf16" if dt == "bf16" else "v_mfma_f32_32x32x16_f16"
+    SC_, SN = (m.SA, m.SB) if T6 % 2 == 0 else (m.SB, m.SA)
+    kslot, vslot = (T6 + 1) % 3, T6 % 3
+    lines, lds_seq = [], []
+    ops = []      # (kind, x, y, reads [(address register, offset)], slots)
+    for ks in range(8):          # the two halves' chains alternate: no MFMA waits for the one just before it
+        kreg = m.KB if ks == 0 else (m.T0 if ks % 2 == 0 else m.T1)
+        for sub in range(2):
+            ops.append(("qk", sub, ks, [(kreg, kslot * 16384 + sub * 8192)], 1))
+    n_qk = len(ops)
+    ops.append(("rs", 0, 0, [], 0))
+    for d in range(4):
+        off = vslot * 8192 + d * 2048
+        ops.append(("pv", d, 0, [(m.VA, off), (m.VA + 1, off)], 2))
+    n = len(ops)
+    slot_of, consumer = {}, [None] * NSLOT8H     # consumer[s] = index of the op that reads slot s (None: free)
+    state = dict(issued=-1)
+
+    def read(j, cur):
+        need = ops[j][4]
+        if need == 0:
+            return
+        for s0 in range(0, NSLOT8H, need):
+            # (cur - 2: the MFMA AFTER the slot's last consumer has been issued, the rule of the e4m3 block's ring)
+            if all(consumer[s0 + u] is None or consumer[s0 + u] <= cur - 2 for u in range(need)):
+                break
+        else:
+            raise AssertionError(("no free operand slot", T6, j, cur, consumer))
+        for u in range(need):
+            consumer[s0 + u] = j
+        slot_of[j] = s0
+        b = m.OP + 4 * s0
+        kind, sub, ks = ops[j][0], ops[j][1], ops[j][2]
+        if kind == "qk" and sub == 0 and ks > 0:
+            assert state["issued"] < n_qk, "T0 / T1 belong to the row maximum from P . V 0 on"
+            lines.append(f"v_xor_b32 {vr(ops[j][3][0][0])}, {hex(ks << 5)}, {vr(m.KB)}")
+        for c2, (areg, off) in enumerate(ops[j][3]):
+            lines.append(f"ds_read_b128 {vr(b + 4 * c2, 4)}, {vr(areg)}" + (f" offset:{off}" if off else ""))
+        lds_seq.append((j, len(ops[j][3])))
+
+    def wait_for(i):
+        idx = [k for k, (t, _) in enumerate(lds_seq) if t == i][-1]
+        lines.append(f"s_waitcnt lgkmcnt({sum(c for _, c in lds_seq[idx + 1:])})")
+
+    # vector work: the code-map conversions of S_cur in place (as gen_block8), then the row maximum of S_nxt
+    def byte(j, e):
+        sub, w4 = divmod(j, 4)
+        return ("cvt8", f"v_cvt_pk_u8_f32 {vr(SC_ + j)}, {vr(SC_ + 16 * sub + 4 * w4 + e)}, {e}, {vr(SC_ + j)}")
+    work = [byte(0, 0), byte(0, 1), byte(1, 0), byte(0, 2), byte(1, 1), byte(0, 3), byte(1, 2), byte(1, 3)]
+    for j in (2, 4, 6):
+        for e in range(4):
+            work += [byte(j, e), byte(j + 1, e)]
+    maxw = [("max", f"v_max_f32 {vr(m.T0)}, {vr(SN)}, {vr(SN + 1)}"), ("max", f"v_max_f32 {vr(m.T1)}, {vr(SN + 2)}, {vr(SN + 3)}")]
+    for i in range(2, 16):
+        t = m.T0 if i % 2 == 0 else m.T1
+        maxw += [("max", f"v_max3_f32 {vr(t)}, {vr(t)}, {vr(SN + 2 * i)}, {vr(SN + 2 * i + 1)}")]
+    maxw += [("max", f"v_max_f32 {vr(m.T0)}, {vr(m.T0)}, {vr(m.T1)}"), ("mov", f"v_mov_b32 {vr(m.T1)}, {vr(m.T0)}"),
+             ("nop", "s_nop 1"), ("swap", f"v_permlane32_swap_b32 {vr(m.T0)}, {vr(m.T1)}"), ("nop", "s_nop 1"),
+             ("max", f"v_max_f32 %[mx], {vr(m.T0)}, {vr(m.T1)}")]
+    wi, mi = 0, 0
+
+    def emit_work(cycles, allow_max, force_all=False):
+        nonlocal wi, mi
+        used = 0
+        while used < cycles or force_all:
+            if wi < len(work):
+                k, t = work[wi]; wi += 1
+            elif allow_max and mi < len(maxw):
+                k, t = maxw[mi]; mi += 1
+            else:
+                break
+            lines.append(t)
+            used += COST[k]
+
+    nxt = 0           # next op whose operand read has not been issued
+
+    def top_up(cur):
+        """issue the reads of the next ops while an operand slot is free (`cur` = the op about to issue)"""
+        nonlocal nxt
+        while nxt < n:
+            try:
+                read(nxt, cur)
+            except AssertionError:
+                break
+            nxt += 1
+
+    lines.append("s_setprio 2")
+    top_up(0)
+    emit_work(48, False)
+    for i, (kind, x, y, _, _) in enumerate(ops):
+        if kind != "qk" and wi < len(work):   # the row sum and P . V read the whole packed P
+            emit_work(0, False, force_all=True)
+        assert i < nxt, ("operand never read", T6, i)
+        if ops[i][4]:
+            wait_for(i)
+        b = m.OP + 4 * slot_of.get(i, 0)
+        if kind == "qk":
+            c = vr(m.MB, 16) if y == 0 else vr(SN + 16 * x, 16)
+            lines.append(f"{mf} {vr(SN + 16 * x, 16)}, {vr(b, 4)}, {vr(m.Q + 4 * y, 4)}, {c}")
+        elif kind == "rs":
+            lines.append("s_nop 1")
+            lines.append(f"v_mfma_f32_16x16x128_f8f6f4 {vr(m.LACC, 4)}, {vr(m.ONES, 8)}, {vr(SC_, 8)}, {vr(m.LACC, 4)}")
+        else:
+            lines.append(f"v_mfma_scale_f32_32x32x64_f8f6f4 {vr(m.O + 16 * x, 16)}, {vr(b, 8)}, {vr(SC_, 8)}, {vr(m.O + 16 * x, 16)}, "
+                         f"{vr(m.SC)}, {vr(m.SC + 1)} op_sel:[1,1,0] op_sel_hi:[0,0,0]")
+        state["issued"] = i
+        top_up(i + 1)
+        # row max of S_nxt: two MFMAs behind the last QK^T MFMA
+        emit_work(10 ** 6 if i == n - 1 else (20 if kind == "qk" else 48), i >= n_qk + 1)
+    assert wi == len(work) and mi == len(maxw) and nxt == n
+    lines.append("s_setprio 0")
+    return lines, m
+
+
+def main8h(out):
+    for dt in ("bf16", "f16"):
+        for T6 in range(6):
+            lines, m = gen_block8h(T6, dt)
+            out.append(f"#define RSA_K5F8H_BLOCK_{dt.upper()}_T{T6} \\")
+            out.append(" \\\n".join(c_string(lines).split("\n")))
+            out.append("")
+    m = Map8H()
+    outs = [f'"+{{{vr(m.O + 16 * d, 16)}}}"(o[{d}])' for d in range(4)]
+    outs += [f'"+{{{vr(m.SA, 16)}}}"(SA[0])', f'"+{{{vr(m.SA + 16, 16)}}}"(SA[1])', f'"+{{{vr(m.SB, 16)}}}"(SB[0])',
+             f'"+{{{vr(m.SB + 16, 16)}}}"(SB[1])', f'"+{{{vr(m.LACC, 4)}}}"(lacc)', '[mx] "=&v"(mx)']
+    ins = [f'"{{{vr(m.Q + 4 * k, 4)}}}"(qh[{k}])' for k in range(8)]
+    ins += [f'"{{{vr(m.MB, 16)}}}"(mblk)', f'"{{{vr(m.SC)}}}"(sca)', f'"{{{vr(m.SC + 1)}}}"(scb)', f'"{{{vr(m.VA, 2)}}}"(vah)',
+            f'"{{{vr(m.KB)}}}"(kah)', f'"{{{vr(m.ONES, 8)}}}"(onesv)']
+    out.append(f"#define RSA_K5F8H_OPS : {', '.join(outs)} : {', '.join(ins)}")
+    out.append("#define RSA_K5F8H_CLOBBER " + ", ".join(f'"v{r}"' for r in range(m.tmp0, m.tmp1)))
+    out.append(f"// pv form: O v[0:63], Q v[{m.Q}:{m.SA - 1}], SA v[{m.SA}:{m.SB - 1}], SB v[{m.SB}:{m.MB - 1}], reference block v[{m.MB}:{m.LACC - 1}], "
+               f"l v[{m.LACC}:{m.LACC + 3}], temporaries v[{m.tmp0}:{m.tmp1 - 1}], scales v[{m.SC}:{m.SC + 1}], V / K addresses v[{m.VA}:{m.KB}], ones v[{m.ONES}:{m.end - 1}]")
 
 
 if __name__ == "__main__":

@@ -134,6 +134,19 @@ __device__ __forceinline__ void k5f8_block(f32x16 (&o)[D8 / 32], const i32x8 (&q
     }
 }
 
+// the pv form's hand-placed block (gen_k5_block.py::gen_block8h, RSA_K5F8H_*): T6 = tile % 6 (three-slot rings, S_cur = SA on even tiles)
+template <int T6, int HYB>
+__device__ __forceinline__ void k5f8h_block(f32x16 (&o)[4], const s16x8 (&qh)[8], f32x16 (&SA)[2], f32x16 (&SB)[2], const f32x16& mblk,
+                                            f32x4& lacc, float& mx, int sca, int scb, int kah, const i32x2& vah, const i32x8& onesv) {
+#define RSA_K5F8H_CASE(T_) \
+    if constexpr (T6 == T_) { \
+        if constexpr (HYB == 2) asm volatile(RSA_K5F8H_BLOCK_F16_T##T_ RSA_K5F8H_OPS : RSA_K5F8H_CLOBBER, "memory"); \
+        else asm volatile(RSA_K5F8H_BLOCK_BF16_T##T_ RSA_K5F8H_OPS : RSA_K5F8H_CLOBBER, "memory"); \
+    }
+    RSA_K5F8H_CASE(0) RSA_K5F8H_CASE(1) RSA_K5F8H_CASE(2) RSA_K5F8H_CASE(3) RSA_K5F8H_CASE(4) RSA_K5F8H_CASE(5)
+#undef RSA_K5F8H_CASE
+}
+
 // PIPE_OPT bit 0: the hand-placed block (clear: the block as hipcc schedules it, same arithmetic, for A/B);
 // bit 1: s_setprio around the compiled block; bit 2: the code-map form of P (PMap above).  Product = 7.
 // D8: head dim = bytes per Q / K row (128; 64 = the CogVideoX shape, hand-placed code-map form only).
@@ -141,10 +154,10 @@ __device__ __forceinline__ void k5f8_block(f32x16 (&o)[D8 / 32], const i32x8 (&q
 // bytes staged like the 2-byte kernels' -- rsa_attn_kernel.hip -- and multiplied by v_mfma_f32_32x32x16), e4m3 only for P and V.
 // The scores are then the 2-byte path's (the e4m3 rounding of Q and K is 90 % of the fp8 path's error: DESIGN 4b), P . V runs at
 // the fp8 rate: 800 instead of 1 024 (2-byte) or 544 (e4m3) matrix cycles per 64 keys and 32 rows.  Three-slot rings (K 3 x 16
-// KiB, V 3 x 8 KiB: two workgroups per CU), the compiled block only.
+// KiB, V 3 x 8 KiB: two workgroups per CU); PIPE_OPT 7 = the hand-placed block (six tiles per loop trip), 6 = its compiled twin.
 template <int PIPE_OPT, int D8 = 128, int HYB = 0>
 __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
-    static_assert(HYB == 0 || (D8 == 128 && (PIPE_OPT & 1) == 0), "the pv form: head dim 128, compiled block");
+    static_assert(HYB == 0 || (D8 == 128 && (PIPE_OPT & 4) != 0), "the pv form: head dim 128, code-map P");
     constexpr int TILE8 = 64 * D8;        // bytes of one K tile (64 keys x D8) and of one V tile (D8 rows x 64 keys)
     constexpr int TILEK = HYB ? 64 * 2 * D8 : TILE8;     // K tile: e4m3 rows, or the 2-byte rows themselves
     constexpr int NSK = HYB ? 3 : NSLOT, NSV = HYB ? 3 : NSLOT;
@@ -412,6 +425,17 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     va[0] = (int)lds_base + voff_rd[0];
     va[1] = (int)lds_base + voff_rd[1];
     const int ona = (int)lds_base + ONES + ones_off;
+    // pv form: K fragment of k-step ks = 16-byte chunk 2 ks + hh of row r (+ 8 192 per 32-key half, + 16 384 per ring slot):
+    // tile_off's XOR puts ks into address bits 5..7, the block derives the eight addresses from k-step 0's (lds_base is 1 KiB
+    // aligned: the kernel's first dynamic LDS byte).  The V addresses carry the V ring's base.
+    const int kah = (int)lds_base + (HYB ? tile_off<128>(r, hh) : 0);
+    i32x2 vah;
+    // (the hand-placed pv block keeps the row-sum product's A operand -- e4m3 1.0 or 0 in every byte -- in registers)
+    i32x8 onesv;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) onesv[i] = ones_off == 0 ? 0x38383838 : 0;
+    vah[0] = va[0] + VBASE;
+    vah[1] = va[1] + VBASE;
 
     auto ld32 = [&](const unsigned char* p0, const unsigned char* p1) -> i32x8 {
         const i32x4 lo = *reinterpret_cast<const i32x4*>(p0);
@@ -479,8 +503,10 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
         }
         __syncthreads();
         // ring slots: tile & 3 of four (ts), or tile mod 3 of three in the pv form
-        const int ks_dma = HYB ? tile % 3 : (ts + 3) & (NSLOT - 1), vs_dma = HYB ? (tile + 2) % 3 : (ts + 2) & (NSLOT - 1);
-        const int ks_nxt = HYB ? (tile + 1) % 3 : (ts + 1) & (NSLOT - 1), vs_cur = HYB ? tile % 3 : ts;
+        // (pv form, hand-placed: TS = tile % 6 at compile time)
+        const int t3 = (PIPE_OPT & 1) != 0 ? ts % 3 : tile % 3;
+        const int ks_dma = HYB ? t3 : (ts + 3) & (NSLOT - 1), vs_dma = HYB ? (t3 + 2) % 3 : (ts + 2) & (NSLOT - 1);
+        const int ks_nxt = HYB ? (t3 + 1) % 3 : (ts + 1) & (NSLOT - 1), vs_cur = HYB ? t3 : ts;
         if (tile + 3 < n_tiles) dma_k(kq3, ks_dma);
         if (tile + 2 < n_tiles) dma_v(kq2, vs_dma);
         // ---- head (rare branches): boundary mask, deferred rescale ----
@@ -516,6 +542,10 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
         if constexpr ((PIPE_OPT & 1) != 0) {
             constexpr int tsc = decltype(TS)::value;
             // S_cur is SA on even tiles, SB on odd ones (tile & 1 == TS & 1)
+            if constexpr (HYB != 0) {
+                if constexpr ((tsc & 1) == 0) k5f8h_block<tsc, HYB>(o, qh, S_cur, S_nxt, mblk, lacc, mx_nxt, sc_a, sc_b, kah, vah, onesv);
+                else k5f8h_block<tsc, HYB>(o, qh, S_nxt, S_cur, mblk, lacc, mx_nxt, sc_a, sc_b, kah, vah, onesv);
+            } else
             if constexpr ((tsc & 1) == 0) k5f8_block<tsc, CODEMAP, D8>(o, qf, S_cur, S_nxt, mblk, lacc, mx_nxt, sc_a, sc_b, ka, va, ona);
             else k5f8_block<tsc, CODEMAP, D8>(o, qf, S_nxt, S_cur, mblk, lacc, mx_nxt, sc_a, sc_b, ka, va, ona);
             return;
@@ -583,6 +613,34 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
         sw3 = e4 >> 16;
         pref_raw = raw_item(tile + 5);
     };
+    if constexpr ((PIPE_OPT & 1) != 0 && HYB != 0) {   // pv form: six tiles per trip (three ring slots x two score registers sets)
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        using I3 = std::integral_constant<int, 3>;
+        using I4 = std::integral_constant<int, 4>;
+        using I5 = std::integral_constant<int, 5>;
+        int tile = 0;
+        for (; tile + 5 < n_tiles; tile += 6) {
+            step(I0{}, tile, key0, SA, mxA, SB, mxB);
+            advance(tile);
+            step(I1{}, tile + 1, key0, SB, mxB, SA, mxA);
+            advance(tile + 1);
+            step(I2{}, tile + 2, key0, SA, mxA, SB, mxB);
+            advance(tile + 2);
+            step(I3{}, tile + 3, key0, SB, mxB, SA, mxA);
+            advance(tile + 3);
+            step(I4{}, tile + 4, key0, SA, mxA, SB, mxB);
+            advance(tile + 4);
+            step(I5{}, tile + 5, key0, SB, mxB, SA, mxA);
+            advance(tile + 5);
+        }
+        if (tile < n_tiles) { step(I0{}, tile, key0, SA, mxA, SB, mxB); advance(tile); }
+        if (tile + 1 < n_tiles) { step(I1{}, tile + 1, key0, SB, mxB, SA, mxA); advance(tile + 1); }
+        if (tile + 2 < n_tiles) { step(I2{}, tile + 2, key0, SA, mxA, SB, mxB); advance(tile + 2); }
+        if (tile + 3 < n_tiles) { step(I3{}, tile + 3, key0, SB, mxB, SA, mxA); advance(tile + 3); }
+        if (tile + 4 < n_tiles) step(I4{}, tile + 4, key0, SA, mxA, SB, mxB);
+    } else
     if constexpr ((PIPE_OPT & 1) != 0) {   // four tiles per trip: the ring slot is a compile-time constant of every block
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
@@ -720,8 +778,14 @@ int launch_attn8(Attn8Args& a, int BH, int D8, size_t tpart_bytes, hipStream_t s
     if (hyb != 0) {   // the pv form: 2-byte Q . K^T, e4m3 P . V (three-slot rings: K 3 x 16 KiB, V 3 x 8 KiB)
         if (D8 != 128) return RSA_ERR_UNSUPPORTED;
         const size_t lds_h = (size_t)3 * 16384 + (size_t)3 * 8192 + 64 + (((size_t)a.NB_total * 4 + 15) & ~(size_t)15);
-        if (hyb == 2) RSA_LAUNCH_GSYNC(2, (bsfwd_fp8_kernel<6, 128, 2>), a, a.mode == MODE_SPARSE, dim3((unsigned)nblocks), 256, lds_h, s);
-        else RSA_LAUNCH_GSYNC(2, (bsfwd_fp8_kernel<6, 128, 1>), a, a.mode == MODE_SPARSE, dim3((unsigned)nblocks), 256, lds_h, s);
+        // (tuning key fp8_variant 1 = the compiled twin of the hand-placed block: same arithmetic, hipcc's schedule)
+        if (g_fp8_variant == 1) {
+            if (hyb == 2) RSA_LAUNCH_GSYNC(2, (bsfwd_fp8_kernel<6, 128, 2>), a, a.mode == MODE_SPARSE, dim3((unsigned)nblocks), 256, lds_h, s);
+            else RSA_LAUNCH_GSYNC(2, (bsfwd_fp8_kernel<6, 128, 1>), a, a.mode == MODE_SPARSE, dim3((unsigned)nblocks), 256, lds_h, s);
+        } else {
+            if (hyb == 2) RSA_LAUNCH_GSYNC(2, (bsfwd_fp8_kernel<7, 128, 2>), a, a.mode == MODE_SPARSE, dim3((unsigned)nblocks), 256, lds_h, s);
+            else RSA_LAUNCH_GSYNC(2, (bsfwd_fp8_kernel<7, 128, 1>), a, a.mode == MODE_SPARSE, dim3((unsigned)nblocks), 256, lds_h, s);
+        }
     } else
     if (D8 == 64) {   // head dim 64: the product form and its compiled twin
         if (g_fp8_variant == 1) RSA_LAUNCH_GSYNC(2, (bsfwd_fp8_kernel<6, 64>), a, a.mode == MODE_SPARSE, dim3((unsigned)nblocks), 256, lds_bytes, s);

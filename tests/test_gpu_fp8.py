@@ -456,6 +456,30 @@ def test_fp8_pv_form(case):
         assert e16.mean() < 0.6 * e8.mean(), "the pv form is meant to be clearly closer to the bf16 oracle than the all-e4m3 form"
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_fp8_pv_hand_placed_block_against_its_compiled_twin(dt):
+    """The pv kernel's tile block is one hand-placed instruction stream (gen_k5_block.py::gen_block8h), six tiles per loop trip;
+    tuning key fp8_variant 1 launches the same arithmetic as hipcc schedules it.  Bit for bit equal, for kept lists of every
+    length 1 .. 14 blocks (2 .. 28 tiles: every remainder of the six-tile trip, with and without the half tile at the end of the
+    valid keys) and with text rows."""
+    from rectified_spaattn_amd import _core, _lib, synth
+    L = _lib.lib()
+    lays = [("wan", orc.layout_wan(14 * 128 - 40, 1)), ("hunyuan", orc.layout_hunyuan(9 * 128 + 256, 9 * 128 + 130))]
+    for name, lay in lays:
+        q, k, v = synth.structured_qkv(31 + len(name), 1, 2, lay.S, 128, smooth=0.0)
+        tq, tk, tv = (torch.from_numpy(x).to(DEV, dt) for x in (q, k, v))
+        for top_k in range(1, lay.NBv + 1):
+            outs = {}
+            try:
+                for var in (0, 1):
+                    assert L.rsa_set_tuning(b"fp8_variant", var) == 0
+                    outs[var] = _core.rectified_attention(tq, tk, tv, _spec(lay), top_k, 0.0, None, qkv_fp8="pv")
+            finally:
+                L.rsa_set_tuning(b"fp8_variant", 0)
+            assert torch.isfinite(outs[0].float()).all()
+            assert torch.equal(outs[0], outs[1]), (name, top_k)
+
+
 def test_fp8_pv_form_public_switch_and_head_dim_64():
     """set_qkv_fp8("pv") reaches the operators; head dim 64 has no pv kernel: the operator keeps the 2-byte kernel there (as the
     e4m3 switch does for head dims without an fp8 kernel), a StagedCall refuses."""
