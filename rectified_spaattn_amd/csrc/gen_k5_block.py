@@ -442,6 +442,10 @@ NSLOT8H = 6      # 4-register operand slots (256 registers per wave at two waves
 
 
 def gen_block8h(T6, dt):
+    """xf (env RSA_GEN8H_X, comma separated; timing experiments of tools/r5_pvx.sh, results are garbage): halfk = the second
+    32-key half re-uses the first half's K fragment (8 instead of 16 K reads), nov = no V reads, novalu = no conversions / row max."""
+    import os
+    xf = set(filter(None, os.environ.get("RSA_GEN8H_X", "").split(",")))
     m = Map8H()
     mf = "v_mfma_f32_32x32x16_bf16" if dt == "bf16" else "v_mfma_f32_32x32x16_f16"
     SC_, SN = (m.SA, m.SB) if T6 % 2 == 0 else (m.SB, m.SA)
@@ -451,12 +455,15 @@ def gen_block8h(T6, dt):
     for ks in range(8):          # the two halves' chains alternate: no MFMA waits for the one just before it
         kreg = m.KB if ks == 0 else (m.T0 if ks % 2 == 0 else m.T1)
         for sub in range(2):
-            ops.append(("qk", sub, ks, [(kreg, kslot * 16384 + sub * 8192)], 1))
+            if ("halfk" in xf and sub == 1) or "nok" in xf:
+                ops.append(("qk", sub, ks, [], 0))
+            else:
+                ops.append(("qk", sub, ks, [(kreg, kslot * 16384 + sub * 8192)], 1))
     n_qk = len(ops)
     ops.append(("rs", 0, 0, [], 0))
     for d in range(4):
         off = vslot * 8192 + d * 2048
-        ops.append(("pv", d, 0, [(m.VA, off), (m.VA + 1, off)], 2))
+        ops.append(("pv", d, 0, [] if "nov" in xf else [(m.VA, off), (m.VA + 1, off)], 0 if "nov" in xf else 2))
     n = len(ops)
     slot_of, consumer = {}, [None] * NSLOT8H     # consumer[s] = index of the op that reads slot s (None: free)
     state = dict(issued=-1)
@@ -476,7 +483,7 @@ def gen_block8h(T6, dt):
         slot_of[j] = s0
         b = m.OP + 4 * s0
         kind, sub, ks = ops[j][0], ops[j][1], ops[j][2]
-        if kind == "qk" and sub == 0 and ks > 0:
+        if kind == "qk" and sub == 0 and ks > 0 and "nok" not in xf:
             assert state["issued"] < n_qk, "T0 / T1 belong to the row maximum from P . V 0 on"
             lines.append(f"v_xor_b32 {vr(ops[j][3][0][0])}, {hex(ks << 5)}, {vr(m.KB)}")
         for c2, (areg, off) in enumerate(ops[j][3]):
@@ -503,6 +510,8 @@ def gen_block8h(T6, dt):
              ("nop", "s_nop 1"), ("swap", f"v_permlane32_swap_b32 {vr(m.T0)}, {vr(m.T1)}"), ("nop", "s_nop 1"),
              ("max", f"v_max_f32 %[mx], {vr(m.T0)}, {vr(m.T1)}")]
     wi, mi = 0, 0
+    if "novalu" in xf:
+        work, maxw = [], [("mov", "v_mov_b32 %[mx], 0")]
 
     def emit_work(cycles, allow_max, force_all=False):
         nonlocal wi, mi
@@ -538,7 +547,7 @@ def gen_block8h(T6, dt):
         assert i < nxt, ("operand never read", T6, i)
         if ops[i][4]:
             wait_for(i)
-        b = m.OP + 4 * slot_of.get(i, 0)
+        b = m.OP + 4 * slot_of.get(i, slot_of.get(i - 1, 0))
         if kind == "qk":
             c = vr(m.MB, 16) if y == 0 else vr(SN + 16 * x, 16)
             lines.append(f"{mf} {vr(SN + 16 * x, 16)}, {vr(b, 4)}, {vr(m.Q + 4 * y, 4)}, {c}")

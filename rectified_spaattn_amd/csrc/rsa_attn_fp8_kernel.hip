@@ -501,14 +501,18 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+#ifndef RSA_PVX_NOBAR
         __syncthreads();
+#endif
         // ring slots: tile & 3 of four (ts), or tile mod 3 of three in the pv form
         // (pv form, hand-placed: TS = tile % 6 at compile time)
         const int t3 = (PIPE_OPT & 1) != 0 ? ts % 3 : tile % 3;
         const int ks_dma = HYB ? t3 : (ts + 3) & (NSLOT - 1), vs_dma = HYB ? (t3 + 2) % 3 : (ts + 2) & (NSLOT - 1);
         const int ks_nxt = HYB ? (t3 + 1) % 3 : (ts + 1) & (NSLOT - 1), vs_cur = HYB ? t3 : ts;
+#ifndef RSA_PVX_NODMA   // (RSA_PVX_*: timing experiments of tools/r5_pvx.sh, never defined in the product)
         if (tile + 3 < n_tiles) dma_k(kq3, ks_dma);
         if (tile + 2 < n_tiles) dma_v(kq2, vs_dma);
+#endif
         // ---- head (rare branches): boundary mask, deferred rescale ----
         if (key0 < lo_max || key0 + 64 > hi_min) {
             apply_mask(S_cur, key0);
