@@ -231,6 +231,7 @@ def main():
 # loop-invariant VGPR plus an immediate (the compiled block spent ~16 v_add_u32 per tile on them).
 # =====================================================================================================================
 AHEAD8, RING8 = 3, 4
+DMA8_GAPS = [0, 2, 4, 6]      # dma form: K piece 0, K piece 1, V piece 0, V piece 1 behind these MFMAs of the nine
 
 
 class Map8:
@@ -253,10 +254,19 @@ class Map8:
         self.KA = r; r += 2 * self.KS   # K read addresses [ks][chunk]
         self.VA = r; r += 2          # V read addresses [chunk]
         self.ON = r; r += 1          # address of this lane's ones / zeros pattern
+        r = (r + 1) & ~1
+        self.DK = r; r += 2          # LDS-DMA lane offsets of the wave's two K pieces (the second = the first + 4 096): dma form
+        self.DV = r; r += 2          # ... of its two V pieces
         self.end = r
 
 
-def gen_block8(TS, codemap=False, D8=128):
+def gen_block8(TS, codemap=False, D8=128, dma=False):
+    """dma (round 5; head dim 128): the block also issues the wave's four LDS-DMA pieces -- K(tile + 3) into ring slot (TS + 3) & 3,
+    V(tile + 2) into (TS + 2) & 3 -- one per MFMA shadow instead of as a burst behind the barrier (there the eight waves' pieces queue
+    at the CU's one addresser: profiles/r05_pv_hand_placed.txt).  Scalar operands: %[ksrc] / %[vsrc] = first byte of the wave's
+    first piece, %[ldsw] = LDS address of the wave's first piece in slot 0 of the K ring."""
+    import os
+    xf = set(filter(None, os.environ.get("RSA_GEN8_X", "").split(",")))   # timing experiments (tools/r5_pvx_build.sh): halfk, nolds
     m = Map8(D8)
     SC_, SN = (m.SA, m.SB) if TS % 2 == 0 else (m.SB, m.SA)
     TILE8 = 64 * D8
@@ -267,14 +277,16 @@ def gen_block8(TS, codemap=False, D8=128):
     for sub in range(2):
         for ks in range(m.KS):
             off = kslot * TILE8 + sub * 32 * D8
-            ops.append(("qk", sub, ks, [(m.KA + 2 * ks, off), (m.KA + 2 * ks + 1, off)]))
+            ops.append(("qk", sub, ks, [] if ("halfk" in xf and sub == 1) or "nolds" in xf else [(m.KA + 2 * ks, off), (m.KA + 2 * ks + 1, off)]))
     n_qk = len(ops)
-    ops.append(("rs", 0, 0, [(m.ON, 0), (m.ON, 16)]))
+    ops.append(("rs", 0, 0, [] if "nolds" in xf else [(m.ON, 0), (m.ON, 16)]))
     for dt in range(m.DT):
         off = (4 + TS) * TILE8 + dt * 2048
-        ops.append(("pv", dt, 0, [(m.VA, off), (m.VA + 1, off)]))
+        ops.append(("pv", dt, 0, [] if "nolds" in xf else [(m.VA, off), (m.VA + 1, off)]))
 
     def read(i):
+        if not ops[i][3]:
+            return
         b = m.OP + 8 * (i % RING8)
         for c2, (areg, off) in enumerate(ops[i][3]):
             lines.append(f"ds_read_b128 {vr(b + 4 * c2, 4)}, {vr(areg)}" + (f" offset:{off}" if off else ""))
@@ -342,8 +354,9 @@ def gen_block8(TS, codemap=False, D8=128):
     for i, (kind, x, y, _) in enumerate(ops):
         if kind != "qk" and wi < len(work):   # the row sum and PV read the whole packed P
             emit_work(0, False, force_all=True)
-        wait_for(i)
-        a = vr(m.OP + 8 * (i % RING8), 8)
+        if ops[i][3]:
+            wait_for(i)
+        a = vr(m.OP + 8 * ((i if ops[i][3] or "nolds" in xf else i - m.KS) % RING8), 8)
         if kind == "qk":
             c = vr(m.MB, 16) if y == 0 else vr(SN + 16 * x, 16)
             lines.append(f"v_mfma_scale_f32_32x32x64_f8f6f4 {vr(SN + 16 * x, 16)}, {a}, {vr(m.Q + 8 * y, 8)}, {c}, "
@@ -356,6 +369,13 @@ def gen_block8(TS, codemap=False, D8=128):
             lines.append(f"v_mfma_scale_f32_32x32x64_f8f6f4 {vr(m.O + 16 * x, 16)}, {a}, {vr(SC_, 8)}, {vr(m.O + 16 * x, 16)}, "
                          f"{vr(m.SC)}, {vr(m.SC + 1)} op_sel:[1,1,0] op_sel_hi:[0,0,0]")
         if i + AHEAD8 < n: read(i + AHEAD8)
+        if dma and i in DMA8_GAPS:
+            j = DMA8_GAPS.index(i)
+            isv, hi = divmod(j, 2)
+            dst = (4 + ((TS + 2) & 3)) * TILE8 + hi * 4096 if isv else ((TS + 3) & 3) * TILE8 + hi * 4096
+            lines.append(f"s_add_u32 m0, %[ldsw], {dst}")
+            lines.append("s_nop 0")      # (M0 write -> LDS-DMA: one wait state)
+            lines.append(f"global_load_lds_dwordx4 {vr((m.DV if isv else m.DK) + hi)}, " + ("%[vsrc]" if isv else "%[ksrc]"))
         # row max of S_nxt: two MFMAs behind the last QK^T MFMA (index n_qk - 1): from the shadow of PV 0 (index n_qk + 1) on
         emit_work(10 ** 6 if i == n - 1 else 48, i >= n_qk + 1)
     assert wi == len(work) and mi == len(maxw)
@@ -370,6 +390,11 @@ def main8(out):
             out.append(f"#define RSA_K5F8_BLOCK{'C' if codemap else ''}_T{TS} \\")
             out.append(" \\\n".join(c_string(lines).split("\n")))
             out.append("")
+    for TS in range(4):   # the product at head dim 128: code map + the wave's LDS-DMA pieces inside the block
+        lines, m = gen_block8(TS, True, 128, dma=True)
+        out.append(f"#define RSA_K5F8_BLOCKCD_T{TS} \\")
+        out.append(" \\\n".join(c_string(lines).split("\n")))
+        out.append("")
     for TS in range(4):   # head dim 64 (CogVideoX): the product form only
         lines, m = gen_block8(TS, True, 64)
         out.append(f"#define RSA_K5F8_BLOCKC64_T{TS} \\")
@@ -395,6 +420,8 @@ def main8(out):
            f'"{{{vr(m.SC)}}}"(sca)', f'"{{{vr(m.SC + 1)}}}"(scb)', f'"{{{vr(m.KA, 4)}}}"(ka)', f'"{{{vr(m.VA, 2)}}}"(va)',
            f'"{{{vr(m.ON)}}}"(ona)']
     out.append(f"#define RSA_K5F8_OPS : {', '.join(outs)} : {', '.join(ins)}")
+    insd = ins + [f'"{{{vr(m.DK, 2)}}}"(dk)', f'"{{{vr(m.DV, 2)}}}"(dv)', '[ksrc] "s"(ksrc)', '[vsrc] "s"(vsrc)', '[ldsw] "s"(ldsw)']
+    out.append(f"#define RSA_K5F8_OPSD : {', '.join(outs)} : {', '.join(insd)}")
     out.append("#define RSA_K5F8_CLOBBER " + ", ".join(f'"v{r}"' for r in range(m.tmp0, m.tmp1)))
     out.append(f"// e4m3 kernel: O v[0:63], Q v[{m.Q}:{m.SA - 1}], SA v[{m.SA}:{m.SB - 1}], SB v[{m.SB}:{m.MB - 1}], 4 - m v[{m.MB}:{m.LACC - 1}], "
                f"l v[{m.LACC}:{m.LACC + 3}], temporaries v[{m.tmp0}:{m.tmp1 - 1}], scales v[{m.SC}:{m.SC + 1}], "
@@ -435,14 +462,22 @@ class Map8H:
                                      # swizzle), built in T0 / T1 just before the reads; 32-key half and ring slot are immediates
         r = (r + 1) & ~1
         self.ONES = r; r += 8        # A operand of the row-sum product (e4m3 1.0 or 0 in all 32 bytes: a constant of the lane)
+        self.DK = r; r += 4          # dma form: LDS-DMA lane offsets of the wave's four K pieces of tile + 3 (rows clamped: per tile)
+        self.DV = r; r += 2          # ... of its two V pieces (the second = the first + 4 096: constants of the lane)
         self.end = r
 
 
 NSLOT8H = 6      # 4-register operand slots (256 registers per wave at two waves per SIMD: the block pins 212 of them)
 
 
-def gen_block8h(T6, dt):
-    """xf (env RSA_GEN8H_X, comma separated; timing experiments of tools/r5_pvx.sh, results are garbage): halfk = the second
+DMA8H_GAPS = [1, 4, 7, 10, 13, 16]     # dma form: K pieces 0..3, V pieces 0, 1 behind these MFMAs of the 21
+
+
+def gen_block8h(T6, dt, dma=False):
+    """dma: the block also issues the wave's six LDS-DMA pieces -- K(tile + 3) into ring slot T6 % 3 (= K(tile)'s), V(tile + 2) into
+    (T6 + 2) % 3 -- one per MFMA shadow (see gen_block8).  Scalar operands: %[kb16] = the head's K rows, %[vsrc] = first byte of the
+    wave's first V piece, %[ldsw] = LDS address of the wave's first piece in slot 0 of the K ring.
+    xf (env RSA_GEN8H_X, comma separated; timing experiments of tools/r5_pvx.sh, results are garbage): halfk = the second
     32-key half re-uses the first half's K fragment (8 instead of 16 K reads), nov = no V reads, novalu = no conversions / row max."""
     import os
     xf = set(filter(None, os.environ.get("RSA_GEN8H_X", "").split(",")))
@@ -559,6 +594,15 @@ def gen_block8h(T6, dt):
                          f"{vr(m.SC)}, {vr(m.SC + 1)} op_sel:[1,1,0] op_sel_hi:[0,0,0]")
         state["issued"] = i
         top_up(i + 1)
+        if dma and i in DMA8H_GAPS:
+            j = DMA8H_GAPS.index(i)
+            if j < 4:
+                dst, vo, src = (T6 % 3) * 16384 + j * 4096, m.DK + j, "%[kb16]"
+            else:
+                dst, vo, src = 3 * 16384 + ((T6 + 2) % 3) * 8192 + (j - 4) * 4096, m.DV + j - 4, "%[vsrc]"
+            lines.append(f"s_add_u32 m0, %[ldsw], {dst}")
+            lines.append("s_nop 0")      # (M0 write -> LDS-DMA: one wait state)
+            lines.append(f"global_load_lds_dwordx4 {vr(vo)}, {src}")
         # row max of S_nxt: two MFMAs behind the last QK^T MFMA
         emit_work(10 ** 6 if i == n - 1 else (20 if kind == "qk" else 48), i >= n_qk + 1)
     assert wi == len(work) and mi == len(maxw) and nxt == n
@@ -568,19 +612,22 @@ def gen_block8h(T6, dt):
 
 def main8h(out):
     for dt in ("bf16", "f16"):
-        for T6 in range(6):
-            lines, m = gen_block8h(T6, dt)
-            out.append(f"#define RSA_K5F8H_BLOCK_{dt.upper()}_T{T6} \\")
-            out.append(" \\\n".join(c_string(lines).split("\n")))
-            out.append("")
+        for dma in (False, True):
+            for T6 in range(6):
+                lines, m = gen_block8h(T6, dt, dma)
+                out.append(f"#define RSA_K5F8H_BLOCK{'D' if dma else ''}_{dt.upper()}_T{T6} \\")
+                out.append(" \\\n".join(c_string(lines).split("\n")))
+                out.append("")
     m = Map8H()
     outs = [f'"+{{{vr(m.O + 16 * d, 16)}}}"(o[{d}])' for d in range(4)]
     outs += [f'"+{{{vr(m.SA, 16)}}}"(SA[0])', f'"+{{{vr(m.SA + 16, 16)}}}"(SA[1])', f'"+{{{vr(m.SB, 16)}}}"(SB[0])',
              f'"+{{{vr(m.SB + 16, 16)}}}"(SB[1])', f'"+{{{vr(m.LACC, 4)}}}"(lacc)', '[mx] "=&v"(mx)']
-    ins = [f'"{{{vr(m.Q + 4 * k, 4)}}}"(qh[{k}])' for k in range(8)]
+    ins = [f'"{{{vr(m.Q, 16)}}}"(qv[0])', f'"{{{vr(m.Q + 16, 16)}}}"(qv[1])']     # Q fragments of k-steps 0..3 and 4..7
     ins += [f'"{{{vr(m.MB, 16)}}}"(mblk)', f'"{{{vr(m.SC)}}}"(sca)', f'"{{{vr(m.SC + 1)}}}"(scb)', f'"{{{vr(m.VA, 2)}}}"(vah)',
             f'"{{{vr(m.KB)}}}"(kah)', f'"{{{vr(m.ONES, 8)}}}"(onesv)']
     out.append(f"#define RSA_K5F8H_OPS : {', '.join(outs)} : {', '.join(ins)}")
+    insd = ins + [f'"{{{vr(m.DK, 4)}}}"(dk)', f'"{{{vr(m.DV, 2)}}}"(dv)', '[kb16] "s"(kb16)', '[vsrc] "s"(vsrc)', '[ldsw] "s"(ldsw)']
+    out.append(f"#define RSA_K5F8H_OPSD : {', '.join(outs)} : {', '.join(insd)}")
     out.append("#define RSA_K5F8H_CLOBBER " + ", ".join(f'"v{r}"' for r in range(m.tmp0, m.tmp1)))
     out.append(f"// pv form: O v[0:63], Q v[{m.Q}:{m.SA - 1}], SA v[{m.SA}:{m.SB - 1}], SB v[{m.SB}:{m.MB - 1}], reference block v[{m.MB}:{m.LACC - 1}], "
                f"l v[{m.LACC}:{m.LACC + 3}], temporaries v[{m.tmp0}:{m.tmp1 - 1}], scales v[{m.SC}:{m.SC + 1}], V / K addresses v[{m.VA}:{m.KB}], ones v[{m.ONES}:{m.end - 1}]")

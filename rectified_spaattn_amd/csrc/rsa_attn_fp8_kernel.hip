@@ -134,9 +134,22 @@ __device__ __forceinline__ void k5f8_block(f32x16 (&o)[D8 / 32], const i32x8 (&q
     }
 }
 
+// the product's block at head dim 128 (round 5): code map + the wave's four LDS-DMA pieces of K(tile + 3) / V(tile + 2) inside
+template <int TS, typename KA>
+__device__ __forceinline__ void k5f8_block_dma(f32x16 (&o)[4], const i32x8 (&q)[2], f32x16 (&SA)[2], f32x16 (&SB)[2], const f32x16& mblk,
+                                               f32x4& lacc, float& mx, int sca, int scb, const KA& ka, const i32x2& va, int ona,
+                                               const i32x2& dk, const i32x2& dv, const unsigned char* ksrc, const unsigned char* vsrc,
+                                               unsigned ldsw) {
+    if constexpr (TS == 0) asm volatile(RSA_K5F8_BLOCKCD_T0 RSA_K5F8_OPSD : RSA_K5F8_CLOBBER, "scc", "memory");
+    else if constexpr (TS == 1) asm volatile(RSA_K5F8_BLOCKCD_T1 RSA_K5F8_OPSD : RSA_K5F8_CLOBBER, "scc", "memory");
+    else if constexpr (TS == 2) asm volatile(RSA_K5F8_BLOCKCD_T2 RSA_K5F8_OPSD : RSA_K5F8_CLOBBER, "scc", "memory");
+    else asm volatile(RSA_K5F8_BLOCKCD_T3 RSA_K5F8_OPSD : RSA_K5F8_CLOBBER, "scc", "memory");
+}
+
 // the pv form's hand-placed block (gen_k5_block.py::gen_block8h, RSA_K5F8H_*): T6 = tile % 6 (three-slot rings, S_cur = SA on even tiles)
+// (qv: the 2-byte Q fragments of k-steps 0..3 and 4..7 as two 16-register values)
 template <int T6, int HYB>
-__device__ __forceinline__ void k5f8h_block(f32x16 (&o)[4], const s16x8 (&qh)[8], f32x16 (&SA)[2], f32x16 (&SB)[2], const f32x16& mblk,
+__device__ __forceinline__ void k5f8h_block(f32x16 (&o)[4], const f32x16 (&qv)[2], f32x16 (&SA)[2], f32x16 (&SB)[2], const f32x16& mblk,
                                             f32x4& lacc, float& mx, int sca, int scb, int kah, const i32x2& vah, const i32x8& onesv) {
 #define RSA_K5F8H_CASE(T_) \
     if constexpr (T6 == T_) { \
@@ -146,9 +159,25 @@ __device__ __forceinline__ void k5f8h_block(f32x16 (&o)[4], const s16x8 (&qh)[8]
     RSA_K5F8H_CASE(0) RSA_K5F8H_CASE(1) RSA_K5F8H_CASE(2) RSA_K5F8H_CASE(3) RSA_K5F8H_CASE(4) RSA_K5F8H_CASE(5)
 #undef RSA_K5F8H_CASE
 }
+// ... with the wave's six LDS-DMA pieces of K(tile + 3) / V(tile + 2) inside (the product; s_add_u32 m0: SCC is clobbered)
+template <int T6, int HYB>
+__device__ __forceinline__ void k5f8h_block_dma(f32x16 (&o)[4], const f32x16 (&qv)[2], f32x16 (&SA)[2], f32x16 (&SB)[2], const f32x16& mblk,
+                                                f32x4& lacc, float& mx, int sca, int scb, int kah, const i32x2& vah, const i32x8& onesv,
+                                                const i32x4& dk, const i32x2& dv, const unsigned char* kb16, const unsigned char* vsrc,
+                                                unsigned ldsw) {
+#define RSA_K5F8H_CASE(T_) \
+    if constexpr (T6 == T_) { \
+        if constexpr (HYB == 2) asm volatile(RSA_K5F8H_BLOCKD_F16_T##T_ RSA_K5F8H_OPSD : RSA_K5F8H_CLOBBER, "scc", "memory"); \
+        else asm volatile(RSA_K5F8H_BLOCKD_BF16_T##T_ RSA_K5F8H_OPSD : RSA_K5F8H_CLOBBER, "scc", "memory"); \
+    }
+    RSA_K5F8H_CASE(0) RSA_K5F8H_CASE(1) RSA_K5F8H_CASE(2) RSA_K5F8H_CASE(3) RSA_K5F8H_CASE(4) RSA_K5F8H_CASE(5)
+#undef RSA_K5F8H_CASE
+}
 
 // PIPE_OPT bit 0: the hand-placed block (clear: the block as hipcc schedules it, same arithmetic, for A/B);
-// bit 1: s_setprio around the compiled block; bit 2: the code-map form of P (PMap above).  Product = 7.
+// bit 1: s_setprio around the compiled block; bit 2: the code-map form of P (PMap above); bit 3 (round 5, head dim 128, needs
+// bits 0 and 2): the block issues the wave's LDS-DMA pieces itself, one per MFMA shadow, and issues them for every tile (past
+// the end of the walk the last tile again, into a slot nobody reads).  Product = 15 (head dim 64: 7).
 // D8: head dim = bytes per Q / K row (128; 64 = the CogVideoX shape, hand-placed code-map form only).
 // HYB (round 5, "pv" form): 0 = e4m3 everywhere; 1 / 2 = Q . K^T on the bf16 / fp16 inputs themselves (K tiles of 64 keys x 256
 // bytes staged like the 2-byte kernels' -- rsa_attn_kernel.hip -- and multiplied by v_mfma_f32_32x32x16), e4m3 only for P and V.
@@ -166,6 +195,8 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     constexpr int DT8 = D8 / 32;          // 32-row d tiles of O^T
     constexpr int NPC8 = TILE8 / 4096;    // 1-KiB LDS-DMA pieces per wave and tile operand
     constexpr bool CODEMAP = (PIPE_OPT & 4) != 0;
+    constexpr bool DMAB = (PIPE_OPT & 8) != 0;
+    static_assert(!DMAB || (D8 == 128 && CODEMAP && (PIPE_OPT & 1) != 0), "LDS-DMA inside the block: hand-placed code-map forms at head dim 128");
     using PM = PMap<CODEMAP>;
     constexpr float P_BASE = PM::U * PM::OFFSET + PM::BIAS;   // accumulator value of a score equal to the reference m
     constexpr float P_GROW = PM::U * PM::THRESH + P_BASE;     // above it the reference moves
@@ -436,6 +467,20 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     for (int i = 0; i < 8; ++i) onesv[i] = ones_off == 0 ? 0x38383838 : 0;
     vah[0] = va[0] + VBASE;
     vah[1] = va[1] + VBASE;
+    f32x16 qv[2];
+    if constexpr (HYB != 0) {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const i32x4 w = __builtin_bit_cast(i32x4, qh[ks]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) qv[ks >> 2][4 * (ks & 3) + e] = __int_as_float(w[e]);
+        }
+    }
+    // LDS-DMA inside the block (DMAB): lane offsets of a tile operand's two pieces (wave w moves pieces w and w + 4), LDS address
+    // of the wave's first piece in slot 0 of the K ring
+    const i32x2 dv2 = {(int)voffv, (int)voffv + 4096};
+    const i32x2 dk2 = {(int)voffk, (int)voffk + 4096};
+    const unsigned ldsw = lds_base + (unsigned)wv * 1024u;
 
     auto ld32 = [&](const unsigned char* p0, const unsigned char* p1) -> i32x8 {
         const i32x4 lo = *reinterpret_cast<const i32x4*>(p0);
@@ -494,7 +539,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     auto step = [&](auto TS, int tile, int key0, f32x16 (&S_cur)[2], float& mx_cur, f32x16 (&S_nxt)[2], float& mx_nxt) {
         const int ts = TS;  // integral_constant (static LDS addresses) or the runtime tile & 3
         const int sc_a = (int)((sw1 & 0xFFu) | (sw0 & 0xFF00u));   // K(tile + 1) in byte 0, V(tile) in byte 1
-        if (tile + 2 < n_tiles) {   // (the newest tile's pieces may stay in flight: 2 NPC8 per wave; pv form: 4 of K + 2 of V)
+        if (DMAB || tile + 2 < n_tiles) {   // (the newest tile's pieces may stay in flight: 2 NPC8 per wave; pv form: 4 of K + 2 of V)
             if constexpr (HYB != 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else if constexpr (NPC8 == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -509,9 +554,14 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
         const int t3 = (PIPE_OPT & 1) != 0 ? ts % 3 : tile % 3;
         const int ks_dma = HYB ? t3 : (ts + 3) & (NSLOT - 1), vs_dma = HYB ? (t3 + 2) % 3 : (ts + 2) & (NSLOT - 1);
         const int ks_nxt = HYB ? (t3 + 1) % 3 : (ts + 1) & (NSLOT - 1), vs_cur = HYB ? t3 : ts;
-#ifndef RSA_PVX_NODMA   // (RSA_PVX_*: timing experiments of tools/r5_pvx.sh, never defined in the product)
-        if (tile + 3 < n_tiles) dma_k(kq3, ks_dma);
-        if (tile + 2 < n_tiles) dma_v(kq2, vs_dma);
+#if defined(RSA_PVX_HOTDMA)   // (RSA_PVX_*: timing experiments of tools/r5_pvx.sh, never defined in the product)
+        if (tile + 3 < n_tiles) dma_k((tile & 1) * 64, ks_dma);   // every piece issued, every line L2-resident
+        if (tile + 2 < n_tiles) dma_v((tile & 1) * 64, vs_dma);
+#elif !defined(RSA_PVX_NODMA)
+        if constexpr (!DMAB) {
+            if (tile + 3 < n_tiles) dma_k(kq3, ks_dma);
+            if (tile + 2 < n_tiles) dma_v(kq2, vs_dma);
+        }
 #endif
         // ---- head (rare branches): boundary mask, deferred rescale ----
         if (key0 < lo_max || key0 + 64 > hi_min) {
@@ -546,9 +596,27 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
         if constexpr ((PIPE_OPT & 1) != 0) {
             constexpr int tsc = decltype(TS)::value;
             // S_cur is SA on even tiles, SB on odd ones (tile & 1 == TS & 1)
-            if constexpr (HYB != 0) {
-                if constexpr ((tsc & 1) == 0) k5f8h_block<tsc, HYB>(o, qh, S_cur, S_nxt, mblk, lacc, mx_nxt, sc_a, sc_b, kah, vah, onesv);
-                else k5f8h_block<tsc, HYB>(o, qh, S_nxt, S_cur, mblk, lacc, mx_nxt, sc_a, sc_b, kah, vah, onesv);
+            if constexpr (HYB != 0 && DMAB) {
+                // K(tile + 3): the four pieces' rows, clamped like dma_k's; V(tile + 2): first byte of the wave's first piece
+                i32x4 dk4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int krow = kq3 + 16 * j + rowl_h;
+                    krow = krow < kv_limit_h ? krow : kv_limit_h - 1;
+                    dk4[j] = (int)(unsigned)(((long)krow * a.kss + gsw_h * 8) * 2);
+                }
+                const unsigned char* kb16 = reinterpret_cast<const unsigned char*>(a.k16 + (long)b * a.ksb + (long)h * a.ksh);
+                const unsigned char* vsrc = vbase + (long)(kq2 >> 6) * TILE8 + wv * 1024;
+                if constexpr ((tsc & 1) == 0) k5f8h_block_dma<tsc, HYB>(o, qv, S_cur, S_nxt, mblk, lacc, mx_nxt, sc_a, sc_b, kah, vah, onesv, dk4, dv2, kb16, vsrc, ldsw);
+                else k5f8h_block_dma<tsc, HYB>(o, qv, S_nxt, S_cur, mblk, lacc, mx_nxt, sc_a, sc_b, kah, vah, onesv, dk4, dv2, kb16, vsrc, ldsw);
+            } else if constexpr (HYB != 0) {
+                if constexpr ((tsc & 1) == 0) k5f8h_block<tsc, HYB>(o, qv, S_cur, S_nxt, mblk, lacc, mx_nxt, sc_a, sc_b, kah, vah, onesv);
+                else k5f8h_block<tsc, HYB>(o, qv, S_nxt, S_cur, mblk, lacc, mx_nxt, sc_a, sc_b, kah, vah, onesv);
+            } else if constexpr (DMAB) {
+                const unsigned char* ksrc = kbase + (long)kq3 * D8 + wv * 1024;
+                const unsigned char* vsrc = vbase + (long)(kq2 >> 6) * TILE8 + wv * 1024;
+                if constexpr ((tsc & 1) == 0) k5f8_block_dma<tsc>(o, qf, S_cur, S_nxt, mblk, lacc, mx_nxt, sc_a, sc_b, ka, va, ona, dk2, dv2, ksrc, vsrc, ldsw);
+                else k5f8_block_dma<tsc>(o, qf, S_nxt, S_cur, mblk, lacc, mx_nxt, sc_a, sc_b, ka, va, ona, dk2, dv2, ksrc, vsrc, ldsw);
             } else
             if constexpr ((tsc & 1) == 0) k5f8_block<tsc, CODEMAP, D8>(o, qf, S_cur, S_nxt, mblk, lacc, mx_nxt, sc_a, sc_b, ka, va, ona);
             else k5f8_block<tsc, CODEMAP, D8>(o, qf, S_nxt, S_cur, mblk, lacc, mx_nxt, sc_a, sc_b, ka, va, ona);
@@ -676,6 +744,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     }
 
     // ---------------- epilogue ----------------
+    if constexpr (DMAB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the pieces issued past the end of the walk: the LDS is given back at exit)
     asm volatile("s_nop 15\n\ts_nop 5" ::: "memory");   // (the last block's last MFMA -> the reads of O / l below)
     const float l_tot = lacc[0];
     if ((a.mode == MODE_SPARSE && a.tsplit > 1 && qblk >= a.NBv) || tail >= 0) {
@@ -783,12 +852,16 @@ int launch_attn8(Attn8Args& a, int BH, int D8, size_t tpart_bytes, hipStream_t s
         if (D8 != 128) return RSA_ERR_UNSUPPORTED;
         const size_t lds_h = (size_t)3 * 16384 + (size_t)3 * 8192 + 64 + (((size_t)a.NB_total * 4 + 15) & ~(size_t)15);
         // (tuning key fp8_variant 1 = the compiled twin of the hand-placed block: same arithmetic, hipcc's schedule)
+        // and 3 = the hand-placed block with the staging behind the barrier, as the other forms have it)
         if (g_fp8_variant == 1) {
             if (hyb == 2) RSA_LAUNCH_GSYNC(2, (bsfwd_fp8_kernel<6, 128, 2>), a, a.mode == MODE_SPARSE, dim3((unsigned)nblocks), 256, lds_h, s);
             else RSA_LAUNCH_GSYNC(2, (bsfwd_fp8_kernel<6, 128, 1>), a, a.mode == MODE_SPARSE, dim3((unsigned)nblocks), 256, lds_h, s);
-        } else {
+        } else if (g_fp8_variant == 3) {
             if (hyb == 2) RSA_LAUNCH_GSYNC(2, (bsfwd_fp8_kernel<7, 128, 2>), a, a.mode == MODE_SPARSE, dim3((unsigned)nblocks), 256, lds_h, s);
             else RSA_LAUNCH_GSYNC(2, (bsfwd_fp8_kernel<7, 128, 1>), a, a.mode == MODE_SPARSE, dim3((unsigned)nblocks), 256, lds_h, s);
+        } else {
+            if (hyb == 2) RSA_LAUNCH_GSYNC(2, (bsfwd_fp8_kernel<15, 128, 2>), a, a.mode == MODE_SPARSE, dim3((unsigned)nblocks), 256, lds_h, s);
+            else RSA_LAUNCH_GSYNC(2, (bsfwd_fp8_kernel<15, 128, 1>), a, a.mode == MODE_SPARSE, dim3((unsigned)nblocks), 256, lds_h, s);
         }
     } else
     if (D8 == 64) {   // head dim 64: the product form and its compiled twin
@@ -798,7 +871,8 @@ int launch_attn8(Attn8Args& a, int BH, int D8, size_t tpart_bytes, hipStream_t s
         switch (g_fp8_variant) {   // tuning key fp8_variant: 0 = product; 1, 2 = the two verification forms the tests compare it with
             case 1: RSA_LAUNCH_GSYNC(2, (bsfwd_fp8_kernel<6>), a, a.mode == MODE_SPARSE, dim3((unsigned)nblocks), 256, lds_bytes, s); break;   // product arithmetic, hipcc's schedule
             case 2: RSA_LAUNCH_GSYNC(2, (bsfwd_fp8_kernel<3>), a, a.mode == MODE_SPARSE, dim3((unsigned)nblocks), 256, lds_bytes, s); break;   // exact-exponential P, hand-placed
-            default: RSA_LAUNCH_GSYNC(2, (bsfwd_fp8_kernel<7>), a, a.mode == MODE_SPARSE, dim3((unsigned)nblocks), 256, lds_bytes, s);
+            case 3: RSA_LAUNCH_GSYNC(2, (bsfwd_fp8_kernel<7>), a, a.mode == MODE_SPARSE, dim3((unsigned)nblocks), 256, lds_bytes, s); break;   // the product's block, staging behind the barrier (rounds 3-4)
+            default: RSA_LAUNCH_GSYNC(2, (bsfwd_fp8_kernel<15>), a, a.mode == MODE_SPARSE, dim3((unsigned)nblocks), 256, lds_bytes, s);
         }
     }
     const int st = rsa_launch_status();

@@ -360,7 +360,7 @@ def test_fp8_dense_smooth_k():
 
 def test_fp8_p_forms_code_map_against_exact_exponential():
     """The product forms P through the e4m3 code map (one conversion per score); tuning key fp8_variant also reaches its
-    compiled twin (1: must be bit-identical) and the exact-exponential form (2: v_exp_f32 + round-to-nearest e4m3).  Both
+    compiled twin (1: must be bit-identical), the block with the staging behind the barrier (3: bit-identical) and the exact-exponential form (2: v_exp_f32 + round-to-nearest e4m3).  Both
     forms sit inside the fp8 tolerance of the exact-P oracle, the code map within 1.35x of the exponential form's mean error
     (simulation: 1.2x, tests/diag_fp8_pmap.py), and against the bf16 oracle -- where the e4m3 rounding of Q, K, V
     dominates -- the two are indistinguishable (<= 3 %)."""
@@ -372,12 +372,13 @@ def test_fp8_p_forms_code_map_against_exact_exponential():
     q, k, v = (x.float().cpu().numpy() for x in (tq, tk, tv))
     outs = {}
     try:
-        for var in (0, 1, 2):
+        for var in (0, 1, 2, 3):
             assert _lib.lib().rsa_set_tuning(b"fp8_variant", var) == 0
             outs[var] = _core.rectified_attention(tq, tk, tv, _spec(lay), top_k, p, None, qkv_fp8=True).float().cpu().numpy()
     finally:
         _lib.lib().rsa_set_tuning(b"fp8_variant", 0)
     assert np.array_equal(outs[0], outs[1]), "hand-placed block and its compiled twin must agree bit for bit"
+    assert np.array_equal(outs[0], outs[3]), "staging inside the block (product) and behind the barrier (3) must agree bit for bit"
     ref8 = orc.rectified_attention_fp8(q, k, v, lay, top_k, p, None)
     ref16 = orc.rectified_attention(q, k, v, lay, top_k, p, None)
     e_code, e_exp = np.abs(outs[0] - ref8), np.abs(outs[2] - ref8)
@@ -459,7 +460,9 @@ def test_fp8_pv_form(case):
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 def test_fp8_pv_hand_placed_block_against_its_compiled_twin(dt):
     """The pv kernel's tile block is one hand-placed instruction stream (gen_k5_block.py::gen_block8h), six tiles per loop trip;
-    tuning key fp8_variant 1 launches the same arithmetic as hipcc schedules it.  Bit for bit equal, for kept lists of every
+    the product's also issues the wave's LDS-DMA pieces itself (for every tile: past the end of the walk the last tile again).
+    Tuning key fp8_variant 1 launches the same arithmetic as hipcc schedules it, 3 the hand-placed block with the staging behind
+    the barrier.  Bit for bit equal, for kept lists of every
     length 1 .. 14 blocks (2 .. 28 tiles: every remainder of the six-tile trip, with and without the half tile at the end of the
     valid keys) and with text rows."""
     from rectified_spaattn_amd import _core, _lib, synth
@@ -471,13 +474,13 @@ def test_fp8_pv_hand_placed_block_against_its_compiled_twin(dt):
         for top_k in range(1, lay.NBv + 1):
             outs = {}
             try:
-                for var in (0, 1):
+                for var in (0, 1, 3):
                     assert L.rsa_set_tuning(b"fp8_variant", var) == 0
                     outs[var] = _core.rectified_attention(tq, tk, tv, _spec(lay), top_k, 0.0, None, qkv_fp8="pv")
             finally:
                 L.rsa_set_tuning(b"fp8_variant", 0)
             assert torch.isfinite(outs[0].float()).all()
-            assert torch.equal(outs[0], outs[1]), (name, top_k)
+            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[3]), (name, top_k)
 
 
 def test_fp8_pv_form_public_switch_and_head_dim_64():
