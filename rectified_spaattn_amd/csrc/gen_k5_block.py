@@ -57,7 +57,20 @@ class Map:
         r = (r + 3) & ~3
         self.KA = r; r += self.KS
         self.VA = r; r += 2 * self.DT
+        self.RSM = rsm_form(D, negm)
+        if self.RSM:             # row sums on the matrix pipe (head dim 64, round 5): l in four registers, the ones operand
+            r = (r + 3) & ~3
+            self.LACC = r; r += 4
+            self.ONES = r; r += 4
         self.end = r
+
+
+def rsm_form(D, negm):
+    """Head dim 64 (both forms): 8 MFMAs per sub-step against the same softmax make the wave vector-bound
+    (profiles/r05_d64_experiments.txt: without the vector work -29 %), so the 16 row-sum additions go to the matrix pipe as two
+    v_mfma_f32_16x16x32 (ones . P^T, 4 passes each): l = the row sum of the ROUNDED P, complete over both lane halves."""
+    import os
+    return D == 64 and os.environ.get("RSA_GEN_NORSM", "") == ""     # (env: the A/B twin with the additions, tools/r5_d64x_build.sh)
 
 
 def vr(a, n=1):
@@ -65,7 +78,10 @@ def vr(a, n=1):
 
 
 def gen_block(D, dt, VS, SUB, negm):
-    """The asm lines of one block variant."""
+    """The asm lines of one block variant.  (env RSA_GEN_X: timing experiments of tools/r5_d64x_build.sh -- noexp = no exponentials,
+    novalu = no vector work at all, nolds = no LDS operand reads; the results are garbage.)"""
+    import os
+    xf = set(filter(None, os.environ.get("RSA_GEN_X", "").split(",")))
     m = Map(D, negm)
     KS, DT = m.KS, m.DT
     mf = "v_mfma_f32_32x32x16_bf16" if dt == "bf16" else "v_mfma_f32_32x32x16_f16"
@@ -79,10 +95,16 @@ def gen_block(D, dt, VS, SUB, negm):
     lds_seq = []          # issue order of LDS ops: (tag, count)
 
     def k_read(ks):
+        if "nolds" in xf:
+            lds_seq.append((("K", ks), 0))
+            return
         lines.append(f"ds_read_b128 {vr(m.KF + 4 * (ks % AHEAD), 4)}, {vr(m.KA + ks)} offset:{koff}")
         lds_seq.append((("K", ks), 1))
 
     def v_read(p):
+        if "nolds" in xf:
+            lds_seq.append((("V", p), 0))
+            return
         k2, d = divmod(p, DT)
         off = vbase + (2 * SUB + k2) * 16 * D * 2
         b = m.VF + 4 * (p % AHEAD)
@@ -127,6 +149,13 @@ def gen_block(D, dt, VS, SUB, negm):
              ("swap", f"v_permlane32_swap_b32 {vr(m.T0)}, {vr(m.T1)}"), ("nop", "s_nop 1"),
              ("max", f"v_max_f32 %[mx], {vr(m.T0)}, {vr(m.T1)}")]
 
+    if "noexp" in xf:
+        work = [w for w in work if w[0] != "exp"]
+    if "novalu" in xf:
+        work, maxw = [], [("mov", "v_mov_b32 %[mx], 0")]
+    if m.RSM:
+        work = [w for w in work if w[0] != "add"]
+    mf_rs = "v_mfma_f32_16x16x32_bf16" if dt == "bf16" else "v_mfma_f32_16x16x32_f16"
     nm = KS + 2 * DT                      # MFMAs of the block
     total = sum(COST[k] for k, _ in work + maxw)
     pre = 72 if D == 128 else 48          # vector work issued while the first K fragments are in flight
@@ -165,8 +194,11 @@ def gen_block(D, dt, VS, SUB, negm):
             p = i - KS
             k2, d = divmod(p, DT)
             text = "\n".join(lines)
-            for jj in range(4):   # sanity: the half of P this MFMA reads has been packed
+            for jj in range(4 if "novalu" not in xf else 0):   # sanity: the half of P this MFMA reads has been packed
                 assert f"{cv} {vr(m.P + 4 * k2 + jj)}," in text, (D, dt, VS, SUB, "P not packed before PV", p)
+            if m.RSM and d == 0:      # l += ones . P^T over the 16 keys of half k2 (behind the conversions that packed it)
+                lines.append("s_nop 1")
+                lines.append(f"{mf_rs} {vr(m.LACC, 4)}, {vr(m.ONES, 4)}, {vr(m.P + 4 * k2, 4)}, {vr(m.LACC, 4)}")
             wait_for(("V", p))
             lines.append(f"{mf} {vr(m.O + 16 * d, 16)}, {vr(m.VF + 4 * (p % AHEAD), 4)}, {vr(m.P + 4 * k2, 4)}, {vr(m.O + 16 * d, 16)}")
             if p + AHEAD < 2 * DT: v_read(p + AHEAD)
@@ -203,10 +235,12 @@ def main():
         for negm in (False, True):
             m = Map(D, negm)
             outs = [f'"+{{{vr(m.O + 16 * d, 16)}}}"(o[{d}])' for d in range(m.DT)]
-            outs += [f'"+{{{vr(m.SA, 16)}}}"(SA)', f'"+{{{vr(m.SB, 16)}}}"(SB)', '[l] "+v"(l)', '[mx] "=&v"(mx)']
+            outs += [f'"+{{{vr(m.SA, 16)}}}"(SA)', f'"+{{{vr(m.SB, 16)}}}"(SB)',
+                     f'"+{{{vr(m.LACC, 4)}}}"(lacc)' if m.RSM else '[l] "+v"(l)', '[mx] "=&v"(mx)']
             ins = [f'"{{{vr(m.Q + 4 * k, 4)}}}"(q[{k}])' for k in range(m.KS)]
             ins += [f'"{{{vr(m.NM, 16)}}}"(nm)'] if negm else ['[m] "v"(m)']
             ins += [f'"{{{vr(m.KA, m.KS)}}}"(ka)', f'"{{{vr(m.VA, 2 * m.DT)}}}"(va)']
+            if m.RSM: ins += [f'"{{{vr(m.ONES, 4)}}}"(onesv)']
             tag = f"{'N' if negm else ''}_{D}"
             out.append(f"#define RSA_K5_OPS{tag} : {', '.join(outs)} : {', '.join(ins)}")
             out.append(f"#define RSA_K5_CLOBBER{tag} " + ", ".join(f'"v{r}"' for r in range(m.tmp0, m.tmp1)))

@@ -12,6 +12,7 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <typename Tag>
 struct Elem;
@@ -22,6 +23,9 @@ struct Elem<bf16_tag> {
                                                        c, 0, 0, 0);
     }
     // D = A.B + C with D and C in DIFFERENT registers (hipcc ties them and copies C first when given the builtin)
+    static __device__ __forceinline__ f32x4 mfma_rowsum(s16x8 a, s16x8 b, f32x4 c) {   // 16 x 16 x 32 (row sums: rsa_attn_kernel.hip)
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
     static __device__ __forceinline__ f32x16 mfma_from(s16x8 a, s16x8 b, const f32x16& c) {
         f32x16 d;
         asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
@@ -42,6 +46,9 @@ struct Elem<fp16_tag> {
     static __device__ __forceinline__ f32x16 mfma(s16x8 a, s16x8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c,
                                                       0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 mfma_rowsum(s16x8 a, s16x8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     }
     static __device__ __forceinline__ f32x16 mfma_from(s16x8 a, s16x8 b, const f32x16& c) {
         f32x16 d;

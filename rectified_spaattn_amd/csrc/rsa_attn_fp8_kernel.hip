@@ -34,7 +34,6 @@
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct Attn8Args {
     const uint8_t *q8, *k8, *v8t;  // [BH, S_pad, 128], [BH, S_pad, 128], [BH, S_pad/64, 128, 64]

@@ -63,7 +63,8 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // the product's block: S_cur / S_nxt hold S - m (nm = -m in 16 registers), no subtraction in the softmax
 template <int D, typename Tag, int VS, int SUB, typename KA, typename VA>
 __device__ __forceinline__ void k5_block_nm(f32x16 (&o)[D / 32], const s16x8 (&q)[D / 16], f32x16& S_cur, f32x16& S_nxt,
-                                            const f32x16& nm, float& l, float& mx, const KA& ka, const VA& va) {
+                                            const f32x16& nm, float& l, f32x4& lacc, const s16x8& onesv, float& mx, const KA& ka,
+                                            const VA& va) {
     f32x16& SA = SUB == 0 ? S_cur : S_nxt;
     f32x16& SB = SUB == 0 ? S_nxt : S_cur;
     constexpr bool BF = std::is_same<Tag, bf16_tag>::value;
@@ -77,9 +78,11 @@ __device__ __forceinline__ void k5_block_nm(f32x16 (&o)[D / 32], const s16x8 (&q
 }
 // the classic form (S, then S - m by v_sub: the compiled block's arithmetic, bit-identical to the block as hipcc emits it):
 // the product at head dim 64, where it measures 4 % faster than the -m form (at 128 the -m form wins by 3.7 %)
+// (head dim 64, round 5: the row sums ride the matrix pipe -- l lives in lacc, four registers with the lane's complete row sum of
+// the rounded P, onesv is the ones operand of those products; l itself is not touched.  At 128 it is the other way round.)
 template <int D, typename Tag, int VS, int SUB, typename KA, typename VA>
 __device__ __forceinline__ void k5_block(f32x16 (&o)[D / 32], const s16x8 (&q)[D / 16], f32x16& S_cur, f32x16& S_nxt, float m,
-                                         float& l, float& mx, const KA& ka, const VA& va) {
+                                         float& l, f32x4& lacc, const s16x8& onesv, float& mx, const KA& ka, const VA& va) {
     f32x16& SA = SUB == 0 ? S_cur : S_nxt;
     f32x16& SB = SUB == 0 ? S_nxt : S_cur;
     constexpr bool BF = std::is_same<Tag, bf16_tag>::value;
@@ -285,6 +288,24 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) o[dt][i] = 0.0f;
     float m_run = -INFINITY, l_run = 0.0f;
+    // Row sums on the matrix pipe (RSM: head dim 64, gen_k5_block.py::rsm_form): lacc = the lane's complete
+    // row sum of the rounded P in all four registers.  A operand of v_mfma_f32_16x16x32 (lane: row a = l & 15, k-block l >> 4): ones
+    // iff (k-block & 1) == ((a >> 2) & 1) -- the B operand is the P . V product's P fragment, whose k-blocks 0 / 2 are the two lane
+    // halves of query row n and 1 / 3 those of row n + 16, and the lane that owns C rows 4 (l >> 4) .. + 3 of column l & 15 is the
+    // lane of exactly that query row (the construction of the e4m3 kernel's row-sum product).
+#ifdef RSA_K5X_NORSM   // (A/B twin of tools/r5_d64x_build.sh: row sums by vector additions, as rounds 3-4)
+    constexpr bool RSM = false;
+#else
+    constexpr bool RSM = D == 64;
+#endif
+    f32x4 lacc = {0.0f, 0.0f, 0.0f, 0.0f};
+    s16x8 onesv;
+    {
+        const short one = std::is_same<Tag, bf16_tag>::value ? (short)0x3F80 : (short)0x3C00;
+        const short w = (((lane >> 4) & 1) == ((lane >> 2) & 1)) ? one : (short)0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) onesv[i] = w;
+    }
     // m_ref = the finite reference the scores are taken against (S_cur, S_nxt hold S - m_ref), nm = its negation in 16
     // registers (C operand of the first QK^T MFMA), thr = how far a new row maximum may exceed it before the rescale (-inf
     // until the row has seen a finite score: the first finite maximum always becomes the reference).  m_run is the running
@@ -385,6 +406,10 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
                 const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);   // (first: O and l are still zero)
                 m_ref += delta;
                 l_run *= alpha;
+                if constexpr (RSM) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) lacc[i] *= alpha;
+                }
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -393,7 +418,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
                 for (int i = 0; i < 16; ++i) { S_cur[i] -= delta; nm[i] = -m_ref; }
             }
             RSA_STAMP(2);
-            k5_block_nm<D, Tag, vs, sub>(o, qf, S_cur, S_nxt, nm, l_run, mx_nxt, ka, va);
+            k5_block_nm<D, Tag, vs, sub>(o, qf, S_cur, S_nxt, nm, l_run, lacc, onesv, mx_nxt, ka, va);
             RSA_STAMP(3);
         }
         else {   // the classic arithmetic (scores S, reference m_run subtracted in the softmax)
@@ -404,6 +429,10 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
                 const float alpha = __builtin_amdgcn_exp2f(m_run - mu);
                 m_run = m_new;
                 l_run *= alpha;
+                if constexpr (RSM) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) lacc[i] *= alpha;
+                }
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -412,7 +441,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
             const float m_use = (m_run == -INFINITY) ? 0.0f : m_run;
             RSA_STAMP(2);
             if constexpr (FORM == 1) {
-                k5_block<D, Tag, vs, sub>(o, qf, S_cur, S_nxt, m_use, l_run, mx_nxt, ka, va);
+                k5_block<D, Tag, vs, sub>(o, qf, S_cur, S_nxt, m_use, l_run, lacc, onesv, mx_nxt, ka, va);
             }
 #ifdef RSA_K5_FORMS
             else {   // A/B build: the block left to hipcc; iglp_opt(0) = LLVM's small-GEMM MFMA/DS interleave
@@ -432,7 +461,12 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
                     }
                     pb[hf] = E::cvt8(pv8);
                 }
-                l_run += ps;
+                if constexpr (RSM) {
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) lacc = E::mfma_rowsum(onesv, pb[hf], lacc);
+                } else {
+                    l_run += ps;
+                }
                 const unsigned char* vt_ = lds + (2 + vs) * TILE_BYTES;
 #pragma unroll
                 for (int k2 = 0; k2 < 2; ++k2) {
@@ -468,13 +502,17 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+#ifndef RSA_K5X_NOBAR     // (RSA_K5X_*: timing experiments of tools/r5_d64x_build.sh, never defined in the product)
         __syncthreads();
+#endif
         RSA_STAMP(1);
+#ifndef RSA_K5X_NODMA
         if constexpr (sub == 0) {
             if (tile + 1 < n_tiles) dma(1, kq1, (2 + (vs ^ 1)) * TILE_BYTES);
         } else {
             if (tile + 2 < n_tiles) dma(0, kq2, vs * TILE_BYTES);
         }
+#endif
     };
 
     // ---------------- prologue + main loop ----------------
@@ -530,7 +568,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
     asm volatile("s_nop 11" ::: "memory");   // (the last block's last MFMA -> the reads of O below)
     if constexpr (FORM == 2) m_run = thr == -INFINITY ? -INFINITY : m_ref;
     const auto swl = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
-    const float l_tot = __uint_as_float(swl[0]) + __uint_as_float(swl[1]);
+    const float l_tot = RSM ? lacc[0] : __uint_as_float(swl[0]) + __uint_as_float(swl[1]);   // (RSM: already complete over both lane halves)
     bool done = false;
     if (a.mode == MODE_SPARSE && a.tsplit > 1 && qblk >= a.NBv) {
         // split-KV partial of a text block: unnormalised O (fp32), m (log2 domain) and l per row; the combine
