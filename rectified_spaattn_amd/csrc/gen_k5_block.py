@@ -70,7 +70,7 @@ def rsm_form(D, negm):
     (profiles/r05_d64_experiments.txt: without the vector work -29 %), so the 16 row-sum additions go to the matrix pipe as two
     v_mfma_f32_16x16x32 (ones . P^T, 4 passes each): l = the row sum of the ROUNDED P, complete over both lane halves."""
     import os
-    return D == 64 and os.environ.get("RSA_GEN_NORSM", "") == ""     # (env: the A/B twin with the additions, tools/r5_d64x_build.sh)
+    return D == 64 and os.environ.get("RSA_GEN_NORSM", "") == ""     # (env: the A/B twin with the additions, tools/history/r5_d64x_build.sh)
 
 
 def vr(a, n=1):
@@ -78,7 +78,7 @@ def vr(a, n=1):
 
 
 def gen_block(D, dt, VS, SUB, negm):
-    """The asm lines of one block variant.  (env RSA_GEN_X: timing experiments of tools/r5_d64x_build.sh -- noexp = no exponentials,
+    """The asm lines of one block variant.  (env RSA_GEN_X: timing experiments of tools/history/r5_d64x_build.sh -- noexp = no exponentials,
     novalu = no vector work at all, nolds = no LDS operand reads; the results are garbage.)"""
     import os
     xf = set(filter(None, os.environ.get("RSA_GEN_X", "").split(",")))
@@ -300,7 +300,7 @@ def gen_block8(TS, codemap=False, D8=128, dma=False):
     at the CU's one addresser: profiles/r05_pv_hand_placed.txt).  Scalar operands: %[ksrc] / %[vsrc] = first byte of the wave's
     first piece, %[ldsw] = LDS address of the wave's first piece in slot 0 of the K ring."""
     import os
-    xf = set(filter(None, os.environ.get("RSA_GEN8_X", "").split(",")))   # timing experiments (tools/r5_pvx_build.sh): halfk, nolds
+    xf = set(filter(None, os.environ.get("RSA_GEN8_X", "").split(",")))   # timing experiments (tools/history/r5_pvx_build.sh): halfk, nolds
     m = Map8(D8)
     SC_, SN = (m.SA, m.SB) if TS % 2 == 0 else (m.SB, m.SA)
     TILE8 = 64 * D8
@@ -511,7 +511,7 @@ def gen_block8h(T6, dt, dma=False):
     """dma: the block also issues the wave's six LDS-DMA pieces -- K(tile + 3) into ring slot T6 % 3 (= K(tile)'s), V(tile + 2) into
     (T6 + 2) % 3 -- one per MFMA shadow (see gen_block8).  Scalar operands: %[kb16] = the head's K rows, %[vsrc] = first byte of the
     wave's first V piece, %[ldsw] = LDS address of the wave's first piece in slot 0 of the K ring.
-    xf (env RSA_GEN8H_X, comma separated; timing experiments of tools/r5_pvx.sh, results are garbage): halfk = the second
+    xf (env RSA_GEN8H_X, comma separated; timing experiments of tools/history/r5_pvx.sh, results are garbage): halfk = the second
     32-key half re-uses the first half's K fragment (8 instead of 16 K reads), nov = no V reads, novalu = no conversions / row max."""
     import os
     xf = set(filter(None, os.environ.get("RSA_GEN8H_X", "").split(",")))

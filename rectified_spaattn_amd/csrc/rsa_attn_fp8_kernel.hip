@@ -553,7 +553,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
         const int t3 = (PIPE_OPT & 1) != 0 ? ts % 3 : tile % 3;
         const int ks_dma = HYB ? t3 : (ts + 3) & (NSLOT - 1), vs_dma = HYB ? (t3 + 2) % 3 : (ts + 2) & (NSLOT - 1);
         const int ks_nxt = HYB ? (t3 + 1) % 3 : (ts + 1) & (NSLOT - 1), vs_cur = HYB ? t3 : ts;
-#if defined(RSA_PVX_HOTDMA)   // (RSA_PVX_*: timing experiments of tools/r5_pvx.sh, never defined in the product)
+#if defined(RSA_PVX_HOTDMA)   // (RSA_PVX_*: timing experiments of tools/history/r5_pvx.sh, never defined in the product)
         if (tile + 3 < n_tiles) dma_k((tile & 1) * 64, ks_dma);   // every piece issued, every line L2-resident
         if (tile + 2 < n_tiles) dma_v((tile & 1) * 64, vs_dma);
 #elif !defined(RSA_PVX_NODMA)

@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
     // iff (k-block & 1) == ((a >> 2) & 1) -- the B operand is the P . V product's P fragment, whose k-blocks 0 / 2 are the two lane
     // halves of query row n and 1 / 3 those of row n + 16, and the lane that owns C rows 4 (l >> 4) .. + 3 of column l & 15 is the
     // lane of exactly that query row (the construction of the e4m3 kernel's row-sum product).
-#ifdef RSA_K5X_NORSM   // (A/B twin of tools/r5_d64x_build.sh: row sums by vector additions, as rounds 3-4)
+#ifdef RSA_K5X_NORSM   // (A/B twin of tools/history/r5_d64x_build.sh: row sums by vector additions, as rounds 3-4)
     constexpr bool RSM = false;
 #else
     constexpr bool RSM = D == 64;
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_kernel(AttnArgs a) {
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-#ifndef RSA_K5X_NOBAR     // (RSA_K5X_*: timing experiments of tools/r5_d64x_build.sh, never defined in the product)
+#ifndef RSA_K5X_NOBAR     // (RSA_K5X_*: timing experiments of tools/history/r5_d64x_build.sh, never defined in the product)
         __syncthreads();
 #endif
         RSA_STAMP(1);

@@ -1,5 +1,5 @@
 #!/bin/bash
-# times K5 (2-byte, head dim 64: CogVideoX workload) in each experiment library of tools/r5_d64x_build.sh, one process per library
+# times K5 (2-byte, head dim 64: CogVideoX workload) in each experiment library of tools/history/r5_d64x_build.sh, one process per library
 for x in ${RSA_D64X_LIBS:-base noexp novalu nolds nodma nobar norsm base}; do
 python - $x <<'PY' 2>&1 | grep -v amdgpu.ids
 import os, sys, torch

@@ -1,8 +1,8 @@
 #!/bin/bash
 # timing-experiment libraries of the 2-byte 32-row kernel (head dim 64 = CogVideoX is what they are for): one resource removed each
-#   rectified_spaattn_amd/librsa_hip_x_<name>.so, name in: base noexp novalu nolds nodma nobar        (tools/r5_d64x.sh runs them)
+#   rectified_spaattn_amd/librsa_hip_x_<name>.so, name in: base noexp novalu nolds nodma nobar        (tools/history/r5_d64x.sh runs them)
 set -e
-cd "$(dirname "$0")/../rectified_spaattn_amd/csrc"
+cd "$(dirname "$0")/../../rectified_spaattn_amd/csrc"
 make -s
 OBJS="rsa_stats.o rsa_attn.o rsa_attn_kernel64.o rsa_attn_masked.o rsa_fp8.o rsa_attn_fp8_kernel.o rsa_glue.o rsa_geometry.o rsa_comm.o"
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -I../../include -I. -Wall -Wno-unused-function -fno-honor-nans"

@@ -1,6 +1,6 @@
 #!/bin/bash
-# times the pv form's K5 in each experiment library (tools/r5_pvx_build.sh) on the R2 / locality regimes, one process per library
-# usage: tools/r5_pvx.sh [pv|e4m3]
+# times the pv form's K5 in each experiment library (tools/history/r5_pvx_build.sh) on the R2 / locality regimes, one process per library
+# usage: tools/history/r5_pvx.sh [pv|e4m3]
 MODE=${1:-pv}
 if [ "$MODE" = pv ]; then LIBS="${RSA_PVX_LIBS:-base halfk nov nolds novalu nodma nobar nodmabar hotdma base}"; else LIBS="${RSA_PVX_LIBS:-base e8halfk e8nolds nodma nobar nodmabar hotdma base}"; fi
 for x in $LIBS; do

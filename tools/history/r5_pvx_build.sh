@@ -1,9 +1,9 @@
 #!/bin/bash
 # builds the timing-experiment libraries of the pv form's tile block (run HERE, the .so files travel with gpurun):
 #   rectified_spaattn_amd/librsa_hip_x_<name>.so, name in: base halfk nov nolds novalu nodma nobar nodmabar (pv block) e8halfk e8nolds (e4m3 block)
-# (experiments drop one resource each; results are garbage, only the time means something).  tools/r5_pvx.sh runs them.
+# (experiments drop one resource each; results are garbage, only the time means something).  tools/history/r5_pvx.sh runs them.
 set -e
-cd "$(dirname "$0")/../rectified_spaattn_amd/csrc"
+cd "$(dirname "$0")/../../rectified_spaattn_amd/csrc"
 make -s
 OBJS="rsa_stats.o rsa_attn.o rsa_attn_kernel.o rsa_attn_kernel64.o rsa_attn_masked.o rsa_fp8.o rsa_glue.o rsa_geometry.o rsa_comm.o"
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -I../../include -I. -Wall -Wno-unused-function -fno-honor-nans"
