@@ -31,6 +31,7 @@ probe: +-0 sparse, +3 % dense), packed f32 adds for the row sum (+0.8 % time).
 
 usage: python3 gen_k5_block.py > rsa_attn_block.h
 """
+import os
 
 AHEAD = 4          # LDS operand buffers per operand kind (K fragments, V^T fragments)
 COST = dict(sub=4, exp=8, cvt=4, cvt8=5, add=4, max=4, mov=4, nop=8, swap=4)
@@ -266,6 +267,8 @@ def main():
 # =====================================================================================================================
 AHEAD8, RING8 = 3, 4
 DMA8_GAPS = [0, 2, 4, 6]      # dma form: K piece 0, K piece 1, V piece 0, V piece 1 behind these MFMAs of the nine
+if os.environ.get("RSA_GEN8_GAPS"):       # (placement A/B: profiles/r05_pv_hand_placed.txt)
+    DMA8_GAPS = [int(x) for x in os.environ["RSA_GEN8_GAPS"].split(",")]
 
 
 class Map8:
@@ -505,6 +508,8 @@ NSLOT8H = 6      # 4-register operand slots (256 registers per wave at two waves
 
 
 DMA8H_GAPS = [1, 4, 7, 10, 13, 16]     # dma form: K pieces 0..3, V pieces 0, 1 behind these MFMAs of the 21
+if os.environ.get("RSA_GEN8H_GAPS"):
+    DMA8H_GAPS = [int(x) for x in os.environ["RSA_GEN8H_GAPS"].split(",")]
 
 
 def gen_block8h(T6, dt, dma=False):

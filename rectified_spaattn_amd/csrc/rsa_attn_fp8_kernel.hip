@@ -35,6 +35,10 @@ typedef int i32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef RSA_PV_LIST_WINDOW
+#define RSA_PV_LIST_WINDOW 1024      // entries of the pv form's kept-list window in LDS (a power of two; tests build nothing else)
+#endif
+
 struct Attn8Args {
     const uint8_t *q8, *k8, *v8t;  // [BH, S_pad, 128], [BH, S_pad, 128], [BH, S_pad/64, 128, 64]
     const uint32_t* exps;          // [BH, exps_stride] E8M0 block exponents: byte 0 Q, byte 1 K, byte 2 V (rsa_fp8_emit.h)
@@ -315,15 +319,20 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     // of the text range or a dense range), so one LDS read per tile brings the block index AND its two scales
     const uint32_t* ex = a.exps + (long)bh * a.exps_stride;
     if (t < 16) reinterpret_cast<unsigned*>(lds_ones)[t] = t < 8 ? 0x38383838u : 0u;
-    for (int i = t; i < n_items; i += 256) {
+    // pv form: the LDS holds a WINDOW of LWIN entries (a ring: entry i at i & (LWIN - 1)), refilled half a window at a time by the
+    // walk itself (step(), below) -- with the whole list of a long head the rings' 72 KiB would leave one workgroup per CU beyond
+    // ~2 000 key blocks.  The other forms keep the whole list (their rings are 64 KiB).
+    constexpr int LWIN = HYB ? RSA_PV_LIST_WINDOW : 0;
+    auto make_entry = [&](int i) -> unsigned {
         const int blk = list != nullptr ? list[i] : first_blk + i;
-        lds_list[i] = (unsigned)blk | ((ex[blk] >> 8) << 16);
-    }
+        return (unsigned)blk | ((ex[blk] >> 8) << 16);
+    };
+    for (int i = t; i < (LWIN && n_items > LWIN ? LWIN : n_items); i += 256) lds_list[i] = make_entry(i);
     __syncthreads();
-    auto entry_of = [&](int item) -> unsigned { return lds_list[item]; };
+    auto entry_of = [&](int item) -> unsigned { return lds_list[LWIN ? item & (LWIN - 1) : item]; };
     int n_tiles = 2 * n_items;
     if (n_items > 0) {
-        const int last_blk = (int)(entry_of(n_items - 1) & 0xFFFFu);
+        const int last_blk = list != nullptr ? list[n_items - 1] : first_blk + n_items - 1;   // (from memory: it may lie past the window)
         if (last_blk * RSA_BLOCK + 64 >= hi_max) n_tiles -= 1;
     }
     n_tiles = __builtin_amdgcn_readfirstlane(n_tiles);
@@ -548,6 +557,14 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
 #ifndef RSA_PVX_NOBAR
         __syncthreads();
 #endif
+        if constexpr (LWIN != 0) {
+            // every LWIN / 2 items: entries [item + LWIN / 2, item + LWIN) replace those of [item - LWIN / 2, item), which are behind
+            // every reader (the entry of tile + 5 is the furthest read ahead); they are first read LWIN / 2 items -- barriers -- later
+            if ((tile & (LWIN - 1)) == 0 && tile > 0) {
+                const int base = (tile >> 1) + LWIN / 2;
+                for (int i = base + t; i < base + LWIN / 2 && i < n_items; i += 256) lds_list[i & (LWIN - 1)] = make_entry(i);
+            }
+        }
         // ring slots: tile & 3 of four (ts), or tile mod 3 of three in the pv form
         // (pv form, hand-placed: TS = tile % 6 at compile time)
         const int t3 = (PIPE_OPT & 1) != 0 ? ts % 3 : tile % 3;
@@ -849,7 +866,8 @@ int launch_attn8(Attn8Args& a, int BH, int D8, size_t tpart_bytes, hipStream_t s
     const size_t lds_bytes = (size_t)2 * NSLOT * 64 * D8 + 64 + (((size_t)a.NB_total * 4 + 15) & ~(size_t)15);
     if (hyb != 0) {   // the pv form: 2-byte Q . K^T, e4m3 P . V (three-slot rings: K 3 x 16 KiB, V 3 x 8 KiB)
         if (D8 != 128) return RSA_ERR_UNSUPPORTED;
-        const size_t lds_h = (size_t)3 * 16384 + (size_t)3 * 8192 + 64 + (((size_t)a.NB_total * 4 + 15) & ~(size_t)15);
+        const size_t n_list = a.NB_total < RSA_PV_LIST_WINDOW ? a.NB_total : RSA_PV_LIST_WINDOW;     // (the kernel's LWIN)
+        const size_t lds_h = (size_t)3 * 16384 + (size_t)3 * 8192 + 64 + ((n_list * 4 + 15) & ~(size_t)15);
         // (tuning key fp8_variant 1 = the compiled twin of the hand-placed block: same arithmetic, hipcc's schedule)
         // and 3 = the hand-placed block with the staging behind the barrier, as the other forms have it)
         if (g_fp8_variant == 1) {

@@ -483,6 +483,42 @@ def test_fp8_pv_hand_placed_block_against_its_compiled_twin(dt):
             assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[3]), (name, top_k)
 
 
+def test_fp8_pv_kept_lists_longer_than_the_lds_window():
+    """The pv kernel keeps a 1 024-entry window of the kept list in LDS and refills it half a window at a time while it walks
+    (with the whole list of a long head its 72 KiB of rings would leave one workgroup per CU).  2 200 key blocks, 2 150 kept per
+    query block: two refills per walk.  Checked against the 2-byte kernel on the same kept lists (relative L1 and max inside the
+    pv bounds) and bit for bit against the compiled twin."""
+    from rectified_spaattn_amd import _core, _lib
+    L = _lib.lib()
+    NB, top_k = 2200, 2150
+    S = NB * 128 - 77
+    g = torch.Generator(device="cpu").manual_seed(99)
+    q, k, v = (torch.randn(1, 1, S, 128, generator=g).to(torch.bfloat16).to(DEV) for _ in range(3))
+    spec = _core.LayoutSpec.wan(S, 0)
+    ref = _core.StagedCall(q, k, v, spec, top_k, 0.0, None)
+    ref.select()
+    ref.attend()
+    assert int(ref.bufs["counts"].min()) > 2048        # every walk crosses the window twice
+    o16 = ref.out.float().clone()
+    outs = {}
+    try:
+        for var in (0, 1):
+            assert L.rsa_set_tuning(b"fp8_variant", var) == 0
+            c = _core.StagedCall(q, k, v, spec, top_k, 0.0, None, qkv_fp8="pv")
+            c.select()
+            assert torch.equal(c.bufs["bitmask"], ref.bufs["bitmask"]) and torch.equal(c.bufs["counts"], ref.bufs["counts"])
+            c.attend()
+            outs[var] = c.out.float().clone()
+            del c
+    finally:
+        L.rsa_set_tuning(b"fp8_variant", 0)
+    assert torch.equal(outs[0], outs[1])
+    d = (outs[0] - o16).abs()
+    rel = float(d.sum() / o16.abs().sum())
+    print(f"pv vs 2-byte kernel at {NB} key blocks: max {float(d.max()):.3e} rel-L1 {rel:.4f}")
+    assert torch.isfinite(outs[0]).all() and float(d.max()) <= PV_MAX_VS_BF16 and rel <= PV_REL_L1
+
+
 def test_fp8_pv_form_public_switch_and_head_dim_64():
     """set_qkv_fp8("pv") reaches the operators; head dim 64 has no pv kernel: the operator keeps the 2-byte kernel there (as the
     e4m3 switch does for head dims without an fp8 kernel), a StagedCall refuses."""
