@@ -310,6 +310,10 @@ int rsa_dense_fwd_fp8(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor
 int rsa_dense_causal_fwd_fp8(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
                              int q_split, int kv_split, void* workspace, size_t workspace_bytes, rsa_out4 out,
                              void* stream);
+/* The "pv" form of the dense fp8 kernel (round 5; head dim 128): Q . K^T on the 2-byte q and k as they are, e4m3 only for P and the
+ * V image (rsa_block_sparse_fwd_fp8pv's kernel in its dense mode).  causal != 0: as rsa_dense_causal_fwd.  Same workspace. */
+int rsa_dense_fwd_fp8pv(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
+                        int q_split, int kv_split, int causal, void* workspace, size_t workspace_bytes, rsa_out4 out, void* stream);
 
 /* ---- multi-GPU: the exchange step at the layer boundary.  The path itself shards by (batch, head) with
  * NO collective (reference: no cross-head dependency anywhere, rectified_hunyuan_attn.py:211-277, gapr_mask.py:15-42);

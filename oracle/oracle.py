@@ -495,7 +495,8 @@ def _fp8_dequant(ops, bh, i, rows, D):
     return val[:rows]
 
 
-def dense_attention_fp8(q, k, v, q_split: Optional[int] = None, kv_split: Optional[int] = None, causal: bool = False):
+def dense_attention_fp8(q, k, v, q_split: Optional[int] = None, kv_split: Optional[int] = None, causal: bool = False,
+                        qk: str = "e4m3"):
     """Dense attention of ONE head on e4m3 operands as rsa_dense_fwd_fp8 quantises them (block-scaled images over all Sq /
     Sk rows, K minus fp8_kmean over its Sk rows), two-segment semantics of attn.py:107-120.  q [Sq, D], k/v [Sk, D] fp32
     -> [Sq, D].  (With two segments the shift q.mu is still one constant per query row, so both softmaxes are unchanged.)"""
@@ -504,6 +505,10 @@ def dense_attention_fp8(q, k, v, q_split: Optional[int] = None, kv_split: Option
     pad = lambda n: (n + BLOCK - 1) // BLOCK * BLOCK
     ops = _fp8_operands_rows([q[None], k[None], v[None]], (Sq, Sk, Sk), (pad(Sq), pad(Sk), pad(Sk)), True)
     qd, kd, vd = (_fp8_dequant(ops, 0, i, n, D) for i, n in ((0, Sq), (1, Sk), (2, Sk)))
+    if qk == "2byte":    # the pv form (rsa_dense_fwd_fp8pv): the scores from q and k as they are, only V from its e4m3 image
+        qd, kd = np.asarray(q, np.float64), np.asarray(k, np.float64)
+    else:
+        assert qk == "e4m3", qk
     q_split = Sq if q_split is None else q_split
     kv_split = Sk if kv_split is None else kv_split
     out = np.zeros((Sq, D), np.float64)

@@ -378,7 +378,7 @@ def rectified_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, spec:
 
 
 def dense_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, q_split: Optional[int] = None,
-                    kv_split: Optional[int] = None, qkv_fp8: bool = False, causal: bool = False) -> torch.Tensor:
+                    kv_split: Optional[int] = None, qkv_fp8=False, causal: bool = False) -> torch.Tensor:
     """Exact attention on the HIP kernel.  q [B,H,Sq,D], k/v [B,H,Sk,D] -> [B,Sq,H,D].
     Rows < q_split attend kv [0, kv_split); rows >= q_split attend kv [kv_split, Sk) (attn.py:107-120); causal: inside a
     segment key j is visible to row i iff j <= i + (keys - rows) (2-byte kernel only)."""
@@ -395,10 +395,19 @@ def dense_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, q_split: 
     kv_split = Sk if kv_split is None else int(kv_split)
     out = torch.empty((B, Sq, H, D), dtype=q.dtype, device=q.device)
     o4 = RsaOut4(out.data_ptr(), out.stride(0), out.stride(2), out.stride(1))
+    if isinstance(qkv_fp8, str) and qkv_fp8 != "pv":
+        raise ValueError(f"qkv_fp8: False, True or 'pv', got {qkv_fp8!r}")
     if qkv_fp8:  # block-scaled e4m3 images of q, k, v + the fp8 MFMA kernel (head_dim 64 / 128)
         total = ctypes.c_size_t()
         _lib.check(L.rsa_dense_fp8_bytes(B, H, Sq, Sk, D, ctypes.byref(total)), "rsa_dense_fp8_bytes")
         ws = torch.empty(total.value, dtype=torch.uint8, device=q.device)
+        if qkv_fp8 == "pv":   # scores from the 2-byte q and k, e4m3 only for P and the V image (head dim 128)
+            if D != 128:
+                raise NotImplementedError("the pv form of the fp8 kernel serves head dim 128")
+            with torch.cuda.device(q.device):
+                _lib.check(L.rsa_dense_fwd_fp8pv(B, H, Sq, Sk, D, dtype_code(q.dtype), _t4(q), _t4(k), _t4(v), q_split, kv_split,
+                                                 int(bool(causal)), ws.data_ptr(), ws.numel(), o4, _stream()), "rsa_dense_fwd_fp8pv")
+            return out
         with torch.cuda.device(q.device):
             fn8, name8 = ((L.rsa_dense_causal_fwd_fp8, "rsa_dense_causal_fwd_fp8") if causal
                           else (L.rsa_dense_fwd_fp8, "rsa_dense_fwd_fp8"))

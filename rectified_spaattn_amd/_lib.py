@@ -118,6 +118,8 @@ def lib():
     L.rsa_dense_fwd_fp8.argtypes = [i32] * 6 + [RsaTensor4, RsaTensor4, RsaTensor4, i32, i32, vp, sz, RsaOut4, vp]
     L.rsa_dense_causal_fwd_fp8.argtypes = L.rsa_dense_fwd_fp8.argtypes
     L.rsa_dense_causal_fwd_fp8.restype = i32
+    L.rsa_dense_fwd_fp8pv.argtypes = [i32] * 6 + [RsaTensor4, RsaTensor4, RsaTensor4, i32, i32, i32, vp, sz, RsaOut4, vp]
+    L.rsa_dense_fwd_fp8pv.restype = i32
     L.rsa_block_sparse_fwd_fp8.argtypes = [P(RsaLayout), P(RsaFp8Operands), P(RsaBuffers), RsaOut4, vp]
     L.rsa_block_sparse_fwd_fp8pv.argtypes = [P(RsaLayout), RsaTensor4, RsaTensor4, P(RsaFp8Operands), P(RsaBuffers), RsaOut4, vp]
     L.rsa_block_sparse_fwd_fp8pv.restype = i32
@@ -165,7 +167,7 @@ EXPORTED = ("rsa_version", "rsa_buffer_bytes", "rsa_carve_workspace", "rsa_pool_
             "rsa_dense_fwd", "rsa_dense_causal_fwd", "rsa_dense_masked_fwd", "rsa_dense_dropout_fwd", "rsa_estimate_pr_gain", "rsa_status_string", "rsa_last_hip_error", "rsa_set_tuning", "rsa_set_shard_invariant", "rsa_gilbert_mapping",
             "rsa_gilbert_block_neighbors", "rsa_permute_tokens", "rsa_qk_norm_rope", "rsa_qk_layernorm_rope", "rsa_norm_rope_heads", "rsa_fp8_operand_bytes",
             "rsa_carve_fp8_operands", "rsa_quantize_fp8", "rsa_block_sparse_fwd_fp8", "rsa_block_sparse_fwd_fp8pv", "rsa_rectified_attention_fp8",
-            "rsa_pool_stats_fp8", "rsa_dense_fp8_bytes", "rsa_dense_fwd_fp8", "rsa_dense_causal_fwd_fp8", "rsa_rel_l1",
+            "rsa_pool_stats_fp8", "rsa_dense_fp8_bytes", "rsa_dense_fwd_fp8", "rsa_dense_causal_fwd_fp8", "rsa_dense_fwd_fp8pv", "rsa_rel_l1",
             "rsa_comm_unique_id", "rsa_comm_create", "rsa_comm_destroy", "rsa_comm_count", "rsa_allgather_heads",
             "rsa_allgather_heads_p2p", "rsa_p2p_state_bytes", "rsa_p2p_state_alloc", "rsa_p2p_state_free", "rsa_p2p_state_timeout", "rsa_ipc_export", "rsa_ipc_open", "rsa_ipc_close",
             "rsa_ipc_offset")

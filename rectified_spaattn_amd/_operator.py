@@ -50,9 +50,12 @@ def set_qkv_fp8(enabled):
 DENSE_FP8 = False
 
 
-def set_dense_fp8(enabled: bool) -> bool:
+def set_dense_fp8(enabled) -> bool:
+    """False | True (e4m3 q, k, v, P) | "pv" (2-byte Q . K^T, e4m3 P . V; head dim 128, other head dims keep the 2-byte kernel)."""
     global DENSE_FP8
-    old, DENSE_FP8 = DENSE_FP8, bool(enabled)
+    if isinstance(enabled, str) and enabled != "pv":
+        raise ValueError(f"set_dense_fp8: False, True or 'pv', got {enabled!r}")
+    old, DENSE_FP8 = DENSE_FP8, (enabled if isinstance(enabled, str) else bool(enabled))
     return old
 
 

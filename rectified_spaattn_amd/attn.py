@@ -99,7 +99,7 @@ def _device_dense(q, k, v, splits, dense_fp8=None, causal=False):
     """q [b,a,s,d], k/v [b,a,s1,d]; splits: per batch item (q_split, kv_split).  Returns [b,a,s,d] view."""
     B = q.shape[0]
     # e4m3 operands on the fp8 MFMA: per call, else the process default of set_dense_fp8()
-    fp8 = (_operator.DENSE_FP8 if dense_fp8 is None else bool(dense_fp8)) and q.shape[-1] in (64, 128)
+    fp8 = _operator._fp8_mode(_operator.DENSE_FP8 if dense_fp8 is None else dense_fp8, q.shape[-1])
     if len(set(splits)) == 1:
         return _core.dense_attention(q, k, v, splits[0][0], splits[0][1], qkv_fp8=fp8, causal=causal).transpose(1, 2)
     outs = [_core.dense_attention(q[i:i + 1], k[i:i + 1], v[i:i + 1], *splits[i], qkv_fp8=fp8, causal=causal)

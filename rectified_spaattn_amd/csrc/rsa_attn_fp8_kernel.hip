@@ -986,9 +986,10 @@ extern "C" int rsa_rectified_attention_fp8(const rsa_layout* l, rsa_tensor4 q, r
 // its dense mode.  Workspace: rsa_dense_fp8_bytes.
 static int dense_fwd_fp8(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
                          int q_split, int kv_split, int causal, void* workspace, size_t workspace_bytes, rsa_out4 out,
-                         void* stream) {
+                         void* stream, int pv = 0) {
     if (B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0) return RSA_ERR_BAD_ARG;
     if (D != 128 && D != 64) return RSA_ERR_UNSUPPORTED;
+    if (pv && D != 128) return RSA_ERR_UNSUPPORTED;
     if (dtype != RSA_BF16 && dtype != RSA_FP16) return RSA_ERR_UNSUPPORTED;
     if (q_split < 0 || q_split > Sq || kv_split < 0 || kv_split > Sk) return RSA_ERR_BAD_ARG;
     int st;
@@ -997,7 +998,7 @@ static int dense_fwd_fp8(int B, int H, int Sq, int Sk, int D, int dtype, rsa_ten
         return st;
     rsa_fp8_operands ops;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if ((st = rsa_dense_quantize_fp8(B, H, Sq, Sk, D, dtype, q, k, v, workspace, workspace_bytes, &ops, s))) return st;
+    if ((st = rsa_dense_quantize_fp8(B, H, Sq, Sk, D, dtype, q, k, v, workspace, workspace_bytes, &ops, s, pv))) return st;
     Attn8Args a;
     a.q8 = ops.q8; a.k8 = ops.k8; a.v8t = ops.v8t; a.exps = ops.scales;
     a.out = static_cast<unsigned short*>(out.ptr); a.osb = out.stride_b; a.osh = out.stride_h; a.oss = out.stride_s;
@@ -1013,13 +1014,24 @@ static int dense_fwd_fp8(int B, int H, int Sq, int Sk, int D, int dtype, rsa_ten
     a.q_split = q_split; a.kv_split = kv_split; a.causal = causal;
     a.out_fp16 = dtype == RSA_FP16;
     a.q16 = a.k16 = nullptr; a.qsb = a.qsh = a.qss = a.ksb = a.ksh = a.kss = 0; a.qk_scale = 0.0f;
-    return launch_attn8(a, B * H, D, 0, s);
+    if (pv) {   // scores from the 2-byte q and k themselves (rsa_block_sparse_fwd_fp8pv's operands)
+        a.q16 = static_cast<const unsigned short*>(q.ptr); a.qsb = q.stride_b; a.qsh = q.stride_h; a.qss = q.stride_s;
+        a.k16 = static_cast<const unsigned short*>(k.ptr); a.ksb = k.stride_b; a.ksh = k.stride_h; a.kss = k.stride_s;
+        a.qk_scale = (float)((1.0 / sqrt((double)D)) * 1.44269504 * 8.0);
+    }
+    return launch_attn8(a, B * H, D, 0, s, pv ? (dtype == RSA_FP16 ? 2 : 1) : 0);
 }
 
 extern "C" int rsa_dense_fwd_fp8(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k,
                                  rsa_tensor4 v, int q_split, int kv_split, void* workspace, size_t workspace_bytes,
                                  rsa_out4 out, void* stream) {
     return dense_fwd_fp8(B, H, Sq, Sk, D, dtype, q, k, v, q_split, kv_split, 0, workspace, workspace_bytes, out, stream);
+}
+
+extern "C" int rsa_dense_fwd_fp8pv(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
+                                   int q_split, int kv_split, int causal, void* workspace, size_t workspace_bytes, rsa_out4 out,
+                                   void* stream) {
+    return dense_fwd_fp8(B, H, Sq, Sk, D, dtype, q, k, v, q_split, kv_split, causal ? 1 : 0, workspace, workspace_bytes, out, stream, 1);
 }
 
 extern "C" int rsa_dense_causal_fwd_fp8(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k,

@@ -97,7 +97,7 @@ int rsa_pool_stats_f8(const rsa_layout* l, rsa_tensor4 q, rsa_tensor4 k, rsa_ten
 
 // e4m3 images for the dense fp8 kernel, carved out of `ws` (rsa_fp8.hip)
 int rsa_dense_quantize_fp8(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
-                           void* ws, size_t ws_bytes, rsa_fp8_operands* ops, hipStream_t s);
+                           void* ws, size_t ws_bytes, rsa_fp8_operands* ops, hipStream_t s, int v_only = 0);
 
 // last HIP error seen by a launch of this library (for rsa_last_hip_error); defined in rsa_stats.hip
 extern int g_rsa_last_hip_error;

@@ -249,7 +249,7 @@ extern "C" int rsa_dense_fp8_bytes(int B, int H, int Sq, int Sk, int D, size_t* 
 
 // internal: producer for the dense kernel (declared in rsa_common.h).  Both images are S_pad = max(Sq, Sk) rounded to 128 rows.
 int rsa_dense_quantize_fp8(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
-                           void* ws, size_t ws_bytes, rsa_fp8_operands* ops, hipStream_t s) {
+                           void* ws, size_t ws_bytes, rsa_fp8_operands* ops, hipStream_t s, int v_only) {
     if (D != 128 && D != 64) return RSA_ERR_UNSUPPORTED;
     if (!ws || (reinterpret_cast<uintptr_t>(ws) & 255)) return RSA_ERR_BAD_ARG;
     int sqp, skp;
@@ -271,7 +271,12 @@ int rsa_dense_quantize_fp8(int B, int H, int Sq, int Sk, int D, int dtype, rsa_t
     f.kmean = kmean;
     f.qk_const = (float)((1.0 / sqrt((double)D)) * 1.44269504);
     f.S_pad = sqp; f.NB_total = nb;
-    launch_kmean(D, dtype, k, B * H, H, Sk, kmean, s);
+    if (v_only) {   // the pv form: the V image and its exponents only (no Q / K blocks, no K mean)
+        f.q8 = nullptr; f.k8 = nullptr;
+        a.blk1[0] = 0; a.blk1[1] = 0;
+    } else {
+        launch_kmean(D, dtype, k, B * H, H, Sk, kmean, s);
+    }
     launch_blocks(a, D, dtype, B * H, 3, s);
     return rsa_launch_status();
 }

@@ -519,6 +519,63 @@ def test_fp8_pv_kept_lists_longer_than_the_lds_window():
     assert torch.isfinite(outs[0]).all() and float(d.max()) <= PV_MAX_VS_BF16 and rel <= PV_REL_L1
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("Sq,Sk,qs,ks,causal", [(300, 520, None, None, False), (384, 384, 256, 200, False), (129, 1000, 1, 64, False),
+                                                (700, 700, None, None, True), (640, 640, 200, 260, True)],
+                         ids=["plain", "two_segment", "ragged", "causal", "causal_two_segments"])
+def test_fp8_pv_dense_kernel(Sq, Sk, qs, ks, causal, dt):
+    """rsa_dense_fwd_fp8pv (fullattn's device path in the pv form: 2-byte scores, e4m3 P and V) against the dense oracle with the same
+    two choices (qk="2byte"), against the 2-byte dense kernel, and bit for bit against the compiled twin of its tile block."""
+    from rectified_spaattn_amd import _core, _lib
+    g = torch.Generator().manual_seed(Sq * 5 + Sk)
+    H = 2
+    q = torch.randn(1, H, Sq, 128, generator=g).to(DEV, dt)
+    k = torch.randn(1, H, Sk, 128, generator=g).to(DEV, dt)
+    v = torch.randn(1, H, Sk, 128, generator=g).to(DEV, dt)
+    outs = {}
+    try:
+        for var in (0, 1):
+            assert _lib.lib().rsa_set_tuning(b"fp8_variant", var) == 0
+            outs[var] = _core.dense_attention(q, k, v, qs, ks, qkv_fp8="pv", causal=causal)          # [1, Sq, H, D]
+    finally:
+        _lib.lib().rsa_set_tuning(b"fp8_variant", 0)
+    out = outs[0]
+    assert torch.equal(outs[0], outs[1])
+    ref16 = _core.dense_attention(q, k, v, qs, ks, causal=causal)
+    o8 = _core.dense_attention(q, k, v, qs, ks, qkv_fp8=True, causal=causal)
+    assert torch.isfinite(out.float()).all()
+    for h in range(H):
+        ref = orc.dense_attention_fp8(*(t[0, h].float().cpu().numpy() for t in (q, k, v)), qs, ks, causal=causal, qk="2byte")
+        err = np.abs(out[0, :, h].float().cpu().numpy() - ref)
+        # (rows with one or two keys reproduce V: there the e4m3 image of V is the whole error, 2^-4 relative)
+        lim = 0.3 if causal else PV_MAX_VS_ORACLE
+        assert err.max() <= lim and err.mean() <= 5 * PV_MEAN_VS_ORACLE, f"{err.max():.3e} {err.mean():.3e}"
+    d16 = (out.float() - ref16.float()).abs()
+    e16 = (o8.float() - ref16.float()).abs()
+    print(f"pv dense vs 2-byte dense: max {float(d16.max()):.3e} mean {float(d16.mean()):.3e} (all-e4m3: {float(e16.max()):.3e} / {float(e16.mean()):.3e})")
+    assert d16.mean() <= PV_MEAN_VS_BF16 and d16.mean() < 0.75 * e16.mean()
+
+
+def test_fullattn_dense_fp8_pv_switch():
+    import rectified_spaattn_amd as rsa
+    from rectified_spaattn_amd.attn import fullattn
+    g = torch.Generator().manual_seed(4)
+    q, k, v = (torch.randn(1, 3, 500, 128, generator=g).to(DEV, torch.bfloat16) for _ in range(3))
+    o16 = fullattn(q, k, v, mode="torch")
+    old = rsa.set_dense_fp8("pv")
+    try:
+        opv = fullattn(q, k, v, mode="torch")
+        q6, k6, v6 = (t[..., :64].contiguous() for t in (q, k, v))
+        o6 = fullattn(q6, k6, v6, mode="torch")            # head dim 64 has no pv kernel: the 2-byte one
+    finally:
+        rsa.set_dense_fp8(old)
+    assert opv.shape == o16.shape and not torch.equal(opv, o16)
+    assert (opv.float() - o16.float()).abs().max() <= PV_MAX_VS_BF16
+    assert torch.equal(o6, fullattn(q6, k6, v6, mode="torch"))
+    with pytest.raises(ValueError):
+        rsa.set_dense_fp8("qk")
+
+
 def test_fp8_pv_form_public_switch_and_head_dim_64():
     """set_qkv_fp8("pv") reaches the operators; head dim 64 has no pv kernel: the operator keeps the 2-byte kernel there (as the
     e4m3 switch does for head dims without an fp8 kernel), a StagedCall refuses."""
