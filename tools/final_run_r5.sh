@@ -52,6 +52,7 @@ make -s -C rectified_spaattn_amd/csrc diag > /dev/null 2>&1
 python tools/diag_k5w.py > gpurun_out/r5z_diag.txt 2>&1
 RSA_BENCH_ONE_DEVICE=1 python bench.py --gpus 2 --steps 5 --warmup 2 --no-extras --no-cpu-baseline | grep "^{" > gpurun_out/r5z_bench_2ranks_one_device.json 2>> gpurun_out/r5z_bench.err
 for HH in 24 12 6 3; do echo "heads=$HH"; RSA_PERF_H=$HH RSA_PERF_REGIMES=r2 python tools/perf_k5.py regimes; done > gpurun_out/r5z_rank_shapes.txt 2>&1
+python tools/perf_k5.py dense > gpurun_out/r5z_dense.txt 2>&1
 python tools/clock_probe.py > gpurun_out/r5z_clock.txt 2>&1
 du -sh gpurun_out
 tail -3 gpurun_out/r5z_tests.txt; cat gpurun_out/r5z_smoke.txt | tail -2; tail -c 600 gpurun_out/r5z_bench.json

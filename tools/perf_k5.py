@@ -149,6 +149,8 @@ def main():
             print(f"dense S={S} H={H}: median {med:.3f} ms  {fl/med/1e9:.1f} TFLOP/s")
             med8, _ = timeit(lambda: _core.dense_attention(q, k, v, qkv_fp8=True), n=3, warm=1)
             print(f"dense fp8 (incl. quantisation) S={S} H={H}: median {med8:.3f} ms  {fl/med8/1e9:.1f} TFLOP/s")
+            medp, _ = timeit(lambda: _core.dense_attention(q, k, v, qkv_fp8="pv"), n=3, warm=1)
+            print(f"dense pv form (incl. the V image pass) S={S} H={H}: median {medp:.3f} ms  {fl/medp/1e9:.1f} TFLOP/s")
 
 
 if __name__ == "__main__":
