@@ -295,6 +295,12 @@ int rsa_rectified_attention_fp8(const rsa_layout* lay, rsa_tensor4 q, rsa_tensor
                                 const uint8_t* neighbor, int top_k, float p_remain, void* workspace,
                                 size_t workspace_bytes, void* fp8_workspace, size_t fp8_workspace_bytes,
                                 rsa_out4 out, void* stream);
+/* ... in the pv form (head dim 128): K1 writes only the V image and its exponents, K5 = rsa_block_sparse_fwd_fp8pv.  Same workspaces
+ * (the Q / K images' share of fp8_workspace stays untouched). */
+int rsa_rectified_attention_fp8pv(const rsa_layout* lay, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
+                                  const uint8_t* neighbor, int top_k, float p_remain, void* workspace,
+                                  size_t workspace_bytes, void* fp8_workspace, size_t fp8_workspace_bytes,
+                                  rsa_out4 out, void* stream);
 
 /* TeaCache's step-skipping statistic (scripts/main_hunyuan.py:120, main_wan21t2v.py:112): out2[0] =
  * sum |a - b|, out2[1] = sum |b| over two equal-length 2-byte tensors (n elements, 16-B aligned) in one HBM pass

@@ -515,8 +515,9 @@ def rectified_attention_onecall(q: torch.Tensor, k: torch.Tensor, v: torch.Tenso
         o, workspace = rectified_attention_onecall(*pad_small_head_dim(q, k, v), spec, top_k, p_remain, block_neighbor_list,
                                                    workspace, qkv_fp8)
         return o.view(B, S, H, -1)[..., :D].reshape(B, S, H * D), workspace
-    if isinstance(qkv_fp8, str):    # the pv form has no one-call C entry of its own: the staged calls, same kernels
-        return rectified_attention(q, k, v, spec, top_k, p_remain, block_neighbor_list, qkv_fp8=qkv_fp8), workspace
+    if isinstance(qkv_fp8, str) and (qkv_fp8 != "pv" or q.shape[-1] != 128):
+        raise (ValueError(f"qkv_fp8: False, True or 'pv', got {qkv_fp8!r}") if qkv_fp8 != "pv"
+               else NotImplementedError("the pv form of the fp8 kernel serves head dim 128"))
     L = _lib.lib()
     B, H, S, D = q.shape
     q, k, v = _as_bhsd(q), _as_bhsd(k), _as_bhsd(v)
@@ -535,12 +536,12 @@ def rectified_attention_onecall(q: torch.Tensor, k: torch.Tensor, v: torch.Tenso
         _lib.check(L.rsa_fp8_operand_bytes(ctypes.byref(lay), ctypes.byref(s4), ctypes.byref(t8)),
                    "rsa_fp8_operand_bytes")
         ws8 = torch.empty(t8.value, dtype=torch.uint8, device=q.device)
+        fn8, name8 = ((L.rsa_rectified_attention_fp8pv, "rsa_rectified_attention_fp8pv") if qkv_fp8 == "pv"
+                      else (L.rsa_rectified_attention_fp8, "rsa_rectified_attention_fp8"))
         with torch.cuda.device(q.device):
-            _lib.check(L.rsa_rectified_attention_fp8(ctypes.byref(lay), _t4(q), _t4(k), _t4(v),
-                                                     nbr.data_ptr() if nbr is not None else None, int(top_k),
-                                                     float(p_remain), workspace.data_ptr(), workspace.numel(),
-                                                     ws8.data_ptr(), ws8.numel(), o4, _stream()),
-                       "rsa_rectified_attention_fp8")
+            _lib.check(fn8(ctypes.byref(lay), _t4(q), _t4(k), _t4(v), nbr.data_ptr() if nbr is not None else None, int(top_k),
+                           float(p_remain), workspace.data_ptr(), workspace.numel(), ws8.data_ptr(), ws8.numel(), o4, _stream()),
+                       name8)
         return out.view(B, S, H * D), workspace
     with torch.cuda.device(q.device):
         _lib.check(L.rsa_rectified_attention(ctypes.byref(lay), _t4(q), _t4(k), _t4(v),

@@ -125,6 +125,8 @@ def lib():
     L.rsa_block_sparse_fwd_fp8pv.restype = i32
     L.rsa_rectified_attention_fp8.argtypes = [P(RsaLayout), RsaTensor4, RsaTensor4, RsaTensor4, vp, i32, f32, vp, sz,
                                               vp, sz, RsaOut4, vp]
+    L.rsa_rectified_attention_fp8pv.argtypes = L.rsa_rectified_attention_fp8.argtypes
+    L.rsa_rectified_attention_fp8pv.restype = i32
     L.rsa_comm_unique_id.argtypes = [vp]
     L.rsa_comm_create.argtypes = [i32, i32, vp, P(vp)]
     L.rsa_comm_destroy.argtypes = [vp]
@@ -144,7 +146,7 @@ def lib():
                  "rsa_p2p_state_alloc", "rsa_p2p_state_free", "rsa_p2p_state_timeout"):
         getattr(L, name).restype = i32
     for name in ("rsa_fp8_operand_bytes", "rsa_carve_fp8_operands", "rsa_quantize_fp8", "rsa_block_sparse_fwd_fp8",
-                 "rsa_rectified_attention_fp8", "rsa_pool_stats_fp8", "rsa_dense_fp8_bytes",
+                 "rsa_rectified_attention_fp8", "rsa_rectified_attention_fp8pv", "rsa_pool_stats_fp8", "rsa_dense_fp8_bytes",
                  "rsa_dense_fwd_fp8"):
         getattr(L, name).restype = i32
     for name in ("rsa_buffer_bytes", "rsa_carve_workspace", "rsa_pool_stats", "rsa_pooled_scores",
@@ -166,7 +168,7 @@ EXPORTED = ("rsa_version", "rsa_buffer_bytes", "rsa_carve_workspace", "rsa_pool_
             "rsa_select_mask", "rsa_compensation", "rsa_block_sparse_fwd", "rsa_rectified_attention",
             "rsa_dense_fwd", "rsa_dense_causal_fwd", "rsa_dense_masked_fwd", "rsa_dense_dropout_fwd", "rsa_estimate_pr_gain", "rsa_status_string", "rsa_last_hip_error", "rsa_set_tuning", "rsa_set_shard_invariant", "rsa_gilbert_mapping",
             "rsa_gilbert_block_neighbors", "rsa_permute_tokens", "rsa_qk_norm_rope", "rsa_qk_layernorm_rope", "rsa_norm_rope_heads", "rsa_fp8_operand_bytes",
-            "rsa_carve_fp8_operands", "rsa_quantize_fp8", "rsa_block_sparse_fwd_fp8", "rsa_block_sparse_fwd_fp8pv", "rsa_rectified_attention_fp8",
+            "rsa_carve_fp8_operands", "rsa_quantize_fp8", "rsa_block_sparse_fwd_fp8", "rsa_block_sparse_fwd_fp8pv", "rsa_rectified_attention_fp8", "rsa_rectified_attention_fp8pv",
             "rsa_pool_stats_fp8", "rsa_dense_fp8_bytes", "rsa_dense_fwd_fp8", "rsa_dense_causal_fwd_fp8", "rsa_dense_fwd_fp8pv", "rsa_rel_l1",
             "rsa_comm_unique_id", "rsa_comm_create", "rsa_comm_destroy", "rsa_comm_count", "rsa_allgather_heads",
             "rsa_allgather_heads_p2p", "rsa_p2p_state_bytes", "rsa_p2p_state_alloc", "rsa_p2p_state_free", "rsa_p2p_state_timeout", "rsa_ipc_export", "rsa_ipc_open", "rsa_ipc_close",

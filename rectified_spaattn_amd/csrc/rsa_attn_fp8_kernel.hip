@@ -982,6 +982,24 @@ extern "C" int rsa_rectified_attention_fp8(const rsa_layout* l, rsa_tensor4 q, r
     return rsa_block_sparse_fwd_fp8(l, &ops, &buf, out, stream);
 }
 
+extern "C" int rsa_rectified_attention_fp8pv(const rsa_layout* l, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
+                                             const uint8_t* neighbor, int top_k, float p_remain, void* workspace,
+                                             size_t workspace_bytes, void* fp8_workspace, size_t fp8_workspace_bytes,
+                                             rsa_out4 out, void* stream) {
+    rsa_buffers buf;
+    rsa_fp8_operands ops;
+    int st = rsa_carve_workspace(l, workspace, workspace_bytes, &buf);
+    if (st != RSA_OK) return st;
+    if (l->D != 128) return RSA_ERR_UNSUPPORTED;
+    if ((st = rsa_carve_fp8_operands(l, fp8_workspace, fp8_workspace_bytes, &ops))) return st;
+    ops.q8 = nullptr; ops.k8 = nullptr;       // K1 then writes the V image and the V exponents only
+    if ((st = rsa_pool_stats_fp8(l, q, k, v, &buf, &ops, stream))) return st;
+    if ((st = rsa_pooled_scores(l, k, &buf, stream))) return st;
+    if ((st = rsa_select_mask(l, neighbor, top_k, p_remain, &buf, stream))) return st;
+    if ((st = rsa_compensation(l, &buf, stream))) return st;
+    return rsa_block_sparse_fwd_fp8pv(l, q, k, &ops, &buf, out, stream);
+}
+
 // Dense attention (two-segment varlen semantics of rsa_dense_fwd) with fp8 operands: quantise, then the same kernel in
 // its dense mode.  Workspace: rsa_dense_fp8_bytes.
 static int dense_fwd_fp8(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,

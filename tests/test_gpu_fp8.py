@@ -112,6 +112,18 @@ def test_fp8_onecall_matches_staged():
     assert torch.equal(a, b)
 
 
+def test_fp8_pv_onecall_matches_staged():
+    """rsa_rectified_attention_fp8pv (one C call, what a non-Python host uses) = the staged calls of the pv form, bit for bit."""
+    from rectified_spaattn_amd import _core, synth
+    lay = orc.layout_hunyuan(7 * 128 + 256, 7 * 128 + 150)
+    q, k, v = synth.structured_qkv(23, 1, 2, lay.S, 128, smooth=0.0)
+    tq, tk, tv = (torch.from_numpy(x).to(DEV, torch.bfloat16) for x in (q, k, v))
+    nbr = torch.from_numpy(synth.banded_neighbors(lay.NBv, 1))
+    staged = _core.rectified_attention(tq, tk, tv, _spec(lay), 3, 0.3, nbr, qkv_fp8="pv")
+    one, _ = _core.rectified_attention_onecall(tq, tk, tv, _spec(lay), 3, 0.3, nbr, qkv_fp8="pv")
+    assert torch.equal(one.reshape(staged.shape), staged)
+
+
 def test_fp8_rejects_head_dims_it_has_no_kernel_for():
     from rectified_spaattn_amd import _core
     z = torch.zeros(1, 1, 256, 48, dtype=torch.bfloat16, device=DEV)   # (16 / 32 are served zero-padded; 48 is no head dim of the reference)
