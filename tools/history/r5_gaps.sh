@@ -1,8 +1,8 @@
 #!/bin/bash
 # times the pv and the e4m3 K5 in each placement library of tools/history/r5_gaps_build.sh (one process per library and form)
-python -m pytest tests/test_gpu_fp8.py -x -q -k "window or twin" 2>&1 | grep -v amdgpu.ids | tail -3
+
 for rep in 1 2; do
-for x in base early even2 late pvphase; do
+for x in ${RSA_GAPS_LIBS:-base early even2 late pvphase}; do
 python - $x <<'PY' 2>&1 | grep -v amdgpu.ids
 import os, sys, torch
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
