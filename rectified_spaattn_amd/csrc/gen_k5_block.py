@@ -412,8 +412,7 @@ def gen_block8(TS, codemap=False, D8=128, dma=False):
             dst = (4 + ((TS + 2) & 3)) * TILE8 + hi * 4096 if isv else ((TS + 3) & 3) * TILE8 + hi * 4096
             lines.append(f"s_add_u32 m0, %[ldsw], {dst}")
             lines.append("s_nop 0")      # (M0 write -> LDS-DMA: one wait state)
-            lines.append(f"global_load_lds_dwordx4 {vr((m.DV if isv else m.DK) + hi)}, " + ("%[vsrc]" if isv else "%[ksrc]")
-                         + os.environ.get("RSA_GEN_DMAFLAGS", ""))    # (cache-policy A/B: profiles/r05_pv_hand_placed.txt)
+            lines.append(f"global_load_lds_dwordx4 {vr((m.DV if isv else m.DK) + hi)}, " + ("%[vsrc]" if isv else "%[ksrc]"))
         # row max of S_nxt: two MFMAs behind the last QK^T MFMA (index n_qk - 1): from the shadow of PV 0 (index n_qk + 1) on
         emit_work(10 ** 6 if i == n - 1 else 48, i >= n_qk + 1)
     assert wi == len(work) and mi == len(maxw)
@@ -642,7 +641,7 @@ def gen_block8h(T6, dt, dma=False):
                 dst, vo, src = 3 * 16384 + ((T6 + 2) % 3) * 8192 + (j - 4) * 4096, m.DV + j - 4, "%[vsrc]"
             lines.append(f"s_add_u32 m0, %[ldsw], {dst}")
             lines.append("s_nop 0")      # (M0 write -> LDS-DMA: one wait state)
-            lines.append(f"global_load_lds_dwordx4 {vr(vo)}, {src}" + os.environ.get("RSA_GEN_DMAFLAGS", ""))
+            lines.append(f"global_load_lds_dwordx4 {vr(vo)}, {src}")
         # row max of S_nxt: two MFMAs behind the last QK^T MFMA
         emit_work(10 ** 6 if i == n - 1 else (20 if kind == "qk" else 48), i >= n_qk + 1)
     assert wi == len(work) and mi == len(maxw) and nxt == n

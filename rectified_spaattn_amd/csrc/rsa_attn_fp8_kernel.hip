@@ -26,8 +26,16 @@
 // Pipeline (per wave, 64-key tiles, S double-buffered): step t computes S(t+1) while P(t) and O += V(t) P(t) run; the body
 // of a step is one hand-placed instruction block (gen_k5_block.py::gen_block8), four copies per loop trip so that the
 // LDS ring slot is a compile-time constant of each.
-// Staging: K and V tiles are 8 KiB each; 4-slot rings; at the head of step t the wave issues its 2+2 LDS-DMA pieces of
-// K(t+3) and V(t+2) behind `s_waitcnt vmcnt(4)` + barrier, so every tile has two full steps to land.
+// Staging: K and V tiles are 8 KiB each; 4-slot rings; step t stages K(t+3) and V(t+2) behind `s_waitcnt vmcnt(4)` + barrier, so
+// every tile has two full steps to land.  Since round 5 (head dim 128, PIPE_OPT bit 3) the wave's 2 + 2 LDS-DMA pieces are issued
+// INSIDE the hand-placed block, one per MFMA shadow, and for every tile (past the end of the walk the last tile again, into a slot
+// nobody reads), not as a burst of the eight waves behind the barrier: -2..3 % (profiles/r05_pv_hand_placed.txt).
+//
+// The "pv" form (round 5; HYB instances, head dim 128): Q . K^T on the 2-byte q and k themselves -- K tiles of 64 keys x 256 bytes in
+// the 2-byte kernels' image, sixteen v_mfma_f32_32x32x16 per tile whose chain starts from the same reference block (Q carries
+// sm_scale log2e 8, so the accumulator still arrives as the e4m3 code of P) -- and everything behind the scores as above: code-map
+// P, row sum and P . V on the e4m3 V image.  Three-slot rings (K 3 x 16 KiB, V 3 x 8 KiB), six tiles per loop trip, its own
+// hand-placed block (gen_block8h), the kept list as a 1 024-entry LDS window.  Scores of the 2-byte path, P . V at the fp8 rate.
 #include "rsa_attn.h"
 #include "rsa_attn_block.h"
 

@@ -12,6 +12,7 @@ build() {
     echo "built librsa_hip_x_$1.so"
 }
 build base ""
+# (needs the RSA_GEN_DMAFLAGS hook in gen_k5_block.py: see the commit that added this script)
 build sc0 " sc0"
 build sc1 " sc1"
 build sc01 " sc0 sc1"
