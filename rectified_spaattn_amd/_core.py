@@ -283,12 +283,12 @@ class StagedCall:
         self.nbr = neighbor_on_device(block_neighbor_list, spec.NBv, q.device)
         self.t = (_t4(self.q), _t4(self.k), _t4(self.v))
         self.fp8 = None
-        # qkv_fp8: False | True (e4m3 Q, K, V and P) | "pv" (2-byte Q . K^T, e4m3 P . V: head dim 128)
+        # qkv_fp8: False | True (e4m3 Q, K, V and P) | "pv" (2-byte Q . K^T, e4m3 P . V)
         self.fp8_pv = isinstance(qkv_fp8, str) and qkv_fp8 == "pv"
         if isinstance(qkv_fp8, str) and not self.fp8_pv:
             raise ValueError(f"qkv_fp8 must be False, True or 'pv', got {qkv_fp8!r}")
-        if self.fp8_pv and D != 128:
-            raise NotImplementedError("qkv_fp8='pv' (2-byte Q.K^T + e4m3 P.V) is built for head dim 128")
+        if self.fp8_pv and D not in (64, 128):
+            raise NotImplementedError("qkv_fp8='pv' (2-byte Q.K^T + e4m3 P.V) is built for head dims 64 and 128")
         if qkv_fp8:
             self.fp8 = alloc_fp8_operands(spec, B, H, D, q.device, v_only=self.fp8_pv)
             self.cf = RsaFp8Operands(*[self.fp8[n].data_ptr() if self.fp8[n].numel() else None for n in ("q8", "k8", "v8t", "scales")])
@@ -401,9 +401,9 @@ def dense_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, q_split: 
         total = ctypes.c_size_t()
         _lib.check(L.rsa_dense_fp8_bytes(B, H, Sq, Sk, D, ctypes.byref(total)), "rsa_dense_fp8_bytes")
         ws = torch.empty(total.value, dtype=torch.uint8, device=q.device)
-        if qkv_fp8 == "pv":   # scores from the 2-byte q and k, e4m3 only for P and the V image (head dim 128)
-            if D != 128:
-                raise NotImplementedError("the pv form of the fp8 kernel serves head dim 128")
+        if qkv_fp8 == "pv":   # scores from the 2-byte q and k, e4m3 only for P and the V image
+            if D not in (64, 128):
+                raise NotImplementedError("the pv form of the fp8 kernel serves head dims 64 and 128")
             with torch.cuda.device(q.device):
                 _lib.check(L.rsa_dense_fwd_fp8pv(B, H, Sq, Sk, D, dtype_code(q.dtype), _t4(q), _t4(k), _t4(v), q_split, kv_split,
                                                  int(bool(causal)), ws.data_ptr(), ws.numel(), o4, _stream()), "rsa_dense_fwd_fp8pv")
@@ -515,9 +515,9 @@ def rectified_attention_onecall(q: torch.Tensor, k: torch.Tensor, v: torch.Tenso
         o, workspace = rectified_attention_onecall(*pad_small_head_dim(q, k, v), spec, top_k, p_remain, block_neighbor_list,
                                                    workspace, qkv_fp8)
         return o.view(B, S, H, -1)[..., :D].reshape(B, S, H * D), workspace
-    if isinstance(qkv_fp8, str) and (qkv_fp8 != "pv" or q.shape[-1] != 128):
+    if isinstance(qkv_fp8, str) and (qkv_fp8 != "pv" or q.shape[-1] not in (64, 128)):
         raise (ValueError(f"qkv_fp8: False, True or 'pv', got {qkv_fp8!r}") if qkv_fp8 != "pv"
-               else NotImplementedError("the pv form of the fp8 kernel serves head dim 128"))
+               else NotImplementedError("the pv form of the fp8 kernel serves head dims 64 and 128"))
     L = _lib.lib()
     B, H, S, D = q.shape
     q, k, v = _as_bhsd(q), _as_bhsd(k), _as_bhsd(v)

@@ -51,7 +51,7 @@ DENSE_FP8 = False
 
 
 def set_dense_fp8(enabled) -> bool:
-    """False | True (e4m3 q, k, v, P) | "pv" (2-byte Q . K^T, e4m3 P . V; head dim 128, other head dims keep the 2-byte kernel)."""
+    """False | True (e4m3 q, k, v, P) | "pv" (2-byte Q . K^T, e4m3 P . V)."""
     global DENSE_FP8
     if isinstance(enabled, str) and enabled != "pv":
         raise ValueError(f"set_dense_fp8: False, True or 'pv', got {enabled!r}")
@@ -64,7 +64,7 @@ def _fp8_mode(choice, D: int):
     if isinstance(choice, str):
         if choice != "pv":
             raise ValueError(f"qkv_fp8: False, True or 'pv', got {choice!r}")
-        return "pv" if D == 128 else False
+        return "pv" if D in (64, 128) else False
     return bool(choice) and D in (64, 128)
 
 

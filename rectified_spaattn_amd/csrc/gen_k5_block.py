@@ -479,10 +479,12 @@ def main8(out):
 # of the e4m3 block's ring); QK^T fragments are read six MFMAs ahead (a 2-byte MFMA is half as long as an e4m3 one), the rest three.
 # =====================================================================================================================
 class Map8H:
-    def __init__(self):
+    def __init__(self, D8=128):
+        self.D8, self.KS, self.DT = D8, D8 // 16, D8 // 32
+        self.NPK, self.NPV = D8 // 32, D8 // 64          # LDS-DMA pieces per wave: K tile (64 rows x 2 D8 bytes), V tile (D8 x 64 bytes)
         r = 0
-        self.O = r; r += 64
-        self.Q = r; r += 32
+        self.O = r; r += 16 * self.DT
+        self.Q = r; r += 4 * self.KS
         self.SA = r; r += 32
         self.SB = r; r += 32
         self.MB = r; r += 16
@@ -499,20 +501,23 @@ class Map8H:
                                      # swizzle), built in T0 / T1 just before the reads; 32-key half and ring slot are immediates
         r = (r + 1) & ~1
         self.ONES = r; r += 8        # A operand of the row-sum product (e4m3 1.0 or 0 in all 32 bytes: a constant of the lane)
-        self.DK = r; r += 4          # dma form: LDS-DMA lane offsets of the wave's four K pieces of tile + 3 (rows clamped: per tile)
-        self.DV = r; r += 2          # ... of its two V pieces (the second = the first + 4 096: constants of the lane)
+        r = (r + 3) & ~3
+        self.DK = r; r += self.NPK   # dma form: LDS-DMA lane offsets of the wave's K pieces of tile + 3 (rows clamped: per tile)
+        r = (r + 1) & ~1
+        self.DV = r; r += self.NPV   # ... of its V pieces (a second one = the first + 4 096: constants of the lane)
         self.end = r
 
 
-NSLOT8H = 6      # 4-register operand slots (256 registers per wave at two waves per SIMD: the block pins 212 of them)
+NSLOT8H = 6      # 4-register operand slots (256 registers per wave at two waves per SIMD: the block pins 212 of them at head dim 128)
 
 
-DMA8H_GAPS = [1, 4, 7, 10, 13, 16]     # dma form: K pieces 0..3, V pieces 0, 1 behind these MFMAs of the 21
+DMA8H_GAPS = {128: [1, 4, 7, 10, 13, 16],     # dma form: K pieces 0..3, V pieces 0, 1 behind these MFMAs of the 21
+              64: [1, 4, 7]}                  # head dim 64: K pieces 0, 1, V piece 0 of the 11
 if os.environ.get("RSA_GEN8H_GAPS"):
-    DMA8H_GAPS = [int(x) for x in os.environ["RSA_GEN8H_GAPS"].split(",")]
+    DMA8H_GAPS[128] = [int(x) for x in os.environ["RSA_GEN8H_GAPS"].split(",")]
 
 
-def gen_block8h(T6, dt, dma=False):
+def gen_block8h(T6, dt, dma=False, D8=128):
     """dma: the block also issues the wave's six LDS-DMA pieces -- K(tile + 3) into ring slot T6 % 3 (= K(tile)'s), V(tile + 2) into
     (T6 + 2) % 3 -- one per MFMA shadow (see gen_block8).  Scalar operands: %[kb16] = the head's K rows, %[vsrc] = first byte of the
     wave's first V piece, %[ldsw] = LDS address of the wave's first piece in slot 0 of the K ring.
@@ -520,23 +525,24 @@ def gen_block8h(T6, dt, dma=False):
     32-key half re-uses the first half's K fragment (8 instead of 16 K reads), nov = no V reads, novalu = no conversions / row max."""
     import os
     xf = set(filter(None, os.environ.get("RSA_GEN8H_X", "").split(",")))
-    m = Map8H()
+    m = Map8H(D8)
+    KTILE, VTILE = 128 * D8, 64 * D8          # bytes of a K tile (64 keys x 2 D8: 16 / 8 KiB) and of a V tile (D8 x 64: 8 / 4 KiB)
     mf = "v_mfma_f32_32x32x16_bf16" if dt == "bf16" else "v_mfma_f32_32x32x16_f16"
     SC_, SN = (m.SA, m.SB) if T6 % 2 == 0 else (m.SB, m.SA)
     kslot, vslot = (T6 + 1) % 3, T6 % 3
     lines, lds_seq = [], []
     ops = []      # (kind, x, y, reads [(address register, offset)], slots)
-    for ks in range(8):          # the two halves' chains alternate: no MFMA waits for the one just before it
+    for ks in range(m.KS):       # the two halves' chains alternate: no MFMA waits for the one just before it
         kreg = m.KB if ks == 0 else (m.T0 if ks % 2 == 0 else m.T1)
         for sub in range(2):
             if ("halfk" in xf and sub == 1) or "nok" in xf:
                 ops.append(("qk", sub, ks, [], 0))
             else:
-                ops.append(("qk", sub, ks, [(kreg, kslot * 16384 + sub * 8192)], 1))
+                ops.append(("qk", sub, ks, [(kreg, kslot * KTILE + sub * (KTILE // 2))], 1))
     n_qk = len(ops)
     ops.append(("rs", 0, 0, [], 0))
-    for d in range(4):
-        off = vslot * 8192 + d * 2048
+    for d in range(m.DT):
+        off = vslot * VTILE + d * 2048
         ops.append(("pv", d, 0, [] if "nov" in xf else [(m.VA, off), (m.VA + 1, off)], 0 if "nov" in xf else 2))
     n = len(ops)
     slot_of, consumer = {}, [None] * NSLOT8H     # consumer[s] = index of the op that reads slot s (None: free)
@@ -633,12 +639,12 @@ def gen_block8h(T6, dt, dma=False):
                          f"{vr(m.SC)}, {vr(m.SC + 1)} op_sel:[1,1,0] op_sel_hi:[0,0,0]")
         state["issued"] = i
         top_up(i + 1)
-        if dma and i in DMA8H_GAPS:
-            j = DMA8H_GAPS.index(i)
-            if j < 4:
-                dst, vo, src = (T6 % 3) * 16384 + j * 4096, m.DK + j, "%[kb16]"
+        if dma and i in DMA8H_GAPS[D8]:
+            j = DMA8H_GAPS[D8].index(i)
+            if j < m.NPK:
+                dst, vo, src = (T6 % 3) * KTILE + j * 4096, m.DK + j, "%[kb16]"
             else:
-                dst, vo, src = 3 * 16384 + ((T6 + 2) % 3) * 8192 + (j - 4) * 4096, m.DV + j - 4, "%[vsrc]"
+                dst, vo, src = 3 * KTILE + ((T6 + 2) % 3) * VTILE + (j - m.NPK) * 4096, m.DV + j - m.NPK, "%[vsrc]"
             lines.append(f"s_add_u32 m0, %[ldsw], {dst}")
             lines.append("s_nop 0")      # (M0 write -> LDS-DMA: one wait state)
             lines.append(f"global_load_lds_dwordx4 {vr(vo)}, {src}")
@@ -650,27 +656,29 @@ def gen_block8h(T6, dt, dma=False):
 
 
 def main8h(out):
-    for dt in ("bf16", "f16"):
-        for dma in (False, True):
-            for T6 in range(6):
-                lines, m = gen_block8h(T6, dt, dma)
-                out.append(f"#define RSA_K5F8H_BLOCK{'D' if dma else ''}_{dt.upper()}_T{T6} \\")
-                out.append(" \\\n".join(c_string(lines).split("\n")))
-                out.append("")
-    m = Map8H()
-    outs = [f'"+{{{vr(m.O + 16 * d, 16)}}}"(o[{d}])' for d in range(4)]
-    outs += [f'"+{{{vr(m.SA, 16)}}}"(SA[0])', f'"+{{{vr(m.SA + 16, 16)}}}"(SA[1])', f'"+{{{vr(m.SB, 16)}}}"(SB[0])',
-             f'"+{{{vr(m.SB + 16, 16)}}}"(SB[1])', f'"+{{{vr(m.LACC, 4)}}}"(lacc)', '[mx] "=&v"(mx)']
-    ins = [f'"{{{vr(m.Q, 16)}}}"(qv[0])', f'"{{{vr(m.Q + 16, 16)}}}"(qv[1])']     # Q fragments of k-steps 0..3 and 4..7
-    ins += [f'"{{{vr(m.MB, 16)}}}"(mblk)', f'"{{{vr(m.SC)}}}"(sca)', f'"{{{vr(m.SC + 1)}}}"(scb)', f'"{{{vr(m.VA, 2)}}}"(vah)',
-            f'"{{{vr(m.KB)}}}"(kah)', f'"{{{vr(m.ONES, 8)}}}"(onesv)']
-    out.append(f"#define RSA_K5F8H_OPS : {', '.join(outs)} : {', '.join(ins)}")
-    insd = ins + [f'"{{{vr(m.DK, 4)}}}"(dk)', f'"{{{vr(m.DV, 2)}}}"(dv)', '[kb16] "s"(kb16)', '[vsrc] "s"(vsrc)', '[ldsw] "s"(ldsw)']
-    out.append(f"#define RSA_K5F8H_OPSD : {', '.join(outs)} : {', '.join(insd)}")
-    out.append("#define RSA_K5F8H_CLOBBER " + ", ".join(f'"v{r}"' for r in range(m.tmp0, m.tmp1)))
-    out.append(f"// pv form: O v[0:63], Q v[{m.Q}:{m.SA - 1}], SA v[{m.SA}:{m.SB - 1}], SB v[{m.SB}:{m.MB - 1}], reference block v[{m.MB}:{m.LACC - 1}], "
-               f"l v[{m.LACC}:{m.LACC + 3}], temporaries v[{m.tmp0}:{m.tmp1 - 1}], scales v[{m.SC}:{m.SC + 1}], V / K addresses v[{m.VA}:{m.KB}], ones v[{m.ONES}:{m.end - 1}]")
-
+    for D8 in (128, 64):
+        tag = "" if D8 == 128 else "64"
+        for dt in ("bf16", "f16"):
+            for dma in (False, True):
+                for T6 in range(6):
+                    lines, m = gen_block8h(T6, dt, dma, D8)
+                    out.append(f"#define RSA_K5F8H{tag}_BLOCK{'D' if dma else ''}_{dt.upper()}_T{T6} \\")
+                    out.append(" \\\n".join(c_string(lines).split("\n")))
+                    out.append("")
+        m = Map8H(D8)
+        outs = [f'"+{{{vr(m.O + 16 * d, 16)}}}"(o[{d}])' for d in range(m.DT)]
+        outs += [f'"+{{{vr(m.SA, 16)}}}"(SA[0])', f'"+{{{vr(m.SA + 16, 16)}}}"(SA[1])', f'"+{{{vr(m.SB, 16)}}}"(SB[0])',
+                 f'"+{{{vr(m.SB + 16, 16)}}}"(SB[1])', f'"+{{{vr(m.LACC, 4)}}}"(lacc)', '[mx] "=&v"(mx)']
+        ins = [f'"{{{vr(m.Q + 16 * i, 16)}}}"(qv[{i}])' for i in range(m.KS // 4)]     # Q fragments of four k-steps per 16-register value
+        ins += [f'"{{{vr(m.MB, 16)}}}"(mblk)', f'"{{{vr(m.SC)}}}"(sca)', f'"{{{vr(m.SC + 1)}}}"(scb)', f'"{{{vr(m.VA, 2)}}}"(vah)',
+                f'"{{{vr(m.KB)}}}"(kah)', f'"{{{vr(m.ONES, 8)}}}"(onesv)']
+        out.append(f"#define RSA_K5F8H{tag}_OPS : {', '.join(outs)} : {', '.join(ins)}")
+        insd = ins + [f'"{{{vr(m.DK, m.NPK)}}}"(dk)', f'"{{{vr(m.DV, m.NPV)}}}"(dv)', '[kb16] "s"(kb16)', '[vsrc] "s"(vsrc)', '[ldsw] "s"(ldsw)']
+        out.append(f"#define RSA_K5F8H{tag}_OPSD : {', '.join(outs)} : {', '.join(insd)}")
+        out.append(f"#define RSA_K5F8H{tag}_CLOBBER " + ", ".join(f'"v{r}"' for r in range(m.tmp0, m.tmp1)))
+        out.append(f"// pv form, head dim {D8}: O v[0:{m.Q - 1}], Q v[{m.Q}:{m.SA - 1}], SA v[{m.SA}:{m.SB - 1}], SB v[{m.SB}:{m.MB - 1}], reference block "
+                   f"v[{m.MB}:{m.LACC - 1}], l v[{m.LACC}:{m.LACC + 3}], temporaries v[{m.tmp0}:{m.tmp1 - 1}], scales v[{m.SC}:{m.SC + 1}], "
+                   f"V / K addresses v[{m.VA}:{m.KB}], ones v[{m.ONES}:{m.ONES + 7}], DMA lane offsets v[{m.DK}:{m.end - 1}]")
 
 if __name__ == "__main__":
     main()

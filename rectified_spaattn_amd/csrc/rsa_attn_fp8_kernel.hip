@@ -158,28 +158,35 @@ __device__ __forceinline__ void k5f8_block_dma(f32x16 (&o)[4], const i32x8 (&q)[
 }
 
 // the pv form's hand-placed block (gen_k5_block.py::gen_block8h, RSA_K5F8H_*): T6 = tile % 6 (three-slot rings, S_cur = SA on even tiles)
-// (qv: the 2-byte Q fragments of k-steps 0..3 and 4..7 as two 16-register values)
-template <int T6, int HYB>
-__device__ __forceinline__ void k5f8h_block(f32x16 (&o)[4], const f32x16 (&qv)[2], f32x16 (&SA)[2], f32x16 (&SB)[2], const f32x16& mblk,
+// (qv: the 2-byte Q fragments of four k-steps per 16-register value: two values at head dim 128, one at 64)
+template <int T6, int HYB, int D8>
+__device__ __forceinline__ void k5f8h_block(f32x16 (&o)[D8 / 32], const f32x16 (&qv)[D8 / 64], f32x16 (&SA)[2], f32x16 (&SB)[2], const f32x16& mblk,
                                             f32x4& lacc, float& mx, int sca, int scb, int kah, const i32x2& vah, const i32x8& onesv) {
 #define RSA_K5F8H_CASE(T_) \
-    if constexpr (T6 == T_) { \
+    if constexpr (T6 == T_ && D8 == 128) { \
         if constexpr (HYB == 2) asm volatile(RSA_K5F8H_BLOCK_F16_T##T_ RSA_K5F8H_OPS : RSA_K5F8H_CLOBBER, "memory"); \
         else asm volatile(RSA_K5F8H_BLOCK_BF16_T##T_ RSA_K5F8H_OPS : RSA_K5F8H_CLOBBER, "memory"); \
+    } else if constexpr (T6 == T_) { \
+        if constexpr (HYB == 2) asm volatile(RSA_K5F8H64_BLOCK_F16_T##T_ RSA_K5F8H64_OPS : RSA_K5F8H64_CLOBBER, "memory"); \
+        else asm volatile(RSA_K5F8H64_BLOCK_BF16_T##T_ RSA_K5F8H64_OPS : RSA_K5F8H64_CLOBBER, "memory"); \
     }
     RSA_K5F8H_CASE(0) RSA_K5F8H_CASE(1) RSA_K5F8H_CASE(2) RSA_K5F8H_CASE(3) RSA_K5F8H_CASE(4) RSA_K5F8H_CASE(5)
 #undef RSA_K5F8H_CASE
 }
 // ... with the wave's six LDS-DMA pieces of K(tile + 3) / V(tile + 2) inside (the product; s_add_u32 m0: SCC is clobbered)
-template <int T6, int HYB>
-__device__ __forceinline__ void k5f8h_block_dma(f32x16 (&o)[4], const f32x16 (&qv)[2], f32x16 (&SA)[2], f32x16 (&SB)[2], const f32x16& mblk,
-                                                f32x4& lacc, float& mx, int sca, int scb, int kah, const i32x2& vah, const i32x8& onesv,
-                                                const i32x4& dk, const i32x2& dv, const unsigned char* kb16, const unsigned char* vsrc,
-                                                unsigned ldsw) {
+// (dk: lane offsets of the wave's K pieces -- four at head dim 128, two at 64; dv: of its V pieces -- two / one)
+template <int T6, int HYB, int D8, typename DK, typename DV>
+__device__ __forceinline__ void k5f8h_block_dma(f32x16 (&o)[D8 / 32], const f32x16 (&qv)[D8 / 64], f32x16 (&SA)[2], f32x16 (&SB)[2],
+                                                const f32x16& mblk, f32x4& lacc, float& mx, int sca, int scb, int kah, const i32x2& vah,
+                                                const i32x8& onesv, const DK& dk, const DV& dv, const unsigned char* kb16,
+                                                const unsigned char* vsrc, unsigned ldsw) {
 #define RSA_K5F8H_CASE(T_) \
-    if constexpr (T6 == T_) { \
+    if constexpr (T6 == T_ && D8 == 128) { \
         if constexpr (HYB == 2) asm volatile(RSA_K5F8H_BLOCKD_F16_T##T_ RSA_K5F8H_OPSD : RSA_K5F8H_CLOBBER, "scc", "memory"); \
         else asm volatile(RSA_K5F8H_BLOCKD_BF16_T##T_ RSA_K5F8H_OPSD : RSA_K5F8H_CLOBBER, "scc", "memory"); \
+    } else if constexpr (T6 == T_) { \
+        if constexpr (HYB == 2) asm volatile(RSA_K5F8H64_BLOCKD_F16_T##T_ RSA_K5F8H64_OPSD : RSA_K5F8H64_CLOBBER, "scc", "memory"); \
+        else asm volatile(RSA_K5F8H64_BLOCKD_BF16_T##T_ RSA_K5F8H64_OPSD : RSA_K5F8H64_CLOBBER, "scc", "memory"); \
     }
     RSA_K5F8H_CASE(0) RSA_K5F8H_CASE(1) RSA_K5F8H_CASE(2) RSA_K5F8H_CASE(3) RSA_K5F8H_CASE(4) RSA_K5F8H_CASE(5)
 #undef RSA_K5F8H_CASE
@@ -197,7 +204,7 @@ __device__ __forceinline__ void k5f8h_block_dma(f32x16 (&o)[4], const f32x16 (&q
 // KiB, V 3 x 8 KiB: two workgroups per CU); PIPE_OPT 7 = the hand-placed block (six tiles per loop trip), 6 = its compiled twin.
 template <int PIPE_OPT, int D8 = 128, int HYB = 0>
 __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
-    static_assert(HYB == 0 || (D8 == 128 && (PIPE_OPT & 4) != 0), "the pv form: head dim 128, code-map P");
+    static_assert(HYB == 0 || (PIPE_OPT & 4) != 0, "the pv form: code-map P");
     constexpr int TILE8 = 64 * D8;        // bytes of one K tile (64 keys x D8) and of one V tile (D8 rows x 64 keys)
     constexpr int TILEK = HYB ? 64 * 2 * D8 : TILE8;     // K tile: e4m3 rows, or the 2-byte rows themselves
     constexpr int NSK = HYB ? 3 : NSLOT, NSV = HYB ? 3 : NSLOT;
@@ -207,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     constexpr int NPC8 = TILE8 / 4096;    // 1-KiB LDS-DMA pieces per wave and tile operand
     constexpr bool CODEMAP = (PIPE_OPT & 4) != 0;
     constexpr bool DMAB = (PIPE_OPT & 8) != 0;
-    static_assert(!DMAB || (D8 == 128 && CODEMAP && (PIPE_OPT & 1) != 0), "LDS-DMA inside the block: hand-placed code-map forms at head dim 128");
+    static_assert(!DMAB || ((D8 == 128 || HYB != 0) && CODEMAP && (PIPE_OPT & 1) != 0), "LDS-DMA inside the block: hand-placed code-map forms (e4m3: head dim 128)");
     using PM = PMap<CODEMAP>;
     constexpr float P_BASE = PM::U * PM::OFFSET + PM::BIAS;   // accumulator value of a score equal to the reference m
     constexpr float P_GROW = PM::U * PM::THRESH + P_BASE;     // above it the reference moves
@@ -369,11 +376,12 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
 
     // "pv" form: the 2-byte Q fragments (B operand of v_mfma_f32_32x32x16: lane (r, hh) holds k = 16 ks + 8 hh .. + 7), scaled
     using HT = typename std::conditional<HYB == 2, fp16_tag, bf16_tag>::type;
-    s16x8 qh[HYB ? 8 : 1];
+    constexpr int KSH = D8 / 16;          // k-steps of the 2-byte Q . K^T per 32-key half
+    s16x8 qh[HYB ? KSH : 1];
     if constexpr (HYB != 0) {
         const unsigned short* qp16 = a.q16 + (long)b * a.qsb + (long)h * a.qsh + (long)grow * a.qss + 8 * hh;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
+        for (int ks = 0; ks < KSH; ++ks) {
             uint4 raw = make_uint4(0, 0, 0, 0);
             if (grow < a.Sq) raw = *reinterpret_cast<const uint4*>(qp16 + 16 * ks);
             const unsigned w4[4] = {raw.x, raw.y, raw.z, raw.w};
@@ -405,11 +413,12 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
                          : "memory");
         }
     };
-    // "pv" form: the 64-key K tile from the 2-byte tensor, image and swizzle of rsa_attn_kernel.hip (groups of 16 rows = 4 pieces
-    // of 4 rows, wave w moves piece w of every group; source chunk XOR-swizzled, rows past the last valid key clamped)
+    // "pv" form: the 64-key K tile from the 2-byte tensor, image and swizzle of rsa_attn_kernel.hip (groups of 4 pieces = 16 rows at
+    // head dim 128, 32 rows at 64; wave w moves piece w of every group; source chunk XOR-swizzled, rows past the last valid key clamped)
+    constexpr int CHR_H = D8 / 8, RPI_H = 1024 / (2 * D8), NPK_H = 64 / (4 * RPI_H);   // chunks per row, rows per piece, K pieces per wave
     const int kv_limit_h = hi_max < a.Sk ? hi_max : a.Sk;
-    const int rsub_h = lane >> 4, cl_h = lane & 15, rowl_h = wv * 4 + rsub_h;
-    const int gsw_h = cl_h ^ (((rowl_h & 3) << 2) | ((rowl_h >> 2) & 3));
+    const int rsub_h = lane / CHR_H, cl_h = lane % CHR_H, rowl_h = wv * RPI_H + rsub_h;
+    const int gsw_h = D8 == 128 ? (cl_h ^ (((rowl_h & 3) << 2) | ((rowl_h >> 2) & 3))) : (cl_h ^ ((rowl_h >> 1) & 7));
     auto dma_k = [&](int key0, int slot) {
         if constexpr (HYB == 0) {
             dma2(kbase + (long)key0 * D8, lds_base + slot * TILE8, voffk);
@@ -417,8 +426,8 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
             const unsigned char* kb16 = reinterpret_cast<const unsigned char*>(a.k16 + (long)b * a.ksb + (long)h * a.ksh);
             const unsigned ld0 = lds_base + slot * TILEK + wv * 1024;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int krow = key0 + 16 * j + rowl_h;
+            for (int j = 0; j < NPK_H; ++j) {
+                int krow = key0 + 4 * RPI_H * j + rowl_h;
                 krow = krow < kv_limit_h ? krow : kv_limit_h - 1;
                 const unsigned vo = (unsigned)(((long)krow * a.kss + gsw_h * 8) * 2);
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
@@ -475,7 +484,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     // pv form: K fragment of k-step ks = 16-byte chunk 2 ks + hh of row r (+ 8 192 per 32-key half, + 16 384 per ring slot):
     // tile_off's XOR puts ks into address bits 5..7, the block derives the eight addresses from k-step 0's (lds_base is 1 KiB
     // aligned: the kernel's first dynamic LDS byte).  The V addresses carry the V ring's base.
-    const int kah = (int)lds_base + (HYB ? tile_off<128>(r, hh) : 0);
+    const int kah = (int)lds_base + (HYB ? tile_off<D8>(r, hh) : 0);
     i32x2 vah;
     // (the hand-placed pv block keeps the row-sum product's A operand -- e4m3 1.0 or 0 in every byte -- in registers)
     i32x8 onesv;
@@ -483,10 +492,10 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     for (int i = 0; i < 8; ++i) onesv[i] = ones_off == 0 ? 0x38383838 : 0;
     vah[0] = va[0] + VBASE;
     vah[1] = va[1] + VBASE;
-    f32x16 qv[2];
+    f32x16 qv[D8 / 64];
     if constexpr (HYB != 0) {
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
+        for (int ks = 0; ks < KSH; ++ks) {
             const i32x4 w = __builtin_bit_cast(i32x4, qh[ks]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) qv[ks >> 2][4 * (ks & 3) + e] = __int_as_float(w[e]);
@@ -511,8 +520,8 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
             for (int sub = 0; sub < 2; ++sub) {
                 f32x16 acc = mblk;
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) {
-                    const s16x8 kf = *reinterpret_cast<const s16x8*>(kt16 + tile_off<128>(32 * sub + r, 2 * ks + hh));
+                for (int ks = 0; ks < KSH; ++ks) {
+                    const s16x8 kf = *reinterpret_cast<const s16x8*>(kt16 + tile_off<D8>(32 * sub + r, 2 * ks + hh));
                     acc = Elem<HT>::mfma(kf, qh[ks], acc);
                 }
                 S[sub] = acc;
@@ -556,7 +565,8 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
         const int ts = TS;  // integral_constant (static LDS addresses) or the runtime tile & 3
         const int sc_a = (int)((sw1 & 0xFFu) | (sw0 & 0xFF00u));   // K(tile + 1) in byte 0, V(tile) in byte 1
         if (DMAB || tile + 2 < n_tiles) {   // (the newest tile's pieces may stay in flight: 2 NPC8 per wave; pv form: 4 of K + 2 of V)
-            if constexpr (HYB != 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            if constexpr (HYB != 0 && D8 == 128) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if constexpr (HYB != 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");     // head dim 64: 2 of K + 1 of V
             else if constexpr (NPC8 == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         } else {
@@ -622,20 +632,26 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
             // S_cur is SA on even tiles, SB on odd ones (tile & 1 == TS & 1)
             if constexpr (HYB != 0 && DMAB) {
                 // K(tile + 3): the four pieces' rows, clamped like dma_k's; V(tile + 2): first byte of the wave's first piece
-                i32x4 dk4;
+                typename std::conditional<D8 == 128, i32x4, i32x2>::type dkp;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    int krow = kq3 + 16 * j + rowl_h;
+                for (int j = 0; j < NPK_H; ++j) {
+                    int krow = kq3 + 4 * RPI_H * j + rowl_h;
                     krow = krow < kv_limit_h ? krow : kv_limit_h - 1;
-                    dk4[j] = (int)(unsigned)(((long)krow * a.kss + gsw_h * 8) * 2);
+                    dkp[j] = (int)(unsigned)(((long)krow * a.kss + gsw_h * 8) * 2);
                 }
                 const unsigned char* kb16 = reinterpret_cast<const unsigned char*>(a.k16 + (long)b * a.ksb + (long)h * a.ksh);
                 const unsigned char* vsrc = vbase + (long)(kq2 >> 6) * TILE8 + wv * 1024;
-                if constexpr ((tsc & 1) == 0) k5f8h_block_dma<tsc, HYB>(o, qv, S_cur, S_nxt, mblk, lacc, mx_nxt, sc_a, sc_b, kah, vah, onesv, dk4, dv2, kb16, vsrc, ldsw);
-                else k5f8h_block_dma<tsc, HYB>(o, qv, S_nxt, S_cur, mblk, lacc, mx_nxt, sc_a, sc_b, kah, vah, onesv, dk4, dv2, kb16, vsrc, ldsw);
+                if constexpr (D8 == 128) {
+                    if constexpr ((tsc & 1) == 0) k5f8h_block_dma<tsc, HYB, D8>(o, qv, S_cur, S_nxt, mblk, lacc, mx_nxt, sc_a, sc_b, kah, vah, onesv, dkp, dv2, kb16, vsrc, ldsw);
+                    else k5f8h_block_dma<tsc, HYB, D8>(o, qv, S_nxt, S_cur, mblk, lacc, mx_nxt, sc_a, sc_b, kah, vah, onesv, dkp, dv2, kb16, vsrc, ldsw);
+                } else {
+                    const int dv1 = (int)voffv;
+                    if constexpr ((tsc & 1) == 0) k5f8h_block_dma<tsc, HYB, D8>(o, qv, S_cur, S_nxt, mblk, lacc, mx_nxt, sc_a, sc_b, kah, vah, onesv, dkp, dv1, kb16, vsrc, ldsw);
+                    else k5f8h_block_dma<tsc, HYB, D8>(o, qv, S_nxt, S_cur, mblk, lacc, mx_nxt, sc_a, sc_b, kah, vah, onesv, dkp, dv1, kb16, vsrc, ldsw);
+                }
             } else if constexpr (HYB != 0) {
-                if constexpr ((tsc & 1) == 0) k5f8h_block<tsc, HYB>(o, qv, S_cur, S_nxt, mblk, lacc, mx_nxt, sc_a, sc_b, kah, vah, onesv);
-                else k5f8h_block<tsc, HYB>(o, qv, S_nxt, S_cur, mblk, lacc, mx_nxt, sc_a, sc_b, kah, vah, onesv);
+                if constexpr ((tsc & 1) == 0) k5f8h_block<tsc, HYB, D8>(o, qv, S_cur, S_nxt, mblk, lacc, mx_nxt, sc_a, sc_b, kah, vah, onesv);
+                else k5f8h_block<tsc, HYB, D8>(o, qv, S_nxt, S_cur, mblk, lacc, mx_nxt, sc_a, sc_b, kah, vah, onesv);
             } else if constexpr (DMAB) {
                 const unsigned char* ksrc = kbase + (long)kq3 * D8 + wv * 1024;
                 const unsigned char* vsrc = vbase + (long)(kq2 >> 6) * TILE8 + wv * 1024;
@@ -872,6 +888,17 @@ int launch_attn8(Attn8Args& a, int BH, int D8, size_t tpart_bytes, hipStream_t s
     if (nblocks > 0x7FFFFFFF) return RSA_ERR_UNSUPPORTED;
     if (a.NB_total > 8192) return RSA_ERR_UNSUPPORTED;
     const size_t lds_bytes = (size_t)2 * NSLOT * 64 * D8 + 64 + (((size_t)a.NB_total * 4 + 15) & ~(size_t)15);
+    if (hyb != 0 && D8 == 64) {   // the pv form at head dim 64 (K 3 x 8 KiB, V 3 x 4 KiB): product and compiled twin
+        const size_t n_list = a.NB_total < RSA_PV_LIST_WINDOW ? a.NB_total : RSA_PV_LIST_WINDOW;
+        const size_t lds_h = (size_t)3 * 8192 + (size_t)3 * 4096 + 64 + ((n_list * 4 + 15) & ~(size_t)15);
+        if (g_fp8_variant == 1) {
+            if (hyb == 2) RSA_LAUNCH_GSYNC(2, (bsfwd_fp8_kernel<6, 64, 2>), a, a.mode == MODE_SPARSE, dim3((unsigned)nblocks), 256, lds_h, s);
+            else RSA_LAUNCH_GSYNC(2, (bsfwd_fp8_kernel<6, 64, 1>), a, a.mode == MODE_SPARSE, dim3((unsigned)nblocks), 256, lds_h, s);
+        } else {
+            if (hyb == 2) RSA_LAUNCH_GSYNC(2, (bsfwd_fp8_kernel<15, 64, 2>), a, a.mode == MODE_SPARSE, dim3((unsigned)nblocks), 256, lds_h, s);
+            else RSA_LAUNCH_GSYNC(2, (bsfwd_fp8_kernel<15, 64, 1>), a, a.mode == MODE_SPARSE, dim3((unsigned)nblocks), 256, lds_h, s);
+        }
+    } else
     if (hyb != 0) {   // the pv form: 2-byte Q . K^T, e4m3 P . V (three-slot rings: K 3 x 16 KiB, V 3 x 8 KiB)
         if (D8 != 128) return RSA_ERR_UNSUPPORTED;
         const size_t n_list = a.NB_total < RSA_PV_LIST_WINDOW ? a.NB_total : RSA_PV_LIST_WINDOW;     // (the kernel's LWIN)
@@ -952,7 +979,7 @@ extern "C" int rsa_block_sparse_fwd_fp8pv(const rsa_layout* l, rsa_tensor4 q, rs
                                           const rsa_buffers* buf, rsa_out4 out, void* stream) {
     int st = rsa_check_layout(l);
     if (st != RSA_OK) return st;
-    if (l->D != 128) return RSA_ERR_UNSUPPORTED;
+    if (l->D != 128 && l->D != 64) return RSA_ERR_UNSUPPORTED;
     if (!ops || !ops->v8t || !ops->scales) return RSA_ERR_BAD_ARG;
     if ((st = rsa_check_tensor(q)) || (st = rsa_check_tensor(k)) || (st = check_out8(out))) return st;
     if (!buf || (l->NBv > 0 && (!buf->cols || !buf->counts))) return RSA_ERR_BAD_ARG;
@@ -998,7 +1025,7 @@ extern "C" int rsa_rectified_attention_fp8pv(const rsa_layout* l, rsa_tensor4 q,
     rsa_fp8_operands ops;
     int st = rsa_carve_workspace(l, workspace, workspace_bytes, &buf);
     if (st != RSA_OK) return st;
-    if (l->D != 128) return RSA_ERR_UNSUPPORTED;
+    if (l->D != 128 && l->D != 64) return RSA_ERR_UNSUPPORTED;
     if ((st = rsa_carve_fp8_operands(l, fp8_workspace, fp8_workspace_bytes, &ops))) return st;
     ops.q8 = nullptr; ops.k8 = nullptr;       // K1 then writes the V image and the V exponents only
     if ((st = rsa_pool_stats_fp8(l, q, k, v, &buf, &ops, stream))) return st;
@@ -1015,7 +1042,6 @@ static int dense_fwd_fp8(int B, int H, int Sq, int Sk, int D, int dtype, rsa_ten
                          void* stream, int pv = 0) {
     if (B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0) return RSA_ERR_BAD_ARG;
     if (D != 128 && D != 64) return RSA_ERR_UNSUPPORTED;
-    if (pv && D != 128) return RSA_ERR_UNSUPPORTED;
     if (dtype != RSA_BF16 && dtype != RSA_FP16) return RSA_ERR_UNSUPPORTED;
     if (q_split < 0 || q_split > Sq || kv_split < 0 || kv_split > Sk) return RSA_ERR_BAD_ARG;
     int st;

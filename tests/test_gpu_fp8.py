@@ -350,9 +350,9 @@ def test_fp8_random_layouts(case):
     assert err.max() <= 6e-2 and err.mean() <= 6e-3, f"case {i}: max {err.max():.3e} mean {err.mean():.3e}"
 
 
-@pytest.mark.parametrize("case", [c for c in _random_fp8_cases() if c[2] == 128], ids=lambda c: f"{c[0]}-{c[1]}")
+@pytest.mark.parametrize("case", _random_fp8_cases(), ids=lambda c: f"{c[0]}-{c[1]}")
 def test_fp8_pv_random_layouts(case):
-    """The randomised layouts (head dim 128) through the pv form: the 2-byte path's mask, the fp8 path's V image, output within the
+    """The randomised layouts (both head dims) through the pv form: the 2-byte path's mask, the fp8 path's V image, output within the
     pv tolerance of the oracle with the same two choices, bit-identical to the compiled twin, no NaN in the awkward corners."""
     from rectified_spaattn_amd import _core, _lib, synth
     i, variant, D, H, lay, top_k, p, nbw = case
@@ -380,7 +380,8 @@ def test_fp8_pv_random_layouts(case):
     # (max: a score on a rounding boundary of the code map moves one P by a whole e4m3 step; with few kept keys -- these layouts keep
     # two to five blocks -- one such step shows in the output: 5e-2 here against 3e-2 on the structured cases; the all-e4m3 form's
     # random-layout bound is 6e-2)
-    assert err.max() <= 5e-2 and err.mean() <= PV_MEAN_VS_ORACLE, f"case {i}: max {err.max():.3e} mean {err.mean():.3e}"
+    # mean: some of these layouts are a few dozen rows (1.1e-3 on 29 rows at head dim 64): twice the structured cases' bound
+    assert err.max() <= 5e-2 and err.mean() <= 2 * PV_MEAN_VS_ORACLE, f"case {i}: max {err.max():.3e} mean {err.mean():.3e}"
 
 
 def test_fp8_dense_smooth_k():
@@ -611,19 +612,19 @@ def test_fullattn_dense_fp8_pv_switch():
     try:
         opv = fullattn(q, k, v, mode="torch")
         q6, k6, v6 = (t[..., :64].contiguous() for t in (q, k, v))
-        o6 = fullattn(q6, k6, v6, mode="torch")            # head dim 64 has no pv kernel: the 2-byte one
+        o6 = fullattn(q6, k6, v6, mode="torch")            # head dim 64 has the form too
     finally:
         rsa.set_dense_fp8(old)
     assert opv.shape == o16.shape and not torch.equal(opv, o16)
     assert (opv.float() - o16.float()).abs().max() <= PV_MAX_VS_BF16
-    assert torch.equal(o6, fullattn(q6, k6, v6, mode="torch"))
+    o6_16 = fullattn(q6, k6, v6, mode="torch")
+    assert not torch.equal(o6, o6_16) and (o6.float() - o6_16.float()).abs().max() <= PV_MAX_VS_BF16
     with pytest.raises(ValueError):
         rsa.set_dense_fp8("qk")
 
 
-def test_fp8_pv_form_public_switch_and_head_dim_64():
-    """set_qkv_fp8("pv") reaches the operators; head dim 64 has no pv kernel: the operator keeps the 2-byte kernel there (as the
-    e4m3 switch does for head dims without an fp8 kernel), a StagedCall refuses."""
+def test_fp8_pv_form_public_switch():
+    """set_qkv_fp8("pv") reaches the operators; anything but False / True / "pv" is refused."""
     import rectified_spaattn_amd as rsa
     from rectified_spaattn_amd import _core, rectified_wan21_attn as rw, synth
     S = 6 * 128
@@ -637,8 +638,48 @@ def test_fp8_pv_form_public_switch_and_head_dim_64():
     finally:
         rsa.set_qkv_fp8(old)
     assert torch.equal(got.reshape(want.shape), want)
-    q6, k6, v6 = (torch.randn(1, 2, S, 64, device=DEV).to(torch.bfloat16) for _ in range(3))
-    with pytest.raises(NotImplementedError):
-        _core.StagedCall(q6, k6, v6, spec, 2, 0.3, None, qkv_fp8="pv")
     with pytest.raises(ValueError):
         rsa.set_qkv_fp8("qk")
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_fp8_pv_form_head_dim_64(dt):
+    """The pv form at head dim 64 (CogVideoX's): K tiles of 64 keys x 128 bytes, eight v_mfma_f32_32x32x16 per tile, two P . V MFMAs.
+    Against the oracle with the same two choices, against the bf16 oracle (inside 8e-2, clearly closer than the all-e4m3 form), bit for
+    bit against the compiled twin for kept lists of every length, and the dense kernel in the same form."""
+    from rectified_spaattn_amd import _core, _lib, synth
+    L = _lib.lib()
+    lay = orc.layout_cogvideo(9 * 128 - 30, 226) if hasattr(orc, "layout_cogvideo") else orc.layout_wan(9 * 128 - 30, 1)
+    H = 2
+    q, k, v = synth.structured_qkv(77, 1, H, lay.S, 64, smooth=0.0)
+    tq, tk, tv = (torch.from_numpy(x).to(DEV, dt) for x in (q, k, v))
+    q, k, v = (x.float().cpu().numpy() for x in (tq, tk, tv))
+    for top_k in range(1, lay.NBv + 1):
+        outs = {}
+        try:
+            for var in (0, 1):
+                assert L.rsa_set_tuning(b"fp8_variant", var) == 0
+                outs[var] = _core.rectified_attention(tq, tk, tv, _spec(lay), top_k, 0.0, None, qkv_fp8="pv")
+        finally:
+            L.rsa_set_tuning(b"fp8_variant", 0)
+        assert torch.equal(outs[0], outs[1]), top_k
+    top_k, p = 3, 0.3
+    out, parts = _core.rectified_attention(tq, tk, tv, _spec(lay), top_k, p, None, return_parts=True, qkv_fp8="pv")
+    out8 = _core.rectified_attention(tq, tk, tv, _spec(lay), top_k, p, None, qkv_fp8=True)
+    o = out.float().cpu().numpy()
+    refc = orc.rectified_attention_fp8(q, k, v, lay, top_k, p, None, p_form="code", qk="2byte")
+    ref16 = orc.rectified_attention(q, k, v, lay, top_k, p, None)
+    ec, e16, e8 = np.abs(o - refc), np.abs(o - ref16), np.abs(out8.float().cpu().numpy() - ref16)
+    print(f"D=64 pv vs its oracle {ec.max():.3e} / {ec.mean():.3e}; vs bf16 oracle {e16.max():.3e} / {e16.mean():.3e} (all-e4m3 {e8.max():.3e} / {e8.mean():.3e})")
+    assert ec.max() <= PV_MAX_VS_ORACLE and ec.mean() <= PV_MEAN_VS_ORACLE
+    assert e16.max() <= PV_MAX_VS_BF16 and e16.mean() <= PV_MEAN_VS_BF16 and e16.mean() < 0.75 * e8.mean()
+    # dense kernel, same form
+    g = torch.Generator().manual_seed(5)
+    dq, dk, dv = (torch.randn(1, 2, n, 64, generator=g).to(DEV, dt) for n in (300, 520, 520))
+    od = _core.dense_attention(dq, dk, dv, qkv_fp8="pv")
+    rd = _core.dense_attention(dq, dk, dv)
+    for h in range(2):
+        ref = orc.dense_attention_fp8(*(t[0, h].float().cpu().numpy() for t in (dq, dk, dv)), qk="2byte")
+        err = np.abs(od[0, :, h].float().cpu().numpy() - ref)
+        assert err.max() <= PV_MAX_VS_ORACLE and err.mean() <= 5 * PV_MEAN_VS_ORACLE, (err.max(), err.mean())
+    assert (od.float() - rd.float()).abs().mean() <= PV_MEAN_VS_BF16
