@@ -69,6 +69,18 @@ K5_SOURCES = {False: ("rsa_attn_kernel64.hip", "gen_k5_block64.py", "rsa_attn_ke
               True: ("rsa_attn_fp8_kernel.hip", "rsa_attn.h", "rsa_attn.hip", "gen_k5_block.py")}
 
 
+def k5_peak(qkv_fp8) -> float:
+    """Dense MFMA peak the K5 of this operand form is priced against; the pv form runs half its FLOPs (Q.K^T) on the 2-byte
+    pipe and half (P.V) on the fp8 pipe: 1 / (0.5 / 2500 + 0.5 / 5000) = 3 333 TFLOP/s."""
+    if qkv_fp8 == "pv":
+        return round(1.0 / (0.5 / MFMA_BF16_PEAK_TFLOPS + 0.5 / MFMA_FP8_PEAK_TFLOPS), 1)
+    return MFMA_FP8_PEAK_TFLOPS if qkv_fp8 else MFMA_BF16_PEAK_TFLOPS
+
+
+def traffic_suffix(qkv_fp8) -> str:
+    return "_pv" if qkv_fp8 == "pv" else ("_fp8" if qkv_fp8 else "")
+
+
 def kernel_source_sha(fp8: bool = False) -> str:
     """sha256 over the CODE of one K5 kernel's sources (the 2-byte kernel or the e4m3 one; `//` and `#` comments, blank
     lines and indentation do not count): profiles/*traffic*.json carry the value they were collected with."""
@@ -560,7 +572,7 @@ def measure_traffic_live(regime: str, fp8: bool, timeout_s: int = 150, workload:
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     if fp8:
-        env["RSA_PERF_FP8"] = "1"
+        env["RSA_PERF_FP8"] = "pv" if fp8 == "pv" else "1"
     acc, walks = {}, {}
     t0 = time.time()
     with tempfile.TemporaryDirectory(dir="/tmp") as td:
@@ -625,8 +637,9 @@ def main():
     ap.add_argument("--regime", default="r2", choices=list(REGIMES), help="regime of the headline value")
     ap.add_argument("--p-remain", type=float, default=None, help="override the cumulative-probability threshold (r2)")
     ap.add_argument("--neighbors", default=None, help="override the block-neighbour matrix (r2): none | gilbert | <band>")
-    ap.add_argument("--qkv-fp8", action="store_true",
-                    help="K5 on e4m3 images of Q/K/V (fp8 MFMA); the quantisation pass is inside the timed step")
+    ap.add_argument("--qkv-fp8", nargs="?", const=True, default=False, type=lambda x: x if x == "pv" else bool(int(x)),
+                    help="K5 on e4m3 images of Q/K/V (fp8 MFMA); `--qkv-fp8 pv`: the pv form (2-byte Q.K^T, e4m3 P.V); "
+                         "the quantisation pass is inside the timed step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the headline regime (no r1/locality/api/sustained)")
     ap.add_argument("--no-live-traffic", action="store_true",
@@ -800,13 +813,13 @@ def main():
                 r2, call = run_regime(comm, args, wl, rg, q, k, v, spec, max(5, args.steps // 2), 2, want_call=True)
             else:
                 r2 = run_regime(comm, args, wl, rg, q, k, v, spec, max(5, args.steps // 2), 2)
-            peak_ = MFMA_FP8_PEAK_TFLOPS if args.qkv_fp8 else MFMA_BF16_PEAK_TFLOPS
+            peak_ = k5_peak(args.qkv_fp8)
             regs[rg] = dict(neighbors=r2["neighbors"], p_remain=r2["p_remain"], top_k=r2["top_k"],
                             kept_block_fraction=round(r2["kept_block_fraction"], 4),
                             ms_per_step=round(r2["ms_per_step"], 4), value=round(r2["value"], 3),
                             k5_ms=round(r2["k5_ms"], 4), k5_tflops=round(r2["k5_tflops"], 2),
                             k5_frac=round(r2["k5_tflops"] / peak_, 4), select_pass_ms=round(r2["select_pass_ms"], 4))
-            tb, _ = load_traffic(f"r05_k5_traffic_{rg}{'_fp8' if args.qkv_fp8 else ''}.json")
+            tb, _ = load_traffic(f"r05_k5_traffic_{rg}{traffic_suffix(args.qkv_fp8)}.json")
             regs[rg]["traffic"] = tb
         extras["regimes"] = regs
         if not args.qkv_fp8 and args.workload == "hunyuan_720p_128f":
@@ -820,8 +833,8 @@ def main():
         comm.close()
         return
 
-    peak = MFMA_FP8_PEAK_TFLOPS if args.qkv_fp8 else MFMA_BF16_PEAK_TFLOPS
-    tname = f"r05_k5_traffic_{main_regime}{'_fp8' if args.qkv_fp8 else ''}.json"
+    peak = k5_peak(args.qkv_fp8)
+    tname = f"r05_k5_traffic_{main_regime}{traffic_suffix(args.qkv_fp8)}.json"
     traffic, tnote = (None, "N > 1: traffic is collected at N = 1")
     if world == 1:
         traffic, tnote = load_traffic(tname) if args.workload == "hunyuan_720p_128f" else (None, "no committed traffic json for this workload")
@@ -843,7 +856,8 @@ def main():
         "metric": "attention-layer TFLOPs/sec (rectified block-sparse attention, HunyuanVideo seq~120k d=128 bf16)",
         "value": round(rec["value"], 3), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(rec["ms_per_step"], 4), "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "fp8_e4m3" if args.qkv_fp8 else "bf16",
+        "scaling": "strong", "vs_baseline": None,
+        "dtype": "bf16 Q.K^T + fp8_e4m3 P.V" if args.qkv_fp8 == "pv" else ("fp8_e4m3" if args.qkv_fp8 else "bf16"),
         "data": "synthetic (counter-based SplitMix64/Box-Muller generator on the device, seed 20251212 + head)",
         "config": {"workload": f"{args.workload}: B=1 H={H} S={S} ({wl['S_vis']} visual + {wl['text']} text, "
                                f"{wl['text_valid']} valid) D={D}, top_k={wl['top_k']}, regime={main_regime} "
@@ -854,7 +868,9 @@ def main():
                    "per_rank_ms": per_rank_ms,
                    "imbalance": round(max(per_rank_ms) / (sum(per_rank_ms) / len(per_rank_ms)), 4),
                    "gather_output": gather},
-        "roofline": {"kernel": "bsfwd_fp8_kernel (K5 block_sparse_fwd_fp8)" if args.qkv_fp8 else
+        "roofline": {"kernel": ("bsfwd_fp8_kernel<..., HYB> (K5 block_sparse_fwd_fp8pv; peak = both products at their own dense peaks: "
+                                "half the FLOPs at 2.5, half at 5 PFLOP/s)") if args.qkv_fp8 == "pv" else
+                     "bsfwd_fp8_kernel (K5 block_sparse_fwd_fp8)" if args.qkv_fp8 else
                      ("bsfwd64_kernel<bf16_tag,...> (K5 block_sparse_fwd, 64 rows per wave)" if D == 128 else
                       "bsfwd_kernel<64,bf16_tag,...> (K5 block_sparse_fwd)"), "bound": "mfma",
                      "achieved": round(rec["k5_tflops"], 2), "peak": peak, "unit": "TFLOP/s",

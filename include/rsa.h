@@ -285,7 +285,7 @@ int rsa_block_sparse_fwd_fp8(const rsa_layout* lay, const rsa_fp8_operands* ops,
 /* The "pv" form (since 0.5.0): Q . K^T on the 2-byte q and k themselves (v_mfma_f32_32x32x16), e4m3 only for P and V
  * (ops->v8t and the V bytes of ops->scales; q8 / k8 are not read).  The scores are then the 2-byte path's -- the e4m3 rounding of
  * Q and K is nine tenths of rsa_block_sparse_fwd_fp8's error -- while P . V still runs at the fp8 rate: 800 matrix cycles per 64
- * keys and 32 rows against 1 024 (2-byte) and 544 (e4m3).  Head dim 128. */
+ * keys and 32 rows against 1 024 (2-byte) and 544 (e4m3) at head dim 128.  Head dims 64 and 128. */
 int rsa_block_sparse_fwd_fp8pv(const rsa_layout* lay, rsa_tensor4 q, rsa_tensor4 k, const rsa_fp8_operands* ops,
                                const rsa_buffers* buf, rsa_out4 out, void* stream);
 
@@ -295,7 +295,7 @@ int rsa_rectified_attention_fp8(const rsa_layout* lay, rsa_tensor4 q, rsa_tensor
                                 const uint8_t* neighbor, int top_k, float p_remain, void* workspace,
                                 size_t workspace_bytes, void* fp8_workspace, size_t fp8_workspace_bytes,
                                 rsa_out4 out, void* stream);
-/* ... in the pv form (head dim 128): K1 writes only the V image and its exponents, K5 = rsa_block_sparse_fwd_fp8pv.  Same workspaces
+/* ... in the pv form (head dims 64, 128): K1 writes only the V image and its exponents, K5 = rsa_block_sparse_fwd_fp8pv.  Same workspaces
  * (the Q / K images' share of fp8_workspace stays untouched). */
 int rsa_rectified_attention_fp8pv(const rsa_layout* lay, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
                                   const uint8_t* neighbor, int top_k, float p_remain, void* workspace,
@@ -316,7 +316,7 @@ int rsa_dense_fwd_fp8(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor
 int rsa_dense_causal_fwd_fp8(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
                              int q_split, int kv_split, void* workspace, size_t workspace_bytes, rsa_out4 out,
                              void* stream);
-/* The "pv" form of the dense fp8 kernel (round 5; head dim 128): Q . K^T on the 2-byte q and k as they are, e4m3 only for P and the
+/* The "pv" form of the dense fp8 kernel (round 5; head dims 64, 128): Q . K^T on the 2-byte q and k as they are, e4m3 only for P and the
  * V image (rsa_block_sparse_fwd_fp8pv's kernel in its dense mode).  causal != 0: as rsa_dense_causal_fwd.  Same workspace. */
 int rsa_dense_fwd_fp8pv(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4 q, rsa_tensor4 k, rsa_tensor4 v,
                         int q_split, int kv_split, int causal, void* workspace, size_t workspace_bytes, rsa_out4 out, void* stream);

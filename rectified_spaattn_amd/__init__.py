@@ -22,15 +22,14 @@ __version__ = "0.5.0"
 def set_qkv_fp8(enabled):
     """Run the block-sparse kernel of every sparse operator / processor call on e4m3 operands (fp8 MFMA): True = e4m3 images of
     Q, K, V (head dim 64 / 128; relative L1 distance 0.12 of the layer output from the 2-byte path), "pv" = Q . K^T on the 2-byte
-    inputs and only P . V on e4m3 (head dim 128; relative L1 0.04, within SURVEY 8(d)'s 8e-2 of the bf16 oracle); returns the
+    inputs and only P . V on e4m3 (head dims 64 and 128; relative L1 0.04, within SURVEY 8(d)'s 8e-2 of the bf16 oracle); returns the
     previous setting.  Default off = the reference's input-dtype behaviour."""
     from . import _operator
     return _operator.set_qkv_fp8(enabled)
 
 
 def set_dense_fp8(enabled) -> bool:
-    """Run fullattn's device path (dense attention, head dims 64 / 128) on e4m3 images of Q, K, V (True), or -- "pv", head dim
-    128 -- take the scores from the 2-byte q and k and use e4m3 only for P and V (relative L1 0.04 instead of 0.12); returns the
+    """Run fullattn's device path (dense attention, head dims 64 / 128) on e4m3 images of Q, K, V (True), or -- "pv" -- take the scores from the 2-byte q and k and use e4m3 only for P and V (relative L1 0.04 instead of 0.12); returns the
     previous setting.  Default off."""
     from . import _operator
     return _operator.set_dense_fp8(enabled)

@@ -16,11 +16,16 @@ done
 bash tools/pmc_traffic.sh r5z_pmc_r2_fp8 r2 fp8 > gpurun_out/r5z_pmc_r2_fp8.txt 2>&1
 cp gpurun_out/r5z_pmc_r2_fp8/traffic.json gpurun_out/r05_k5_traffic_r2_fp8.json; cp gpurun_out/r5z_pmc_r2_fp8/traffic.json profiles/r05_k5_traffic_r2_fp8.json
 rm -rf gpurun_out/r5z_pmc_r2_fp8
+bash tools/pmc_traffic.sh r5z_pmc_r2_pv r2 pv > gpurun_out/r5z_pmc_r2_pv.txt 2>&1
+cp gpurun_out/r5z_pmc_r2_pv/traffic.json gpurun_out/r05_k5_traffic_r2_pv.json; cp gpurun_out/r5z_pmc_r2_pv/traffic.json profiles/r05_k5_traffic_r2_pv.json
+rm -rf gpurun_out/r5z_pmc_r2_pv
 python bench.py --steps 20 --warmup 5 > gpurun_out/r5z_bench.json 2> gpurun_out/r5z_bench.err
 python bench.py --steps 20 --warmup 5 --qkv-fp8 --no-cpu-baseline > gpurun_out/r5z_bench_fp8.json 2>> gpurun_out/r5z_bench.err
+python bench.py --steps 20 --warmup 5 --qkv-fp8 pv --no-cpu-baseline > gpurun_out/r5z_bench_pv.json 2>> gpurun_out/r5z_bench.err
 for WL in flux_4096 wan21_720p_81f wan22_ti2v_720p_121f cogvideox_768p_81f; do
   python bench.py --steps 20 --warmup 3 --workload $WL --no-cpu-baseline --no-live-traffic > gpurun_out/r5z_bench_$WL.json 2>> gpurun_out/r5z_bench.err
   python bench.py --steps 20 --warmup 3 --workload $WL --qkv-fp8 --no-cpu-baseline --no-extras > gpurun_out/r5z_bench_${WL}_fp8.json 2>> gpurun_out/r5z_bench.err
+  python bench.py --steps 20 --warmup 3 --workload $WL --qkv-fp8 pv --no-cpu-baseline --no-extras > gpurun_out/r5z_bench_${WL}_pv.json 2>> gpurun_out/r5z_bench.err
 done
 R=$PWD; cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r5z_prof -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $R/gpurun_out/r5z_prof.log 2>&1
@@ -53,6 +58,7 @@ python tools/diag_k5w.py > gpurun_out/r5z_diag.txt 2>&1
 RSA_BENCH_ONE_DEVICE=1 python bench.py --gpus 2 --steps 5 --warmup 2 --no-extras --no-cpu-baseline | grep "^{" > gpurun_out/r5z_bench_2ranks_one_device.json 2>> gpurun_out/r5z_bench.err
 for HH in 24 12 6 3; do echo "heads=$HH"; RSA_PERF_H=$HH RSA_PERF_REGIMES=r2 python tools/perf_k5.py regimes; done > gpurun_out/r5z_rank_shapes.txt 2>&1
 python tools/perf_k5.py dense > gpurun_out/r5z_dense.txt 2>&1
+bash tools/history/r5_pv_d64.sh > gpurun_out/r5z_pv_d64.txt 2>&1
 python tools/clock_probe.py > gpurun_out/r5z_clock.txt 2>&1
 du -sh gpurun_out
 tail -3 gpurun_out/r5z_tests.txt; cat gpurun_out/r5z_smoke.txt | tail -2; tail -c 600 gpurun_out/r5z_bench.json

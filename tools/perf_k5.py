@@ -95,7 +95,7 @@ def main():
         return
     if "pmc" in what:  # few launches, for rocprofv3 --pmc passes (env RSA_PERF_REGIME selects the regime)
         H = int(os.environ.get("RSA_PERF_H", "0"))   # 0 = the workload's head count
-        fp8 = os.environ.get("RSA_PERF_FP8", "0") == "1"
+        fp8 = {"1": True, "pv": "pv"}.get(os.environ.get("RSA_PERF_FP8", "0"), False)
         call, spec = regime_call(os.environ.get("RSA_PERF_REGIME", "r2"), H, dev, fp8=fp8)
         if os.environ.get("RSA_PERF_NODENSE", "0") == "1":
             for _ in range(3):
