@@ -29,8 +29,9 @@ def set_qkv_fp8(enabled):
 
 
 def set_dense_fp8(enabled) -> bool:
-    """Run fullattn's device path (dense attention, head dims 64 / 128) on e4m3 images of Q, K, V (True), or -- "pv" -- take the scores from the 2-byte q and k and use e4m3 only for P and V (relative L1 0.04 instead of 0.12); returns the
-    previous setting.  Default off."""
+    """Run fullattn's device path (dense attention, head dims 64 / 128) on e4m3 images of Q, K, V (True), or -- "pv" -- take the
+    scores from the 2-byte q and k and use e4m3 only for P and V (relative L1 0.04 instead of 0.12); returns the previous setting.
+    Default off."""
     from . import _operator
     return _operator.set_dense_fp8(enabled)
 
