@@ -293,7 +293,8 @@ class Map8:
         self.ON = r; r += 1          # address of this lane's ones / zeros pattern
         r = (r + 1) & ~1
         self.DK = r; r += 2          # LDS-DMA lane offsets of the wave's two K pieces (the second = the first + 4 096): dma form
-        self.DV = r; r += 2          # ... of its two V pieces
+        self.DV = r; r += 2          # ... of its two V pieces (head dim 64: one piece each)
+        self.ONES = r; r += 8        # head dim 64, dma form: the row-sum product's ones operand in registers (as the pv block)
         self.end = r
 
 
@@ -316,7 +317,8 @@ def gen_block8(TS, codemap=False, D8=128, dma=False):
             off = kslot * TILE8 + sub * 32 * D8
             ops.append(("qk", sub, ks, [] if ("halfk" in xf and sub == 1) or "nolds" in xf else [(m.KA + 2 * ks, off), (m.KA + 2 * ks + 1, off)]))
     n_qk = len(ops)
-    ops.append(("rs", 0, 0, [] if "nolds" in xf else [(m.ON, 0), (m.ON, 16)]))
+    ones_reg = dma and D8 == 64         # (at head dim 128 the block has no eight registers to spare)
+    ops.append(("rs", 0, 0, [] if "nolds" in xf or ones_reg else [(m.ON, 0), (m.ON, 16)]))
     for dt in range(m.DT):
         off = (4 + TS) * TILE8 + dt * 2048
         ops.append(("pv", dt, 0, [] if "nolds" in xf else [(m.VA, off), (m.VA + 1, off)]))
@@ -400,15 +402,16 @@ def gen_block8(TS, codemap=False, D8=128, dma=False):
                          f"{vr(m.SC)}, {vr(m.SC + 1)} op_sel_hi:[0,0,0]")
         elif kind == "rs":
             lines.append("s_nop 1")   # the last word of P was packed just above
-            lines.append(f"v_mfma_f32_16x16x128_f8f6f4 {vr(m.LACC, 4)}, {a}, {vr(SC_, 8)}, {vr(m.LACC, 4)}")
+            lines.append(f"v_mfma_f32_16x16x128_f8f6f4 {vr(m.LACC, 4)}, {vr(m.ONES, 8) if ones_reg else a}, {vr(SC_, 8)}, {vr(m.LACC, 4)}")
         else:
             # (byte 1 of the scale registers: the V block's scale on A, 1.0 on the P operand)
             lines.append(f"v_mfma_scale_f32_32x32x64_f8f6f4 {vr(m.O + 16 * x, 16)}, {a}, {vr(SC_, 8)}, {vr(m.O + 16 * x, 16)}, "
                          f"{vr(m.SC)}, {vr(m.SC + 1)} op_sel:[1,1,0] op_sel_hi:[0,0,0]")
         if i + AHEAD8 < n: read(i + AHEAD8)
-        if dma and i in DMA8_GAPS:
-            j = DMA8_GAPS.index(i)
-            isv, hi = divmod(j, 2)
+        gaps = DMA8_GAPS if D8 == 128 else [0, 2]      # head dim 64: one K piece, one V piece per wave and tile
+        if dma and i in gaps:
+            j = gaps.index(i)
+            isv, hi = divmod(j, TILE8 // 4096)
             dst = (4 + ((TS + 2) & 3)) * TILE8 + hi * 4096 if isv else ((TS + 3) & 3) * TILE8 + hi * 4096
             lines.append(f"s_add_u32 m0, %[ldsw], {dst}")
             lines.append("s_nop 0")      # (M0 write -> LDS-DMA: one wait state)
@@ -432,11 +435,12 @@ def main8(out):
         out.append(f"#define RSA_K5F8_BLOCKCD_T{TS} \\")
         out.append(" \\\n".join(c_string(lines).split("\n")))
         out.append("")
-    for TS in range(4):   # head dim 64 (CogVideoX): the product form only
-        lines, m = gen_block8(TS, True, 64)
-        out.append(f"#define RSA_K5F8_BLOCKC64_T{TS} \\")
-        out.append(" \\\n".join(c_string(lines).split("\n")))
-        out.append("")
+    for TS in range(4):   # head dim 64 (CogVideoX): the code-map form, staging behind the barrier / inside the block (product)
+        for dma in (False, True):
+            lines, m = gen_block8(TS, True, 64, dma=dma)
+            out.append(f"#define RSA_K5F8_BLOCKC{'D' if dma else ''}64_T{TS} \\")
+            out.append(" \\\n".join(c_string(lines).split("\n")))
+            out.append("")
     m = Map8(64)
     outs = [f'"+{{{vr(m.O + 16 * d, 16)}}}"(o[{d}])' for d in range(2)]
     outs += [f'"+{{{vr(m.SA, 16)}}}"(SA[0])', f'"+{{{vr(m.SA + 16, 16)}}}"(SA[1])', f'"+{{{vr(m.SB, 16)}}}"(SB[0])',
@@ -445,6 +449,8 @@ def main8(out):
            f'"{{{vr(m.SC)}}}"(sca)', f'"{{{vr(m.SC + 1)}}}"(scb)', f'"{{{vr(m.KA, 2)}}}"(ka)', f'"{{{vr(m.VA, 2)}}}"(va)',
            f'"{{{vr(m.ON)}}}"(ona)']
     out.append(f"#define RSA_K5F8_OPS64 : {', '.join(outs)} : {', '.join(ins)}")
+    insd = ins[:-1] + [f'"{{{vr(m.ONES, 8)}}}"(onesv)', f'"{{{vr(m.DK)}}}"(dk)', f'"{{{vr(m.DV)}}}"(dv)', '[ksrc] "s"(ksrc)', '[vsrc] "s"(vsrc)', '[ldsw] "s"(ldsw)']
+    out.append(f"#define RSA_K5F8_OPS64D : {', '.join(outs)} : {', '.join(insd)}")
     out.append("#define RSA_K5F8_CLOBBER64 " + ", ".join(f'"v{r}"' for r in range(m.tmp0, m.tmp1)))
     out.append(f"// e4m3 kernel, head dim 64: O v[0:{m.Q - 1}], Q v[{m.Q}:{m.SA - 1}], SA v[{m.SA}:{m.SB - 1}], SB v[{m.SB}:{m.MB - 1}], "
                f"reference block v[{m.MB}:{m.LACC - 1}], l v[{m.LACC}:{m.LACC + 3}], temporaries v[{m.tmp0}:{m.tmp1 - 1}], "

@@ -157,6 +157,17 @@ __device__ __forceinline__ void k5f8_block_dma(f32x16 (&o)[4], const i32x8 (&q)[
     else asm volatile(RSA_K5F8_BLOCKCD_T3 RSA_K5F8_OPSD : RSA_K5F8_CLOBBER, "scc", "memory");
 }
 
+// ... and at head dim 64: one K and one V piece per wave and tile, the row-sum product's ones operand in registers
+template <int TS>
+__device__ __forceinline__ void k5f8_block_dma64(f32x16 (&o)[2], const i32x8 (&q)[1], f32x16 (&SA)[2], f32x16 (&SB)[2], const f32x16& mblk,
+                                                 f32x4& lacc, float& mx, int sca, int scb, const i32x2& ka, const i32x2& va, const i32x8& onesv,
+                                                 int dk, int dv, const unsigned char* ksrc, const unsigned char* vsrc, unsigned ldsw) {
+    if constexpr (TS == 0) asm volatile(RSA_K5F8_BLOCKCD64_T0 RSA_K5F8_OPS64D : RSA_K5F8_CLOBBER64, "scc", "memory");
+    else if constexpr (TS == 1) asm volatile(RSA_K5F8_BLOCKCD64_T1 RSA_K5F8_OPS64D : RSA_K5F8_CLOBBER64, "scc", "memory");
+    else if constexpr (TS == 2) asm volatile(RSA_K5F8_BLOCKCD64_T2 RSA_K5F8_OPS64D : RSA_K5F8_CLOBBER64, "scc", "memory");
+    else asm volatile(RSA_K5F8_BLOCKCD64_T3 RSA_K5F8_OPS64D : RSA_K5F8_CLOBBER64, "scc", "memory");
+}
+
 // the pv form's hand-placed block (gen_k5_block.py::gen_block8h, RSA_K5F8H_*): T6 = tile % 6 (three-slot rings, S_cur = SA on even tiles)
 // (qv: the 2-byte Q fragments of four k-steps per 16-register value: two values at head dim 128, one at 64)
 template <int T6, int HYB, int D8>
@@ -195,7 +206,7 @@ __device__ __forceinline__ void k5f8h_block_dma(f32x16 (&o)[D8 / 32], const f32x
 // PIPE_OPT bit 0: the hand-placed block (clear: the block as hipcc schedules it, same arithmetic, for A/B);
 // bit 1: s_setprio around the compiled block; bit 2: the code-map form of P (PMap above); bit 3 (round 5, head dim 128, needs
 // bits 0 and 2): the block issues the wave's LDS-DMA pieces itself, one per MFMA shadow, and issues them for every tile (past
-// the end of the walk the last tile again, into a slot nobody reads).  Product = 15 (head dim 64: 7).
+// the end of the walk the last tile again, into a slot nobody reads).  Product = 15.
 // D8: head dim = bytes per Q / K row (128; 64 = the CogVideoX shape, hand-placed code-map form only).
 // HYB (round 5, "pv" form): 0 = e4m3 everywhere; 1 / 2 = Q . K^T on the bf16 / fp16 inputs themselves (K tiles of 64 keys x 256
 // bytes staged like the 2-byte kernels' -- rsa_attn_kernel.hip -- and multiplied by v_mfma_f32_32x32x16), e4m3 only for P and V.
@@ -214,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     constexpr int NPC8 = TILE8 / 4096;    // 1-KiB LDS-DMA pieces per wave and tile operand
     constexpr bool CODEMAP = (PIPE_OPT & 4) != 0;
     constexpr bool DMAB = (PIPE_OPT & 8) != 0;
-    static_assert(!DMAB || ((D8 == 128 || HYB != 0) && CODEMAP && (PIPE_OPT & 1) != 0), "LDS-DMA inside the block: hand-placed code-map forms (e4m3: head dim 128)");
+    static_assert(!DMAB || (CODEMAP && (PIPE_OPT & 1) != 0), "LDS-DMA inside the block: hand-placed code-map forms");
     using PM = PMap<CODEMAP>;
     constexpr float P_BASE = PM::U * PM::OFFSET + PM::BIAS;   // accumulator value of a score equal to the reference m
     constexpr float P_GROW = PM::U * PM::THRESH + P_BASE;     // above it the reference moves
@@ -652,6 +663,11 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
             } else if constexpr (HYB != 0) {
                 if constexpr ((tsc & 1) == 0) k5f8h_block<tsc, HYB, D8>(o, qv, S_cur, S_nxt, mblk, lacc, mx_nxt, sc_a, sc_b, kah, vah, onesv);
                 else k5f8h_block<tsc, HYB, D8>(o, qv, S_nxt, S_cur, mblk, lacc, mx_nxt, sc_a, sc_b, kah, vah, onesv);
+            } else if constexpr (DMAB && D8 == 64) {
+                const unsigned char* ksrc = kbase + (long)kq3 * D8 + wv * 1024;
+                const unsigned char* vsrc = vbase + (long)(kq2 >> 6) * TILE8 + wv * 1024;
+                if constexpr ((tsc & 1) == 0) k5f8_block_dma64<tsc>(o, qf, S_cur, S_nxt, mblk, lacc, mx_nxt, sc_a, sc_b, ka, va, onesv, (int)voffk, (int)voffv, ksrc, vsrc, ldsw);
+                else k5f8_block_dma64<tsc>(o, qf, S_nxt, S_cur, mblk, lacc, mx_nxt, sc_a, sc_b, ka, va, onesv, (int)voffk, (int)voffv, ksrc, vsrc, ldsw);
             } else if constexpr (DMAB) {
                 const unsigned char* ksrc = kbase + (long)kq3 * D8 + wv * 1024;
                 const unsigned char* vsrc = vbase + (long)(kq2 >> 6) * TILE8 + wv * 1024;
@@ -916,9 +932,10 @@ int launch_attn8(Attn8Args& a, int BH, int D8, size_t tpart_bytes, hipStream_t s
             else RSA_LAUNCH_GSYNC(2, (bsfwd_fp8_kernel<15, 128, 1>), a, a.mode == MODE_SPARSE, dim3((unsigned)nblocks), 256, lds_h, s);
         }
     } else
-    if (D8 == 64) {   // head dim 64: the product form and its compiled twin
+    if (D8 == 64) {   // head dim 64: the product form, its compiled twin (1), the hand-placed block with the staging behind the barrier (3)
         if (g_fp8_variant == 1) RSA_LAUNCH_GSYNC(2, (bsfwd_fp8_kernel<6, 64>), a, a.mode == MODE_SPARSE, dim3((unsigned)nblocks), 256, lds_bytes, s);
-        else RSA_LAUNCH_GSYNC(2, (bsfwd_fp8_kernel<7, 64>), a, a.mode == MODE_SPARSE, dim3((unsigned)nblocks), 256, lds_bytes, s);
+        else if (g_fp8_variant == 3) RSA_LAUNCH_GSYNC(2, (bsfwd_fp8_kernel<7, 64>), a, a.mode == MODE_SPARSE, dim3((unsigned)nblocks), 256, lds_bytes, s);
+        else RSA_LAUNCH_GSYNC(2, (bsfwd_fp8_kernel<15, 64>), a, a.mode == MODE_SPARSE, dim3((unsigned)nblocks), 256, lds_bytes, s);
     } else {
         switch (g_fp8_variant) {   // tuning key fp8_variant: 0 = product; 1, 2 = the two verification forms the tests compare it with
             case 1: RSA_LAUNCH_GSYNC(2, (bsfwd_fp8_kernel<6>), a, a.mode == MODE_SPARSE, dim3((unsigned)nblocks), 256, lds_bytes, s); break;   // product arithmetic, hipcc's schedule

@@ -663,6 +663,16 @@ def test_fp8_pv_form_head_dim_64(dt):
         finally:
             L.rsa_set_tuning(b"fp8_variant", 0)
         assert torch.equal(outs[0], outs[1]), top_k
+        # the all-e4m3 kernel at this head dim: product (staging inside the block, ones operand in registers) = compiled twin (1) =
+        # hand-placed block with the staging behind the barrier (3), bit for bit
+        outs = {}
+        try:
+            for var in (0, 1, 3):
+                assert L.rsa_set_tuning(b"fp8_variant", var) == 0
+                outs[var] = _core.rectified_attention(tq, tk, tv, _spec(lay), top_k, 0.0, None, qkv_fp8=True)
+        finally:
+            L.rsa_set_tuning(b"fp8_variant", 0)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[3]), top_k
     top_k, p = 3, 0.3
     out, parts = _core.rectified_attention(tq, tk, tv, _spec(lay), top_k, p, None, return_parts=True, qkv_fp8="pv")
     out8 = _core.rectified_attention(tq, tk, tv, _spec(lay), top_k, p, None, qkv_fp8=True)

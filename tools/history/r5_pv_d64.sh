@@ -1,5 +1,6 @@
 #!/bin/bash
-# the pv form at head dim 64 (CogVideoX 768p): K5 of the 2-byte / pv (product, compiled twin) / e4m3 kernels + accuracy, one process
+# the pv form at head dim 64 (CogVideoX 768p): K5 of the 2-byte / pv (product, compiled twin) / e4m3 (product, variant 3 = staging
+# behind the barrier + ones read from LDS) kernels + accuracy, one process
 export RSA_TUNING=1
 python - <<'PY' 2>&1 | grep -v amdgpu.ids
 import os, sys, torch
@@ -19,7 +20,7 @@ for regime in ("r2", "script"):
         c = _core.StagedCall(q, k, v, spec, regime_top_k(wl, regime), p, nbr, qkv_fp8=mode)
         c.select(); torch.cuda.synchronize()
         pairs = c.bufs["counts"].sum().item()
-        for var in ((0, 1) if mode == "pv" else (0,)):
+        for var in ((0, 1) if mode == "pv" else ((0, 3) if mode is True else (0,))):
             L.rsa_set_tuning(b"fp8_variant", var)
             med, mn = timeit(c.attend, n=9, warm=3)
             res[(mode, var)] = (med, c.out.float().clone())
@@ -29,7 +30,7 @@ for regime in ("r2", "script"):
         del c
     ref = res[(False, 0)][1]
     fl = 4.0 * 64 * 128 * 128 * pairs + 4.0 * 64 * spec.q_text_valid * spec.kv_text_valid * wl["H"]
-    for key in ((False, 0), ("pv", 0), ("pv", 1), (True, 0)):
+    for key in ((False, 0), ("pv", 0), ("pv", 1), (True, 0), (True, 3)):
         med, o = res[key]
         d = (o - ref).abs()
         print(f"CogVideoX {regime}: {str(key[0]):5} variant {key[1]}: K5 {med:.3f} ms = {fl/med/1e9:.0f} TFLOP/s, select {res[(key[0], 'sel')]:.3f} ms | vs 2-byte: rel-L1 {float(d.sum()/ref.abs().sum()):.4f} max {float(d.max()):.3f}", flush=True)
