@@ -294,7 +294,7 @@ class Map8:
         r = (r + 1) & ~1
         self.DK = r; r += 2          # LDS-DMA lane offsets of the wave's two K pieces (the second = the first + 4 096): dma form
         self.DV = r; r += 2          # ... of its two V pieces (head dim 64: one piece each)
-        self.ONES = r; r += 8        # head dim 64, dma form: the row-sum product's ones operand in registers (as the pv block)
+        self.ONES = r; r += 8        # dma form: the row-sum product's ones operand in registers (as the pv block): 2 KiB fewer LDS reads per tile and wave
         self.end = r
 
 
@@ -317,7 +317,7 @@ def gen_block8(TS, codemap=False, D8=128, dma=False):
             off = kslot * TILE8 + sub * 32 * D8
             ops.append(("qk", sub, ks, [] if ("halfk" in xf and sub == 1) or "nolds" in xf else [(m.KA + 2 * ks, off), (m.KA + 2 * ks + 1, off)]))
     n_qk = len(ops)
-    ones_reg = dma and D8 == 64         # (at head dim 128 the block has no eight registers to spare)
+    ones_reg = dma      # (round 5: -3 % at head dim 128, profiles/r05_pv_hand_placed.txt)
     ops.append(("rs", 0, 0, [] if "nolds" in xf or ones_reg else [(m.ON, 0), (m.ON, 16)]))
     for dt in range(m.DT):
         off = (4 + TS) * TILE8 + dt * 2048
@@ -463,7 +463,7 @@ def main8(out):
            f'"{{{vr(m.SC)}}}"(sca)', f'"{{{vr(m.SC + 1)}}}"(scb)', f'"{{{vr(m.KA, 4)}}}"(ka)', f'"{{{vr(m.VA, 2)}}}"(va)',
            f'"{{{vr(m.ON)}}}"(ona)']
     out.append(f"#define RSA_K5F8_OPS : {', '.join(outs)} : {', '.join(ins)}")
-    insd = ins + [f'"{{{vr(m.DK, 2)}}}"(dk)', f'"{{{vr(m.DV, 2)}}}"(dv)', '[ksrc] "s"(ksrc)', '[vsrc] "s"(vsrc)', '[ldsw] "s"(ldsw)']
+    insd = ins[:-1] + [f'"{{{vr(m.ONES, 8)}}}"(onesv)', f'"{{{vr(m.DK, 2)}}}"(dk)', f'"{{{vr(m.DV, 2)}}}"(dv)', '[ksrc] "s"(ksrc)', '[vsrc] "s"(vsrc)', '[ldsw] "s"(ldsw)']
     out.append(f"#define RSA_K5F8_OPSD : {', '.join(outs)} : {', '.join(insd)}")
     out.append("#define RSA_K5F8_CLOBBER " + ", ".join(f'"v{r}"' for r in range(m.tmp0, m.tmp1)))
     out.append(f"// e4m3 kernel: O v[0:63], Q v[{m.Q}:{m.SA - 1}], SA v[{m.SA}:{m.SB - 1}], SB v[{m.SB}:{m.MB - 1}], 4 - m v[{m.MB}:{m.LACC - 1}], "

@@ -148,7 +148,7 @@ __device__ __forceinline__ void k5f8_block(f32x16 (&o)[D8 / 32], const i32x8 (&q
 // the product's block at head dim 128 (round 5): code map + the wave's four LDS-DMA pieces of K(tile + 3) / V(tile + 2) inside
 template <int TS, typename KA>
 __device__ __forceinline__ void k5f8_block_dma(f32x16 (&o)[4], const i32x8 (&q)[2], f32x16 (&SA)[2], f32x16 (&SB)[2], const f32x16& mblk,
-                                               f32x4& lacc, float& mx, int sca, int scb, const KA& ka, const i32x2& va, int ona,
+                                               f32x4& lacc, float& mx, int sca, int scb, const KA& ka, const i32x2& va, const i32x8& onesv,
                                                const i32x2& dk, const i32x2& dv, const unsigned char* ksrc, const unsigned char* vsrc,
                                                unsigned ldsw) {
     if constexpr (TS == 0) asm volatile(RSA_K5F8_BLOCKCD_T0 RSA_K5F8_OPSD : RSA_K5F8_CLOBBER, "scc", "memory");
@@ -671,8 +671,8 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
             } else if constexpr (DMAB) {
                 const unsigned char* ksrc = kbase + (long)kq3 * D8 + wv * 1024;
                 const unsigned char* vsrc = vbase + (long)(kq2 >> 6) * TILE8 + wv * 1024;
-                if constexpr ((tsc & 1) == 0) k5f8_block_dma<tsc>(o, qf, S_cur, S_nxt, mblk, lacc, mx_nxt, sc_a, sc_b, ka, va, ona, dk2, dv2, ksrc, vsrc, ldsw);
-                else k5f8_block_dma<tsc>(o, qf, S_nxt, S_cur, mblk, lacc, mx_nxt, sc_a, sc_b, ka, va, ona, dk2, dv2, ksrc, vsrc, ldsw);
+                if constexpr ((tsc & 1) == 0) k5f8_block_dma<tsc>(o, qf, S_cur, S_nxt, mblk, lacc, mx_nxt, sc_a, sc_b, ka, va, onesv, dk2, dv2, ksrc, vsrc, ldsw);
+                else k5f8_block_dma<tsc>(o, qf, S_nxt, S_cur, mblk, lacc, mx_nxt, sc_a, sc_b, ka, va, onesv, dk2, dv2, ksrc, vsrc, ldsw);
             } else
             if constexpr ((tsc & 1) == 0) k5f8_block<tsc, CODEMAP, D8>(o, qf, S_cur, S_nxt, mblk, lacc, mx_nxt, sc_a, sc_b, ka, va, ona);
             else k5f8_block<tsc, CODEMAP, D8>(o, qf, S_nxt, S_cur, mblk, lacc, mx_nxt, sc_a, sc_b, ka, va, ona);
