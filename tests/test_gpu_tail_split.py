@@ -134,9 +134,10 @@ def test_text_split_is_clamped_to_the_declared_capacity():
     assert float((o.float() - ref.float()).abs().max()) <= 2 * 2.0 ** -7 * max(1.0, float(ref.float().abs().max()))
 
 
-def test_split_tail_in_the_e4m3_kernel():
-    """The same split in the e4m3 K5 (head dim 128): split and whole walks agree within the rounding of a different summation
-    order, blocks outside the tail byte for byte, and the result is deterministic."""
+@pytest.mark.parametrize("mode", [True, "pv"], ids=["e4m3", "pv"])
+def test_split_tail_in_the_e4m3_kernel(mode):
+    """The same split in the e4m3 K5 and in its pv form (head dim 128): split and whole walks agree within the rounding of a different
+    summation order, blocks outside the tail byte for byte, and the result is deterministic."""
     from rectified_spaattn_amd import _core, _lib
     H, nbv, top_k = 8, 72, 12
     S = nbv * 128
@@ -147,7 +148,7 @@ def test_split_tail_in_the_e4m3_kernel():
     try:
         for split in (0, 1, 1):
             assert L.rsa_set_tuning(b"k5_tail_split", split) == 0
-            o = _core.rectified_attention(q, k, v, spec, top_k, 0.05, None, shape_xfuse=True, qkv_fp8=True)
+            o = _core.rectified_attention(q, k, v, spec, top_k, 0.05, None, shape_xfuse=True, qkv_fp8=mode)
             torch.cuda.synchronize()
             outs.setdefault(split, []).append(o)
     finally:
