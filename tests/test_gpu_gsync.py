@@ -42,7 +42,8 @@ def test_aligned_starts_do_not_change_a_byte(w64, D, dt):
         assert np.array_equal(o, outs[0])
 
 
-def test_aligned_starts_do_not_change_a_byte_of_the_e4m3_path():
+@pytest.mark.parametrize("mode", [True, "pv"], ids=["e4m3", "pv"])
+def test_aligned_starts_do_not_change_a_byte_of_the_e4m3_path(mode):
     from rectified_spaattn_amd import _core, _lib
     H, nb, top_k = 8, 168, 14
     q, k, v = _inputs(H, nb, 128, 12, torch.bfloat16)
@@ -52,7 +53,7 @@ def test_aligned_starts_do_not_change_a_byte_of_the_e4m3_path():
     try:
         for gs in (0, 3, 0, 3):
             assert L.rsa_set_tuning(b"k5_gsync", gs) == 0
-            out = _core.rectified_attention(q, k, v, spec, top_k, 0.05, None, qkv_fp8=True)
+            out = _core.rectified_attention(q, k, v, spec, top_k, 0.05, None, qkv_fp8=mode)
             torch.cuda.synchronize()
             outs.append(out.view(torch.int16).cpu().numpy().copy())
     finally:
