@@ -49,6 +49,8 @@ WORKLOADS = {
     # CogVideoX1.5 81f 768x1280 (scripts/main_cogvideox.py:226-235; not one of BASELINE's configs): head dim 64
     "cogvideox_768p_81f": dict(H=48, S_vis=42240, text=226, text_valid=226, top_k=82, variant="cogvideo", D=64,
                                latent=(11, 48, 80)),
+    # eight heads, one per rank of an 8-process functional run on one device (tests/test_gpu_shard_invariance.py)
+    "tiny8": dict(H=8, S_vis=8192, text=256, text_valid=200, top_k=6, variant="hunyuan", latent=(8, 32, 32)),
     "tiny": dict(H=4, S_vis=4096, text=256, text_valid=200, top_k=6, variant="hunyuan", latent=(4, 32, 32)),
 }
 
@@ -342,6 +344,68 @@ def timed_steps(comm, step, steps, warmup, events=None, want_busy=False):
     comm.sync()
     total = time.perf_counter() - t0
     return (total, busy) if want_busy else total
+
+
+CHECK_TOL = {False: (2e-2, 2e-3), True: (1.6e-1, 1.5e-2), "pv": (8e-2, 1e-2)}   # (max, mean) |dO|: the operator tests' bounds
+
+
+def check_output(call, spec, qkv_fp8=False, n_heads=3, n_blocks=8):
+    """What the timed steps PRODUCED, checked after the timed region (the launch that is timed -- all local heads, aligned starts,
+    tail split as planned from its size -- is the launch that is checked): every element of O finite; `n_blocks` query blocks
+    (first, last and evenly spaced ones) of `n_heads` heads (first, middle, last) and every text row of those heads against a
+    dense-masked fp32 reference computed here with plain torch ops on the device from the call's OWN kept lists, R and comp
+    (softmax over the kept keys below kv_valid, x R + comp; text rows: exact attention over the valid keys; padded text rows
+    zero).  The selection pass that made the lists is checked bit for bit elsewhere (tests/test_gpu_fullsize.py); this is the
+    check of K5 at the launch's own size.  Returns the record of the bench line's `check` field."""
+    import torch
+    q, k, v, out = call.q, call.k, call.v, call.out          # [B,H,S,D] x 3, [B,S,H,D]
+    B, H, S, D = q.shape
+    dev = q.device
+    finite = bool(torch.isfinite(out).all())
+    heads = sorted({0, H // 2, H - 1})[:max(1, n_heads)]
+    NBv = spec.NBv
+    blocks = sorted({int(round(i * (NBv - 1) / max(1, n_blocks - 1))) for i in range(n_blocks)}) if NBv > 0 else []
+    cols, counts, Rb, compb = (call.bufs[n] for n in ("cols", "counts", "R", "comp"))
+    scale = float(D) ** -0.5
+    ar = torch.arange(128, device=dev)
+    tol_max, tol_mean = CHECK_TOL["pv" if qkv_fp8 == "pv" else bool(qkv_fp8)]
+    worst, mean_sum, n_cmp, worst_at, text_rows = 0.0, 0.0, 0, None, 0
+    for h in heads:
+        qf, kf, vf = (x[0, h].float() for x in (q, k, v))
+        for i in blocks:
+            n = int(counts[h, i].item())
+            sel = cols[h, i, :n].long()
+            key_idx = (sel[:, None] * 128 + ar[None]).reshape(-1)
+            valid = key_idx < spec.kv_valid
+            key_idx = key_idx.clamp(max=S - 1)
+            rows = slice(i * 128, min(S, (i + 1) * 128))
+            sc = (qf[rows] @ kf[key_idx].t()) * scale
+            sc = sc.masked_fill(~valid[None, :], float("-inf"))
+            ref = torch.softmax(sc, dim=-1) @ vf[key_idx] * Rb[h, i] + compb[h, i][None, :]
+            err = (out[0, rows, h].float() - ref).abs()
+            e = float(err.max())
+            if e > worst:
+                worst, worst_at = e, (h, i)
+            mean_sum += float(err.mean()); n_cmp += 1
+        if spec.q_text_valid > 0:
+            r0 = NBv * 128
+            sc = (qf[r0:r0 + spec.q_text_valid] @ kf[:spec.kv_text_valid].t()) * scale
+            ref = torch.softmax(sc, dim=-1) @ vf[:spec.kv_text_valid]
+            err = (out[0, r0:r0 + spec.q_text_valid, h].float() - ref).abs()
+            e = float(err.max())
+            if e > worst:
+                worst, worst_at = e, (h, "text")
+            mean_sum += float(err.mean()); n_cmp += 1
+            text_rows += spec.q_text_valid
+            if r0 + spec.q_text_valid < S and float(out[0, r0 + spec.q_text_valid:, h].float().abs().max()) != 0.0:
+                worst, worst_at = float("inf"), (h, "padded text rows not zero")
+    mean_abs = mean_sum / max(1, n_cmp)
+    ok = finite and worst <= tol_max and mean_abs <= tol_mean
+    return dict(ok=bool(ok), finite=finite, heads=heads, blocks=len(blocks) * len(heads), text_rows=text_rows,
+                max_abs=round(worst, 6), mean_abs=round(mean_abs, 6), worst_at=list(worst_at) if worst_at else None,
+                tol=dict(max_abs=tol_max, mean_abs=tol_mean),
+                what="O of the last timed step (all local heads in one launch): finite everywhere; sampled query blocks + all text rows "
+                     "of the listed heads vs a dense-masked fp32 torch reference on the device built from the call's own kept lists, R, comp")
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -681,6 +745,13 @@ def main():
     main_regime = args.regime
     q, k, v = gen_inputs(wl, H_local, head0, dev, REGIMES[main_regime][0], D=D)
     rec, call = run_regime(comm, args, wl, main_regime, q, k, v, spec, args.steps, args.warmup, want_call=True)
+    # the headline launch's own output, checked on every rank (a rank with a wrong O fails the whole line)
+    comm.local_sync()
+    try:
+        check = check_output(call, spec, args.qkv_fp8)
+    except Exception as e:  # noqa: BLE001
+        check = dict(ok=False, error=repr(e)[:300])
+    check["ok"] = comm.all_ok(bool(check.get("ok")))
     sample = capture_sparse_sample(call) if (world == 1 and not args.no_cpu_baseline) else None
 
     extras = {}
@@ -831,6 +902,8 @@ def main():
 
     if rank != 0:
         comm.close()
+        if not check.get("ok"):
+            sys.exit(3)
         return
 
     peak = k5_peak(args.qkv_fp8)
@@ -860,7 +933,7 @@ def main():
         "dtype": "bf16 Q.K^T + fp8_e4m3 P.V" if args.qkv_fp8 == "pv" else ("fp8_e4m3" if args.qkv_fp8 else "bf16"),
         "data": "synthetic (counter-based SplitMix64/Box-Muller generator on the device, seed 20251212 + head)",
         "config": {"workload": f"{args.workload}: B=1 H={H} S={S} ({wl['S_vis']} visual + {wl['text']} text, "
-                               f"{wl['text_valid']} valid) D={D}, top_k={wl['top_k']}, regime={main_regime} "
+                               f"{wl['text_valid']} valid) D={D}, top_k={regime_top_k(wl, main_regime)}, regime={main_regime} "
                                f"(p_remain={rec['p_remain']}, neighbors={rec['neighbors']})",
                    "kept_block_fraction": round(rec["kept_block_fraction"], 4), "heads_per_gpu": H_local,
                    "dense_equivalent_tflops": round(4.0 * S * S * D * H / (rec["elapsed"] / args.steps) / 1e12, 1),
@@ -884,6 +957,7 @@ def main():
         res["config"]["one_device_test"] = "all ranks time-slice cuda:0 over gloo: functional evidence, not a measurement"
     if args.gather_output and gather is not None and "value" in gather:  # headline = the gather-inclusive variant
         res["value"], res["ms_per_step"] = gather["value"], gather["ms_per_step"]
+    res["check"] = check
     res.update(extras)
     if traffic is not None:   # the second wall: memory-side (Infinity Fabric / Infinity Cache) bytes per second under K5
         res["roofline"]["traffic_tbps"] = round(traffic / max(rec["k5_ms"], 1e-6) / 1e9, 3)
@@ -903,6 +977,9 @@ def main():
             res["cpu_baseline"] = cb
     print(json.dumps(res))
     comm.close()
+    if not check.get("ok"):
+        print(f"bench.py: the output check FAILED: {check}", file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -28,8 +28,9 @@ int main(int argc, char** argv) {
     const size_t n = (size_t)B * H * S * D, bytes = n * 2;
 
     rsa_layout lay;
-    if (rsa_version() < 500) {   /* this host was built against the 0.5.0 header (rsa_buffers: 15 members + tpart_bytes) */
-        fprintf(stderr, "librsa_hip %d is older than the header this demo was built with\n", rsa_version());
+    /* struct sizes and major.minor of the header this host was compiled against must be the library's (rsa_buffers grew in 0.5.0) */
+    if (rsa_abi_check(RSA_HEADER_VERSION, sizeof(rsa_buffers), sizeof(rsa_layout)) != RSA_OK) {
+        fprintf(stderr, "librsa_hip %d does not match the header this demo was built with (%d)\n", rsa_version(), RSA_HEADER_VERSION);
         return 1;
     }
     memset(&lay, 0, sizeof lay);

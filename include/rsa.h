@@ -102,6 +102,15 @@ typedef struct rsa_buffers {
 /* Library identification: returns 10000*major + 100*minor + patch. */
 int rsa_version(void);
 
+/* ABI guard (since 0.6.0).  rsa_buffers GREW in 0.5.0 (tpart_bytes behind the 15 pointers) and carries no size member of
+ * its own: a host compiled against an older header hands the library a shorter struct, and what lies behind it is read as a
+ * capacity.  Call this ONCE after loading the library, with the macros of the header the host was compiled against:
+ *     if (rsa_abi_check(RSA_HEADER_VERSION, sizeof(rsa_buffers), sizeof(rsa_layout)) != RSA_OK) refuse to run;
+ * RSA_OK iff the library was built from a header with the same struct sizes and the same major.minor; RSA_ERR_UNSUPPORTED
+ * otherwise.  (The Python host calls it when it loads the library; examples/c_host does too.) */
+#define RSA_HEADER_VERSION 600
+int rsa_abi_check(int header_version, size_t sizeof_rsa_buffers, size_t sizeof_rsa_layout);
+
 /* Process-global switch (default 0).  K5 plans two things from the SIZE OF THE LAUNCH: how many pieces the dense text rows
  * are split into (32 on grids of fewer than 8 generations, else 16) and whether the walks of the last, partial generation are
  * split over its idle slots.  Both change the summation order of the rows they touch, so a head-sharded run (3 heads per

@@ -136,6 +136,14 @@ def _as_bhsd(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+def _k_for_pv(k: torch.Tensor) -> torch.Tensor:
+    """The pv kernel addresses a key row as a 32-bit byte offset from its head's base (the library refuses longer spans with
+    RSA_ERR_UNSUPPORTED): a strided [B,S,H,D] view of more than 4 GiB per head span is made head-contiguous first."""
+    if k.shape[2] * k.stride(2) * k.element_size() >= 1 << 32:
+        k = k.contiguous()
+    return k
+
+
 def _t4(t: torch.Tensor) -> RsaTensor4:
     return RsaTensor4(t.data_ptr(), t.stride(0), t.stride(1), t.stride(2))
 
@@ -274,6 +282,8 @@ class StagedCall:
         if S != spec.S:
             raise ValueError(f"layout S={spec.S} does not match tensors S={S}")
         self.q, self.k, self.v = _as_bhsd(q), _as_bhsd(k), _as_bhsd(v)
+        if isinstance(qkv_fp8, str) and qkv_fp8 == "pv":
+            self.k = _k_for_pv(self.k)
         self.spec, self.top_k, self.p = spec, int(top_k), float(p_remain)
         self.lay = spec.to_c(B, H, D, q.dtype)
         self.bufs = cached_buffers(spec, B, H, D, q.device) if reuse_buffers else alloc_buffers(spec, B, H, D, q.device)
@@ -404,6 +414,7 @@ def dense_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, q_split: 
         if qkv_fp8 == "pv":   # scores from the 2-byte q and k, e4m3 only for P and the V image
             if D not in (64, 128):
                 raise NotImplementedError("the pv form of the fp8 kernel serves head dims 64 and 128")
+            k = _k_for_pv(k)
             with torch.cuda.device(q.device):
                 _lib.check(L.rsa_dense_fwd_fp8pv(B, H, Sq, Sk, D, dtype_code(q.dtype), _t4(q), _t4(k), _t4(v), q_split, kv_split,
                                                  int(bool(causal)), ws.data_ptr(), ws.numel(), o4, _stream()), "rsa_dense_fwd_fp8pv")
@@ -437,7 +448,7 @@ def dense_attention_masked(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, ma
     if D not in (64, 128):
         raise NotImplementedError(f"device fullattn with a row-dependent mask: head dim {D} (64 and 128 are built)")
     if mask.device != q.device:
-        raise RsaError("attn_mask must live on the device of q")
+        raise _lib.RsaError("attn_mask must live on the device of q")
     if mask.dtype == torch.bool:
         kind = MASK_BOOL
     elif mask.dtype == q.dtype:
@@ -531,6 +542,8 @@ def rectified_attention_onecall(q: torch.Tensor, k: torch.Tensor, v: torch.Tenso
     o4 = RsaOut4(out.data_ptr(), out.stride(0), out.stride(2), out.stride(1))
     nbr = neighbor_on_device(block_neighbor_list, spec.NBv, q.device)
     if qkv_fp8:
+        if qkv_fp8 == "pv":
+            k = _k_for_pv(k)
         s4 = (ctypes.c_size_t * 4)()
         t8 = ctypes.c_size_t()
         _lib.check(L.rsa_fp8_operand_bytes(ctypes.byref(lay), ctypes.byref(s4), ctypes.byref(t8)),

@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(_HERE, "librsa_hip.so")
 
 RSA_BF16, RSA_FP16 = 0, 1
 BLOCK = 128
+HEADER_VERSION = 600   # RSA_HEADER_VERSION of include/rsa.h this ctypes mirror follows (rsa_abi_check)
 
 
 class RsaError(RuntimeError):
@@ -70,6 +71,11 @@ def lib():
     P = ctypes.POINTER
     vp, i32, f32, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
     L.rsa_version.restype = i32
+    L.rsa_abi_check.argtypes = [i32, sz, sz]
+    L.rsa_abi_check.restype = i32
+    if L.rsa_abi_check(HEADER_VERSION, ctypes.sizeof(RsaBuffers), ctypes.sizeof(RsaLayout)) != 0:
+        raise RsaError(f"{LIB_PATH} (version {L.rsa_version()}) was built from another include/rsa.h than this package's "
+                       f"ctypes mirror (header {HEADER_VERSION}, rsa_buffers {ctypes.sizeof(RsaBuffers)} B): rebuild it")
     L.rsa_status_string.restype = ctypes.c_char_p
     L.rsa_status_string.argtypes = [i32]
     L.rsa_last_hip_error.restype = ctypes.c_char_p
@@ -164,7 +170,7 @@ def lib():
     return L
 
 
-EXPORTED = ("rsa_version", "rsa_buffer_bytes", "rsa_carve_workspace", "rsa_pool_stats", "rsa_pooled_scores",
+EXPORTED = ("rsa_version", "rsa_abi_check", "rsa_buffer_bytes", "rsa_carve_workspace", "rsa_pool_stats", "rsa_pooled_scores",
             "rsa_select_mask", "rsa_compensation", "rsa_block_sparse_fwd", "rsa_rectified_attention",
             "rsa_dense_fwd", "rsa_dense_causal_fwd", "rsa_dense_masked_fwd", "rsa_dense_dropout_fwd", "rsa_estimate_pr_gain", "rsa_status_string", "rsa_last_hip_error", "rsa_set_tuning", "rsa_set_shard_invariant", "rsa_gilbert_mapping",
             "rsa_gilbert_block_neighbors", "rsa_permute_tokens", "rsa_qk_norm_rope", "rsa_qk_layernorm_rope", "rsa_norm_rope_heads", "rsa_fp8_operand_bytes",

@@ -37,7 +37,7 @@ QKV_FP8 = False
 def set_qkv_fp8(enabled):
     """Switch the sparse operator (and therefore every processor's sparse steps) to fp8 K5 operands: True = e4m3 Q, K, V and P;
     "pv" = Q . K^T on the 2-byte inputs, e4m3 only for P . V (relative L1 0.04 of the layer output instead of 0.12, at 0.8 of the
-    2-byte kernel's matrix work; head dims 64 and 128, the zero-padded 16 / 32 with them); False = off.  Returns the previous setting."""
+    2-byte kernel's matrix work; head dims 64 and 128 -- the head dims 16 / 32 keep the 2-byte kernel, `_fp8_mode`); False = off.  Returns the previous setting."""
     global QKV_FP8
     if isinstance(enabled, str) and enabled != "pv":
         raise ValueError(f"set_qkv_fp8: False, True or 'pv', got {enabled!r}")

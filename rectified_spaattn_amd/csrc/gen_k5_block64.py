@@ -225,7 +225,7 @@ def gen_block(dt, U, dma, chain=None, xf=frozenset(), dma_cost=None, pre=64, sal
         has the 2048 subtracted.  The source base is the half-tile's row 0 (re-based once per block); lane offset register j
         holds the rows of piece j.  One SALU instruction per two pieces instead of four per piece."""
         nonlocal dma_j
-        if "nodma" in xf:
+        if "nodma" in xf or ("halfdma" in xf and (dma_j & 1)):
             dma_j += 1
             return
         pair, sub = divmod(dma_j, 2)
@@ -251,7 +251,12 @@ def gen_block(dt, U, dma, chain=None, xf=frozenset(), dma_cost=None, pre=64, sal
             if h == 0:
                 wait_for(("K", ks))
             c = vr(NM[h], 16) if ks == 0 else vr(SN[h], 16)
-            lines.append(f"{mf} {vr(SN[h], 16)}, {vr(KF + 4 * (ks % AHEAD), 4)}, {ar(AQ(h, ks), 4)}, {c}")
+            if "m16" in xf:      # timing-only: the same FLOPs and operand registers as two 16x16x32 MFMAs (results are garbage)
+                c0 = NM[h] if ks == 0 else SN[h]
+                for q4 in (0, 4):
+                    lines.append(f"v_mfma_f32_16x16x32_bf16 {vr(SN[h] + q4, 4)}, {vr(KF + 4 * (ks % AHEAD), 4)}, {ar(AQ(h, ks), 4)}, {vr(c0 + q4, 4)}")
+            else:
+                lines.append(f"{mf} {vr(SN[h], 16)}, {vr(KF + 4 * (ks % AHEAD), 4)}, {ar(AQ(h, ks), 4)}, {c}")
             fixed = 0
             if h == 1 and ks + AHEAD < KS:
                 k_read(ks + AHEAD); fixed += COST["lds"]
@@ -271,7 +276,11 @@ def gen_block(dt, U, dma, chain=None, xf=frozenset(), dma_cost=None, pre=64, sal
                 nk = ((U + 2) & 3) * HALF
                 if "nolds" not in xf:
                     lines.extend(f"ds_read_b128 {vr(KF + 4 * ks, 4)}, {vr(KA + ks)} offset:{nk}" for ks in range(AHEAD))
-            lines.append(f"{mf} {ar(AO(h, d), 16)}, {vr(VF + 4 * (p % AHEAD), 4)}, {vr(P[h] + 4 * k2, 4)}, {ar(AO(h, d), 16)}")
+            if "m16" in xf:
+                for q4 in (0, 4):
+                    lines.append(f"v_mfma_f32_16x16x32_bf16 {ar(AO(h, d) + q4, 4)}, {vr(VF + 4 * (p % AHEAD), 4)}, {vr(P[h] + 4 * k2, 4)}, {ar(AO(h, d) + q4, 4)}")
+            else:
+                lines.append(f"{mf} {ar(AO(h, d), 16)}, {vr(VF + 4 * (p % AHEAD), 4)}, {vr(P[h] + 4 * k2, 4)}, {ar(AO(h, d), 16)}")
             fixed = 0
             if h == 1 and p + AHEAD < 2 * DT:
                 v_read(p + AHEAD); fixed += 2 * COST["lds"]
@@ -398,7 +407,7 @@ def gen_loop(dt, diag=False, xf=frozenset(), dma_cost=None, pre=64, tight=False)
     def boundary(diag):
         """end of a sub-step: the pieces of two blocks ago have landed, every wave has finished its LDS reads"""
         if not diag:
-            return ([] if "novm" in xf else ["s_waitcnt vmcnt(16)"]) + ([] if "nobar" in xf else ["s_barrier"])
+            return ([] if "novm" in xf else [f"s_waitcnt vmcnt({8 if 'halfdma' in xf else 16})"]) + ([] if "nobar" in xf else ["s_barrier"])
         tm, tt = sr(76, 2), sr(S_T2)
         return [f"s_memtime {tm}", "s_waitcnt lgkmcnt(0)", f"s_mov_b32 {tt}, s76", "s_waitcnt vmcnt(16)",
                 f"s_memtime {tm}", "s_waitcnt lgkmcnt(0)", f"s_sub_u32 {tt}, s76, {tt}", f"s_add_u32 s78, s78, {tt}",
@@ -490,6 +499,14 @@ FORMS = {
     12: dict(xf=set(), tight=True, pre=0, dma_cost=4),
     13: dict(xf=set(), tight=True, pre=24),
     8: dict(xf={"nodma", "nobar", "novm"}),                         # MFMAs + LDS reads + all vector work, no memory side
+    14: dict(xf={"m16"}, tight=True, pre=24),                       # round 6: every 32x32x16 MFMA as two 16x16x32 (same FLOPs, same operand traffic; garbage results)
+    15: dict(xf={"halfdma"}, tight=True, pre=24),                   # round 6: every second LDS-DMA piece dropped (a 256-row workgroup's pieces per wave; garbage results)
+    16: dict(xf={"m16", "halfdma"}, tight=True, pre=24),
+    17: dict(xf={"m16", "novalu", "notest", "nodma", "nobar", "novm"}, tight=True, pre=24),   # form 5 on the 16x16x32 shape
+    18: dict(xf={"noadd"}, tight=True, pre=24),                     # no row-sum additions (what moving them to the matrix pipe could buy at most)
+    19: dict(xf={"nomax", "notest"}, tight=True, pre=24),           # no row maxima, no rescale test
+    20: dict(xf={"novalu", "notest"}, tight=True, pre=24),          # form 4 on the product's schedule
+    21: dict(xf={"nocvt"}, tight=True, pre=24),                     # no packing of P
 }
 
 

@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256, 2) void bsfwd_fp8_kernel(Attn8Args a) {
     // byte 0 = K exponent of the tile whose scores the block computes, byte 1 = V exponent of the tile it multiplies P with.
     const int sc_b = (int)(((ex[qblk < a.exps_stride ? qblk : 0] & 0xFFu) + (unsigned)PM::EXP) | (127u << 8));
     i32x8 qf[KS8];
-    {
+    if constexpr (HYB == 0) {   // (the pv form has no e4m3 image of Q: a.q8 is null there)
         const uint8_t* qp = a.q8 + ((long)bh * a.Sq_pad + grow) * D8 + 32 * hh;  // rows < Sq_pad always exist (zero-padded)
 #pragma unroll
         for (int ks = 0; ks < KS8; ++ks) {
@@ -903,6 +903,11 @@ int launch_attn8(Attn8Args& a, int BH, int D8, size_t tpart_bytes, hipStream_t s
     if (nblocks <= 0) return RSA_OK;
     if (nblocks > 0x7FFFFFFF) return RSA_ERR_UNSUPPORTED;
     if (a.NB_total > 8192) return RSA_ERR_UNSUPPORTED;
+    // pv form: a K row is addressed as a 32-bit byte offset from its head's base (the LDS-DMA's vector offset): refuse spans the
+    // offset cannot reach instead of reading wrapped addresses (a [B,S,H,D]-strided K at 6 144 B per row wraps near 700 k keys;
+    // a head-contiguous K at 256 B per row reaches 16 M).  The 2-byte and e4m3 kernels walk a 64-bit scalar base instead.
+    if (hyb != 0 && (unsigned long long)a.Sk * (unsigned long long)(a.kss < 0 ? -a.kss : a.kss) * 2ull >= (1ull << 32))
+        return RSA_ERR_UNSUPPORTED;
     const size_t lds_bytes = (size_t)2 * NSLOT * 64 * D8 + 64 + (((size_t)a.NB_total * 4 + 15) & ~(size_t)15);
     if (hyb != 0 && D8 == 64) {   // the pv form at head dim 64 (K 3 x 8 KiB, V 3 x 4 KiB): product and compiled twin
         const size_t n_list = a.NB_total < RSA_PV_LIST_WINDOW ? a.NB_total : RSA_PV_LIST_WINDOW;

@@ -1193,4 +1193,8 @@ extern "C" const char* rsa_status_string(int status) {
 int g_rsa_last_hip_error = 0;
 extern "C" const char* rsa_last_hip_error(void) { return hipGetErrorString((hipError_t)g_rsa_last_hip_error); }
 
-extern "C" int rsa_version(void) { return 500; }  // 0.5.0: rsa_buffers.tpart_bytes (declared capacity of the partial buffer; carve_workspace hands tpart out for every layout), rsa_set_shard_invariant, rsa_comm_count; 0.4.0: rsa_p2p_state_alloc / _free / _timeout (fine-grained exchange state), rsa_dense_masked_fwd; 0.3.1: block-scaled fp8 operands (rsa_fp8_operands.scales = E8M0 words + K mean), K1 writes the images, rsa_fp8_images gone; 0.3.0: rsa_buffers has 15 members, rsa_allgather_heads_p2p is stream-ordered (+ state buffers), rsa_ipc_offset
+extern "C" int rsa_abi_check(int header_version, size_t sizeof_rsa_buffers, size_t sizeof_rsa_layout) {
+    return (header_version / 100 == RSA_HEADER_VERSION / 100 && sizeof_rsa_buffers == sizeof(rsa_buffers) &&
+            sizeof_rsa_layout == sizeof(rsa_layout)) ? RSA_OK : RSA_ERR_UNSUPPORTED;
+}
+extern "C" int rsa_version(void) { return 600; }  // 0.6.0: rsa_abi_check; the pv entry points refuse K spans a 32-bit row offset cannot reach; 0.5.0: rsa_buffers.tpart_bytes (declared capacity of the partial buffer; carve_workspace hands tpart out for every layout), rsa_set_shard_invariant, rsa_comm_count; 0.4.0: rsa_p2p_state_alloc / _free / _timeout (fine-grained exchange state), rsa_dense_masked_fwd; 0.3.1: block-scaled fp8 operands (rsa_fp8_operands.scales = E8M0 words + K mean), K1 writes the images, rsa_fp8_images gone; 0.3.0: rsa_buffers has 15 members, rsa_allgather_heads_p2p is stream-ordered (+ state buffers), rsa_ipc_offset

@@ -1,7 +1,7 @@
 """Print the fp8 K5's output errors against the fp8-aware oracle and the bf16 oracle for the test cases."""
 import sys, numpy as np, torch
 import os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import oracle as orc

@@ -5,7 +5,7 @@ so +-2^-4 rounding).  Code map (the product, rsa_attn_fp8_kernel.hip PMap<true>)
 format's own piecewise-linear log2 -- P = 2^e (1 + m3/8) where e + m3/8 ~ x; against 2^x that is a smooth factor in
 [1, 1.0615] (constant factors cancel between numerator and row sum) on top of the same +-1/16 mantissa rounding.  This script
 measures the attention-output error of both against exact P on random scores: the code map costs 1.18-1.26x the exact form's RMS
-error; run on CPU: python tests/diag_fp8_pmap.py"""
+error; run on CPU: python tests/diag/diag_fp8_pmap.py"""
 import numpy as np
 
 rng = np.random.default_rng(0)

@@ -3,14 +3,14 @@
 of the e4m3 scales?  Quantises Q, K (minus its mean), V with (a) one scale per head (what rsa_fp8.hip did until round 3), (b) one
 power-of-two scale per 128-token block, (c) one power-of-two scale per token row, dequantises, and runs the exact (fp64)
 rectified attention on those values -- so the numbers isolate the operand rounding (P is NOT rounded here).
-    python tests/diag_fp8_scale_granularity.py
+    python tests/diag/diag_fp8_scale_granularity.py
 """
 import os
 import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import oracle as orc  # noqa: E402
 from rectified_spaattn_amd import synth  # noqa: E402
 

@@ -1,7 +1,7 @@
-"""Diagnostic script (uses the oracle, hence kept under tests/): run on the GPU box with python tests/diag_fp8_smooth_k.py."""
+"""Diagnostic script (uses the oracle, hence kept under tests/): run on the GPU box with python tests/diag/diag_fp8_smooth_k.py."""
 import sys, numpy as np, torch
 import os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import oracle as orc
 os.environ.setdefault("RSA_TUNING", "1")

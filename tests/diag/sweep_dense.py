@@ -1,12 +1,12 @@
 """Not collected by pytest: randomized sweep of the dense kernel (fullattn's device path): random Sq / Sk, two-segment
-splits, causal, head dim 64 / 128, bf16 / fp16, and the e4m3 form, against the oracle.  python tests/sweep_dense.py <seed> <n>"""
+splits, causal, head dim 64 / 128, bf16 / fp16, and the e4m3 form, against the oracle.  python tests/diag/sweep_dense.py <seed> <n>"""
 import os
 import sys
 
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import oracle as orc  # noqa: E402
 from rectified_spaattn_amd import _core  # noqa: E402

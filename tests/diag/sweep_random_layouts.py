@@ -1,5 +1,5 @@
 """Not collected by pytest: a wider one-off sweep of test_gpu_random_layouts' generator (other seeds, up to 40 visual blocks,
-both operand paths) for hunting rare failures on the GPU box:  python tests/sweep_random_layouts.py <seed> <count>
+both operand paths) for hunting rare failures on the GPU box:  python tests/diag/sweep_random_layouts.py <seed> <count>
 Prints one line per failing case and a summary; exit code 1 if anything failed."""
 import os
 import sys
@@ -7,7 +7,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import oracle as orc  # noqa: E402
 from rectified_spaattn_amd import _core, synth  # noqa: E402

@@ -18,7 +18,7 @@ from oracle import oracle as orc
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
-FP8_MAX_VS_BF16, FP8_MEAN_VS_BF16 = 1.6e-1, 1.5e-2   # measured 1.4e-1 / 1.3e-2; see tests/diag_fp8_scale_granularity.py
+FP8_MAX_VS_BF16, FP8_MEAN_VS_BF16 = 1.6e-1, 1.5e-2   # measured 1.4e-1 / 1.3e-2; see tests/diag/diag_fp8_scale_granularity.py
 FP8_MAX_VS_FP8, FP8_MEAN_VS_FP8 = 4e-2, 4e-3
 FP8_MAX_VS_PCODE, FP8_MEAN_VS_PCODE = 2e-2, 4e-4     # oracle with the kernel's own P map (p_form="code"); measured <= 1.2e-2 / 2.0e-4
 FP8_ROW_REL_MEDIAN, FP8_ROW_REL_MAX = 0.13, 0.30   # measured: median 0.06-0.12, max 0.08-0.27 (e4m3: 2^-4 relative steps on Q, K, V and P)
@@ -408,7 +408,7 @@ def test_fp8_p_forms_code_map_against_exact_exponential():
     """The product forms P through the e4m3 code map (one conversion per score); tuning key fp8_variant also reaches its
     compiled twin (1: must be bit-identical), the block with the staging behind the barrier (3: bit-identical) and the exact-exponential form (2: v_exp_f32 + round-to-nearest e4m3).  Both
     forms sit inside the fp8 tolerance of the exact-P oracle, the code map within 1.35x of the exponential form's mean error
-    (simulation: 1.2x, tests/diag_fp8_pmap.py), and against the bf16 oracle -- where the e4m3 rounding of Q, K, V
+    (simulation: 1.2x, tests/diag/diag_fp8_pmap.py), and against the bf16 oracle -- where the e4m3 rounding of Q, K, V
     dominates -- the two are indistinguishable (<= 3 %)."""
     from rectified_spaattn_amd import _core, _lib, synth
     lay = orc.layout_hunyuan(6 * 128 + 256, 6 * 128 + 200)

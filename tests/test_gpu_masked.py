@@ -168,3 +168,18 @@ def test_dropout_with_masks_and_causal():
     out = attn.fullattn(q.to(DEV), k.to(DEV), v.to(DEV), mode="vanilla", drop_rate=0.25, attn_mask=mask.to(DEV)).float().cpu()
     assert float(out[0, 1][~mask[0, 0]].abs().max()) == 0.0, "a masked key contributed"
     assert abs(float(out.sum(-1).mean()) - 1.0) < 0.05
+
+
+def test_a_mask_on_another_device_is_refused_with_the_librarys_error_type():
+    """this branch raised NameError (RsaError was not imported in _core.py).  Both entry points -- the masked
+    one and its dropout twin -- must refuse a CPU mask for device tensors with RsaError, and fullattn must pass it through."""
+    from rectified_spaattn_amd import _core, _lib, attn
+    g = torch.Generator(device="cuda:0").manual_seed(3)
+    q, k, v = (torch.randn(1, 2, 256, 128, generator=g, device="cuda:0").to(torch.bfloat16) for _ in range(3))
+    cpu_mask = torch.ones(1, 1, 256, 256, dtype=torch.bool)
+    with pytest.raises(_lib.RsaError, match="device of q"):
+        _core.dense_attention_masked(q, k, v, cpu_mask)
+    with pytest.raises(_lib.RsaError, match="device of q"):
+        _core.dense_attention_dropout(q, k, v, 0.1, 7, mask=cpu_mask)
+    with pytest.raises(_lib.RsaError):
+        attn.fullattn(q, k, v, mode="torch", attn_mask=cpu_mask)

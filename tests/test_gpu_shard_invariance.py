@@ -154,3 +154,67 @@ def test_p2p_gather_two_processes_one_device():
                         os.path.join(here, "_ipc_gather_worker.py")],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "IPC_GATHER_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_p2p_gather_eight_processes_one_device():
+    """Software pre-flight of the first 8-GPU run: the same worker with EIGHT processes on cuda:0 -- 7 IPC peers
+    per rank, 8 flags per state block, six stream-ordered gathers alternating between the two result buffers under uneven load,
+    the exchange object constructed and destroyed twice per process."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                        "--master-addr", "127.0.0.1", "--master-port", "29641",
+                        os.path.join(here, "_ipc_gather_worker.py")],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "IPC_GATHER_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_bench_eight_ranks_on_one_device():
+    """`python bench.py --gpus 8` as the driver starts it, at a reduced shape (8 heads x 8 448 tokens, one head per rank), every
+    rank on cuda:0: spawn, head shards, per-rank timing, the output check on every rank, the torch exchange and BOTH library
+    transports.  p2p must run and verify across the eight processes; RCCL refuses eight ranks on one device -- its set-up failure must
+    be agreed on by all ranks and reported as an error record, never as a hang or a time."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RSA_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--workload", "tiny8", "--steps", "4",
+                        "--warmup", "1", "--no-extras", "--no-cpu-baseline", "--gather-transports", "rccl,p2p"],
+                       capture_output=True, text=True, timeout=1200, env=env, cwd=root)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["n_gpus"] == 8 and rec["config"]["heads_per_gpu"] == 1 and rec["config"]["world_size"] == 8
+    assert len(rec["config"]["per_rank_ms"]) == 8 and all(ms > 0 for ms in rec["config"]["per_rank_ms"])
+    assert rec["check"]["ok"] is True, rec["check"]
+    g = rec["config"]["gather_output"]
+    assert g.get("verified") is True, g
+    assert g["p2p"].get("verified") is True and g["p2p"]["ms_per_step"] > 0, g
+    assert ("error" in g["rccl"]) or g["rccl"].get("verified") is True, g
+
+
+@pytest.mark.parametrize("transport", ["rccl", "p2p"])
+def test_head_gather_twice_in_one_process(transport):
+    """Construct, use and destroy the exchange object twice (a pipeline that rebuilds its processors does): nothing of the first one
+    -- the RCCL communicator, the fine-grained state block, its flags -- may leak into the second."""
+    from rectified_spaattn_amd import parallel
+    B, S, Hl, D = 1, 777, 2, 128
+    for n in range(2):
+        x = torch.randn(B, S, Hl, D, device=DEV).to(torch.bfloat16)
+        g = parallel.HeadGather(B, S, Hl, D, torch.bfloat16, torch.device(DEV), transport=transport)
+        try:
+            for i in range(3):
+                full = g.gather(x + i).clone()
+            torch.cuda.synchronize()
+            g.check()
+            assert torch.equal(full, (x + 2).reshape(B, S, Hl * D)), (transport, n)
+        finally:
+            g.close()

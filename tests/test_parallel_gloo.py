@@ -56,6 +56,67 @@ def test_head_shard_gather_and_reduce_world2():
         assert el == 2.0 and fl == 30.0 and pr == 6.0 and k5 == 1.5 and per == [1.0, 2.0]
 
 
+def _worker8(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        H, B, S, D = 24, 1, 9, 8                      # the headline's 24 heads over 8 ranks: 3 per rank
+        g = torch.Generator().manual_seed(5)
+        full = torch.randn(B, S, H, D, generator=g).to(torch.bfloat16)
+        h0, hl = parallel.head_shard(H, world, rank)
+        mine = full[:, :, h0:h0 + hl].contiguous()
+        got = parallel.gather_heads(mine)
+        ok = torch.equal(got, full.reshape(B, S, H * D))
+        want = parallel.exchange_checksums(parallel.head_checksums(mine, D), "cpu")
+        ok = ok and tuple(want.shape)[0] == H and parallel.verify_gathered(got, want, D) is None
+        # two ranks' slabs exchanged (ranks 2 and 5): the fingerprints must notice
+        perm = list(range(H)); perm[6:9], perm[15:18] = perm[15:18], perm[6:9]
+        ok = ok and isinstance(parallel.verify_gathered(got.view(B, S, H, D)[:, :, perm].reshape(B, S, H * D), want, D), str)
+        el, fl, pr, k5, per = parallel.reduce_step_stats(1.0 + 0.5 * rank, 2.0, 1.0, 0.25 * (rank + 1), "cpu", busy_s=0.1 * (rank + 1))
+        q.put((rank, ok, (h0, hl), el, fl, pr, k5, per))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_head_shard_gather_and_reduce_world8():
+    """The host logic of the 8-GPU run (world 2 above): shards of 3 heads, gather order, the exchange self-check
+    and the max-over-ranks / sum-of-work reduction with eight gloo ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert [r[2] for r in res] == [(3 * i, 3) for i in range(8)]
+    for rank, ok, _, el, fl, pr, k5, per in res:
+        assert ok, f"rank {rank}"
+        assert el == 4.5 and fl == 16.0 and pr == 8.0 and k5 == 2.0
+        assert len(per) == 8 and abs(per[7] - 0.8) < 1e-6 and abs(per[0] - 0.1) < 1e-6
+
+
+def test_bench_dry_world8():
+    """`python bench.py --gpus 8 --dry`: the parent starts eight gloo ranks as the driver's launcher would; one JSON line, 3 heads
+    per rank, eight per-rank times, the slowest rank sets the step."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dry", "--steps", "4",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["heads_per_gpu"] == 3 and len(rec["per_rank_ms"]) == 8
+    assert rec["per_rank_ms"][7] > rec["per_rank_ms"][0] and rec["ms_per_step"] >= max(rec["per_rank_ms"]) * 0.99
+
+
 def test_head_shard_rules():
     assert parallel.head_shard(24, 8, 3) == (9, 3)
     assert parallel.head_shard(40, 8, 7) == (35, 5)
