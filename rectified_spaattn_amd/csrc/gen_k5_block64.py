@@ -72,6 +72,10 @@ VOK, VOV = 168, 172           # per-lane DMA source offsets of the wave's four K
 # scalar registers owned by the loop statement
 S_KB, S_KL, S_VB, S_VL, S_BLK, S_CNT, S_T0, S_T2, S_K128, S_V128, S_KST, S_VST = 80, 82, 84, 86, 87, 88, 90, 92, 94, 95, 96, 97
 S_CLOB = list(range(80, 98))
+# schedule of the online body (round 6, profiles/r06_k5_forms.txt form 23: byte-identical outputs, -0.4 % R2 / -3 % dense): the row
+# maxima go ahead of the row sums once S_nxt is complete, so the deferred-rescale test's two compares ride inside the block and
+# only `s_or_b64` + the branch sit between two blocks
+LOOP_XF = frozenset({"maxfirst", "earlytest"})
 LOOP_PRE = 24                 # issue cycles of vector work the loop's blocks put in front of their first MFMA (the boundary blocks: 64)
 DMA_GAPS = [4 * j + 1 for j in range(8)]      # the 8 gaps that carry the wave's LDS-DMA pieces: every fourth gap
 STATS = None
@@ -169,6 +173,17 @@ def gen_block(dt, U, dma, chain=None, xf=frozenset(), dma_cost=None, pre=64, sal
     tail = ["s_nop 0", f"v_permlane32_swap_b32 {vr(T[0])}, {vr(T[1])}", f"v_permlane32_swap_b32 {vr(T[2])}, {vr(T[3])}", "s_nop 0",
             f"v_max_f32 %[mx0], {vr(T[0])}, {vr(T[1])}", f"v_max_f32 %[mx1], {vr(T[2])}, {vr(T[3])}"]
 
+    if "earlytest" in xf:      # the deferred-rescale test's compares ride in the block, behind the row maxima (the loop keeps the branch)
+        tail = tail + ["v_cmp_gt_f32 vcc, %[mx0], %[th0]", f"v_cmp_gt_f32 {sr(S_T2, 2)}, %[mx1], %[th1]"]
+    if "max8" in xf:           # one max3 chain per half: 8 instructions instead of 10
+        maxq = []
+        for h in (0, 1):
+            maxq += [("max", f"v_max3_f32 {vr(T[2 * h])}, {vr(SN[h])}, {vr(SN[h] + 1)}, {vr(SN[h] + 2)}")]
+        for i in range(6):
+            for h in (0, 1):
+                maxq += [("max", f"v_max3_f32 {vr(T[2 * h])}, {vr(T[2 * h])}, {vr(SN[h] + 3 + 2 * i)}, {vr(SN[h] + 4 + 2 * i)}")]
+        maxq += [("max", f"v_max_f32 {vr(T[2 * h])}, {vr(T[2 * h])}, {vr(SN[h] + 15)}") for h in (0, 1)]
+        maxq += [("mov", f"v_mov_b32 {vr(T[2 * h + 1])}, {vr(T[2 * h])}") for h in (0, 1)]
     if "novalu" in xf:
         EXP, cvq, addq, maxq, tail = [], [], [], [], []
     if "noadd" in xf:
@@ -186,6 +201,9 @@ def gen_block(dt, U, dma, chain=None, xf=frozenset(), dma_cost=None, pre=64, sal
     salu = salu or {}
     ei = 0             # exponentials issued
     last_exp_line = -10
+    exp_line = {}      # exponential n -> index of its line
+    cvtlag = next((int(f[6:]) for f in xf if f.startswith("cvtlag")), 0)
+    maxfirst = "maxfirst" in xf
 
     def emit_slot(cycles, gap, final=False):
         """Fill one slot: up to two exponentials while there are any, then whatever is ready, by issue cost."""
@@ -195,7 +213,8 @@ def gen_block(dt, U, dma, chain=None, xf=frozenset(), dma_cost=None, pre=64, sal
         progress = True
         while progress and (used < cycles or final):
             progress = False
-            if cvq and cvq[0][2] <= ei and len(lines) - last_exp_line >= 1 + (1 if cvq[0][2] == ei else 0):
+            if cvq and cvq[0][2] <= ei and (len(lines) - exp_line.get(cvq[0][2] - 1, -99) >= cvtlag if cvtlag
+                                             else len(lines) - last_exp_line >= 1 + (1 if cvq[0][2] == ei else 0)):
                 k, t, need = cvq.pop(0)
                 lines.append(t); used += COST[k]; progress = True
                 continue
@@ -203,7 +222,15 @@ def gen_block(dt, U, dma, chain=None, xf=frozenset(), dma_cost=None, pre=64, sal
                 h, i = EXP[ei]
                 lines.append(f"v_exp_f32 {vr(SC[h] + i)}, {vr(SC[h] + i)}")
                 last_exp_line = len(lines) - 1
+                exp_line[ei] = last_exp_line
                 ei += 1; nexp += 1; used += COST["exp"]; progress = True
+                continue
+            if maxfirst and maxq and gap >= E:
+                k, t = maxq.pop(0)
+                lines.append(t); used += COST[k]; progress = True
+                continue
+            if maxfirst and not maxq and tail and gap >= E:
+                lines.extend(tail); used += len(tail) * 4; tail.clear(); progress = True
                 continue
             if addq and addq[0][2] <= ei and len(lines) - last_exp_line >= 2:
                 k, t, need = addq.pop(0)
@@ -383,11 +410,15 @@ def gen_loop_head0(t0, t1):
             f"s_mov_b32 {sr(S_KL)}, %[ldsk]"]
 
 
-def gen_loop(dt, diag=False, xf=frozenset(), dma_cost=None, pre=64, tight=False):
+def gen_loop(dt, diag=False, xf=frozenset(), dma_cost=None, pre=64, tight=False, static=False):
     """The steady-state loop, one asm statement (see the file docstring).  Operands: cnt (kept blocks to process, >= 0),
     blk0 / blk1 (block index of the first one and of its successor), la (VGPR: LDS byte address of the list entry two blocks
     ahead), kb / vb (64-bit bases of this head's K / V), krow / vrow (bytes per key row), ldsk / ldsv (LDS address of the wave's
-    first piece in slot 0 of the K / V ring)."""
+    first piece in slot 0 of the K / V ring).
+    static (round 6): the statement carries a SECOND body, taken when the scalar operand `stat` is non-zero: the same four blocks
+    without the row maxima and without the deferred-rescale test -- the walk then keeps the softmax reference it entered the
+    loop with (rsa_attn_kernel64.hip: "optimistic static reference"; the kernel checks l and O afterwards and redoes the walk
+    through the first body if anything overflowed)."""
     t0, t1 = sr(S_T0), sr(S_T0 + 1)
     L = [f"s_mov_b32 {sr(S_CNT)}, %[cnt]",
          f"s_cmp_eq_u32 {sr(S_CNT)}, 0",
@@ -414,64 +445,71 @@ def gen_loop(dt, diag=False, xf=frozenset(), dma_cost=None, pre=64, tight=False)
                 f"s_mov_b32 {tt}, s76", "s_barrier",
                 f"s_memtime {tm}", "s_waitcnt lgkmcnt(0)", f"s_sub_u32 {tt}, s76, {tt}", f"s_add_u32 s79, s79, {tt}"]
     # entry: the boundary in front of the first block and its first K reads (slot 1: U = 0 reads K(u+1))
-    L += ["s_waitcnt vmcnt(16)", "s_barrier"] + [f"ds_read_b128 {vr(KF + 4 * ks, 4)}, {vr(KA + ks)} offset:{HALF}" for ks in range(AHEAD)]
+    L += [f"s_waitcnt vmcnt({8 if 'halfdma' in xf else 16})", "s_barrier"] + [f"ds_read_b128 {vr(KF + 4 * ks, 4)}, {vr(KA + ks)} offset:{HALF}" for ks in range(AHEAD)]
     if diag:
         L += ["s_mov_b32 s78, 0", "s_mov_b32 s79, 0"]
-    L += [".Lk5w_loop_%=:"]
-    for U in range(4):
-        head = []
-        if U == 0:     # K walker: the next kept block, key 0; K pieces go to slot 0.., V pieces to slot 3
-            head += [f"s_mul_i32 {t0}, {sr(S_BLK)}, {sr(S_K128)}", f"s_mul_hi_u32 {t1}, {sr(S_BLK)}, {sr(S_K128)}",
-                     f"s_mov_b64 {sr(S_KB, 2)}, %[kb]",
-                     f"s_add_u32 {sr(S_KB)}, {sr(S_KB)}, {t0}", f"s_addc_u32 {sr(S_KB + 1)}, {sr(S_KB + 1)}, {t1}",
-                     f"s_mov_b32 {sr(S_KL)}, %[ldsk]", f"s_add_u32 {sr(S_VL)}, %[ldsv], {3 * HALF}"]
-        if U == 1:     # V walker: the next kept block, key 0; V pieces to slot 0..
-            head += [f"s_mul_i32 {t0}, {sr(S_BLK)}, {sr(S_V128)}", f"s_mul_hi_u32 {t1}, {sr(S_BLK)}, {sr(S_V128)}",
-                     f"s_mov_b64 {sr(S_VB, 2)}, %[vb]",
-                     f"s_add_u32 {sr(S_VB)}, {sr(S_VB)}, {t0}", f"s_addc_u32 {sr(S_VB + 1)}, {sr(S_VB + 1)}, {t1}",
-                     f"s_mov_b32 {sr(S_VL)}, %[ldsv]"]
-        tail = boundary(diag)
-        if U == 1:     # list entry of the block after next: an LDS read older than every K read of block 2 (made scalar in block 3)
-            tail = tail + ["ds_read_u16 %[lv], %[la]"]
-        # the DMA walkers step to the next half-tile (re-based at U = 0 / 1 where a new kept block starts)
-        kstep = [f"s_add_u32 {sr(S_KB)}, {sr(S_KB)}, {sr(S_KST)}", f"s_addc_u32 {sr(S_KB + 1)}, {sr(S_KB + 1)}, 0",
-                 f"s_add_u32 {sr(S_KL)}, {sr(S_KL)}, {HALF}"]
-        vstep = [f"s_add_u32 {sr(S_VB)}, {sr(S_VB)}, {sr(S_VST)}", f"s_addc_u32 {sr(S_VB + 1)}, {sr(S_VB + 1)}, 0",
-                 f"s_add_u32 {sr(S_VL)}, {sr(S_VL)}, {HALF}"]
-        nxt = [f"v_readfirstlane_b32 {sr(S_BLK)}, %[lv]", "v_add_u32 %[la], 2, %[la]"]   # (read two blocks ago) -> the next iteration's block index
-        if not tight:
-            blk = gen_block(dt, U, True, chain=tail, xf=xf, dma_cost=dma_cost, pre=pre)
-            blk = head + blk + kstep[:2] + vstep[:2] + [kstep[2], vstep[2]] + (nxt if U == 3 else [])
-        else:
-            # the scalar bookkeeping rides in MFMA gaps (a scalar instruction beside an MFMA is free, between two blocks it is not:
-            # one wave per SIMD).  The wave's K pieces sit in gaps 1, 5, 17, 21, its V pieces in gaps 9, 13, 25, 29: the K walker
-            # steps (U = 3: is re-based on the next kept block) behind gap 21, the V walker steps behind gap 29 -- except in
-            # front of block 1, which re-bases it in its own gaps 2..4, ahead of its first V piece.
-            salu = {}
-            if U == 3:
-                k0 = [l for l in gen_loop_head0(t0, t1)]
-                salu[22] = nxt[:1] + k0[:2]
-                salu[23] = k0[2:5]
-                salu[24] = k0[5:] + nxt[1:]
+    if static:
+        L += ["s_cmp_lg_u32 %[stat], 0", "s_cbranch_scc1 .Lk5w_sloop_%="]
+    bodies = [(xf, "loop")] + ([(frozenset(xf | {"nomax", "notest"}), "sloop")] if static else [])
+    for xf, lname in bodies:
+        L += [f".Lk5w_{lname}_%=:"]
+        for U in range(4):
+            head = []
+            if U == 0:     # K walker: the next kept block, key 0; K pieces go to slot 0.., V pieces to slot 3
+                head += [f"s_mul_i32 {t0}, {sr(S_BLK)}, {sr(S_K128)}", f"s_mul_hi_u32 {t1}, {sr(S_BLK)}, {sr(S_K128)}",
+                         f"s_mov_b64 {sr(S_KB, 2)}, %[kb]",
+                         f"s_add_u32 {sr(S_KB)}, {sr(S_KB)}, {t0}", f"s_addc_u32 {sr(S_KB + 1)}, {sr(S_KB + 1)}, {t1}",
+                         f"s_mov_b32 {sr(S_KL)}, %[ldsk]", f"s_add_u32 {sr(S_VL)}, %[ldsv], {3 * HALF}"]
+            if U == 1:     # V walker: the next kept block, key 0; V pieces to slot 0..
+                head += [f"s_mul_i32 {t0}, {sr(S_BLK)}, {sr(S_V128)}", f"s_mul_hi_u32 {t1}, {sr(S_BLK)}, {sr(S_V128)}",
+                         f"s_mov_b64 {sr(S_VB, 2)}, %[vb]",
+                         f"s_add_u32 {sr(S_VB)}, {sr(S_VB)}, {t0}", f"s_addc_u32 {sr(S_VB + 1)}, {sr(S_VB + 1)}, {t1}",
+                         f"s_mov_b32 {sr(S_VL)}, %[ldsv]"]
+            tail = boundary(diag)
+            if U == 1:     # list entry of the block after next: an LDS read older than every K read of block 2 (made scalar in block 3)
+                tail = tail + ["ds_read_u16 %[lv], %[la]"]
+            # the DMA walkers step to the next half-tile (re-based at U = 0 / 1 where a new kept block starts)
+            kstep = [f"s_add_u32 {sr(S_KB)}, {sr(S_KB)}, {sr(S_KST)}", f"s_addc_u32 {sr(S_KB + 1)}, {sr(S_KB + 1)}, 0",
+                     f"s_add_u32 {sr(S_KL)}, {sr(S_KL)}, {HALF}"]
+            vstep = [f"s_add_u32 {sr(S_VB)}, {sr(S_VB)}, {sr(S_VST)}", f"s_addc_u32 {sr(S_VB + 1)}, {sr(S_VB + 1)}, 0",
+                     f"s_add_u32 {sr(S_VL)}, {sr(S_VL)}, {HALF}"]
+            nxt = [f"v_readfirstlane_b32 {sr(S_BLK)}, %[lv]", "v_add_u32 %[la], 2, %[la]"]   # (read two blocks ago) -> the next iteration's block index
+            if not tight:
+                blk = gen_block(dt, U, True, chain=tail, xf=xf, dma_cost=dma_cost, pre=pre)
+                blk = head + blk + kstep[:2] + vstep[:2] + [kstep[2], vstep[2]] + (nxt if U == 3 else [])
             else:
-                salu[22] = kstep
-            if U == 0:
-                pass                      # (block 1 re-bases the V walker itself)
-            else:
-                salu[30] = vstep
-            if U == 1:
-                salu[2] = head[:3]
-                salu[3] = head[3:]
-            blk = gen_block(dt, U, True, chain=tail, xf=xf, dma_cost=dma_cost, pre=pre, salu=salu)
-        # deferred-rescale test on the scores the NEXT block consumes (S_nxt of this block)
-        tst = ["v_cmp_gt_f32 vcc, %[mx0], %[th0]", f"v_cmp_gt_f32 {sr(S_T2, 2)}, %[mx1], %[th1]",
-               f"s_or_b64 vcc, vcc, {sr(S_T2, 2)}", f"s_cbranch_vccnz .Lk5w_resc{U}_%="]
-        if "notest" in xf:
-            tst = []
-        L += blk + tst + [f".Lk5w_back{U}_%=:"]
-    L += [f"s_sub_u32 {sr(S_CNT)}, {sr(S_CNT)}, 1", f"s_cmp_lg_u32 {sr(S_CNT)}, 0", "s_cbranch_scc1 .Lk5w_loop_%=",
-          "s_waitcnt lgkmcnt(0)",       # (the K reads the last block issued for its successor: nothing may land behind the statement)
-          "s_branch .Lk5w_done_%="]
+                # the scalar bookkeeping rides in MFMA gaps (a scalar instruction beside an MFMA is free, between two blocks it is not:
+                # one wave per SIMD).  The wave's K pieces sit in gaps 1, 5, 17, 21, its V pieces in gaps 9, 13, 25, 29: the K walker
+                # steps (U = 3: is re-based on the next kept block) behind gap 21, the V walker steps behind gap 29 -- except in
+                # front of block 1, which re-bases it in its own gaps 2..4, ahead of its first V piece.
+                salu = {}
+                if U == 3:
+                    k0 = [l for l in gen_loop_head0(t0, t1)]
+                    salu[22] = nxt[:1] + k0[:2]
+                    salu[23] = k0[2:5]
+                    salu[24] = k0[5:] + nxt[1:]
+                else:
+                    salu[22] = kstep
+                if U == 0:
+                    pass                      # (block 1 re-bases the V walker itself)
+                else:
+                    salu[30] = vstep
+                if U == 1:
+                    salu[2] = head[:3]
+                    salu[3] = head[3:]
+                blk = gen_block(dt, U, True, chain=tail, xf=xf, dma_cost=dma_cost, pre=pre, salu=salu)
+            # deferred-rescale test on the scores the NEXT block consumes (S_nxt of this block)
+            tst = ["v_cmp_gt_f32 vcc, %[mx0], %[th0]", f"v_cmp_gt_f32 {sr(S_T2, 2)}, %[mx1], %[th1]",
+                   f"s_or_b64 vcc, vcc, {sr(S_T2, 2)}", f"s_cbranch_vccnz .Lk5w_resc{U}_%="]
+            if "earlytest" in xf:
+                tst = [f"s_or_b64 vcc, vcc, {sr(S_T2, 2)}", f"s_cbranch_vccnz .Lk5w_resc{U}_%="]
+            if "notest" in xf:
+                tst = []
+            L += blk + tst + ([f".Lk5w_back{U}_%=:"] if lname == "loop" else [])
+        L += [f"s_sub_u32 {sr(S_CNT)}, {sr(S_CNT)}, 1", f"s_cmp_lg_u32 {sr(S_CNT)}, 0", f"s_cbranch_scc1 .Lk5w_{lname}_%=",
+              "s_waitcnt lgkmcnt(0)",       # (the K reads the last block issued for its successor: nothing may land behind the statement)
+              "s_branch .Lk5w_done_%="]
+    xf = bodies[0][0]
     for U in range(4):
         S = SB if U % 2 == 0 else SA          # S_nxt of block U
         L += [f".Lk5w_resc{U}_%=:"] + (["s_add_u32 s79, s79, 0x1000000"] if diag else []) + rescale_decide()
@@ -503,6 +541,11 @@ FORMS = {
     15: dict(xf={"halfdma"}, tight=True, pre=24),                   # round 6: every second LDS-DMA piece dropped (a 256-row workgroup's pieces per wave; garbage results)
     16: dict(xf={"m16", "halfdma"}, tight=True, pre=24),
     17: dict(xf={"m16", "novalu", "notest", "nodma", "nobar", "novm"}, tight=True, pre=24),   # form 5 on the 16x16x32 shape
+    22: dict(xf={"cvtlag4"}, tight=True, pre=24),                   # VALID: a packing issues no sooner than 4 lines behind its second exponential
+    23: dict(xf={"maxfirst", "earlytest"}, tight=True, pre=24),     # VALID: row maxima before the row sums, the rescale test's compares inside the block
+    24: dict(xf={"max8"}, tight=True, pre=24),                      # VALID: one max3 chain per half
+    25: dict(xf={"maxfirst", "earlytest", "max8", "cvtlag4"}, tight=True, pre=24),
+    26: dict(xf={"maxfirst", "earlytest", "max8"}, tight=True, pre=24),
     18: dict(xf={"noadd"}, tight=True, pre=24),                     # no row-sum additions (what moving them to the matrix pipe could buy at most)
     19: dict(xf={"nomax", "notest"}, tight=True, pre=24),           # no row maxima, no rescale test
     20: dict(xf={"novalu", "notest"}, tight=True, pre=24),          # form 4 on the product's schedule
@@ -531,10 +574,15 @@ def main():
             out.append(c_string(gen_block(dt, U, False)))
             out.append("")
         out.append(f"#define RSA_K5W_LOOP_{dt.upper()} \\")
-        out.append(c_string(gen_loop(dt, pre=LOOP_PRE, tight=True)))
+        out.append(c_string(gen_loop(dt, pre=LOOP_PRE, tight=True, static=(dt == "bf16"), xf=LOOP_XF)))   # (fp16 P overflows at 2^16: no static body)
+        out.append("")
+        # the 256-row dense form (four waves on one K/V ring): the same loop with every second LDS-DMA piece dropped -- each wave stages
+        # 2 + 2 of a half-tile's 8 + 8 pieces (lane offset registers 0 and 2), vmcnt(8) at the sub-step boundary
+        out.append(f"#define RSA_K5W_LOOP_{dt.upper()}_R256 \\")
+        out.append(c_string(gen_loop(dt, pre=LOOP_PRE, tight=True, static=(dt == "bf16"), xf=LOOP_XF | {"halfdma"})))
         out.append("")
         out.append(f"#define RSA_K5W_LOOP_{dt.upper()}_DIAG \\")
-        out.append(c_string(gen_loop(dt, diag=True, pre=LOOP_PRE, tight=True)))
+        out.append(c_string(gen_loop(dt, diag=True, pre=LOOP_PRE, tight=True, xf=LOOP_XF)))
         out.append("")
         out.append(f"#define RSA_K5W_QK0_{dt.upper()} \\")
         out.append(c_string(gen_qk0(dt)))
@@ -590,7 +638,7 @@ def main():
                             '[la] "+v"(la)', '[lv] "=&v"(lv)']
     lins = [f'"{{{vr(KA, 8)}}}"(ka)', f'"{{{vr(VA, 8)}}}"(va)', f'"{{{vr(VOK, 4)}}}"(vok)', f'"{{{vr(VOV, 4)}}}"(vov)',
             '[cnt] "s"(cnt)', '[blk0] "s"(blk0)', '[blk1] "s"(blk1)', '[kb] "s"(kb)', '[vb] "s"(vb)', '[krow] "s"(krow)',
-            '[vrow] "s"(vrow)', '[ldsk] "s"(ldsk)', '[ldsv] "s"(ldsv)', '[ninf] "v"(ninf)', '[eight] "v"(eight)']
+            '[vrow] "s"(vrow)', '[ldsk] "s"(ldsk)', '[ldsv] "s"(ldsv)', '[ninf] "v"(ninf)', '[eight] "v"(eight)', '[stat] "s"(stat)']
     out.append(f"#define RSA_K5W_OPS_LOOP : {', '.join(louts)} : {', '.join(lins)}")
     dl = louts + ['[d0] "=s"(d0)', '[d1] "=s"(d1)']
     out.append(f"#define RSA_K5W_OPS_LOOP_DIAG : {', '.join(dl)} : {', '.join(lins)}")

@@ -95,6 +95,8 @@ struct AttnArgs {
     unsigned* gsync;                          // 64-row kernel: start-alignment counters of this launch (rsa_attn_kernel64.hip), or null
     int gsync_gen;                            // ... workgroups an XCD holds at a time (a generation)
     int gsync_ratio;                          // ... walks that keep 1 / gsync_ratio of the keys or more are not held (default 2)
+    int rows256;                              // 64-row kernel, dense calls: NQB / NBv count 256-row tiles (four waves per workgroup, one K/V ring)
+    int k5_static;                            // 64-row kernel, bf16: the steady state keeps the softmax reference it is entered with (checked, redone if it overflowed)
 #ifdef RSA_K5_DIAG
     unsigned long long* dbg;                  // diagnostics build only (make diag): per-wave s_memtime sums, see tools/diag_k5.py
 #endif
@@ -154,6 +156,7 @@ __device__ __forceinline__ void rsa_gsync_wait(unsigned* gsync, GsyncTicket tk, 
 // wait, profiles/r04_k5_gsync.md) -- bits of the tuning key "k5_gsync"; wg_per_cu = what the runtime says fits
 // (hipOccupancyMaxActiveBlocksPerMultiprocessor); *gen = workgroups per XCD generation
 unsigned* rsa_gsync_slot(int which, unsigned grid, int wg_per_cu, hipStream_t s, int* gen);
+int rsa_k5_static();      // tuning key "k5_static" (default 1): rsa_attn_kernel64.hip, optimistic static reference
 int rsa_gsync_ratio();    // tuning key "k5_gsync_ratio" (default 2: walks keeping half of the keys or more are not held)
 int rsa_wg_per_cu(const void* kernel, int block, size_t lds_bytes);   // cached hipOccupancyMaxActiveBlocksPerMultiprocessor; 0 = unknown
 // launch `kernel` with the launch's alignment counters filled into its argument struct (sparse lists only: dense walks share their keys anyway)
@@ -161,7 +164,7 @@ int rsa_wg_per_cu(const void* kernel, int block, size_t lds_bytes);   // cached 
     do { \
         auto kfn_ = kernel; \
         auto aa_ = args; \
-        aa_.gsync = nullptr; aa_.gsync_gen = 64; aa_.gsync_ratio = rsa_gsync_ratio(); \
+        aa_.gsync = nullptr; aa_.gsync_gen = 64; aa_.gsync_ratio = rsa_gsync_ratio(); aa_.k5_static = rsa_k5_static(); \
         if (MODE_IS_SPARSE) \
             aa_.gsync = rsa_gsync_slot(which, (grid).x, rsa_wg_per_cu(reinterpret_cast<const void*>(kfn_), block, lds_bytes), stream, \
                                        &aa_.gsync_gen); \

@@ -12,11 +12,15 @@
 static int g_k5_tsplit = 1;     // 1 = split-KV for the text query blocks when the partial buffer is given
 extern int g_rsa_k3_prefix;
 extern int g_rsa_k3_long;
+extern int g_rsa_k4_split;
 static int g_k5_tail_split = 1; // 64-row kernel: the last, partial generation's walks split over its idle slots (k5w_map)
 static int g_k5_text_last = 1;  // 64-row kernel: split text-row pieces at the end of the grid (rsa_attn_kernel64.hip::k5w_map)
 static int g_shard_invariant = 0; // rsa_set_shard_invariant: nothing about a row's arithmetic may depend on the size of the launch
 static int g_k5_gsync_ratio = 2; // aligned starts: walks that keep 1 / ratio of the keys or more are not held back
 int rsa_gsync_ratio() { return g_k5_gsync_ratio; }
+static int g_k5_rows256 = 1;    // dense calls at head dim 128: 256-row tiles (0 = 128-row tiles, the sparse calls' form)
+static int g_k5_static = 1;     // 64-row kernel, bf16: optimistic static softmax reference in the steady-state loop (0 = online body only)
+int rsa_k5_static() { return g_k5_static; }
 static int g_k5_gsync = 1;      // aligned starts of the sparse walks (rsa_attn.h): bit 0 = in the 64-row kernel, bit 1 = in the 32-row and e4m3 kernels
 #ifdef RSA_K5_FORMS
 extern int g_rsa_k5_form;
@@ -41,6 +45,7 @@ extern "C" int rsa_set_tuning(const char* key, int value) {
     if (!enabled) return RSA_ERR_UNSUPPORTED;
     if (strcmp(key, "k3_prefix") == 0) { g_rsa_k3_prefix = value; return RSA_OK; }
     if (strcmp(key, "k3_long") == 0) { g_rsa_k3_long = value; return RSA_OK; }
+    if (strcmp(key, "k4_split") == 0) { g_rsa_k4_split = value; return RSA_OK; }
 #ifdef RSA_K5_FORMS
     if (strcmp(key, "k5_form") == 0) { g_rsa_k5_form = value; return RSA_OK; }
     if (strcmp(key, "k5w_form") == 0) { g_rsa_k5w_form = value; return RSA_OK; }
@@ -49,6 +54,8 @@ extern "C" int rsa_set_tuning(const char* key, int value) {
     if (strcmp(key, "dbg_lo") == 0) { g_dbg_ptr = (g_dbg_ptr & 0xFFFFFFFF00000000ull) | (unsigned)value; return RSA_OK; }
     if (strcmp(key, "dbg_hi") == 0) { g_dbg_ptr = (g_dbg_ptr & 0xFFFFFFFFull) | ((unsigned long long)(unsigned)value << 32); return RSA_OK; }
 #endif
+    if (strcmp(key, "k5_static") == 0) { g_k5_static = value; return RSA_OK; }
+    if (strcmp(key, "k5_rows256") == 0) { g_k5_rows256 = value; return RSA_OK; }
     if (strcmp(key, "k5_tsplit") == 0) { g_k5_tsplit = value; return RSA_OK; }
     if (strcmp(key, "k5_w64") == 0) { g_k5_w64 = value; return RSA_OK; }
     if (strcmp(key, "k5_gsync") == 0) { g_k5_gsync = value; return RSA_OK; }
@@ -257,7 +264,7 @@ int rsa_wg_per_cu(const void* kernel, int block, size_t lds_bytes) {
 static int launch_attn(AttnArgs& a, int BH, int D, int dtype, size_t tpart_bytes, hipStream_t s) {
     const int ntq = a.NQB - a.NBv;
     if (a.tpart && tpart_bytes == 0) return RSA_ERR_WORKSPACE;   // capacity not declared (rsa_buffers.tpart_bytes, 0.5.0)
-    a.gsync = nullptr; a.gsync_gen = 64; a.gsync_ratio = 2;
+    a.gsync = nullptr; a.gsync_gen = 64; a.gsync_ratio = 2; a.k5_static = g_k5_static;
     // split-KV for the dense text rows: without it one workgroup walks every key block of a text query block (902 at the
     // HunyuanVideo shape = 10 kept lists) -- hidden among 21 600 sparse blocks on one GPU, the critical path when the
     // heads are sharded over 8
@@ -346,7 +353,7 @@ extern "C" int rsa_block_sparse_fwd(const rsa_layout* l, rsa_tensor4 q, rsa_tens
     a.NBv = l->NBv; a.NQB = l->NB_total; a.NB_total = l->NB_total;
     a.kv_valid = l->kv_valid; a.kv_text_valid = l->kv_text_valid;
     a.q_text_end = l->NBv * RSA_BLOCK + l->q_text_valid;
-    a.q_split = 0; a.kv_split = 0; a.causal = 0;
+    a.q_split = 0; a.kv_split = 0; a.causal = 0; a.rows256 = 0;
     a.qk_scale = (float)((1.0 / sqrt((double)l->D)) * 1.44269504);  // sm_scale * 1.44269504 (hunyuan :145)
 #ifdef RSA_K5_DIAG
     a.dbg = reinterpret_cast<unsigned long long*>(g_dbg_ptr);
@@ -370,7 +377,10 @@ static int dense_fwd(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4
     a.tpart = nullptr;
     a.tsplit = 1; a.tper = 0;
     a.mode = MODE_DENSE; a.H = H; a.Sq = Sq; a.Sk = Sk;
-    a.NQB = (Sq + RSA_BLOCK - 1) / RSA_BLOCK; a.NBv = a.NQB; a.NB_total = (Sk + RSA_BLOCK - 1) / RSA_BLOCK;
+    // head dim 128 through the 64-row kernel: 256-row tiles once there are at least two of them (a shorter call keeps 128-row tiles)
+    a.rows256 = (D == 128 && (g_k5_w64 & 1) && g_k5_rows256 && Sq > 256) ? 1 : 0;
+    const int rw = a.rows256 ? 2 * RSA_BLOCK : RSA_BLOCK;
+    a.NQB = (Sq + rw - 1) / rw; a.NBv = a.NQB; a.NB_total = (Sk + RSA_BLOCK - 1) / RSA_BLOCK;
     a.kv_valid = Sk; a.kv_text_valid = Sk; a.q_text_end = 0;
     a.q_split = q_split; a.kv_split = kv_split; a.causal = causal;
     a.qk_scale = (float)((1.0 / sqrt((double)D)) * 1.44269504);

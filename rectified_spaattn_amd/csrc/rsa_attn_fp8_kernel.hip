@@ -66,7 +66,7 @@ struct Attn8Args {
     float* tpart;        // split-KV partials of the text query blocks (layout of rsa_attn.hip's combine kernel) or null
     int tsplit, tper;
     unsigned* gsync;     // aligned starts (rsa_attn.h): this launch's counters or null
-    int gsync_gen, gsync_ratio;
+    int gsync_gen, gsync_ratio, k5_static;   // (k5_static: set by RSA_LAUNCH_GSYNC for every K5 args struct; only the 64-row 2-byte kernel reads it)
     int heavy_last;      // the split text-row pieces behind the sparse blocks in the grid
     int tail_first, tail_n, tail_p;   // tail split (rsa_attn.hip::launch_attn, rsa_attn_kernel64.hip::k5w_map): head dim 128 only
     float* tail_part;

@@ -123,10 +123,17 @@ __device__ __forceinline__ bool k5w_map(const AttnArgs& a, int work, int& bh, in
 
 // WIDE: 16-byte output stores after a permlane32_swap regroup (needs 16-byte aligned output rows), else 8-byte stores.
 // XF (A/B build only, -DRSA_K5_FORMS): one of the loop forms of rsa_attn_block64_forms.h instead of the product's loop.
-template <typename Tag, bool WIDE, int XF = 0>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) void bsfwd64_kernel(AttnArgs a) {
+// NW (round 6): waves per workgroup.  2 = one 128-row query block (every sparse call: the mask's granularity).  4 = a 256-ROW
+// tile of a DENSE call (rsa_dense_fwd / _causal_: all rows walk the same keys): four waves, one per SIMD, ONE workgroup per CU on ONE
+// K/V ring -- every half-tile is staged once per 256 rows instead of once per 128, each wave issues 4 LDS-DMA pieces per sub-step
+// instead of 8 (what that buys at most: form x15 of profiles/r06_k5_forms.txt).  The loop statement is the same generator's with
+// every second piece dropped (gen_k5_block64.py, RSA_K5W_LOOP_*_R256); `qblk` then counts 256-row tiles (the host sets NQB so).
+template <typename Tag, bool WIDE, int XF = 0, int NW = 2>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 1))) void bsfwd64_kernel(AttnArgs a) {
     constexpr int D = 128;
-    constexpr int NW = 2;                   // 2 waves x 64 query rows
+    constexpr int RW = 64 * NW;             // query rows per workgroup: NW waves x 64 rows
+    constexpr int NPW = 8 / NW;             // 1-KiB pieces of a 32-key half-tile each wave stages
+    static_assert(NW == 2 || NW == 4, "two or four waves");
     constexpr int KS = D / 16;
     constexpr int DT = D / 32;
     constexpr int HALF = 32 * D * 2;        // bytes of a 32-key half-tile
@@ -134,6 +141,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     using E = Elem<Tag>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned short* lds_list = reinterpret_cast<unsigned short*>(lds + 8 * HALF);
+    __shared__ int redo_flag;               // optimistic static reference (below): a wave whose walk overflowed asks the workgroup for a second pass
 
     const GsyncTicket gs_tk = rsa_gsync_announce(a.gsync, a.gsync_gen);   // aligned starts (rsa_attn.h)
 
@@ -145,7 +153,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int r = lane & 31, hh = lane >> 5;
     int grow[2];
-    grow[0] = qblk * 128 + 64 * wv + r;
+    grow[0] = qblk * RW + 64 * wv + r;
     grow[1] = grow[0] + 32;
 
     // ---------------- per-row plan (per row half) ----------------
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     } else {
         // dense mode: one or two (query rows, key rows) segments; causal = bottom-right aligned inside a segment (see
         // rsa_attn_kernel.hip for the conventions)
-        const int row0 = qblk * 128, row1 = row0 + 128;
+        const int row0 = qblk * RW, row1 = row0 + RW;
         auto seg_hi = [&](int row) -> int {
             const bool s1 = row >= a.q_split;
             const int lo = s1 ? a.kv_split : 0, hi = s1 ? a.Sk : a.kv_split;
@@ -213,14 +221,14 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // reads its block indices from there in every mode (one entry of slack: the loop looks two blocks ahead)
     for (int i = t; i < n_items + 2; i += 64 * NW)
         lds_list[i] = (unsigned short)(i < n_items ? (list ? list[i] : first_blk + i) : 0);
+    if (t == 0) redo_flag = 0;
     __syncthreads();
     auto blk_of = [&](int item) -> int { return __builtin_amdgcn_readfirstlane((int)lds_list[item]); };
     const int n_sub = 4 * n_items;            // 32-key sub-steps: four per kept block (scores past the row's range are masked)
     const int kv_limit = hi_max < a.Sk ? hi_max : a.Sk;
     auto key_of = [&](int x) -> int { return blk_of(x >> 2) * RSA_BLOCK + (x & 3) * 32; };   // first key of half-tile x
 
-    // ---------------- Q fragments (B operand) -> accumulator file; O = 0 ----------------
-    asm volatile(RSA_K5W_OZERO ::: RSA_K5W_CLOBBER_O);
+    // ---------------- Q fragments (B operand) -> accumulator file (O is zeroed at the head of a pass) ----------------
     {
         auto load_frag = [&](int x, int ks) -> s16x8 {
             const unsigned short* qp = a.q + (long)b * a.qsb + (long)h * a.qsh + (long)grow[x] * a.qss + 8 * hh;
@@ -251,20 +259,26 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
     const unsigned char* kbase = uni64(reinterpret_cast<const unsigned char*>(a.k + (long)b * a.ksb + (long)h * a.ksh));
     const unsigned char* vbase = uni64(reinterpret_cast<const unsigned char*>(a.v + (long)b * a.vsb + (long)h * a.vsh));
-    // A 32-key half-tile = 8 one-KiB pieces of 4 rows; wave w moves pieces 2j + w (rows 8j + 4w .. +3), j = 0..3.  The XOR
-    // swizzle of a row's source chunk depends on (row & 3) and ((row >> 2) & 3) = (2j + w) & 3: two per-lane offsets
-    // (even / odd j); the piece walks a scalar base by 8 rows.
+    // A 32-key half-tile = 8 one-KiB pieces of 4 rows; wave w moves pieces NW j + w (rows 4 NW j + 4w .. +3), j = 0 .. NPW - 1.  The
+    // XOR swizzle of a row's source chunk depends on (row & 3) and ((row >> 2) & 3) = (NW j + w) & 3: two per-lane offsets (even /
+    // odd j) with two waves, one with four; the piece walks a scalar base.
     const int rsub = lane >> 4, cl = lane & 15;
     const int rowl = 4 * wv + rsub;
-    const int gsw0 = cl ^ ((rsub << 2) | wv), gsw1 = cl ^ ((rsub << 2) | (2 + wv));
+    const int gsw0 = cl ^ ((rsub << 2) | (wv & 3)), gsw1 = cl ^ ((rsub << 2) | ((NW + wv) & 3));
     const unsigned krow = (unsigned)(a.kss * 2), vrow = (unsigned)(a.vss * 2);   // bytes per key row (< 4 GiB)
-    // lane offsets of the wave's four pieces of a half-tile, for the loop's staging: piece j = rows 8j + rowl; odd pieces carry
-    // the instruction offset 2048 (their LDS destination), which also moves the source: taken out here
+    // lane offsets of the wave's pieces of a half-tile, for the loop's staging.  Two waves: piece j = rows 8j + rowl in register j;
+    // odd pieces carry the instruction offset 2048 (their LDS destination), which also moves the source: taken out here.  Four
+    // waves: the loop issues only its even slots (registers 0 and 2): piece j' = rows 16 j' + rowl in register 2 j'.
     u32x4 vok, vov;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        vok[j] = (8 * j + rowl) * krow + ((j & 1) ? gsw1 : gsw0) * 16 - ((j & 1) ? 2048u : 0u);
-        vov[j] = (8 * j + rowl) * vrow + ((j & 1) ? gsw1 : gsw0) * 16 - ((j & 1) ? 2048u : 0u);
+        if constexpr (NW == 2) {
+            vok[j] = (8 * j + rowl) * krow + ((j & 1) ? gsw1 : gsw0) * 16 - ((j & 1) ? 2048u : 0u);
+            vov[j] = (8 * j + rowl) * vrow + ((j & 1) ? gsw1 : gsw0) * 16 - ((j & 1) ? 2048u : 0u);
+        } else {
+            vok[j] = (16 * (j >> 1) + rowl) * krow + gsw0 * 16;
+            vov[j] = (16 * (j >> 1) + rowl) * vrow + gsw0 * 16;
+        }
     }
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
     // staging from C++ (prologue, boundary blocks): the 32-key half-tile starting at key `key_first` -> LDS byte offset
@@ -274,20 +288,58 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const unsigned char* base = is_v ? vbase : kbase;
         const unsigned rowb = is_v ? vrow : krow;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int krow_ = key_first + 8 * j + rowl;
+        for (int j = 0; j < NPW; ++j) {
+            int krow_ = key_first + 4 * NW * j + rowl;
             krow_ = krow_ < kv_limit ? krow_ : kv_limit - 1;
             const unsigned vo = (unsigned)krow_ * rowb + ((j & 1) ? gsw1 : gsw0) * 16;
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                         :: "v"(vo), "s"(base), "s"(ld0 + j * 2048) : "memory");
+                         :: "v"(vo), "s"(base), "s"(ld0 + j * NW * 1024) : "memory");
         }
     };
 
+    // ---------------- optimistic static reference (round 6; bf16 only) ----------------
+    // The online softmax pays, per 32-key sub-step, a row maximum of 64 x 32 scores (20 vector instructions, two lane swaps), a
+    // compare-and-branch on it and the rare rescale -- with one wave per SIMD all of it in the issue slots the MFMAs leave
+    // (removal experiment, profiles/r06_k5_forms.txt: -3.9 % R2 / -5.3 % dense).  bf16 P has fp32's exponent range, so the reference
+    // m_ref need not follow the running maximum: the steady-state loop keeps the reference it is ENTERED with (the finite row
+    // maxima of the keys before it: at least the first 32) and computes no maxima at all (second body of the loop statement,
+    // gen_k5_block64.py `static`).  exp2(S - m_ref) then overflows only if a later score exceeds that reference by more than
+    // 127 -- and every overflow leaves a trace: an infinite P makes l infinite and O infinite or NaN.  So the walk is checked
+    // afterwards (l below 2^100 and every O element finite, on the bit patterns: this file is compiled with -fno-honor-nans) and,
+    // if any wave of the workgroup failed the check, the whole workgroup walks again through the online body and stores again.
+    // Same softmax either way (the reference cancels in O / l); which body ran depends only on the rows' own data, never on the
+    // launch.  Tuning key k5_static = 0: online body only.
+    constexpr bool MAY_STATIC = std::is_same<Tag, bf16_tag>::value && XF == 0;
+    static_assert(NW == 2 || XF == 0, "the A/B forms are forms of the 128-row kernel");
+    const bool may_static = MAY_STATIC && a.k5_static != 0;
+    // state the epilogue reads (set at the head of a pass)
+    float l_run[2], m_ref[2], thr[2];
+    int i0 = 0, i1 = 0;
+#ifdef RSA_K5_DIAG
+    // diagnostics build: s_memtime around the phases of the walk, summed per wave (scalar registers)
+    unsigned long long tprev = 0, tsum[4] = {0, 0, 0, 0}, tkern0, tprologue = 0;
+    auto stamp_now = [&]() -> unsigned long long {
+        unsigned long long tt;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt) :: "memory");
+        return tt;
+    };
+    tkern0 = stamp_now();
+#define RSA_STAMP0() do { tprev = stamp_now(); } while (0)
+#define RSA_STAMP(i) do { const unsigned long long tn_ = stamp_now(); tsum[i] += tn_ - tprev; tprev = tn_; } while (0)
+#else
+#define RSA_STAMP0() do { } while (0)
+#define RSA_STAMP(i) do { } while (0)
+#endif
+#pragma nounroll
+    for (int pass = 0; pass < 2; ++pass) {
+    asm volatile(RSA_K5W_OZERO ::: RSA_K5W_CLOBBER_O);
+    bool used_static = false;
     // ---------------- state ----------------
-    float l_run[2] = {0.0f, 0.0f};
     // m_ref = the finite reference the scores are taken against, nm = its negation in 16 registers (C operand of the first
     // QK^T MFMA), thr = how far a new row maximum may exceed it before the rescale (-inf until the row has seen a finite score)
-    float m_ref[2] = {0.0f, 0.0f}, thr[2] = {-INFINITY, -INFINITY};
+    l_run[0] = l_run[1] = 0.0f;
+    m_ref[0] = m_ref[1] = 0.0f;
+    thr[0] = thr[1] = -INFINITY;
     f32x16 nm[2];
     asm volatile(RSA_K5W_NMZERO RSA_K5W_OPS_NMZERO);
 
@@ -303,22 +355,6 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         va[2 * dt] = (int)lds_base + tile_off<D>(4 * hh + tq, ch) + 8 * (tp & 1);
         va[2 * dt + 1] = (int)lds_base + tile_off<D>(4 * hh + tq + 8, ch) + 8 * (tp & 1);
     }
-
-#ifdef RSA_K5_DIAG
-    // diagnostics build: s_memtime around the phases of the walk, summed per wave (scalar registers)
-    unsigned long long tprev = 0, tsum[4] = {0, 0, 0, 0}, tkern0;
-    auto stamp_now = [&]() -> unsigned long long {
-        unsigned long long tt;
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt) :: "memory");
-        return tt;
-    };
-    tkern0 = stamp_now();
-#define RSA_STAMP0() do { tprev = stamp_now(); } while (0)
-#define RSA_STAMP(i) do { const unsigned long long tn_ = stamp_now(); tsum[i] += tn_ - tprev; tprev = tn_; } while (0)
-#else
-#define RSA_STAMP0() do { } while (0)
-#define RSA_STAMP(i) do { } while (0)
-#endif
 
     f32x16 SA[2], SB[2];
     float mxA[2] = {-INFINITY, -INFINITY}, mxB[2] = {-INFINITY, -INFINITY};
@@ -354,7 +390,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         constexpr int U = decltype(UC)::value;
         float (&mx_cur)[2] = (U & 1) == 0 ? mxA : mxB;
         float (&mx_nxt)[2] = (U & 1) == 0 ? mxB : mxA;
-        if (u + 4 <= n_sub) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        if (u + 4 <= n_sub) { if constexpr (NW == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (u + 3 < n_sub) dma_half(1, key_of(u + 3), VRING + ((U + 3) & 3) * HALF);
@@ -387,7 +423,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // aligned starts: in front of the first staging instruction (the pieces of a split tail and of the text rows do not wait:
     // short walks over different parts of the key range, the last workgroups of the launch)
-    if (tail < 0 && qblk < a.NBv) rsa_gsync_wait(a.gsync, gs_tk, n_items, a.NB_total, a.gsync_ratio);
+    if (pass == 0 && tail < 0 && qblk < a.NBv) rsa_gsync_wait(a.gsync, gs_tk, n_items, a.NB_total, a.gsync_ratio);
 
     // ---------------- prologue: half-tiles K(0..3), V(0..2); scores of sub-step 0 ----------------
     if (n_sub > 0) {
@@ -405,16 +441,16 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     RSA_STAMP0();
 #ifdef RSA_K5_DIAG
-    const unsigned long long tprologue = tprev - tkern0;
+    tprologue = tprev - tkern0;
 #endif
     // Which kept blocks the asm loop takes: [i0, i1) such that no score of block i needs the boundary mask and block i + 1
     // (whose half-tiles the loop stages while it works on i) exists and lies inside the valid keys: i0 = the leading blocks
     // below lo_max (second segment of a two-segment dense call), i1 from the end of the ascending list.
-    int i0 = 0;
+    i0 = 0;
     while (i0 < n_items && blk_of(i0) * RSA_BLOCK < lo_max) ++i0;
     int nfull = n_items;
     while (nfull > i0 && blk_of(nfull - 1) * RSA_BLOCK + RSA_BLOCK > hi_min) --nfull;
-    const int i1 = nfull - 1 > i0 ? nfull - 1 : i0;
+    i1 = nfull - 1 > i0 ? nfull - 1 : i0;
     run_items(0, i0);
     RSA_STAMP(0);
     {
@@ -426,6 +462,12 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const unsigned ldsk = lds_base + wv * 1024, ldsv = lds_base + VRING + wv * 1024;
         float (&l)[2] = l_run;
         float (&mx)[2] = mxA;
+        // static body iff every row of the wave has a finite reference by now (a row that has seen only masked keys has none)
+        unsigned stat = 0;
+        if (may_static && pass == 0 && cnt != 0 &&
+            __builtin_amdgcn_ballot_w64(thr[0] == -INFINITY || thr[1] == -INFINITY) == 0ull) stat = 1;
+        stat = __builtin_amdgcn_readfirstlane(stat);
+        used_static = stat != 0;
 #ifdef RSA_K5_DIAG
         unsigned d0 = 0, d1 = 0;   // in-loop stamps: cycles parked on the vmcnt wait / on the barrier (+ rescales taken << 24)
         if constexpr (std::is_same<Tag, bf16_tag>::value)
@@ -440,10 +482,14 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define RSA_K5W_XFORM(N) else if constexpr (XF == N) \
             asm volatile(RSA_K5W_LOOP_BF16_X##N RSA_K5W_OPS_LOOP : RSA_K5W_CLOBBER_TMP, RSA_K5W_CLOBBER_O, RSA_K5W_CLOBBER_LOOP, "memory");
         if constexpr (false) {}
-        RSA_K5W_XFORM(1) RSA_K5W_XFORM(2) RSA_K5W_XFORM(3) RSA_K5W_XFORM(4) RSA_K5W_XFORM(5) RSA_K5W_XFORM(6) RSA_K5W_XFORM(7) RSA_K5W_XFORM(8) RSA_K5W_XFORM(9) RSA_K5W_XFORM(10) RSA_K5W_XFORM(11) RSA_K5W_XFORM(12) RSA_K5W_XFORM(13) RSA_K5W_XFORM(14) RSA_K5W_XFORM(15) RSA_K5W_XFORM(16) RSA_K5W_XFORM(17) RSA_K5W_XFORM(18) RSA_K5W_XFORM(19) RSA_K5W_XFORM(20) RSA_K5W_XFORM(21)
+        RSA_K5W_XFORM(1) RSA_K5W_XFORM(2) RSA_K5W_XFORM(3) RSA_K5W_XFORM(4) RSA_K5W_XFORM(5) RSA_K5W_XFORM(6) RSA_K5W_XFORM(7) RSA_K5W_XFORM(8) RSA_K5W_XFORM(9) RSA_K5W_XFORM(10) RSA_K5W_XFORM(11) RSA_K5W_XFORM(12) RSA_K5W_XFORM(13) RSA_K5W_XFORM(14) RSA_K5W_XFORM(15) RSA_K5W_XFORM(16) RSA_K5W_XFORM(17) RSA_K5W_XFORM(18) RSA_K5W_XFORM(19) RSA_K5W_XFORM(20) RSA_K5W_XFORM(21) RSA_K5W_XFORM(22) RSA_K5W_XFORM(23) RSA_K5W_XFORM(24) RSA_K5W_XFORM(25) RSA_K5W_XFORM(26)
         else
 #endif
-        if constexpr (std::is_same<Tag, bf16_tag>::value)
+        if constexpr (NW == 4 && std::is_same<Tag, bf16_tag>::value)
+            asm volatile(RSA_K5W_LOOP_BF16_R256 RSA_K5W_OPS_LOOP : RSA_K5W_CLOBBER_TMP, RSA_K5W_CLOBBER_O, RSA_K5W_CLOBBER_LOOP, "memory");
+        else if constexpr (NW == 4)
+            asm volatile(RSA_K5W_LOOP_F16_R256 RSA_K5W_OPS_LOOP : RSA_K5W_CLOBBER_TMP, RSA_K5W_CLOBBER_O, RSA_K5W_CLOBBER_LOOP, "memory");
+        else if constexpr (std::is_same<Tag, bf16_tag>::value)
             asm volatile(RSA_K5W_LOOP_BF16 RSA_K5W_OPS_LOOP : RSA_K5W_CLOBBER_TMP, RSA_K5W_CLOBBER_O, RSA_K5W_CLOBBER_LOOP, "memory");
         else
             asm volatile(RSA_K5W_LOOP_F16 RSA_K5W_OPS_LOOP : RSA_K5W_CLOBBER_TMP, RSA_K5W_CLOBBER_O, RSA_K5W_CLOBBER_LOOP, "memory");
@@ -453,6 +499,31 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     RSA_STAMP(1);
     run_items(i1, n_items);
     RSA_STAMP(2);
+    if (!may_static) break;                      // (uniform over the launch)
+    {
+        // the overflow trace of a static walk: l of either half at 2^100 or beyond (or infinite, or NaN), or an O element that is
+        // not finite -- on the bit patterns (-fno-honor-nans).  Reading the whole tile costs ~400 vector instructions per wave
+        // life (of ~500 k cycles); nothing has been stored yet.
+        asm volatile("s_nop 11" ::: "memory");   // (the last block's last MFMA -> the reads of O below)
+        unsigned emax = 0;
+        auto track = [&](const f32x16& o) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const unsigned bits = __float_as_uint(o[i]) & 0x7FFFFFFFu;
+                emax = emax > bits ? emax : bits;
+            }
+        };
+        if (used_static) {
+            track(k5w_oread<0, 0>()); track(k5w_oread<0, 1>()); track(k5w_oread<0, 2>()); track(k5w_oread<0, 3>());
+            track(k5w_oread<1, 0>()); track(k5w_oread<1, 1>()); track(k5w_oread<1, 2>()); track(k5w_oread<1, 3>());
+        }
+        const bool lbad = (__float_as_uint(l_run[0]) & 0x7FFFFFFFu) >= 0x71800000u || (__float_as_uint(l_run[1]) & 0x7FFFFFFFu) >= 0x71800000u;
+        const bool bad = used_static && (emax >= 0x7F800000u || lbad);
+        if (__builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) redo_flag = 1;
+        __syncthreads();
+        if (redo_flag == 0) break;               // (a second pass leaves the flag set: it is the last one)
+    }
+    }   // pass
 
     // ---------------- epilogue ----------------
     asm volatile("s_nop 11" ::: "memory");   // (the last block's last MFMA -> the reads of O below)
@@ -490,7 +561,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     auto finish_half = [&](auto HX) {
         constexpr int x = decltype(HX)::value;
-        const int grow2 = qblk2 * 128 + 64 * wv + 32 * x + r;
+        const int grow2 = qblk2 * RW + 64 * wv + 32 * x + r;
         const float mrun = thr[x] == -INFINITY ? -INFINITY : m_ref[x];
         const auto swl = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run[x]), __float_as_uint(l_run[x]), false, false);
         const float l_tot = __uint_as_float(swl[0]) + __uint_as_float(swl[1]);
@@ -592,8 +663,19 @@ int rsa_launch_bsfwd64(const AttnArgs& a, dim3 grid, size_t lds_bytes, int dtype
     lds_bytes += 16;   // the loop reads its list two entries ahead
 #ifdef RSA_K5_FORMS
 #define RSA_K5W_XLAUNCH(N) if (g_rsa_k5w_form == N && dtype == RSA_BF16 && wide) { RSA_LAUNCH_GSYNC(1, (bsfwd64_kernel<bf16_tag, true, N>), a, a.mode == MODE_SPARSE, grid, 128, lds_bytes, s); return rsa_launch_status(); }
-    RSA_K5W_XLAUNCH(1) RSA_K5W_XLAUNCH(2) RSA_K5W_XLAUNCH(3) RSA_K5W_XLAUNCH(4) RSA_K5W_XLAUNCH(5) RSA_K5W_XLAUNCH(6) RSA_K5W_XLAUNCH(7) RSA_K5W_XLAUNCH(8) RSA_K5W_XLAUNCH(9) RSA_K5W_XLAUNCH(10) RSA_K5W_XLAUNCH(11) RSA_K5W_XLAUNCH(12) RSA_K5W_XLAUNCH(13) RSA_K5W_XLAUNCH(14) RSA_K5W_XLAUNCH(15) RSA_K5W_XLAUNCH(16) RSA_K5W_XLAUNCH(17) RSA_K5W_XLAUNCH(18) RSA_K5W_XLAUNCH(19) RSA_K5W_XLAUNCH(20) RSA_K5W_XLAUNCH(21)
+    RSA_K5W_XLAUNCH(1) RSA_K5W_XLAUNCH(2) RSA_K5W_XLAUNCH(3) RSA_K5W_XLAUNCH(4) RSA_K5W_XLAUNCH(5) RSA_K5W_XLAUNCH(6) RSA_K5W_XLAUNCH(7) RSA_K5W_XLAUNCH(8) RSA_K5W_XLAUNCH(9) RSA_K5W_XLAUNCH(10) RSA_K5W_XLAUNCH(11) RSA_K5W_XLAUNCH(12) RSA_K5W_XLAUNCH(13) RSA_K5W_XLAUNCH(14) RSA_K5W_XLAUNCH(15) RSA_K5W_XLAUNCH(16) RSA_K5W_XLAUNCH(17) RSA_K5W_XLAUNCH(18) RSA_K5W_XLAUNCH(19) RSA_K5W_XLAUNCH(20) RSA_K5W_XLAUNCH(21) RSA_K5W_XLAUNCH(22) RSA_K5W_XLAUNCH(23) RSA_K5W_XLAUNCH(24) RSA_K5W_XLAUNCH(25) RSA_K5W_XLAUNCH(26)
 #endif
+    if (a.rows256) {     // dense calls: 256-row tiles, four waves on one K/V ring (the host counted the grid in such tiles)
+        if (a.mode != MODE_DENSE) return RSA_ERR_BAD_ARG;
+        if (dtype == RSA_BF16) {
+            if (wide) RSA_LAUNCH_GSYNC(1, (bsfwd64_kernel<bf16_tag, true, 0, 4>), a, false, grid, 256, lds_bytes, s);
+            else RSA_LAUNCH_GSYNC(1, (bsfwd64_kernel<bf16_tag, false, 0, 4>), a, false, grid, 256, lds_bytes, s);
+        } else {
+            if (wide) RSA_LAUNCH_GSYNC(1, (bsfwd64_kernel<fp16_tag, true, 0, 4>), a, false, grid, 256, lds_bytes, s);
+            else RSA_LAUNCH_GSYNC(1, (bsfwd64_kernel<fp16_tag, false, 0, 4>), a, false, grid, 256, lds_bytes, s);
+        }
+        return rsa_launch_status();
+    }
     if (dtype == RSA_BF16) {
         if (wide) RSA_LAUNCH_GSYNC(1, (bsfwd64_kernel<bf16_tag, true>), a, a.mode == MODE_SPARSE, grid, 128, lds_bytes, s);
         else RSA_LAUNCH_GSYNC(1, (bsfwd64_kernel<bf16_tag, false>), a, a.mode == MODE_SPARSE, grid, 128, lds_bytes, s);

@@ -920,6 +920,110 @@ __global__ __launch_bounds__(D * 2) void compensation_kernel(const float* w, con
 }
 
 // =====================================================================================================
+// K4, split form (round 6; the product): the same product on the 2-byte matrix pipe.  comp is a tolerance-only quantity
+// (<= 1e-5 against the oracle's fp32 chain), so the fp32 operands are split x = hi + lo + rest, hi = bf16(x), lo = bf16(x - hi)
+// (|rest| <= 2^-17 |x|), and w . vbar = hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: three MFMAs of
+// 32 cycles per 16 j where the fp32 chain takes eight of 64 -- 5.3x fewer matrix cycles; the dropped terms are 2^-16 relative per
+// product (measured on the headline shape: max |comp - oracle| 3e-7, tests/test_gpu_select_paths.py).
+// Same tiling as the chain form (32 rows x D per workgroup, wave = one 32 x 32 tile, j in chunks, register-staged loads of the
+// next chunk in flight during the MFMAs).  The STAGING threads do the split, once per element: the chunk sits in LDS as four
+// bf16 planes [row][64 j] -- w hi / lo by query-block row, vbar hi / lo TRANSPOSED ([d][j], written as packed pairs of adjacent
+// j, so both operands are k-contiguous: lane (r, h) of the MFMA phase reads its 8 bf16 of a k-step with two ds_read_b64).
+// Row stride 136 B: writes of a wave fall on 16 banks twice (free), the b64 reads on 32 distinct even bank pairs.
+// =====================================================================================================
+typedef short k4_s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 k4_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 k4_bf16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void k4_split2(float x0, float x1, unsigned& hi, unsigned& lo) {
+    k4_bf16x2 h2;
+    h2[0] = (__bf16)x0; h2[1] = (__bf16)x1;
+    hi = __builtin_bit_cast(unsigned, h2);
+    const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xFFFF0000u);
+    k4_bf16x2 l2;
+    l2[0] = (__bf16)r0; l2[1] = (__bf16)r1;
+    lo = __builtin_bit_cast(unsigned, l2);
+}
+__device__ __forceinline__ k4_bf16x8 k4_read8(const unsigned char* p) {   // 8 bf16 = two 8-byte aligned LDS reads
+    const uint2 a = *reinterpret_cast<const uint2*>(p), b = *reinterpret_cast<const uint2*>(p + 8);
+    const uint4 v = make_uint4(a.x, a.y, b.x, b.y);
+    return __builtin_bit_cast(k4_bf16x8, v);
+}
+
+template <int D>
+__global__ __launch_bounds__(D * 2) void compensation_split_kernel(const float* w, const float* vbar, float* comp, int NBv,
+                                                                   int L, int NB_total) {
+    constexpr int TJ = 64, RS = 2 * TJ + 8, NT = D * 2, RPP = NT / 32, WP = 32 / RPP, VP = TJ / 4;
+    __shared__ __attribute__((aligned(16))) unsigned char Wh[32 * RS], Wl[32 * RS], Vh[D * RS], Vl[D * RS];
+    const int bh = blockIdx.y, i0 = blockIdx.x * 32, t = threadIdx.x, lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const float* wp = w + (long)bh * NBv * L;
+    const float* vp = vbar + (long)bh * NB_total * D;
+    k2_f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    // staging slots of this thread: w pairs (row (t >> 5) + RPP k, j = 2 (t & 31)), vbar pairs (d = t % D, j = 2 (t / D + 2 k))
+    const int wj = 2 * (t & 31), wi = t >> 5, vd = t % D, vj = 2 * (t / D);
+    float wr[WP][2], vr[VP][2];
+    auto load_chunk = [&](int j0) {
+#pragma unroll
+        for (int k = 0; k < WP; ++k) {
+            const float* row = wp + (long)min(i0 + wi + RPP * k, NBv - 1) * L;   // rows past NBv feed outputs that are not stored
+            const int j = j0 + wj;
+            wr[k][0] = j < L ? row[j] : 0.0f;
+            wr[k][1] = j + 1 < L ? row[j + 1] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < VP; ++k) {
+            const int j = j0 + vj + 4 * k;
+            vr[k][0] = j < L ? vp[(long)j * D + vd] : 0.0f;
+            vr[k][1] = j + 1 < L ? vp[(long)(j + 1) * D + vd] : 0.0f;
+        }
+    };
+    load_chunk(0);
+    const unsigned char* pah = Wh + r * RS + 16 * h;
+    const unsigned char* pal = Wl + r * RS + 16 * h;
+    const unsigned char* pbh = Vh + (32 * wv + r) * RS + 16 * h;
+    const unsigned char* pbl = Vl + (32 * wv + r) * RS + 16 * h;
+    for (int j0 = 0; j0 < L; j0 += TJ) {
+        __syncthreads();   // the previous chunk's LDS reads are done
+#pragma unroll
+        for (int k = 0; k < WP; ++k) {
+            unsigned hi, lo;
+            k4_split2(wr[k][0], wr[k][1], hi, lo);
+            const int off = (wi + RPP * k) * RS + 2 * wj;
+            *reinterpret_cast<unsigned*>(Wh + off) = hi;
+            *reinterpret_cast<unsigned*>(Wl + off) = lo;
+        }
+#pragma unroll
+        for (int k = 0; k < VP; ++k) {
+            unsigned hi, lo;
+            k4_split2(vr[k][0], vr[k][1], hi, lo);
+            const int off = vd * RS + 2 * (vj + 4 * k);
+            *reinterpret_cast<unsigned*>(Vh + off) = hi;
+            *reinterpret_cast<unsigned*>(Vl + off) = lo;
+        }
+        __syncthreads();
+        if (j0 + TJ < L) load_chunk(j0 + TJ);   // in flight during the MFMAs below
+#pragma unroll
+        for (int ks = 0; ks < TJ / 16; ++ks) {
+            const k4_bf16x8 ah = k4_read8(pah + 32 * ks), al = k4_read8(pal + 32 * ks);
+            const k4_bf16x8 bh8 = k4_read8(pbh + 32 * ks), bl8 = k4_read8(pbl + 32 * ks);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh8, acc, 0, 0, 0);   // the small terms first
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl8, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh8, acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int i = i0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (i < NBv) comp[((long)bh * NBv + i) * D + 32 * wv + r] = acc[e];
+    }
+}
+int g_rsa_k4_split = 1;   // tuning key "k4_split": 0 = the fp32 chain form (A/B, tests)
+
+// =====================================================================================================
 // stand-alone GAPR mask for estimate_pr_gain callers: mask = !(|s| > |aq.kbar| + |qbar.ak|)
 // =====================================================================================================
 __global__ void gapr_compare_kernel(const float* qbar, const float* aq, const float* kbar, const float* ak,
@@ -1134,6 +1238,13 @@ extern "C" int rsa_compensation(const rsa_layout* l, const rsa_buffers* buf, voi
     const int L = l->NBv + (l->n_txt > 0 ? 1 : 0);
     hipStream_t s = static_cast<hipStream_t>(stream);
     dim3 grid((l->NBv + 31) / 32, l->B * l->H);
+    // (measured, HunyuanVideo 720p: 24 heads 66.8 -> 58.8 us, 3 heads 30.7 -> 34.3 us: the split form only where the grid fills the chip;
+    // k4_split = 2 forces it)
+    if (g_rsa_k4_split == 2 || (g_rsa_k4_split == 1 && (long)grid.x * grid.y >= 512)) {
+        if (l->D == 128) compensation_split_kernel<128><<<grid, 256, 0, s>>>(buf->w, buf->vbar, buf->comp, l->NBv, L, l->NB_total);
+        else compensation_split_kernel<64><<<grid, 128, 0, s>>>(buf->w, buf->vbar, buf->comp, l->NBv, L, l->NB_total);
+        return rsa_launch_status();
+    }
     if (l->D == 128) compensation_kernel<128><<<grid, 256, 0, s>>>(buf->w, buf->vbar, buf->comp, l->NBv, L, l->NB_total);
     else compensation_kernel<64><<<grid, 128, 0, s>>>(buf->w, buf->vbar, buf->comp, l->NBv, L, l->NB_total);
     return rsa_launch_status();

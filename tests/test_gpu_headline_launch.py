@@ -73,7 +73,7 @@ def test_the_24_head_headline_launch_is_checked_and_aligned_starts_do_not_change
         L.rsa_set_tuning(b"k5_gsync", 1)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "aligned starts changed the output bytes"
     counts = call.bufs["counts"]
-    assert int(counts.min()) == TOP_K + 2 and int(counts.max()) == TOP_K + 2      # R2: exactly top_k visual + the two text blocks
+    assert int(counts.min()) >= TOP_K + 1 and int(counts.max()) == TOP_K + 2      # R2: top_k columns (the text column may be one of them) + the two text blocks
     chk = bench.check_output(call, spec)
     assert chk["ok"] and chk["finite"], chk
     assert chk["blocks"] >= 24 and chk["text_rows"] == 3 * spec.q_text_valid

@@ -227,3 +227,42 @@ def test_k5_32row_kernel_still_serves_head_dim_128(name, dt):
     ulp = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10
     assert np.abs(outs[0] - outs[1]).max() <= ulp * max(1.0, np.abs(ref).max())
 
+
+
+@pytest.mark.parametrize("cfg", [("hunyuan", 2, 115456, 115400, 128, 90), ("wan", 3, 27280, 0, 128, 53),
+                                 ("cogvideo", 3, 42466, 226, 64, 82), ("wan", 2, 4000, 0, 128, 4)])
+def test_k4_split_form_against_fp64_and_the_chain_form(cfg):
+    """K4 (round 6): comp = w . vbar on the 2-byte matrix pipe with the fp32 operands split hi + lo (three MFMAs per product), at
+    full-size rows (901 columns, HunyuanVideo), a padded layout, head dim 64 and a short ragged one.  comp is a tolerance-only
+    quantity: <= 1e-5 against the oracle (tests/test_gpu_parity.py); here both forms against an fp64 product of the device's own
+    w and vbar, and against each other."""
+    from rectified_spaattn_amd import _core, _lib
+    from bench import gen_qkv
+    variant, H, S, aux, D, top_k = cfg
+    if variant == "hunyuan":
+        spec = _core.LayoutSpec.hunyuan(S, aux)
+    elif variant == "cogvideo":
+        spec = _core.LayoutSpec.cogvideo(S, aux)
+    else:
+        spec = _core.LayoutSpec.wan(S, 2)
+    q, k, v = gen_qkv(H, 0, S, S, D, torch.device(DEV), seed=31)
+    L = _lib.lib()
+    comps = {}
+    try:
+        for form in (1, 0):
+            assert L.rsa_set_tuning(b"k4_split", 2 * form) == 0        # (2 = the split form at every grid size)
+            call = _core.StagedCall(q, k, v, spec, top_k, 0.05, None, reuse_buffers=False)
+            call.select()
+            torch.cuda.synchronize()
+            comps[form] = call.bufs["comp"].clone()
+            if form == 1:
+                w, vbar = call.bufs["w"].double(), call.bufs["vbar"].double()
+                ref = torch.einsum("hij,hjd->hid", w, vbar[:, : w.shape[-1]])
+                mag = float(torch.einsum("hij,hjd->hid", w.abs(), vbar[:, : w.shape[-1]].abs()).max())   # sum |w| |vbar|
+    finally:
+        L.rsa_set_tuning(b"k4_split", 1)
+    # the split form drops terms of 2^-16 per product (bound: 2^-15 sum |w| |vbar|); the chain form is fp32-exact to ~1e-7 relative
+    for form, rel in ((1, 3.1e-5), (0, 1e-6)):
+        err = float((comps[form].double() - ref).abs().max())
+        assert err <= rel * mag + 1e-12 and err <= 2e-6, (form, err, mag)
+    assert mag > 0.0
