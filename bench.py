@@ -890,7 +890,7 @@ def main():
                             ms_per_step=round(r2["ms_per_step"], 4), value=round(r2["value"], 3),
                             k5_ms=round(r2["k5_ms"], 4), k5_tflops=round(r2["k5_tflops"], 2),
                             k5_frac=round(r2["k5_tflops"] / peak_, 4), select_pass_ms=round(r2["select_pass_ms"], 4))
-            tb, _ = load_traffic(f"r05_k5_traffic_{rg}{traffic_suffix(args.qkv_fp8)}.json")
+            tb, _ = load_traffic(f"r06_k5_traffic_{rg}{traffic_suffix(args.qkv_fp8)}.json")
             regs[rg]["traffic"] = tb
         extras["regimes"] = regs
         if not args.qkv_fp8 and args.workload == "hunyuan_720p_128f":
@@ -907,7 +907,7 @@ def main():
         return
 
     peak = k5_peak(args.qkv_fp8)
-    tname = f"r05_k5_traffic_{main_regime}{traffic_suffix(args.qkv_fp8)}.json"
+    tname = f"r06_k5_traffic_{main_regime}{traffic_suffix(args.qkv_fp8)}.json"
     traffic, tnote = (None, "N > 1: traffic is collected at N = 1")
     if world == 1:
         traffic, tnote = load_traffic(tname) if args.workload == "hunyuan_720p_128f" else (None, "no committed traffic json for this workload")

@@ -546,6 +546,12 @@ FORMS = {
     24: dict(xf={"max8"}, tight=True, pre=24),                      # VALID: one max3 chain per half
     25: dict(xf={"maxfirst", "earlytest", "max8", "cvtlag4"}, tight=True, pre=24),
     26: dict(xf={"maxfirst", "earlytest", "max8"}, tight=True, pre=24),
+    # round 6, on top of the static body (= form 27: the online machinery removed; valid on ordinary data, no overflow check)
+    27: dict(xf={"nomax", "notest"}, tight=True, pre=24),
+    28: dict(xf={"nomax", "notest"}, tight=True, pre=24, dma_cost=4),     # vector work may share a gap with an LDS-DMA piece
+    29: dict(xf={"nomax", "notest"}, tight=True, pre=0),                  # no vector work in front of a block's first MFMA
+    30: dict(xf={"nomax", "notest"}, tight=True, pre=48),
+    31: dict(xf={"nomax", "notest"}, tight=True, pre=24, dma_cost=12),
     18: dict(xf={"noadd"}, tight=True, pre=24),                     # no row-sum additions (what moving them to the matrix pipe could buy at most)
     19: dict(xf={"nomax", "notest"}, tight=True, pre=24),           # no row maxima, no rescale test
     20: dict(xf={"novalu", "notest"}, tight=True, pre=24),          # form 4 on the product's schedule

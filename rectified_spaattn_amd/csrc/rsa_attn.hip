@@ -13,6 +13,7 @@ static int g_k5_tsplit = 1;     // 1 = split-KV for the text query blocks when t
 extern int g_rsa_k3_prefix;
 extern int g_rsa_k3_long;
 extern int g_rsa_k4_split;
+extern int g_rsa_k2_dma;
 static int g_k5_tail_split = 1; // 64-row kernel: the last, partial generation's walks split over its idle slots (k5w_map)
 static int g_k5_text_last = 1;  // 64-row kernel: split text-row pieces at the end of the grid (rsa_attn_kernel64.hip::k5w_map)
 static int g_shard_invariant = 0; // rsa_set_shard_invariant: nothing about a row's arithmetic may depend on the size of the launch
@@ -46,6 +47,7 @@ extern "C" int rsa_set_tuning(const char* key, int value) {
     if (strcmp(key, "k3_prefix") == 0) { g_rsa_k3_prefix = value; return RSA_OK; }
     if (strcmp(key, "k3_long") == 0) { g_rsa_k3_long = value; return RSA_OK; }
     if (strcmp(key, "k4_split") == 0) { g_rsa_k4_split = value; return RSA_OK; }
+    if (strcmp(key, "k2_dma") == 0) { g_rsa_k2_dma = value; return RSA_OK; }
 #ifdef RSA_K5_FORMS
     if (strcmp(key, "k5_form") == 0) { g_rsa_k5_form = value; return RSA_OK; }
     if (strcmp(key, "k5w_form") == 0) { g_rsa_k5w_form = value; return RSA_OK; }
@@ -379,6 +381,9 @@ static int dense_fwd(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4
     a.mode = MODE_DENSE; a.H = H; a.Sq = Sq; a.Sk = Sk;
     // head dim 128 through the 64-row kernel: 256-row tiles once there are at least two of them (a shorter call keeps 128-row tiles)
     a.rows256 = (D == 128 && (g_k5_w64 & 1) && g_k5_rows256 && Sq > 256) ? 1 : 0;
+#ifdef RSA_K5_FORMS
+    if (g_rsa_k5w_form != 0) a.rows256 = 0;     // (the A/B forms are forms of the 128-row kernel)
+#endif
     const int rw = a.rows256 ? 2 * RSA_BLOCK : RSA_BLOCK;
     a.NQB = (Sq + rw - 1) / rw; a.NBv = a.NQB; a.NB_total = (Sk + RSA_BLOCK - 1) / RSA_BLOCK;
     a.kv_valid = Sk; a.kv_text_valid = Sk; a.q_text_end = 0;

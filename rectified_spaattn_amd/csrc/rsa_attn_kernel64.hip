@@ -482,7 +482,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #define RSA_K5W_XFORM(N) else if constexpr (XF == N) \
             asm volatile(RSA_K5W_LOOP_BF16_X##N RSA_K5W_OPS_LOOP : RSA_K5W_CLOBBER_TMP, RSA_K5W_CLOBBER_O, RSA_K5W_CLOBBER_LOOP, "memory");
         if constexpr (false) {}
-        RSA_K5W_XFORM(1) RSA_K5W_XFORM(2) RSA_K5W_XFORM(3) RSA_K5W_XFORM(4) RSA_K5W_XFORM(5) RSA_K5W_XFORM(6) RSA_K5W_XFORM(7) RSA_K5W_XFORM(8) RSA_K5W_XFORM(9) RSA_K5W_XFORM(10) RSA_K5W_XFORM(11) RSA_K5W_XFORM(12) RSA_K5W_XFORM(13) RSA_K5W_XFORM(14) RSA_K5W_XFORM(15) RSA_K5W_XFORM(16) RSA_K5W_XFORM(17) RSA_K5W_XFORM(18) RSA_K5W_XFORM(19) RSA_K5W_XFORM(20) RSA_K5W_XFORM(21) RSA_K5W_XFORM(22) RSA_K5W_XFORM(23) RSA_K5W_XFORM(24) RSA_K5W_XFORM(25) RSA_K5W_XFORM(26)
+        RSA_K5W_XFORM(1) RSA_K5W_XFORM(2) RSA_K5W_XFORM(3) RSA_K5W_XFORM(4) RSA_K5W_XFORM(5) RSA_K5W_XFORM(6) RSA_K5W_XFORM(7) RSA_K5W_XFORM(8) RSA_K5W_XFORM(9) RSA_K5W_XFORM(10) RSA_K5W_XFORM(11) RSA_K5W_XFORM(12) RSA_K5W_XFORM(13) RSA_K5W_XFORM(14) RSA_K5W_XFORM(15) RSA_K5W_XFORM(16) RSA_K5W_XFORM(17) RSA_K5W_XFORM(18) RSA_K5W_XFORM(19) RSA_K5W_XFORM(20) RSA_K5W_XFORM(21) RSA_K5W_XFORM(22) RSA_K5W_XFORM(23) RSA_K5W_XFORM(24) RSA_K5W_XFORM(25) RSA_K5W_XFORM(26) RSA_K5W_XFORM(27) RSA_K5W_XFORM(28) RSA_K5W_XFORM(29) RSA_K5W_XFORM(30) RSA_K5W_XFORM(31)
         else
 #endif
         if constexpr (NW == 4 && std::is_same<Tag, bf16_tag>::value)
@@ -663,7 +663,7 @@ int rsa_launch_bsfwd64(const AttnArgs& a, dim3 grid, size_t lds_bytes, int dtype
     lds_bytes += 16;   // the loop reads its list two entries ahead
 #ifdef RSA_K5_FORMS
 #define RSA_K5W_XLAUNCH(N) if (g_rsa_k5w_form == N && dtype == RSA_BF16 && wide) { RSA_LAUNCH_GSYNC(1, (bsfwd64_kernel<bf16_tag, true, N>), a, a.mode == MODE_SPARSE, grid, 128, lds_bytes, s); return rsa_launch_status(); }
-    RSA_K5W_XLAUNCH(1) RSA_K5W_XLAUNCH(2) RSA_K5W_XLAUNCH(3) RSA_K5W_XLAUNCH(4) RSA_K5W_XLAUNCH(5) RSA_K5W_XLAUNCH(6) RSA_K5W_XLAUNCH(7) RSA_K5W_XLAUNCH(8) RSA_K5W_XLAUNCH(9) RSA_K5W_XLAUNCH(10) RSA_K5W_XLAUNCH(11) RSA_K5W_XLAUNCH(12) RSA_K5W_XLAUNCH(13) RSA_K5W_XLAUNCH(14) RSA_K5W_XLAUNCH(15) RSA_K5W_XLAUNCH(16) RSA_K5W_XLAUNCH(17) RSA_K5W_XLAUNCH(18) RSA_K5W_XLAUNCH(19) RSA_K5W_XLAUNCH(20) RSA_K5W_XLAUNCH(21) RSA_K5W_XLAUNCH(22) RSA_K5W_XLAUNCH(23) RSA_K5W_XLAUNCH(24) RSA_K5W_XLAUNCH(25) RSA_K5W_XLAUNCH(26)
+    RSA_K5W_XLAUNCH(1) RSA_K5W_XLAUNCH(2) RSA_K5W_XLAUNCH(3) RSA_K5W_XLAUNCH(4) RSA_K5W_XLAUNCH(5) RSA_K5W_XLAUNCH(6) RSA_K5W_XLAUNCH(7) RSA_K5W_XLAUNCH(8) RSA_K5W_XLAUNCH(9) RSA_K5W_XLAUNCH(10) RSA_K5W_XLAUNCH(11) RSA_K5W_XLAUNCH(12) RSA_K5W_XLAUNCH(13) RSA_K5W_XLAUNCH(14) RSA_K5W_XLAUNCH(15) RSA_K5W_XLAUNCH(16) RSA_K5W_XLAUNCH(17) RSA_K5W_XLAUNCH(18) RSA_K5W_XLAUNCH(19) RSA_K5W_XLAUNCH(20) RSA_K5W_XLAUNCH(21) RSA_K5W_XLAUNCH(22) RSA_K5W_XLAUNCH(23) RSA_K5W_XLAUNCH(24) RSA_K5W_XLAUNCH(25) RSA_K5W_XLAUNCH(26) RSA_K5W_XLAUNCH(27) RSA_K5W_XLAUNCH(28) RSA_K5W_XLAUNCH(29) RSA_K5W_XLAUNCH(30) RSA_K5W_XLAUNCH(31)
 #endif
     if (a.rows256) {     // dense calls: 256-row tiles, four waves on one K/V ring (the host counted the grid in such tiles)
         if (a.mode != MODE_DENSE) return RSA_ERR_BAD_ARG;

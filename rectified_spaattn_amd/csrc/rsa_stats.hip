@@ -292,12 +292,109 @@ __device__ __forceinline__ void pooled_scores_tile(const ScoreArgs& a, int bh, i
     }
 }
 
+// K2, visual columns, round 6: the same three fp32 chains fed by LDS-DMA into a DOUBLE-BUFFERED tile, one barrier per 32-k chunk, no
+// register staging (the lever profiles/r05_k2_experiments.md names).  The chunk of an operand is [64 rows][32 k] fp32 = 8 KiB as
+// eight 1-KiB pieces (8 rows x 128 B); wave w stages operand w (q, k, aq, ak) with global_load_lds_dwordx4 -- the LDS image of a
+// piece is lane-linear, so the bank swizzle is applied to the SOURCE: position c of row `row` holds the row's 16-byte chunk
+// c ^ ((row >> 1) & 7).  Lane (r, h) of the MFMA phase reads the four k of TWO chain steps with one ds_read_b128 (conflict-free: the
+// 16 lanes of a b128 group cover 16 distinct (row & 1, chunk position) pairs) and picks k = 2 step + h by its lane half -- the
+// chain is the contract's, operand for operand, so scores and GAPR bytes are bit-identical to the register-staged form (tests:
+// test_gpu_select_paths.py::test_k2_dma_form_equals_the_staged_form).  Per chunk: wait for the own pieces of chunk c, ONE barrier
+// (chunk c visible to everyone, everyone past chunk c - 1), issue chunk c + 1 into the other buffer, 16 x 3 MFMAs.
+template <typename Tag, int DK>
+__device__ __forceinline__ void pooled_scores_tile_dma(const ScoreArgs& a, int bh, int i0, int j0, float* smem) {
+    // DK = k per chunk: 32 (rows of 128 B, two 32-KiB buffers: two workgroups per CU) or 16 (rows of 64 B, two 16-KiB buffers: the
+    // register-staged form's three workgroups per CU and more)
+    constexpr int ROWB = DK * 4, OPB = 64 * ROWB, BUFB = 4 * OPB, NPC = OPB / 1024, RPP = 1024 / ROWB, LPR = ROWB / 16;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wi = wv >> 1, wj = wv & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int D = a.D, NBv = a.NBv;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+    auto swz = [](int row) -> int { return DK == 32 ? (row >> 1) & 7 : (row >> 2) & 3; };
+    // ---- staging: wave w moves operand w; piece p = rows RPP p .. of the tile, lane (rr = lane / LPR, c = lane % LPR) ----
+    const float* opbase = (wv == 0 ? a.qbar : wv == 1 ? a.kbar : wv == 2 ? a.aq : a.ak) + (long)bh * NBv * D;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)opbase);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)opbase >> 32));
+    const unsigned char* base = reinterpret_cast<const unsigned char*>(((unsigned long)hi << 32) | lo);
+    const int row0 = (wv & 1) ? j0 : i0;                          // q / aq rows follow i, k / ak rows follow j
+    const int rr = lane / LPR, c = lane % LPR;
+    unsigned voff[NPC];
+#pragma unroll
+    for (int p = 0; p < NPC; ++p) {
+        const int row = RPP * p + rr;
+        const int grow = min(row0 + row, NBv - 1);                // rows past the matrix edge feed outputs that are never stored
+        voff[p] = (unsigned)(((long)grow * D + 4 * (c ^ swz(row))) * 4);
+    }
+    auto stage = [&](int d0, int buf) {
+        const unsigned dst = lds0 + buf * BUFB + wv * OPB;
+#pragma unroll
+        for (int p = 0; p < NPC; ++p)
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                         :: "v"(voff[p] + (unsigned)(d0 * 4)), "s"(base), "s"(dst + p * 1024) : "memory");
+    };
+    const bool live = i0 + 32 * wi < NBv && j0 + 32 * wj < NBv;   // wave-uniform: a dead wave only stages
+    k2_f32x16 s, eq, ek;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { s[i] = 0.0f; eq[i] = 0.0f; ek[i] = 0.0f; }
+    // per-lane read addresses (bytes inside a buffer): operand o, row, chunk position m ^ g -- g is the same for every operand
+    const int g = swz(r);
+    const unsigned char* sm = reinterpret_cast<const unsigned char*>(smem);
+    const int offq = 0 * OPB + (32 * wi + r) * ROWB, offk = 1 * OPB + (32 * wj + r) * ROWB;
+    const int offa = 2 * OPB + (32 * wi + r) * ROWB, offb = 3 * OPB + (32 * wj + r) * ROWB;
+    stage(0, 0);
+    int buf = 0;
+    for (int d0 = 0; d0 < D; d0 += DK, buf ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of the chunk have landed
+        __syncthreads();                                          // ... everyone's have, and everyone has left the other buffer
+        if (d0 + DK < D) stage(d0 + DK, buf ^ 1);
+        if (!live) continue;
+        const unsigned char* bb = sm + buf * BUFB;
+#pragma unroll
+        for (int m = 0; m < DK / 4; ++m) {
+            const int pos = (m ^ g) << 4;
+            const float4 q4 = *reinterpret_cast<const float4*>(bb + offq + pos);
+            const float4 k4 = *reinterpret_cast<const float4*>(bb + offk + pos);
+            const float4 a4 = *reinterpret_cast<const float4*>(bb + offa + pos);
+            const float4 b4 = *reinterpret_cast<const float4*>(bb + offb + pos);
+            // step 2m: k = d0 + 4m + h; step 2m + 1: k = d0 + 4m + 2 + h
+            const float q0 = h ? q4.y : q4.x, q1 = h ? q4.w : q4.z, k0 = h ? k4.y : k4.x, k1 = h ? k4.w : k4.z;
+            const float a0 = h ? a4.y : a4.x, a1 = h ? a4.w : a4.z, b0 = h ? b4.y : b4.x, b1 = h ? b4.w : b4.z;
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(q0, k0, s, 0, 0, 0);
+            eq = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, k0, eq, 0, 0, 0);
+            ek = __builtin_amdgcn_mfma_f32_32x32x2f32(q0, b0, ek, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(q1, k1, s, 0, 0, 0);
+            eq = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, k1, eq, 0, 0, 0);
+            ek = __builtin_amdgcn_mfma_f32_32x32x2f32(q1, b1, ek, 0, 0, 0);
+        }
+    }
+    if (!live) return;
+    const int j = j0 + 32 * wj + r;
+    if (j >= NBv) return;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int i = i0 + 32 * wi + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (i >= NBv) continue;
+        a.scores[((long)bh * NBv + i) * a.NS + j] = s[e];
+        a.unrel[((long)bh * NBv + i) * NBv + j] = !(fabsf(s[e]) > (fabsf(eq[e]) + fabsf(ek[e])));
+    }
+}
+// MEASURED SLOWER than the register-staged form on every shape (profiles/r06_k2_dma.txt, interleaved: HunyuanVideo 24 heads 197.7 us
+// with 16-k chunks / 210.0 with 32-k chunks against 187.9; Wan2.1 40 heads 136.2 / 141.9 / 129.7; 3 heads and Wan2.2 equal within
+// 1 us): the staging pipeline is NOT what bounds K2 -- it sits on the fp32 matrix pipe at the clock the chip holds (16.3 GFLOP in
+// 188 us = 87 TFLOP/s of the 98 a 1.5 GHz clock gives).  Kept as an A/B form (bit-identical by test), off by default.
+int g_rsa_k2_dma = 0;   // tuning key "k2_dma": k per LDS-DMA chunk (32 / 16); 0 = the register-staged form (the product)
+
 // One launch for both column kinds.  1-D grid, XCD-aware: workgroup ids go round-robin over the 8 XCDs, so XCD c takes the
 // c-th contiguous eighth of the (bh, i-tile, j-tile) space -- whole heads per XCD, whose pooled operands (1.8 MB per head)
 // then stay in that L2.  Within a head's row of tiles the visual column tiles come first, then the text-token tiles.
-template <typename Tag>
+template <typename Tag, int DMA>
 __global__ __launch_bounds__(256) void pooled_scores_kernel(ScoreArgs a) {
-    __shared__ __attribute__((aligned(16))) float tile[4][64 * 36];
+    // DMA form: two buffers of four [64][32] operand chunks (64 KiB: two workgroups per CU); the register-staged form (text-token
+    // tiles always, visual tiles when DMA is off) uses the first 36 KiB as its padded [4][64 x 36] tile
+    __shared__ __attribute__((aligned(1024))) float smem[DMA == 32 ? 2 * 4 * 64 * 32 : 4 * 64 * 36];      // (DMA 16: 32 KiB of it)
+    float (*tile)[64 * 36] = reinterpret_cast<float (*)[64 * 36]>(smem);
     const int nti = (a.NBv + 63) / 64, ntj0 = (a.NBv + 63) / 64, ntj1 = (a.n_txt + 63) / 64, ntj = ntj0 + ntj1;
     const int per = (int)(gridDim.x >> 3);          // the grid is a multiple of 8
     const int wid = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
@@ -305,8 +402,10 @@ __global__ __launch_bounds__(256) void pooled_scores_kernel(ScoreArgs a) {
     const int bh = wid / (nti * ntj);
     const int rem = wid % (nti * ntj);
     const int i0 = (rem / ntj) * 64, tj = rem % ntj;
-    if (tj < ntj0) pooled_scores_tile<0, Tag>(a, bh, i0, tj * 64, tile);
-    else pooled_scores_tile<1, Tag>(a, bh, i0, (tj - ntj0) * 64, tile);
+    if (tj < ntj0) {
+        if constexpr (DMA != 0) pooled_scores_tile_dma<Tag, DMA>(a, bh, i0, tj * 64, smem);
+        else pooled_scores_tile<0, Tag>(a, bh, i0, tj * 64, tile);
+    } else pooled_scores_tile<1, Tag>(a, bh, i0, (tj - ntj0) * 64, tile);
 }
 
 // =====================================================================================================
@@ -1158,8 +1257,17 @@ extern "C" int rsa_pooled_scores(const rsa_layout* l, rsa_tensor4 k, const rsa_b
     const unsigned nti = (unsigned)((l->NBv + 63) / 64);
     a.BH = BH;
     dim3 g0((nti * (nti + (unsigned)((l->n_txt + 63) / 64)) * BH + 7) / 8 * 8);
-    if (l->dtype == RSA_BF16) pooled_scores_kernel<bf16_tag><<<g0, 256, 0, s>>>(a);
-    else pooled_scores_kernel<fp16_tag><<<g0, 256, 0, s>>>(a);
+    // (the DMA form addresses an operand row as a 32-bit byte offset from its head's base: NBv * D * 4 < 2^32 always -- NBv <= 8 192)
+    if (g_rsa_k2_dma == 32 && (l->D % 32) == 0) {
+        if (l->dtype == RSA_BF16) pooled_scores_kernel<bf16_tag, 32><<<g0, 256, 0, s>>>(a);
+        else pooled_scores_kernel<fp16_tag, 32><<<g0, 256, 0, s>>>(a);
+    } else if (g_rsa_k2_dma == 16 && (l->D % 32) == 0) {
+        if (l->dtype == RSA_BF16) pooled_scores_kernel<bf16_tag, 16><<<g0, 256, 0, s>>>(a);
+        else pooled_scores_kernel<fp16_tag, 16><<<g0, 256, 0, s>>>(a);
+    } else {
+        if (l->dtype == RSA_BF16) pooled_scores_kernel<bf16_tag, 0><<<g0, 256, 0, s>>>(a);
+        else pooled_scores_kernel<fp16_tag, 0><<<g0, 256, 0, s>>>(a);
+    }
     return rsa_launch_status();
 }
 

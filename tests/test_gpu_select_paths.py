@@ -266,3 +266,35 @@ def test_k4_split_form_against_fp64_and_the_chain_form(cfg):
         err = float((comps[form].double() - ref).abs().max())
         assert err <= rel * mag + 1e-12 and err <= 2e-6, (form, err, mag)
     assert mag > 0.0
+
+
+@pytest.mark.parametrize("cfg", [("hunyuan", 2, 115456, 115400, 128, torch.bfloat16), ("wan", 3, 27280, 0, 128, torch.float16),
+                                 ("cogvideo", 3, 42466, 226, 64, torch.bfloat16), ("wan", 2, 4000, 0, 128, torch.bfloat16),
+                                 ("flux", 2, 66048, 512, 128, torch.bfloat16), ("wan", 5, 128 * 65 - 3, 0, 64, torch.float16)])
+def test_k2_dma_form_equals_the_staged_form(cfg):
+    """K2 (round 6): the visual tiles' operands through LDS-DMA into a double-buffered tile (one barrier per chunk, swizzled source
+    chunks, the two chain steps of a ds_read_b128 picked by lane half) against the register-staged form: the chains are the same
+    operand for operand, so every score and every GAPR byte must be EQUAL -- full-size rows, edge tiles (NBv not a multiple of 64),
+    text-token tiles beside them, both head dims and dtypes."""
+    from rectified_spaattn_amd import _core, _lib
+    from bench import gen_qkv
+    variant, H, S, aux, D, dt = cfg
+    spec = {"hunyuan": lambda: _core.LayoutSpec.hunyuan(S, aux), "cogvideo": lambda: _core.LayoutSpec.cogvideo(S, aux),
+            "flux": lambda: _core.LayoutSpec.flux(S, aux), "wan": lambda: _core.LayoutSpec.wan(S, 2)}[variant]()
+    q, k, v = (x.to(dt) for x in gen_qkv(H, 0, S, S, D, torch.device(DEV), seed=37))
+    L = _lib.lib()
+    got = {}
+    try:
+        for form in (32, 16, 0):
+            assert L.rsa_set_tuning(b"k2_dma", form) == 0
+            call = _core.StagedCall(q, k, v, spec, 8, 0.1, None, reuse_buffers=False)
+            call.bufs["scores"].fill_(float("nan")); call.bufs["unrel"].fill_(7)
+            call.select()
+            torch.cuda.synchronize()
+            got[form] = {n: call.bufs[n].clone() for n in ("scores", "unrel", "bitmask", "counts", "R")}
+    finally:
+        L.rsa_set_tuning(b"k2_dma", 0)
+    for form in (32, 16):
+        assert not torch.isnan(got[form]["scores"]).any() and int(got[form]["unrel"].max()) <= 1      # every element was written
+        for n in got[form]:
+            assert torch.equal(got[form][n].view(torch.uint8), got[0][n].view(torch.uint8)), (form, n)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Prints README.md's results table from profiles/r05_bench*.json (the final set of the round: tools/final_run_r5.sh), so that the
+"""Prints README.md's results table from profiles/r06_bench*.json (the final set of the round: tools/final_run_r5.sh), so that the
 table and the committed bench lines cannot drift apart.  usage: python tools/readme_table.py"""
 import json
 import os
@@ -24,7 +24,7 @@ def pc(x):
 
 
 def main():
-    b, f, p = L("r05_bench.json"), L("r05_bench_fp8.json"), L("r05_bench_pv.json")
+    b, f, p = L("r06_bench.json"), L("r06_bench_fp8.json"), L("r06_bench_pv.json")
     rb, rf, rp = b["roofline"], f["roofline"], p["roofline"]
     print("| workload (24 heads unless noted, D = 128) | K5 operands | layer | algorithmic | block-sparse kernel (fraction of the dense MFMA peak of its operands) |")
     print("|---|---|---|---|---|")
@@ -45,7 +45,7 @@ def main():
            ("wan21", "Wan2.1-T2V 720p 81f, 40 heads, S = 75 600, 25 % kept"),
            ("cogvideox", "CogVideoX1.5 768p 81f, 48 heads, **D = 64**, S = 42 466, 25 % kept (`--workload cogvideox_768p_81f`)")]
     for k, name in wls:
-        x, y, z = L(f"r05_bench_{k}.json"), L(f"r05_bench_{k}_pv.json"), L(f"r05_bench_{k}_fp8.json")
+        x, y, z = L(f"r06_bench_{k}.json"), L(f"r06_bench_{k}_pv.json"), L(f"r06_bench_{k}_fp8.json")
         print(f"| {name} | bf16 / pv / e4m3 | {ms(x['ms_per_step'])} / {ms(y['ms_per_step'])} / {ms(z['ms_per_step'])} ms | {tf(x['value'])} / {tf(y['value'])} / {tf(z['value'])} TFLOP/s | "
               f"{pc(x['roofline']['frac'])} / {pc(y['roofline']['frac'])} / {pc(z['roofline']['frac'])} |")
     print(f"| dense attention 16k × 16k (`box_ref`, the same kernel in dense mode) | bf16 | {ms(b['box_ref']['ms'])} ms | {tf(b['box_ref']['tflops'])} TFLOP/s | "

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Replaces README.md's results table with tools/readme_table.py's output (numbers from profiles/r05_bench*.json)."""
+"""Replaces README.md's results table with tools/readme_table.py's output (numbers from profiles/r06_bench*.json)."""
 import io
 import os
 import sys
