@@ -944,8 +944,7 @@ def main():
         "roofline": {"kernel": ("bsfwd_fp8_kernel<..., HYB> (K5 block_sparse_fwd_fp8pv; peak = both products at their own dense peaks: "
                                 "half the FLOPs at 2.5, half at 5 PFLOP/s)") if args.qkv_fp8 == "pv" else
                      "bsfwd_fp8_kernel (K5 block_sparse_fwd_fp8)" if args.qkv_fp8 else
-                     ("bsfwd64_kernel<bf16_tag,...> (K5 block_sparse_fwd, 64 rows per wave)" if D == 128 else
-                      "bsfwd_kernel<64,bf16_tag,...> (K5 block_sparse_fwd)"), "bound": "mfma",
+                     f"bsfwd64_kernel<bf16_tag,..., D = {D}> (K5 block_sparse_fwd, 64 rows per wave)", "bound": "mfma",
                      "achieved": round(rec["k5_tflops"], 2), "peak": peak, "unit": "TFLOP/s",
                      "frac": round(rec["k5_tflops"] / peak, 4), "traffic": traffic, "traffic_note": tnote,
                      "compulsory_bytes": 4 * 2 * H_local * S * D,

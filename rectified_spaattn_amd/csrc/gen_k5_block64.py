@@ -57,6 +57,27 @@ COST = dict(exp=8, cvt=5, add=4, max=4, mov=4, swap=4, lds=4, wait=1, dma=24)   
 D, KS, DT = 128, 8, 4
 HALF = 32 * D * 2             # bytes of a 32-key half-tile
 VRING = 4 * HALF              # LDS offset of the V ring
+NQK, NPV, NMF = 2 * KS, 4 * DT, 2 * KS + 4 * DT      # MFMAs of a block: scores, P . V, all
+PFX = "K5W"                   # macro prefix: K5W = head dim 128, K5V = head dim 64
+
+
+def configure(d):
+    """Head dim of the streams generated from here on (round 6: 64 beside 128).  Head dim 64: 8 + 8 MFMAs per 32-key sub-step against
+    the same softmax; a half-tile is 4 KiB = 4 LDS-DMA pieces (2 per wave), so the loop issues 2 + 2 pieces per sub-step."""
+    global D, KS, DT, HALF, VRING, NQK, NPV, NMF, PFX, DMA_GAPS, SALU_AT, VMC, GAPC
+    D, KS, DT = d, d // 16, d // 32
+    HALF = 32 * D * 2
+    VRING = 4 * HALF
+    NQK, NPV, NMF = 2 * KS, 4 * DT, 2 * KS + 4 * DT
+    PFX = "K5W" if d == 128 else "K5V"
+    if d == 128:
+        DMA_GAPS = [4 * j + 1 for j in range(8)]
+        SALU_AT = dict(k=22, k3=(22, 23, 24), v=30, h1=(2, 3))
+        VMC, GAPC = 16, 24
+    else:
+        DMA_GAPS = [1, 3, 9, 11]        # K0 K1 | V0 V1: the wave's 2 + 2 pieces of the sub-step
+        SALU_AT = dict(k=4, k3=(4, 5, 6), v=12, h1=(2, 3))
+        VMC, GAPC = 8, 36
 
 # ---- register map ----
 SA = [0, 16]
@@ -78,15 +99,19 @@ S_CLOB = list(range(80, 98))
 LOOP_XF = frozenset({"maxfirst", "earlytest"})
 LOOP_PRE = 24                 # issue cycles of vector work the loop's blocks put in front of their first MFMA (the boundary blocks: 64)
 DMA_GAPS = [4 * j + 1 for j in range(8)]      # the 8 gaps that carry the wave's LDS-DMA pieces: every fourth gap
+SALU_AT = dict(k=22, k3=(22, 23, 24), v=30, h1=(2, 3))     # gaps of the loop's scalar bookkeeping (gen_loop, tight)
+VMC = 16                      # LDS-DMA pieces of the last two sub-steps that may still fly at a sub-step boundary
+GAPC = 24                     # issue cycles of vector work dealt into one MFMA gap (head dim 64: 36 -- 16 MFMAs per sub-step cannot hide
+                              # the softmax of 64 x 32 scores, the stream is paced by the vector port there)
 STATS = None
 
 
 def AO(h, dt):
-    return 16 * (4 * h + dt)
+    return 16 * (DT * h + dt)
 
 
 def AQ(h, ks):
-    return 128 + 4 * (8 * h + ks)
+    return 32 * DT + 4 * (KS * h + ks)
 
 
 def vr(a, n=1):
@@ -156,7 +181,7 @@ def gen_block(dt, U, dma, chain=None, xf=frozenset(), dma_cost=None, pre=64, sal
                     + [("add", f"v_add_f32 {vr(PS[h])}, {vr(PS[h])}, {vr(SC[h] + i)}", pos[(h, i)] + 1) for i in range(2, 16)]
                     + [("add", f"v_add_f32 %[l{h}], %[l{h}], {vr(PS[h])}", 32)])
     addq = [x for pair in zip(*adds) for x in pair]      # the two halves' chains interleaved
-    E = 17             # S_nxt[1]'s last MFMA is MFMA 15: its readers sit two or more MFMAs behind it
+    E = NQK + 1        # S_nxt[1]'s last MFMA is MFMA NQK - 1: its readers sit two or more MFMAs behind it
     maxq = []
     for h in (0, 1):
         maxq += [("max", f"v_max_f32 {vr(T[2 * h])}, {vr(SN[h])}, {vr(SN[h] + 1)}")]
@@ -196,7 +221,7 @@ def gen_block(dt, U, dma, chain=None, xf=frozenset(), dma_cost=None, pre=64, sal
         EXP = []
         cvq = [(k, t, 0) for k, t, _ in cvq]
         addq = [(k, t, 0) for k, t, _ in addq]
-    dcost = COST["dma"] if dma_cost is None else dma_cost
+    dcost = (COST["dma"] if D == 128 else 4) if dma_cost is None else dma_cost
     dgaps = DMA_GAPS if dma else []
     salu = salu or {}
     ei = 0             # exponentials issued
@@ -218,7 +243,7 @@ def gen_block(dt, U, dma, chain=None, xf=frozenset(), dma_cost=None, pre=64, sal
                 k, t, need = cvq.pop(0)
                 lines.append(t); used += COST[k]; progress = True
                 continue
-            if ei < len(EXP) and (nexp < 2 or gap < 0 or final):
+            if ei < len(EXP) and (nexp < (2 if D == 128 else 3) or gap < 0 or final):
                 h, i = EXP[ei]
                 lines.append(f"v_exp_f32 {vr(SC[h] + i)}, {vr(SC[h] + i)}")
                 last_exp_line = len(lines) - 1
@@ -272,8 +297,8 @@ def gen_block(dt, U, dma, chain=None, xf=frozenset(), dma_cost=None, pre=64, sal
         lds_seq.extend(((("K", ks), 1)) for ks in range(AHEAD))      # in flight since the previous block's tail
     emit_slot(pre, -1)
     usage = []
-    for i in range(32):
-        if i < 16:
+    for i in range(NMF):
+        if i < NQK:
             ks, h = divmod(i, 2)
             if h == 0:
                 wait_for(("K", ks))
@@ -287,10 +312,10 @@ def gen_block(dt, U, dma, chain=None, xf=frozenset(), dma_cost=None, pre=64, sal
             fixed = 0
             if h == 1 and ks + AHEAD < KS:
                 k_read(ks + AHEAD); fixed += COST["lds"]
-            if h == 0 and ks >= 4:           # V^T fragments 0..3 ride the last QK^T shadows (gaps 8, 10, 12, 14)
-                v_read(ks - 4); fixed += 2 * COST["lds"]
+            if h == 0 and ks >= KS - AHEAD:   # V^T fragments 0..3 ride the last QK^T shadows (head dim 128: gaps 8, 10, 12, 14)
+                v_read(ks - (KS - AHEAD)); fixed += 2 * COST["lds"]
         else:
-            p, h = divmod(i - 16, 2)
+            p, h = divmod(i - NQK, 2)
             k2, d = divmod(p, DT)
             if h == 0:
                 text = "\n".join(lines)
@@ -298,7 +323,7 @@ def gen_block(dt, U, dma, chain=None, xf=frozenset(), dma_cost=None, pre=64, sal
                     for jj in range(4):
                         assert "novalu" in xf or "nocvt" in xf or f"{cv} {vr(P[hh] + 4 * k2 + jj)}," in text, (dt, U, "P not packed before PV", p)
                 wait_for(("V", p))
-            if chain is not None and i == 30:
+            if chain is not None and i == NMF - 2:
                 lines.extend(chain)
                 nk = ((U + 2) & 3) * HALF
                 if "nolds" not in xf:
@@ -314,7 +339,7 @@ def gen_block(dt, U, dma, chain=None, xf=frozenset(), dma_cost=None, pre=64, sal
         lines.extend(salu.get(i, []))      # scalar bookkeeping of the loop riding in this gap (free beside an MFMA)
         if i in dgaps:
             dma_piece(); fixed += dcost
-        usage.append(fixed + emit_slot(24 - fixed, i, final=(i == 31)))
+        usage.append(fixed + emit_slot(GAPC - fixed, i, final=(i == NMF - 1)))
     assert ei == len(EXP) and not cvq and not addq and not maxq and not tail, (dt, U, "vector work left over")
     assert dma_j == len(dgaps)
     if STATS is not None:
@@ -364,7 +389,7 @@ def rescale_core(S, al, de, ng):
     """O[h] *= al[h], S[h] -= de[h], -m[h] = ng[h] for both halves (operand names given per half)."""
     lines = ["s_nop 11"]     # the last PV MFMA of the preceding block wrote O: 12 wait states before it is read
     for h in (0, 1):
-        for g in range(0, 64, 8):
+        for g in range(0, 16 * DT, 8):
             base = AO(h, 0) + g
             lines += [f"v_accvgpr_read_b32 {vr(TMP0 + j)}, {ar(base + j)}" for j in range(8)]
             lines += [f"v_mul_f32 {vr(TMP0 + j)}, {vr(TMP0 + j)}, {al[h]}" for j in range(8)]
@@ -438,14 +463,14 @@ def gen_loop(dt, diag=False, xf=frozenset(), dma_cost=None, pre=64, tight=False,
     def boundary(diag):
         """end of a sub-step: the pieces of two blocks ago have landed, every wave has finished its LDS reads"""
         if not diag:
-            return ([] if "novm" in xf else [f"s_waitcnt vmcnt({8 if 'halfdma' in xf else 16})"]) + ([] if "nobar" in xf else ["s_barrier"])
-        tm, tt = sr(76, 2), sr(S_T2)
+            return ([] if "novm" in xf else [f"s_waitcnt vmcnt({VMC // 2 if 'halfdma' in xf else VMC})"]) + ([] if "nobar" in xf else ["s_barrier"])
+        tm, tt = sr(76, 2), sr(75)      # (not S_T2: the rescale test's second compare mask lives there from the block's tail to its end)
         return [f"s_memtime {tm}", "s_waitcnt lgkmcnt(0)", f"s_mov_b32 {tt}, s76", "s_waitcnt vmcnt(16)",
                 f"s_memtime {tm}", "s_waitcnt lgkmcnt(0)", f"s_sub_u32 {tt}, s76, {tt}", f"s_add_u32 s78, s78, {tt}",
                 f"s_mov_b32 {tt}, s76", "s_barrier",
                 f"s_memtime {tm}", "s_waitcnt lgkmcnt(0)", f"s_sub_u32 {tt}, s76, {tt}", f"s_add_u32 s79, s79, {tt}"]
     # entry: the boundary in front of the first block and its first K reads (slot 1: U = 0 reads K(u+1))
-    L += [f"s_waitcnt vmcnt({8 if 'halfdma' in xf else 16})", "s_barrier"] + [f"ds_read_b128 {vr(KF + 4 * ks, 4)}, {vr(KA + ks)} offset:{HALF}" for ks in range(AHEAD)]
+    L += [f"s_waitcnt vmcnt({VMC // 2 if 'halfdma' in xf else VMC})", "s_barrier"] + [f"ds_read_b128 {vr(KF + 4 * ks, 4)}, {vr(KA + ks)} offset:{HALF}" for ks in range(AHEAD)]
     if diag:
         L += ["s_mov_b32 s78, 0", "s_mov_b32 s79, 0"]
     if static:
@@ -483,20 +508,21 @@ def gen_loop(dt, diag=False, xf=frozenset(), dma_cost=None, pre=64, tight=False,
                 # steps (U = 3: is re-based on the next kept block) behind gap 21, the V walker steps behind gap 29 -- except in
                 # front of block 1, which re-bases it in its own gaps 2..4, ahead of its first V piece.
                 salu = {}
+                g3, gh = SALU_AT["k3"], SALU_AT["h1"]
                 if U == 3:
                     k0 = [l for l in gen_loop_head0(t0, t1)]
-                    salu[22] = nxt[:1] + k0[:2]
-                    salu[23] = k0[2:5]
-                    salu[24] = k0[5:] + nxt[1:]
+                    salu[g3[0]] = nxt[:1] + k0[:2]
+                    salu[g3[1]] = k0[2:5]
+                    salu[g3[2]] = k0[5:] + nxt[1:]
                 else:
-                    salu[22] = kstep
+                    salu[SALU_AT["k"]] = kstep
                 if U == 0:
                     pass                      # (block 1 re-bases the V walker itself)
                 else:
-                    salu[30] = vstep
+                    salu[SALU_AT["v"]] = vstep
                 if U == 1:
-                    salu[2] = head[:3]
-                    salu[3] = head[3:]
+                    salu[gh[0]] = head[:3]
+                    salu[gh[1]] = head[3:]
                 blk = gen_block(dt, U, True, chain=tail, xf=xf, dma_cost=dma_cost, pre=pre, salu=salu)
             # deferred-rescale test on the scores the NEXT block consumes (S_nxt of this block)
             tst = ["v_cmp_gt_f32 vcc, %[mx0], %[th0]", f"v_cmp_gt_f32 {sr(S_T2, 2)}, %[mx1], %[th1]",
@@ -573,7 +599,16 @@ def c_string(lines):
 
 
 def main():
-    out = ["// GENERATED by gen_k5_block64.py -- do not edit; edit the generator (its docstring says what this is).", "#pragma once", ""]
+    print("// GENERATED by gen_k5_block64.py -- do not edit; edit the generator (its docstring says what this is).\n#pragma once\n")
+    for d in (128, 64):      # RSA_K5W_* = head dim 128, RSA_K5V_* = head dim 64 (the same streams on 8 + 8 MFMAs per sub-step)
+        configure(d)
+        text = main_one()
+        print(text if d == 128 else text.replace("RSA_K5W_", "RSA_K5V_"))
+    configure(128)
+
+
+def main_one():
+    out = []
     for dt in ("bf16", "f16"):
         for U in range(4):
             out.append(f"#define RSA_K5W_BLOCK_{dt.upper()}_U{U} \\")
@@ -584,9 +619,10 @@ def main():
         out.append("")
         # the 256-row dense form (four waves on one K/V ring): the same loop with every second LDS-DMA piece dropped -- each wave stages
         # 2 + 2 of a half-tile's 8 + 8 pieces (lane offset registers 0 and 2), vmcnt(8) at the sub-step boundary
-        out.append(f"#define RSA_K5W_LOOP_{dt.upper()}_R256 \\")
-        out.append(c_string(gen_loop(dt, pre=LOOP_PRE, tight=True, static=(dt == "bf16"), xf=LOOP_XF | {"halfdma"})))
-        out.append("")
+        if D == 128:
+            out.append(f"#define RSA_K5W_LOOP_{dt.upper()}_R256 \\")
+            out.append(c_string(gen_loop(dt, pre=LOOP_PRE, tight=True, static=(dt == "bf16"), xf=LOOP_XF | {"halfdma"})))
+            out.append("")
         out.append(f"#define RSA_K5W_LOOP_{dt.upper()}_DIAG \\")
         out.append(c_string(gen_loop(dt, diag=True, pre=LOOP_PRE, tight=True, xf=LOOP_XF)))
         out.append("")
@@ -621,17 +657,18 @@ def main():
     out.append("")
     # accumulator-file housekeeping: zero O, write one Q fragment, read one O tile
     out.append("#define RSA_K5W_OZERO \\")
-    out.append(c_string([f"v_accvgpr_write_b32 {ar(i)}, 0" for i in range(128)]))
+    out.append(c_string([f"v_accvgpr_write_b32 {ar(i)}, 0" for i in range(32 * DT)]))
     out.append("")
+    # (k-steps / d tiles a head dim does not have get an empty body: the C++ side names all of them and discards by `if constexpr`)
     for h in (0, 1):
-        for ks in range(KS):
+        for ks in range(8):
             out.append(f"#define RSA_K5W_QWRITE_H{h}_K{ks} \\")
-            out.append(c_string([f"v_accvgpr_write_b32 {ar(AQ(h, ks) + j)}, {vr(TMP0 + j)}" for j in range(4)]))
+            out.append(c_string([f"v_accvgpr_write_b32 {ar(AQ(h, ks) + j)}, {vr(TMP0 + j)}" for j in range(4)] if ks < KS else ["s_nop 0"]))
             out.append("")
     for h in (0, 1):
-        for d in range(DT):
+        for d in range(4):
             out.append(f"#define RSA_K5W_OREAD_H{h}_D{d} \\")
-            out.append(c_string([f"v_accvgpr_read_b32 {vr(TMP0 + j)}, {ar(AO(h, d) + j)}" for j in range(16)]))
+            out.append(c_string([f"v_accvgpr_read_b32 {vr(TMP0 + j)}, {ar(AO(h, d) + j)}" for j in range(16)] if d < DT else ["s_nop 0"]))
             out.append("")
     # operand lists
     souts = [f'"+{{{vr(SA[h], 16)}}}"(SA[{h}])' for h in (0, 1)] + [f'"+{{{vr(SB[h], 16)}}}"(SB[{h}])' for h in (0, 1)]
@@ -659,17 +696,17 @@ def main():
                    f"[de0] \"v\"(de0), [de1] \"v\"(de1), [ng0] \"v\"(ng0), [ng1] \"v\"(ng1)")
     out.append(f"#define RSA_K5W_OPS_NMZERO : \"={{{vr(NM[0], 16)}}}\"(nm[0]), \"={{{vr(NM[1], 16)}}}\"(nm[1])")
     tmp = ", ".join(f'"v{r}"' for r in range(TMP0, TMP1))
-    acc_o = ", ".join(f'"a{r}"' for r in range(128))
-    acc_q = ", ".join(f'"a{r}"' for r in range(128, 192))
+    acc_o = ", ".join(f'"a{r}"' for r in range(32 * DT))
+    acc_q = ", ".join(f'"a{r}"' for r in range(32 * DT, 32 * DT + 8 * KS))
     out.append(f"#define RSA_K5W_CLOBBER_TMP {tmp}")
     out.append(f"#define RSA_K5W_CLOBBER_O {acc_o}")
     out.append(f"#define RSA_K5W_CLOBBER_Q {acc_q}")
     out.append("#define RSA_K5W_CLOBBER_LOOP " + ", ".join(f'"s{r}"' for r in S_CLOB) + ', "vcc", "scc"')
-    out.append('#define RSA_K5W_CLOBBER_LOOP_DIAG "s76", "s77", "s78", "s79"')
-    out.append(f"// O a[0:127], Q a[128:191]; SA v[0:31], SB v[32:63], -m v[64:95], temporaries v[{TMP0}:{TMP1 - 1}] "
+    out.append('#define RSA_K5W_CLOBBER_LOOP_DIAG "s75", "s76", "s77", "s78", "s79"')
+    out.append(f"// head dim {D}: O a[0:{32 * DT - 1}], Q a[{32 * DT}:{32 * DT + 8 * KS - 1}]; SA v[0:31], SB v[32:63], -m v[64:95], temporaries v[{TMP0}:{TMP1 - 1}] "
                f"(P v[96:111], K ring v[112:127], V ring v[128:143]), K addresses v[{KA}:{KA + 7}], V addresses v[{VA}:{VA + 7}], "
                f"DMA lane offsets v[{VOK}:{VOV + 1}]; the loop statement owns s[{S_CLOB[0]}:{S_CLOB[-1]}]")
-    print("\n".join(out))
+    return "\n".join(out)
 
 
 if __name__ == "__main__":

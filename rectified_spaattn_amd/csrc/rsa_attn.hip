@@ -34,8 +34,8 @@ static unsigned long long g_dbg_ptr = 0;   // diagnostics build: device buffer f
 void rsa_set_fp8_variant(int v);
 void rsa_set_fp8_smooth_k(int v);
 int rsa_launch_bsfwd(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int dtype, hipStream_t s);
-int rsa_launch_bsfwd64(const AttnArgs& a, dim3 grid, size_t lds_bytes, int dtype, hipStream_t s);
-static int g_k5_w64 = 1;        // head dim 128: bit 0 = the 64-rows-per-wave kernel (rsa_attn_kernel64.hip, the product); 0 = the 32-row kernel (A/B)
+int rsa_launch_bsfwd64(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int dtype, hipStream_t s);
+static int g_k5_w64 = 3;        // the 64-rows-per-wave kernel (rsa_attn_kernel64.hip): bit 0 = at head dim 128, bit 1 = at head dim 64 (round 6); a clear bit = the 32-row kernel (A/B)
 
 // Tuning / diagnostics hook (not part of the data path).  The switches are process-global, so the hook only works in a
 // process that opted in with the environment variable RSA_TUNING=1 (the A/B tools and the variant tests); a production
@@ -313,8 +313,9 @@ static int launch_attn(AttnArgs& a, int BH, int D, int dtype, size_t tpart_bytes
     if (nblocks > 0x7FFFFFFF) return RSA_ERR_UNSUPPORTED;
     if (a.NB_total > 8192) return RSA_ERR_UNSUPPORTED;  // kept list lives in LDS as u16, 16 KiB max
     const size_t lds_bytes = (size_t)4 * 64 * D * 2 + (((size_t)a.NB_total * 2 + 15) & ~(size_t)15);
-    const int st = (D == 128 && (g_k5_w64 & 1)) ? rsa_launch_bsfwd64(a, dim3((unsigned)nblocks), lds_bytes, dtype, s)
-                                          : rsa_launch_bsfwd(a, dim3((unsigned)nblocks), lds_bytes, D, dtype, s);
+    const bool use64 = (D == 128 && (g_k5_w64 & 1)) || (D == 64 && (g_k5_w64 & 2));
+    const int st = use64 ? rsa_launch_bsfwd64(a, dim3((unsigned)nblocks), lds_bytes, D, dtype, s)
+                         : rsa_launch_bsfwd(a, dim3((unsigned)nblocks), lds_bytes, D, dtype, s);
     if (st != RSA_OK) return st;
     if (a.tail_n > 0) {
         const int st2 = launch_tail_combine(a, dtype, s);

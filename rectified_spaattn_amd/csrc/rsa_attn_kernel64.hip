@@ -25,32 +25,43 @@
 #include "rsa_attn_block64_forms.h"
 #endif
 
+// One asm site serves both head dims: RSA_K5W_* (128) / RSA_K5V_* (64) of rsa_attn_block64.h, same arch-register map, different
+// accumulator map (O a[0:32 DT - 1], Q behind it) -- hence the clobber lists by prefix.
+#define RSA_K5W_CL_TO RSA_K5W_CLOBBER_TMP, RSA_K5W_CLOBBER_O
+#define RSA_K5V_CL_TO RSA_K5V_CLOBBER_TMP, RSA_K5V_CLOBBER_O
+#define RSA_K5W_CL_LOOP RSA_K5W_CLOBBER_TMP, RSA_K5W_CLOBBER_O, RSA_K5W_CLOBBER_LOOP
+#define RSA_K5V_CL_LOOP RSA_K5V_CLOBBER_TMP, RSA_K5V_CLOBBER_O, RSA_K5V_CLOBBER_LOOP
+#define RSA_K5_ASM(D_, BODY, OPS, CL, ...) \
+    do { \
+        if constexpr ((D_) == 128) asm volatile(RSA_K5W_##BODY RSA_K5W_##OPS : RSA_K5W_##CL __VA_ARGS__); \
+        else asm volatile(RSA_K5V_##BODY RSA_K5V_##OPS : RSA_K5V_##CL __VA_ARGS__); \
+    } while (0)
+
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // block U without LDS-DMA (the C++-driven sub-steps)
-template <typename Tag, int U>
+template <typename Tag, int U, int D>
 __device__ __forceinline__ void k5w_block(f32x16 (&SA)[2], f32x16 (&SB)[2], const f32x16 (&nm)[2], float (&l)[2], float (&mx)[2],
                                           const i32x8& ka, const i32x8& va) {
-#define RSA_K5W_CL RSA_K5W_CLOBBER_TMP, RSA_K5W_CLOBBER_O
     if constexpr (std::is_same<Tag, bf16_tag>::value) {
-        if constexpr (U == 0) asm volatile(RSA_K5W_BLOCK_BF16_U0 RSA_K5W_OPS : RSA_K5W_CL, "memory");
-        else if constexpr (U == 1) asm volatile(RSA_K5W_BLOCK_BF16_U1 RSA_K5W_OPS : RSA_K5W_CL, "memory");
-        else if constexpr (U == 2) asm volatile(RSA_K5W_BLOCK_BF16_U2 RSA_K5W_OPS : RSA_K5W_CL, "memory");
-        else asm volatile(RSA_K5W_BLOCK_BF16_U3 RSA_K5W_OPS : RSA_K5W_CL, "memory");
+        if constexpr (U == 0) RSA_K5_ASM(D, BLOCK_BF16_U0, OPS, CL_TO, , "memory");
+        else if constexpr (U == 1) RSA_K5_ASM(D, BLOCK_BF16_U1, OPS, CL_TO, , "memory");
+        else if constexpr (U == 2) RSA_K5_ASM(D, BLOCK_BF16_U2, OPS, CL_TO, , "memory");
+        else RSA_K5_ASM(D, BLOCK_BF16_U3, OPS, CL_TO, , "memory");
     } else {
-        if constexpr (U == 0) asm volatile(RSA_K5W_BLOCK_F16_U0 RSA_K5W_OPS : RSA_K5W_CL, "memory");
-        else if constexpr (U == 1) asm volatile(RSA_K5W_BLOCK_F16_U1 RSA_K5W_OPS : RSA_K5W_CL, "memory");
-        else if constexpr (U == 2) asm volatile(RSA_K5W_BLOCK_F16_U2 RSA_K5W_OPS : RSA_K5W_CL, "memory");
-        else asm volatile(RSA_K5W_BLOCK_F16_U3 RSA_K5W_OPS : RSA_K5W_CL, "memory");
+        if constexpr (U == 0) RSA_K5_ASM(D, BLOCK_F16_U0, OPS, CL_TO, , "memory");
+        else if constexpr (U == 1) RSA_K5_ASM(D, BLOCK_F16_U1, OPS, CL_TO, , "memory");
+        else if constexpr (U == 2) RSA_K5_ASM(D, BLOCK_F16_U2, OPS, CL_TO, , "memory");
+        else RSA_K5_ASM(D, BLOCK_F16_U3, OPS, CL_TO, , "memory");
     }
-#undef RSA_K5W_CL
 }
 
 // one Q fragment (4 registers, pinned to v[96:99]) -> its place in the accumulator file
-template <int Hh, int KSI>
+template <int Hh, int KSI, int D>
 __device__ __forceinline__ void k5w_qwrite(const s16x8& f) {
-#define RSA_QW(HH, KK) asm volatile(RSA_K5W_QWRITE_H##HH##_K##KK :: "{v[96:99]}"(f) : RSA_K5W_CLOBBER_Q)
+#define RSA_QW(HH, KK) do { if constexpr (D == 128) asm volatile(RSA_K5W_QWRITE_H##HH##_K##KK :: "{v[96:99]}"(f) : RSA_K5W_CLOBBER_Q); \
+                            else asm volatile(RSA_K5V_QWRITE_H##HH##_K##KK :: "{v[96:99]}"(f) : RSA_K5V_CLOBBER_Q); } while (0)
     if constexpr (Hh == 0) {
         if constexpr (KSI == 0) RSA_QW(0, 0); else if constexpr (KSI == 1) RSA_QW(0, 1); else if constexpr (KSI == 2) RSA_QW(0, 2);
         else if constexpr (KSI == 3) RSA_QW(0, 3); else if constexpr (KSI == 4) RSA_QW(0, 4); else if constexpr (KSI == 5) RSA_QW(0, 5);
@@ -63,10 +74,11 @@ __device__ __forceinline__ void k5w_qwrite(const s16x8& f) {
 #undef RSA_QW
 }
 // one 32 x 32 tile of O (rows of half Hh, d = 32 DTI .. +31) out of the accumulator file
-template <int Hh, int DTI>
+template <int Hh, int DTI, int D>
 __device__ __forceinline__ f32x16 k5w_oread() {
     f32x16 t;
-#define RSA_OR(HH, DD) asm volatile(RSA_K5W_OREAD_H##HH##_D##DD : "={v[96:111]}"(t))
+#define RSA_OR(HH, DD) do { if constexpr (D == 128) asm volatile(RSA_K5W_OREAD_H##HH##_D##DD : "={v[96:111]}"(t)); \
+                            else asm volatile(RSA_K5V_OREAD_H##HH##_D##DD : "={v[96:111]}"(t)); } while (0)
     if constexpr (Hh == 0) {
         if constexpr (DTI == 0) RSA_OR(0, 0); else if constexpr (DTI == 1) RSA_OR(0, 1); else if constexpr (DTI == 2) RSA_OR(0, 2); else RSA_OR(0, 3);
     } else {
@@ -128,12 +140,17 @@ __device__ __forceinline__ bool k5w_map(const AttnArgs& a, int work, int& bh, in
 // K/V ring -- every half-tile is staged once per 256 rows instead of once per 128, each wave issues 4 LDS-DMA pieces per sub-step
 // instead of 8 (what that buys at most: form x15 of profiles/r06_k5_forms.txt).  The loop statement is the same generator's with
 // every second piece dropped (gen_k5_block64.py, RSA_K5W_LOOP_*_R256); `qblk` then counts 256-row tiles (the host sets NQB so).
-template <typename Tag, bool WIDE, int XF = 0, int NW = 2>
+// D (round 6): head dim 128 or 64 (CogVideoX).  At 64 a sub-step is 8 + 8 MFMAs against the same softmax, a half-tile 4 KiB = four
+// LDS-DMA pieces of 8 rows (two per wave); same register map in the arch file, O in a[0:63], Q in a[64:95].
+template <typename Tag, bool WIDE, int XF = 0, int NW = 2, int D = 128>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 1))) void bsfwd64_kernel(AttnArgs a) {
-    constexpr int D = 128;
     constexpr int RW = 64 * NW;             // query rows per workgroup: NW waves x 64 rows
-    constexpr int NPW = 8 / NW;             // 1-KiB pieces of a 32-key half-tile each wave stages
+    constexpr int NPIECE = 32 * D * 2 / 1024;   // 1-KiB pieces of a 32-key half-tile: 8 (4 rows each) / 4 (8 rows each)
+    constexpr int NPW = NPIECE / NW;        // ... of them each wave stages
+    constexpr int RPP = 32 / NPIECE;        // key rows per piece
+    constexpr int LPR = 64 / RPP;           // lanes (16-byte chunks) per key row
     static_assert(NW == 2 || NW == 4, "two or four waves");
+    static_assert(D == 128 || (D == 64 && NW == 2 && XF == 0), "head dim 64: the 128-row product form only");
     constexpr int KS = D / 16;
     constexpr int DT = D / 32;
     constexpr int HALF = 32 * D * 2;        // bytes of a 32-key half-tile
@@ -243,7 +260,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 1)))
             }
             return E::cvt8(f);
         };
-#define RSA_QF(HH, KK) k5w_qwrite<HH, KK>(load_frag(HH, KK))
+#define RSA_QF(HH, KK) do { if constexpr (KK < KS) k5w_qwrite<HH, KK, D>(load_frag(HH, KK)); } while (0)
         RSA_QF(0, 0); RSA_QF(0, 1); RSA_QF(0, 2); RSA_QF(0, 3); RSA_QF(0, 4); RSA_QF(0, 5); RSA_QF(0, 6); RSA_QF(0, 7);
         RSA_QF(1, 0); RSA_QF(1, 1); RSA_QF(1, 2); RSA_QF(1, 3); RSA_QF(1, 4); RSA_QF(1, 5); RSA_QF(1, 6); RSA_QF(1, 7);
 #undef RSA_QF
@@ -259,20 +276,26 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 1)))
     };
     const unsigned char* kbase = uni64(reinterpret_cast<const unsigned char*>(a.k + (long)b * a.ksb + (long)h * a.ksh));
     const unsigned char* vbase = uni64(reinterpret_cast<const unsigned char*>(a.v + (long)b * a.vsb + (long)h * a.vsh));
-    // A 32-key half-tile = 8 one-KiB pieces of 4 rows; wave w moves pieces NW j + w (rows 4 NW j + 4w .. +3), j = 0 .. NPW - 1.  The
-    // XOR swizzle of a row's source chunk depends on (row & 3) and ((row >> 2) & 3) = (NW j + w) & 3: two per-lane offsets (even /
-    // odd j) with two waves, one with four; the piece walks a scalar base.
-    const int rsub = lane >> 4, cl = lane & 15;
-    const int rowl = 4 * wv + rsub;
-    const int gsw0 = cl ^ ((rsub << 2) | (wv & 3)), gsw1 = cl ^ ((rsub << 2) | ((NW + wv) & 3));
+    // A 32-key half-tile = NPIECE one-KiB pieces of RPP rows (8 x 4 rows at head dim 128, 4 x 8 rows at 64); wave w moves pieces
+    // NW j + w, j = 0 .. NPW - 1.  The XOR swizzle of a row's source chunk (rsa_attn.h::tile_off) depends on the row: at head dim 128
+    // on (row & 3) and ((row >> 2) & 3) = piece & 3 -- two per-lane offsets (even / odd j) with two waves, one with four --, at head
+    // dim 64 on (row >> 1) & 7, the same for both of the wave's pieces; the piece walks a scalar base.
+    const int rsub = lane / LPR, cl = lane % LPR;
+    const int rowl = RPP * wv + rsub;
+    const int gsw0 = D == 128 ? (cl ^ ((rsub << 2) | (wv & 3))) : (cl ^ ((4 * wv + (rsub >> 1)) & 7));
+    const int gsw1 = D == 128 ? (cl ^ ((rsub << 2) | ((NW + wv) & 3))) : gsw0;
     const unsigned krow = (unsigned)(a.kss * 2), vrow = (unsigned)(a.vss * 2);   // bytes per key row (< 4 GiB)
-    // lane offsets of the wave's pieces of a half-tile, for the loop's staging.  Two waves: piece j = rows 8j + rowl in register j;
-    // odd pieces carry the instruction offset 2048 (their LDS destination), which also moves the source: taken out here.  Four
-    // waves: the loop issues only its even slots (registers 0 and 2): piece j' = rows 16 j' + rowl in register 2 j'.
+    // lane offsets of the wave's pieces of a half-tile, for the loop's staging.  Head dim 128, two waves: piece j = rows 8j + rowl in
+    // register j; odd pieces carry the instruction offset 2048 (their LDS destination), which also moves the source: taken out here.
+    // Four waves: the loop issues only its even slots (registers 0 and 2): piece j' = rows 16 j' + rowl in register 2 j'.  Head dim
+    // 64: two pieces, rows 16 j + rowl in registers 0 and 1 (the second with the instruction offset 2048).
     u32x4 vok, vov;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        if constexpr (NW == 2) {
+        if constexpr (D == 64) {
+            vok[j] = j < 2 ? (16 * j + rowl) * krow + gsw0 * 16 - (j ? 2048u : 0u) : 0u;
+            vov[j] = j < 2 ? (16 * j + rowl) * vrow + gsw0 * 16 - (j ? 2048u : 0u) : 0u;
+        } else if constexpr (NW == 2) {
             vok[j] = (8 * j + rowl) * krow + ((j & 1) ? gsw1 : gsw0) * 16 - ((j & 1) ? 2048u : 0u);
             vov[j] = (8 * j + rowl) * vrow + ((j & 1) ? gsw1 : gsw0) * 16 - ((j & 1) ? 2048u : 0u);
         } else {
@@ -289,7 +312,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 1)))
         const unsigned rowb = is_v ? vrow : krow;
 #pragma unroll
         for (int j = 0; j < NPW; ++j) {
-            int krow_ = key_first + 4 * NW * j + rowl;
+            int krow_ = key_first + RPP * NW * j + rowl;
             krow_ = krow_ < kv_limit ? krow_ : kv_limit - 1;
             const unsigned vo = (unsigned)krow_ * rowb + ((j & 1) ? gsw1 : gsw0) * 16;
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
@@ -332,7 +355,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #endif
 #pragma nounroll
     for (int pass = 0; pass < 2; ++pass) {
-    asm volatile(RSA_K5W_OZERO ::: RSA_K5W_CLOBBER_O);
+    if constexpr (D == 128) asm volatile(RSA_K5W_OZERO ::: RSA_K5W_CLOBBER_O); else asm volatile(RSA_K5V_OZERO ::: RSA_K5V_CLOBBER_O);
     bool used_static = false;
     // ---------------- state ----------------
     // m_ref = the finite reference the scores are taken against, nm = its negation in 16 registers (C operand of the first
@@ -341,14 +364,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 1)))
     m_ref[0] = m_ref[1] = 0.0f;
     thr[0] = thr[1] = -INFINITY;
     f32x16 nm[2];
-    asm volatile(RSA_K5W_NMZERO RSA_K5W_OPS_NMZERO);
+    asm volatile(RSA_K5W_NMZERO RSA_K5W_OPS_NMZERO);      // (arch registers only: the same for both head dims)
 
     // per-lane LDS read addressing (half-tile rows 0..31 of slot 0; slot and k-step are immediates of the block)
-    const int kswz = ((r & 3) << 2) | ((r >> 2) & 3);
     const int g4 = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
     i32x8 ka, va;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) ka[ks] = (int)lds_base + r * 256 + (((2 * ks + hh) ^ kswz) << 4);
+    for (int i = 0; i < 8; ++i) { ka[i] = 0; va[i] = 0; }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) ka[ks] = (int)lds_base + tile_off<D>(r, 2 * ks + hh);
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
         const int ch = 4 * dt + 2 * (g4 & 1) + (tp >> 1);
@@ -380,8 +404,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 1)))
                 al[x] = alpha; de[x] = delta; ng[x] = -m_ref[x];
             }
             const float al0 = al[0], al1 = al[1], de0 = de[0], de1 = de[1], ng0 = ng[0], ng1 = ng[1];
-            if constexpr ((U & 1) == 0) asm volatile(RSA_K5W_RESCALE_A RSA_K5W_OPS_RESCALE_A : RSA_K5W_CLOBBER_TMP, RSA_K5W_CLOBBER_O);
-            else asm volatile(RSA_K5W_RESCALE_B RSA_K5W_OPS_RESCALE_B : RSA_K5W_CLOBBER_TMP, RSA_K5W_CLOBBER_O);
+            if constexpr ((U & 1) == 0) RSA_K5_ASM(D, RESCALE_A, OPS_RESCALE_A, CL_TO);
+            else RSA_K5_ASM(D, RESCALE_B, OPS_RESCALE_B, CL_TO);
         }
     };
     // One C++-driven sub-step u (U = u & 3): wait + barrier, staging of V(u+3) and K(u+4) (rows clamped), boundary mask and
@@ -390,7 +414,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 1)))
         constexpr int U = decltype(UC)::value;
         float (&mx_cur)[2] = (U & 1) == 0 ? mxA : mxB;
         float (&mx_nxt)[2] = (U & 1) == 0 ? mxB : mxA;
-        if (u + 4 <= n_sub) { if constexpr (NW == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+        if (u + 4 <= n_sub) { if constexpr (NW == 2 && D == 128) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (u + 3 < n_sub) dma_half(1, key_of(u + 3), VRING + ((U + 3) & 3) * HALF);
@@ -409,7 +433,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 1)))
             }
         }
         rescale_check(UC, mx_cur, SA, SB, nm);
-        k5w_block<Tag, U>(SA, SB, nm, l_run, mx_nxt, ka, va);
+        k5w_block<Tag, U, D>(SA, SB, nm, l_run, mx_nxt, ka, va);
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -434,10 +458,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 1)))
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         float (&mx)[2] = mxA;
-        if constexpr (std::is_same<Tag, bf16_tag>::value)
-            asm volatile(RSA_K5W_QK0_BF16 RSA_K5W_OPS_QK0 : RSA_K5W_CLOBBER_TMP, "memory");
-        else
-            asm volatile(RSA_K5W_QK0_F16 RSA_K5W_OPS_QK0 : RSA_K5W_CLOBBER_TMP, "memory");
+        if constexpr (std::is_same<Tag, bf16_tag>::value) RSA_K5_ASM(D, QK0_BF16, OPS_QK0, CLOBBER_TMP, , "memory");
+        else RSA_K5_ASM(D, QK0_F16, OPS_QK0, CLOBBER_TMP, , "memory");
     }
     RSA_STAMP0();
 #ifdef RSA_K5_DIAG
@@ -470,12 +492,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 1)))
         used_static = stat != 0;
 #ifdef RSA_K5_DIAG
         unsigned d0 = 0, d1 = 0;   // in-loop stamps: cycles parked on the vmcnt wait / on the barrier (+ rescales taken << 24)
-        if constexpr (std::is_same<Tag, bf16_tag>::value)
-            asm volatile(RSA_K5W_LOOP_BF16_DIAG RSA_K5W_OPS_LOOP_DIAG : RSA_K5W_CLOBBER_TMP, RSA_K5W_CLOBBER_O, RSA_K5W_CLOBBER_LOOP,
-                         RSA_K5W_CLOBBER_LOOP_DIAG, "memory");
-        else
-            asm volatile(RSA_K5W_LOOP_F16_DIAG RSA_K5W_OPS_LOOP_DIAG : RSA_K5W_CLOBBER_TMP, RSA_K5W_CLOBBER_O, RSA_K5W_CLOBBER_LOOP,
-                         RSA_K5W_CLOBBER_LOOP_DIAG, "memory");
+        if constexpr (std::is_same<Tag, bf16_tag>::value) RSA_K5_ASM(D, LOOP_BF16_DIAG, OPS_LOOP_DIAG, CL_LOOP, , RSA_K5W_CLOBBER_LOOP_DIAG, "memory");
+        else RSA_K5_ASM(D, LOOP_F16_DIAG, OPS_LOOP_DIAG, CL_LOOP, , RSA_K5W_CLOBBER_LOOP_DIAG, "memory");
         tsum[3] = ((unsigned long long)d1 << 32) | d0;
 #else
 #ifdef RSA_K5_FORMS
@@ -489,10 +507,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 1)))
             asm volatile(RSA_K5W_LOOP_BF16_R256 RSA_K5W_OPS_LOOP : RSA_K5W_CLOBBER_TMP, RSA_K5W_CLOBBER_O, RSA_K5W_CLOBBER_LOOP, "memory");
         else if constexpr (NW == 4)
             asm volatile(RSA_K5W_LOOP_F16_R256 RSA_K5W_OPS_LOOP : RSA_K5W_CLOBBER_TMP, RSA_K5W_CLOBBER_O, RSA_K5W_CLOBBER_LOOP, "memory");
-        else if constexpr (std::is_same<Tag, bf16_tag>::value)
-            asm volatile(RSA_K5W_LOOP_BF16 RSA_K5W_OPS_LOOP : RSA_K5W_CLOBBER_TMP, RSA_K5W_CLOBBER_O, RSA_K5W_CLOBBER_LOOP, "memory");
-        else
-            asm volatile(RSA_K5W_LOOP_F16 RSA_K5W_OPS_LOOP : RSA_K5W_CLOBBER_TMP, RSA_K5W_CLOBBER_O, RSA_K5W_CLOBBER_LOOP, "memory");
+        else if constexpr (std::is_same<Tag, bf16_tag>::value) RSA_K5_ASM(D, LOOP_BF16, OPS_LOOP, CL_LOOP, , "memory");
+        else RSA_K5_ASM(D, LOOP_F16, OPS_LOOP, CL_LOOP, , "memory");
 #endif
         (void)lv;
     }
@@ -514,8 +530,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 1)))
             }
         };
         if (used_static) {
-            track(k5w_oread<0, 0>()); track(k5w_oread<0, 1>()); track(k5w_oread<0, 2>()); track(k5w_oread<0, 3>());
-            track(k5w_oread<1, 0>()); track(k5w_oread<1, 1>()); track(k5w_oread<1, 2>()); track(k5w_oread<1, 3>());
+            track(k5w_oread<0, 0, D>()); track(k5w_oread<0, 1, D>()); track(k5w_oread<1, 0, D>()); track(k5w_oread<1, 1, D>());
+            if constexpr (DT == 4) {
+                track(k5w_oread<0, 2, D>()); track(k5w_oread<0, 3, D>()); track(k5w_oread<1, 2, D>()); track(k5w_oread<1, 3, D>());
+            }
         }
         const bool lbad = (__float_as_uint(l_run[0]) & 0x7FFFFFFFu) >= 0x71800000u || (__float_as_uint(l_run[1]) & 0x7FFFFFFFu) >= 0x71800000u;
         const bool bad = used_static && (emax >= 0x7F800000u || lbad);
@@ -580,7 +598,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 1)))
                     *reinterpret_cast<float2*>(pp + d0 + 2) = make_float2(o[4 * g + 2], o[4 * g + 3]);
                 }
             };
-            put(0, k5w_oread<x, 0>()); put(1, k5w_oread<x, 1>()); put(2, k5w_oread<x, 2>()); put(3, k5w_oread<x, 3>());
+            put(0, k5w_oread<x, 0, D>()); put(1, k5w_oread<x, 1, D>());
+            if constexpr (DT == 4) { put(2, k5w_oread<x, 2, D>()); put(3, k5w_oread<x, 3, D>()); }
             if (hh == 0) *reinterpret_cast<float2*>(pp + D) = make_float2(mrun, l_tot);
             return;
         }
@@ -640,7 +659,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 1)))
                 }
             }
         };
-        put(0, k5w_oread<x, 0>()); put(1, k5w_oread<x, 1>()); put(2, k5w_oread<x, 2>()); put(3, k5w_oread<x, 3>());
+        put(0, k5w_oread<x, 0, D>()); put(1, k5w_oread<x, 1, D>());
+        if constexpr (DT == 4) { put(2, k5w_oread<x, 2, D>()); put(3, k5w_oread<x, 3, D>()); }
     };
     finish_half(std::integral_constant<int, 0>{});
     finish_half(std::integral_constant<int, 1>{});
@@ -657,10 +677,22 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #ifdef RSA_K5_FORMS
 int g_rsa_k5w_form = 0;   // A/B build: tuning key "k5w_form" (loop forms of rsa_attn_block64_forms.h)
 #endif
-// launch hook used by rsa_attn.hip::launch_attn (head dim 128 only)
-int rsa_launch_bsfwd64(const AttnArgs& a, dim3 grid, size_t lds_bytes, int dtype, hipStream_t s) {
+// launch hook used by rsa_attn.hip::launch_attn (head dims 128 and 64)
+int rsa_launch_bsfwd64(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int dtype, hipStream_t s) {
     const bool wide = !(((uintptr_t)a.out & 15) || ((a.osb | a.osh | a.oss) & 7));
     lds_bytes += 16;   // the loop reads its list two entries ahead
+    if (D == 64) {
+        if (a.rows256) return RSA_ERR_BAD_ARG;
+        if (dtype == RSA_BF16) {
+            if (wide) RSA_LAUNCH_GSYNC(1, (bsfwd64_kernel<bf16_tag, true, 0, 2, 64>), a, a.mode == MODE_SPARSE, grid, 128, lds_bytes, s);
+            else RSA_LAUNCH_GSYNC(1, (bsfwd64_kernel<bf16_tag, false, 0, 2, 64>), a, a.mode == MODE_SPARSE, grid, 128, lds_bytes, s);
+        } else {
+            if (wide) RSA_LAUNCH_GSYNC(1, (bsfwd64_kernel<fp16_tag, true, 0, 2, 64>), a, a.mode == MODE_SPARSE, grid, 128, lds_bytes, s);
+            else RSA_LAUNCH_GSYNC(1, (bsfwd64_kernel<fp16_tag, false, 0, 2, 64>), a, a.mode == MODE_SPARSE, grid, 128, lds_bytes, s);
+        }
+        return rsa_launch_status();
+    }
+    if (D != 128) return RSA_ERR_UNSUPPORTED;
 #ifdef RSA_K5_FORMS
 #define RSA_K5W_XLAUNCH(N) if (g_rsa_k5w_form == N && dtype == RSA_BF16 && wide) { RSA_LAUNCH_GSYNC(1, (bsfwd64_kernel<bf16_tag, true, N>), a, a.mode == MODE_SPARSE, grid, 128, lds_bytes, s); return rsa_launch_status(); }
     RSA_K5W_XLAUNCH(1) RSA_K5W_XLAUNCH(2) RSA_K5W_XLAUNCH(3) RSA_K5W_XLAUNCH(4) RSA_K5W_XLAUNCH(5) RSA_K5W_XLAUNCH(6) RSA_K5W_XLAUNCH(7) RSA_K5W_XLAUNCH(8) RSA_K5W_XLAUNCH(9) RSA_K5W_XLAUNCH(10) RSA_K5W_XLAUNCH(11) RSA_K5W_XLAUNCH(12) RSA_K5W_XLAUNCH(13) RSA_K5W_XLAUNCH(14) RSA_K5W_XLAUNCH(15) RSA_K5W_XLAUNCH(16) RSA_K5W_XLAUNCH(17) RSA_K5W_XLAUNCH(18) RSA_K5W_XLAUNCH(19) RSA_K5W_XLAUNCH(20) RSA_K5W_XLAUNCH(21) RSA_K5W_XLAUNCH(22) RSA_K5W_XLAUNCH(23) RSA_K5W_XLAUNCH(24) RSA_K5W_XLAUNCH(25) RSA_K5W_XLAUNCH(26) RSA_K5W_XLAUNCH(27) RSA_K5W_XLAUNCH(28) RSA_K5W_XLAUNCH(29) RSA_K5W_XLAUNCH(30) RSA_K5W_XLAUNCH(31)

@@ -19,7 +19,8 @@ def _inputs(H, nb, D, seed, dt):
     return mk(), mk(), torch.randn(1, H, S, D, generator=g, device="cuda:0").to(dt)
 
 
-@pytest.mark.parametrize("w64,D,dt", [(1, 128, torch.bfloat16), (1, 128, torch.float16), (0, 128, torch.bfloat16), (0, 64, torch.bfloat16)])
+@pytest.mark.parametrize("w64,D,dt", [(1, 128, torch.bfloat16), (1, 128, torch.float16), (0, 128, torch.bfloat16), (0, 64, torch.bfloat16),
+                                       (3, 64, torch.bfloat16), (3, 64, torch.float16)])
 def test_aligned_starts_do_not_change_a_byte(w64, D, dt):
     from rectified_spaattn_amd import _core, _lib
     H, nb, top_k = 8, 168, 14          # 1 344 workgroups (more than two generations of 8 x 64), 8 % of the keys kept: the walks wait
@@ -35,7 +36,7 @@ def test_aligned_starts_do_not_change_a_byte(w64, D, dt):
             torch.cuda.synchronize()
             outs.append(out.view(torch.int16).cpu().numpy().copy())
     finally:
-        L.rsa_set_tuning(b"k5_w64", 1)
+        L.rsa_set_tuning(b"k5_w64", 3)
         L.rsa_set_tuning(b"k5_gsync", 1)
     assert np.isfinite(out.float().cpu().numpy()).all()
     for o in outs[1:]:

@@ -219,13 +219,46 @@ def test_k5_32row_kernel_still_serves_head_dim_128(name, dt):
             torch.cuda.synchronize()
             outs.append(out.float().cpu().numpy().reshape(ref.shape))
     finally:
-        _lib.lib().rsa_set_tuning(b"k5_w64", 1)
+        _lib.lib().rsa_set_tuning(b"k5_w64", 3)
     mx, mean = TOL[dt]
     for o in outs:
         err = np.abs(o - ref)
         assert err.max() <= mx and err.mean() <= mean
     ulp = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10
     assert np.abs(outs[0] - outs[1]).max() <= ulp * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("name", ["wan_d64_1100", "cogvideo_994"])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_k5_64row_kernel_at_head_dim_64_against_the_32row_kernel(name, dt):
+    """Round 6: head dim 64 (CogVideoX; the wan_d64 fixture) runs the 64-rows-per-wave K5 too (bit 1 of k5_w64; 8 + 8 MFMAs per
+    sub-step, 4-KiB half-tiles).  Both kernels against the oracle and against each other within one output ulp."""
+    from conftest import case_inputs, load_op_case
+    from oracle import oracle as orc
+    from rectified_spaattn_amd import _core, _lib
+    from test_gpu_parity import TOL, _spec
+    meta, _ = load_op_case(name)
+    assert meta["D"] == 64
+    q, k, v, lay, nbr = case_inputs(meta)
+    tq, tk, tv = (torch.from_numpy(x).to("cuda:0", dt) for x in (q, k, v))
+    q, k, v = (x.float().cpu().numpy() for x in (tq, tk, tv))
+    ref = orc.rectified_attention(q, k, v, lay, meta["top_k"], meta["p"], nbr)
+    outs = []
+    try:
+        for w in (3, 1):
+            assert _lib.lib().rsa_set_tuning(b"k5_w64", w) == 0
+            out = _core.rectified_attention(tq, tk, tv, _spec(lay), meta["top_k"], meta["p"],
+                                            torch.from_numpy(nbr) if nbr is not None else None)
+            torch.cuda.synchronize()
+            outs.append(out.float().cpu().numpy().reshape(ref.shape))
+    finally:
+        _lib.lib().rsa_set_tuning(b"k5_w64", 3)
+    mx, mean = TOL[dt]
+    for o in outs:
+        err = np.abs(o - ref)
+        assert err.max() <= mx and err.mean() <= mean, (err.max(), err.mean())
+    ulp = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10
+    assert np.abs(outs[0] - outs[1]).max() <= 2 * ulp * max(1.0, np.abs(ref).max())
 
 
 

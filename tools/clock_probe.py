@@ -60,7 +60,7 @@ def main():
         assert L.rsa_set_tuning(b"k5_w64", w64) == 0
         run_for(call.attend, float(os.environ.get("SECS", "5")), f"sparse R2, {'64' if w64 else '32'}-row K5")
         run_for(lambda: _core.dense_attention(qd, qd, qd), 3, f"dense 16k, {'64' if w64 else '32'}-row K5")
-    L.rsa_set_tuning(b"k5_w64", 1)
+    L.rsa_set_tuning(b"k5_w64", 3)
 
 if __name__ == "__main__":
     main()

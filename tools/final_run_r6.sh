@@ -62,6 +62,7 @@ RSA_PERF_WORKLOAD=wan22_ti2v_720p_121f python tools/perf_select.py >> gpurun_out
 make -s -C rectified_spaattn_amd/csrc diag > /dev/null 2>&1
 python tools/diag_k5w.py > gpurun_out/r6z_diag.txt 2>&1
 RSA_BENCH_ONE_DEVICE=1 python bench.py --gpus 2 --steps 5 --warmup 2 --no-extras --no-cpu-baseline | grep "^{" > gpurun_out/r6z_bench_2ranks_one_device.json 2>> gpurun_out/r6z_bench.err
+RSA_BENCH_ONE_DEVICE=1 python bench.py --gpus 8 --workload tiny8 --steps 4 --warmup 1 --no-extras --no-cpu-baseline | grep "^{" > gpurun_out/r6z_bench_8ranks_one_device.json 2>> gpurun_out/r6z_bench.err
 for HH in 24 12 6 3; do echo "heads=$HH"; RSA_PERF_H=$HH RSA_PERF_REGIMES=r2 python tools/perf_k5.py regimes; done > gpurun_out/r6z_rank_shapes.txt 2>&1
 python tools/perf_k5.py dense > gpurun_out/r6z_dense.txt 2>&1
 
