@@ -50,6 +50,7 @@ Two products:
 
 usage: python3 gen_k5_block64.py > rsa_attn_block64.h        (python3 gen_k5_block64.py stats: per-gap issue costs)
 """
+import os
 import sys
 
 AHEAD = 4
@@ -77,7 +78,7 @@ def configure(d):
     else:
         DMA_GAPS = [1, 3, 9, 11]        # K0 K1 | V0 V1: the wave's 2 + 2 pieces of the sub-step
         SALU_AT = dict(k=4, k3=(4, 5, 6), v=12, h1=(2, 3))
-        VMC, GAPC = 8, 36
+        VMC, GAPC = 8, int(os.environ.get("RSA_GEN64_GAPC", "36"))
 
 # ---- register map ----
 SA = [0, 16]
@@ -243,7 +244,7 @@ def gen_block(dt, U, dma, chain=None, xf=frozenset(), dma_cost=None, pre=64, sal
                 k, t, need = cvq.pop(0)
                 lines.append(t); used += COST[k]; progress = True
                 continue
-            if ei < len(EXP) and (nexp < (2 if D == 128 else 3) or gap < 0 or final):
+            if ei < len(EXP) and (nexp < (2 if D == 128 else int(os.environ.get("RSA_GEN64_NEXP", "4"))) or gap < 0 or final):
                 h, i = EXP[ei]
                 lines.append(f"v_exp_f32 {vr(SC[h] + i)}, {vr(SC[h] + i)}")
                 last_exp_line = len(lines) - 1
@@ -624,7 +625,7 @@ def main_one():
             out.append(c_string(gen_loop(dt, pre=LOOP_PRE, tight=True, static=(dt == "bf16"), xf=LOOP_XF | {"halfdma"})))
             out.append("")
         out.append(f"#define RSA_K5W_LOOP_{dt.upper()}_DIAG \\")
-        out.append(c_string(gen_loop(dt, diag=True, pre=LOOP_PRE, tight=True, xf=LOOP_XF)))
+        out.append(c_string(gen_loop(dt, diag=True, pre=LOOP_PRE, tight=True, static=(dt == "bf16"), xf=LOOP_XF)))
         out.append("")
         out.append(f"#define RSA_K5W_QK0_{dt.upper()} \\")
         out.append(c_string(gen_qk0(dt)))
