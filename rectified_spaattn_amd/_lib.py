@@ -160,7 +160,7 @@ def lib():
                  "rsa_dense_fwd", "rsa_dense_masked_fwd", "rsa_estimate_pr_gain"):
         getattr(L, name).restype = i32
     # kernel-variant switches for A/B runs and the variant tests; rsa_set_tuning works only under RSA_TUNING=1
-    for key in ("k5_tsplit", "k3_prefix", "k3_long", "k4_split", "k5_w64", "k5_gsync", "k5_gsync_ratio", "k5_text_last", "k5_tail_split"):
+    for key in ("k5_tsplit", "k3_prefix", "k3_long", "k4_split", "k5_rows256", "k5_static", "k5_w64", "k5_gsync", "k5_gsync_ratio", "k5_text_last", "k5_tail_split"):
         val = os.environ.get("RSA_" + key.upper())
         if val is not None:
             check_rc = L.rsa_set_tuning(key.encode(), int(val))

@@ -620,10 +620,9 @@ def main_one():
         out.append("")
         # the 256-row dense form (four waves on one K/V ring): the same loop with every second LDS-DMA piece dropped -- each wave stages
         # 2 + 2 of a half-tile's 8 + 8 pieces (lane offset registers 0 and 2), vmcnt(8) at the sub-step boundary
-        if D == 128:
-            out.append(f"#define RSA_K5W_LOOP_{dt.upper()}_R256 \\")
-            out.append(c_string(gen_loop(dt, pre=LOOP_PRE, tight=True, static=(dt == "bf16"), xf=LOOP_XF | {"halfdma"})))
-            out.append("")
+        out.append(f"#define RSA_K5W_LOOP_{dt.upper()}_R256 \\")
+        out.append(c_string(gen_loop(dt, pre=LOOP_PRE, tight=True, static=(dt == "bf16"), xf=LOOP_XF | {"halfdma"})))
+        out.append("")
         out.append(f"#define RSA_K5W_LOOP_{dt.upper()}_DIAG \\")
         out.append(c_string(gen_loop(dt, diag=True, pre=LOOP_PRE, tight=True, static=(dt == "bf16"), xf=LOOP_XF)))
         out.append("")

@@ -381,7 +381,7 @@ static int dense_fwd(int B, int H, int Sq, int Sk, int D, int dtype, rsa_tensor4
     a.tsplit = 1; a.tper = 0;
     a.mode = MODE_DENSE; a.H = H; a.Sq = Sq; a.Sk = Sk;
     // head dim 128 through the 64-row kernel: 256-row tiles once there are at least two of them (a shorter call keeps 128-row tiles)
-    a.rows256 = (D == 128 && (g_k5_w64 & 1) && g_k5_rows256 && Sq > 256) ? 1 : 0;
+    a.rows256 = (((D == 128 && (g_k5_w64 & 1)) || (D == 64 && (g_k5_w64 & 2))) && g_k5_rows256 && Sq > 256) ? 1 : 0;
 #ifdef RSA_K5_FORMS
     if (g_rsa_k5w_form != 0) a.rows256 = 0;     // (the A/B forms are forms of the 128-row kernel)
 #endif

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 1)))
     constexpr int RPP = 32 / NPIECE;        // key rows per piece
     constexpr int LPR = 64 / RPP;           // lanes (16-byte chunks) per key row
     static_assert(NW == 2 || NW == 4, "two or four waves");
-    static_assert(D == 128 || (D == 64 && NW == 2 && XF == 0), "head dim 64: the 128-row product form only");
+    static_assert(D == 128 || (D == 64 && XF == 0), "head dim 64: the product forms only");
     constexpr int KS = D / 16;
     constexpr int DT = D / 32;
     constexpr int HALF = 32 * D * 2;        // bytes of a 32-key half-tile
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 1)))
     u32x4 vok, vov;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        if constexpr (D == 64) {
+        if constexpr (D == 64) {      // (four waves: one piece each, register 0)
             vok[j] = j < 2 ? (16 * j + rowl) * krow + gsw0 * 16 - (j ? 2048u : 0u) : 0u;
             vov[j] = j < 2 ? (16 * j + rowl) * vrow + gsw0 * 16 - (j ? 2048u : 0u) : 0u;
         } else if constexpr (NW == 2) {
@@ -414,7 +414,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 1)))
         constexpr int U = decltype(UC)::value;
         float (&mx_cur)[2] = (U & 1) == 0 ? mxA : mxB;
         float (&mx_nxt)[2] = (U & 1) == 0 ? mxB : mxA;
-        if (u + 4 <= n_sub) { if constexpr (NW == 2 && D == 128) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+        if (u + 4 <= n_sub) {      // the 2 NPW pieces of each of the last two sub-steps may still fly
+            if constexpr (NPW == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if constexpr (NPW == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (u + 3 < n_sub) dma_half(1, key_of(u + 3), VRING + ((U + 3) & 3) * HALF);
@@ -503,10 +507,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 1)))
         RSA_K5W_XFORM(1) RSA_K5W_XFORM(2) RSA_K5W_XFORM(3) RSA_K5W_XFORM(4) RSA_K5W_XFORM(5) RSA_K5W_XFORM(6) RSA_K5W_XFORM(7) RSA_K5W_XFORM(8) RSA_K5W_XFORM(9) RSA_K5W_XFORM(10) RSA_K5W_XFORM(11) RSA_K5W_XFORM(12) RSA_K5W_XFORM(13) RSA_K5W_XFORM(14) RSA_K5W_XFORM(15) RSA_K5W_XFORM(16) RSA_K5W_XFORM(17) RSA_K5W_XFORM(18) RSA_K5W_XFORM(19) RSA_K5W_XFORM(20) RSA_K5W_XFORM(21) RSA_K5W_XFORM(22) RSA_K5W_XFORM(23) RSA_K5W_XFORM(24) RSA_K5W_XFORM(25) RSA_K5W_XFORM(26) RSA_K5W_XFORM(27) RSA_K5W_XFORM(28) RSA_K5W_XFORM(29) RSA_K5W_XFORM(30) RSA_K5W_XFORM(31)
         else
 #endif
-        if constexpr (NW == 4 && std::is_same<Tag, bf16_tag>::value)
-            asm volatile(RSA_K5W_LOOP_BF16_R256 RSA_K5W_OPS_LOOP : RSA_K5W_CLOBBER_TMP, RSA_K5W_CLOBBER_O, RSA_K5W_CLOBBER_LOOP, "memory");
-        else if constexpr (NW == 4)
-            asm volatile(RSA_K5W_LOOP_F16_R256 RSA_K5W_OPS_LOOP : RSA_K5W_CLOBBER_TMP, RSA_K5W_CLOBBER_O, RSA_K5W_CLOBBER_LOOP, "memory");
+        if constexpr (NW == 4 && std::is_same<Tag, bf16_tag>::value) RSA_K5_ASM(D, LOOP_BF16_R256, OPS_LOOP, CL_LOOP, , "memory");
+        else if constexpr (NW == 4) RSA_K5_ASM(D, LOOP_F16_R256, OPS_LOOP, CL_LOOP, , "memory");
         else if constexpr (std::is_same<Tag, bf16_tag>::value) RSA_K5_ASM(D, LOOP_BF16, OPS_LOOP, CL_LOOP, , "memory");
         else RSA_K5_ASM(D, LOOP_F16, OPS_LOOP, CL_LOOP, , "memory");
 #endif
@@ -681,8 +683,18 @@ int g_rsa_k5w_form = 0;   // A/B build: tuning key "k5w_form" (loop forms of rsa
 int rsa_launch_bsfwd64(const AttnArgs& a, dim3 grid, size_t lds_bytes, int D, int dtype, hipStream_t s) {
     const bool wide = !(((uintptr_t)a.out & 15) || ((a.osb | a.osh | a.oss) & 7));
     lds_bytes += 16;   // the loop reads its list two entries ahead
+    if (D == 64 && a.rows256) {
+        if (a.mode != MODE_DENSE) return RSA_ERR_BAD_ARG;
+        if (dtype == RSA_BF16) {
+            if (wide) RSA_LAUNCH_GSYNC(1, (bsfwd64_kernel<bf16_tag, true, 0, 4, 64>), a, false, grid, 256, lds_bytes, s);
+            else RSA_LAUNCH_GSYNC(1, (bsfwd64_kernel<bf16_tag, false, 0, 4, 64>), a, false, grid, 256, lds_bytes, s);
+        } else {
+            if (wide) RSA_LAUNCH_GSYNC(1, (bsfwd64_kernel<fp16_tag, true, 0, 4, 64>), a, false, grid, 256, lds_bytes, s);
+            else RSA_LAUNCH_GSYNC(1, (bsfwd64_kernel<fp16_tag, false, 0, 4, 64>), a, false, grid, 256, lds_bytes, s);
+        }
+        return rsa_launch_status();
+    }
     if (D == 64) {
-        if (a.rows256) return RSA_ERR_BAD_ARG;
         if (dtype == RSA_BF16) {
             if (wide) RSA_LAUNCH_GSYNC(1, (bsfwd64_kernel<bf16_tag, true, 0, 2, 64>), a, a.mode == MODE_SPARSE, grid, 128, lds_bytes, s);
             else RSA_LAUNCH_GSYNC(1, (bsfwd64_kernel<bf16_tag, false, 0, 2, 64>), a, a.mode == MODE_SPARSE, grid, 128, lds_bytes, s);

@@ -1,4 +1,4 @@
-"""The 256-row form of the 64-row K5 for DENSE calls (round 6; rsa_attn_kernel64.hip NW = 4, tuning key k5_rows256): four waves, one
+"""The 256-row form of the 64-row K5 for DENSE calls (round 6; rsa_attn_kernel64.hip NW = 4, both head dims, tuning key k5_rows256): four waves, one
 per SIMD, on ONE K/V ring -- every half-tile staged once per 256 query rows.  A row's arithmetic does not depend on the tile it sits
 in (same 64-row waves, same key order, same reference), so for a plain dense call the two forms must agree BYTE FOR BYTE; with a
 causal limit or two segments the tiles differ in which kept blocks take the boundary path, still the same arithmetic per row."""
@@ -43,10 +43,11 @@ def _ref(q, k, v, q_split=None, kv_split=None, causal=False):
 
 @pytest.mark.parametrize("Sq,Sk", [(257, 300), (512, 512), (1000, 777), (1536, 4096), (3001, 129)])
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
-def test_plain_dense_calls_agree_byte_for_byte_with_the_128_row_form(Sq, Sk, dt):
+@pytest.mark.parametrize("D", [128, 64])
+def test_plain_dense_calls_agree_byte_for_byte_with_the_128_row_form(Sq, Sk, dt, D):
     from rectified_spaattn_amd import _core
     g = torch.Generator(device=DEV).manual_seed(Sq + Sk)
-    H, D = 3, 128
+    H = 3
     q = torch.randn(1, H, Sq, D, generator=g, device=DEV).to(dt)
     k, v = (torch.randn(1, H, Sk, D, generator=g, device=DEV).to(dt) for _ in range(2))
     a = _run(1, lambda: _core.dense_attention(q, k, v))
@@ -60,11 +61,12 @@ def test_plain_dense_calls_agree_byte_for_byte_with_the_128_row_form(Sq, Sk, dt)
 @pytest.mark.parametrize("case", [dict(Sq=900, Sk=900, causal=True), dict(Sq=700, Sk=1100, causal=True),
                                   dict(Sq=1280, Sk=1280, q_split=1024, kv_split=1024), dict(Sq=1111, Sk=999, q_split=300, kv_split=640),
                                   dict(Sq=1111, Sk=999, q_split=300, kv_split=640, causal=True)])
-def test_causal_and_two_segment_calls(case):
+@pytest.mark.parametrize("D", [128, 64])
+def test_causal_and_two_segment_calls(case, D):
     from rectified_spaattn_amd import _core
     Sq, Sk = case["Sq"], case["Sk"]
     g = torch.Generator(device=DEV).manual_seed(Sq * 7 + Sk)
-    H, D = 2, 128
+    H = 2
     q = torch.randn(1, H, Sq, D, generator=g, device=DEV).to(torch.bfloat16)
     k, v = (torch.randn(1, H, Sk, D, generator=g, device=DEV).to(torch.bfloat16) for _ in range(2))
     kw = dict(q_split=case.get("q_split"), kv_split=case.get("kv_split"), causal=case.get("causal", False))
