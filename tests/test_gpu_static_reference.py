@@ -122,3 +122,30 @@ def test_sparse_operator_static_and_online_against_the_oracle(layout):
         for o in outs:
             err = np.abs(o.view(1, S, H * D).float().cpu().numpy() - ref)
             assert err.max() <= 2e-2 and err.mean() <= 2e-3, (layout, blow, err.max(), err.mean())
+
+
+def test_redone_workgroups_inside_the_headline_launch():
+    """The second pass at the SIZE of the headline launch: 24 heads x 902 blocks (aligned starts, text rows split, 43 generations),
+    with the later keys of three heads blown up so that thousands of workgroups overflow their static walk and walk again while the
+    others do not.  Static on / off must agree (same lists: the selection pass reads the same inputs) and stay finite; heads that
+    were not touched are byte-identical between the two runs only where no workgroup was redone, so they are compared within
+    rounding as well."""
+    import bench
+    from rectified_spaattn_amd import _core
+    wl = bench.WORKLOADS["hunyuan_720p_128f"]
+    spec = bench.make_spec(wl)
+    q, k, v = bench.gen_inputs(wl, 24, 0, torch.device(DEV), "iid")
+    for h in (3, 11, 22):
+        k[:, h, 40000:] *= 16.0
+    call = _core.StagedCall(q, k, v, spec, 90, 0.0, None, reuse_buffers=False)
+    call.select()
+    outs = []
+    for f in (1, 0):
+        outs.append(_with_static(f, lambda: call.attend().clone()))
+    assert torch.isfinite(outs[0]).all() and torch.isfinite(outs[1]).all()
+    d = (outs[0].float() - outs[1].float()).abs()
+    # (blown-up keys make the softmax of those heads one-hot: outputs are single V rows of magnitude up to ~4, where two bf16 ulps are 0.03)
+    ulp2 = 2 * 2.0 ** -7 * max(1.0, float(outs[1].float().abs().max()))
+    assert float(d.max()) <= ulp2 and float(d.mean()) <= 4e-4, (float(d.max()), float(d.mean()), ulp2)
+    chk = bench.check_output(call, spec)          # (the output of the last attend: the online body)
+    assert chk["finite"]
