@@ -1,4 +1,5 @@
 #!/usr/bin/env python3
+# (round 6: head dim 64 beside 128 -- RSA_K5V_* beside RSA_K5W_*, configure(d) below; the docstring describes head dim 128)
 """Generator of the 64-rows-per-wave form of K5's main loop (rsa_attn_block64.h), head dim 128.
 
 One wave owns 64 query rows (two 32-row halves h = 0, 1) and the WHOLE register file of its SIMD (one wave per SIMD, 512

@@ -1,4 +1,4 @@
-// K5, 64-rows-per-wave form (head dim 128): block-sparse flash attention forward for gfx950 with the rectification
+// K5, 64-rows-per-wave form: block-sparse flash attention forward for gfx950 with the rectification
 // epilogue fused -- same semantics, work mapping, per-row plan and epilogue as bsfwd_kernel (rsa_attn_kernel.hip; the
 // reference kernel it follows: rectified_hunyuan_attn.py:15-105), different occupancy model:
 //
@@ -18,6 +18,13 @@
 // or two of a list, the diagonal blocks of a causal call) run block by block, staged from here.
 //
 // LDS = [K ring: 4 x 8 KiB | V ring: 4 x 8 KiB | list (u16)]: half-tile x (32 keys) of the walk sits in slot x & 3.
+//
+// (The text above describes head dim 128, two waves.)  Round 6 -- each described where it is implemented below:
+//   * head dim 64 (template parameter D; CogVideoX): 8 + 8 MFMAs per sub-step, 4-KiB half-tiles of four pieces, O in a[0:63], Q in
+//     a[64:95]; the streams come from the same generator (RSA_K5V_* beside RSA_K5W_*);
+//   * NW = 4: a 256-row tile of a DENSE call on ONE K/V ring (each wave stages every second piece);
+//   * the optimistic static softmax reference (bf16): a second body of the loop statement without row maxima and rescale test, the
+//     walk checked afterwards and redone through the online body if anything overflowed.
 #include "rsa_attn.h"
 #include <atomic>
 #include "rsa_attn_block64.h"
