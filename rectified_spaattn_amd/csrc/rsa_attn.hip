@@ -87,18 +87,43 @@ __global__ __launch_bounds__(256) void text_combine_kernel(const float* __restri
     if (grow >= Sq) return;
     const float* base = tpart + (bhq * tsplit * RSA_BLOCK + r) * (long)(D + 2);
     const long pstride = (long)RSA_BLOCK * (D + 2);
+    // (round 6: every load of the row issued up front -- (m, l) of all pieces, then the pieces' values eight at a time -- instead of
+    // one dependent round trip per piece; the sums run in the same order, piece 0 first: same bytes)
+    constexpr int MAXP = RSA_TEXT_SPLIT;
+    float mv[MAXP], lv[MAXP];
+#pragma unroll
+    for (int s = 0; s < MAXP; ++s) {
+        const int sc = s < tsplit ? s : 0;
+        const float2 ml = *reinterpret_cast<const float2*>(base + sc * pstride + D);
+        mv[s] = s < tsplit ? ml.x : -INFINITY;
+        lv[s] = ml.y;
+    }
     float M = -INFINITY;
-    for (int s = 0; s < tsplit; ++s) M = fmaxf(M, base[s * pstride + D]);
+#pragma unroll
+    for (int s = 0; s < MAXP; ++s) M = fmaxf(M, mv[s]);
     float L = 0.0f;
     float acc[2] = {0.0f, 0.0f};
-    for (int s = 0; s < tsplit; ++s) {
-        const float m = base[s * pstride + D], l = base[s * pstride + D + 1];
-        const float wgt = (m == -INFINITY) ? 0.0f : __builtin_amdgcn_exp2f(m - M);
-        L += l * wgt;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int d = lane + 64 * e;
-            if (d < D) acc[e] += base[s * pstride + d] * wgt;
+    for (int s0 = 0; s0 < MAXP; s0 += 8) {
+        if (s0 >= tsplit) break;
+        float x[8][2];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int sc = s0 + u < tsplit ? s0 + u : 0;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int d = lane + 64 * e;
+                x[u][e] = d < D ? base[sc * pstride + d] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (s0 + u < tsplit) {
+                const float wgt = (mv[s0 + u] == -INFINITY) ? 0.0f : __builtin_amdgcn_exp2f(mv[s0 + u] - M);
+                L += lv[s0 + u] * wgt;
+                acc[0] += x[u][0] * wgt;
+                acc[1] += x[u][1] * wgt;
+            }
         }
     }
     const float inv = (grow < q_text_end && L > 0.0f) ? 1.0f / L : 0.0f;
