@@ -20,18 +20,18 @@ from rectified_spaattn_amd import _core  # noqa: E402
 def main():
     L = _lib.lib()
     dev = torch.device("cuda:0")
-    H = int(os.environ.get("RSA_PERF_H", "24"))
-    wl = WORKLOADS["hunyuan_720p_128f"]
+    wl = WORKLOADS[os.environ.get("RSA_PERF_WORKLOAD", "hunyuan_720p_128f")]      # (cogvideox_768p_81f: the head-dim-64 kernel)
+    H = int(os.environ.get("RSA_PERF_H", str(wl["H"])))
     spec = make_spec(wl)
     cent, nbr_kind, p = REGIMES["r2"]
-    q, k, v = gen_inputs(wl, H, 0, dev, cent)
+    q, k, v = gen_inputs(wl, H, 0, dev, cent, D=wl.get("D", 128))
     call = _core.StagedCall(q, k, v, spec, wl["top_k"], p, make_neighbors(wl, spec, nbr_kind))
     call.select()
     torch.cuda.synchronize()
     nwg = 8 + H * 2 * 16 + H * ((spec.NBv + 7) // 8 * 8) + 64 + 1024   # (+ the pieces of a split tail)
     dbg = torch.zeros(nwg * 4 * 8, dtype=torch.int64, device=dev)
     ptr = dbg.data_ptr()
-    assert L.rsa_set_tuning(b"k5_w64", 1) == 0
+    assert L.rsa_set_tuning(b"k5_w64", 3) == 0
     assert L.rsa_set_tuning(b"dbg_lo", ctypes.c_int(ptr & 0xFFFFFFFF).value) == 0
     assert L.rsa_set_tuning(b"dbg_hi", ctypes.c_int(ptr >> 32).value) == 0
     for gs in (0, 1):
