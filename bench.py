@@ -346,7 +346,54 @@ def timed_steps(comm, step, steps, warmup, events=None, want_busy=False):
     return (total, busy) if want_busy else total
 
 
-CHECK_TOL = {False: (2e-2, 2e-3), True: (1.6e-1, 1.5e-2), "pv": (8e-2, 1e-2)}   # (max, mean) |dO|: the operator tests' bounds
+# (max, mean) |dO| of the output check below.  2-byte operands: against the dense-masked fp32 reference on the inputs themselves (the
+# operator tests' bound).  fp8 forms: against the same reference on the operands the kernel MULTIPLIES (the dequantised e4m3 images;
+# pv: the 2-byte q, k and the dequantised V) -- what is left is the e4m3 rounding of P, fp32 accumulation and the output's rounding
+# (tests/test_gpu_fp8.py: 4e-2 / 4e-3 against that oracle on full blocks, measured 1.6e-2..2.3e-2 / 2.6e-3..2.9e-3; 3e-2..5e-2 /
+# 6e-3 on the 16-row last block of Wan2.2-TI2V, whose rows hang on a handful of keys and average less of it).  The distance to the
+# UN-quantised reference is the number format's, not the kernel's (tests/diag/diag_fp8_ragged_block.py: the oracle on the e4m3
+# operands alone is 0.35 away on the 16-row last block of Wan2.2-TI2V, whose rows hang on a handful of keys, and 0.04-0.07
+# elsewhere); it is reported in `vs_unquantised` and only its mean is bounded.
+CHECK_TOL = {False: (2e-2, 2e-3), True: (8e-2, 5e-3), "pv": (8e-2, 5e-3)}
+CHECK_TOL_UNQUANTISED_MEAN = {True: 2e-2, "pv": 1e-2}
+
+
+def _e4m3_lut(dev):
+    """fp32 value of every e4m3 byte (OCP e4m3fn: bias 7, 3 mantissa bits, subnormals in steps of 2^-9)."""
+    import torch
+    b = torch.arange(256, device=dev)
+    expo, mant = (b >> 3) & 15, (b & 7).float()
+    val = torch.where(expo == 0, mant * 2.0 ** -9, (1.0 + mant / 8.0) * torch.exp2(expo.float() - 7.0))
+    return torch.where((b & 0x80) != 0, -val, val)
+
+
+def fp8_multiplied_operands(call, spec, h, pv):
+    """fp32 [S, D] q, k, v of local head h AS THE fp8 K5 MULTIPLIES THEM, rebuilt from the call's own images with plain torch ops
+    (include/rsa.h::rsa_fp8_operands): block-scaled e4m3 bytes x 2^(E8M0 - 127); q back in its own units (the image holds
+    q * sm_scale * log2 e), k = K minus the head's smooth-K vector (a shift of every score of a row alike: the softmax does not
+    see it), V from its transposed tiles ([S_pad / 64, D, 64], key order of a tile = rsa_fp8.hip's k-slot order).  pv form: q and
+    k are the 2-byte inputs themselves, only V comes from its image."""
+    import torch
+    from rectified_spaattn_amd import _core
+    B, H, S, D = call.q.shape
+    dev = call.q.device
+    BH, NBt = B * H, spec.NB_total
+    lut = _e4m3_lut(dev)
+    ex = _core.fp8_exps(call.fp8["scales"], BH, NBt)[h]
+    blk_scale = lambda byte: torch.exp2(((ex >> (8 * byte)) & 0xFF).float() - 127.0).repeat_interleave(128)[:, None]   # noqa: E731
+    v8t = call.fp8["v8t"].view(BH, NBt * 2, D, 64)[h]
+    p = torch.arange(64, device=dev)
+    j = p & 31
+    key_of_slot = 32 * (j >> 4) + (j & 3) + 8 * ((j & 15) >> 2) + 4 * (p >> 5)
+    vt = torch.empty((NBt * 2, 64, D), dtype=torch.float32, device=dev)
+    vt[:, key_of_slot, :] = lut[v8t.long()].permute(0, 2, 1)
+    vd = (vt.reshape(NBt * 128, D) * blk_scale(2))[:S]
+    if pv:
+        return call.q[0, h].float(), call.k[0, h].float(), vd
+    qk_const = float(D) ** -0.5 * 1.44269504
+    qd = (lut[call.fp8["q8"].view(BH, NBt * 128, D)[h].long()] * blk_scale(0))[:S] / qk_const
+    kd = (lut[call.fp8["k8"].view(BH, NBt * 128, D)[h].long()] * blk_scale(1))[:S]
+    return qd, kd, vd
 
 
 def check_output(call, spec, qkv_fp8=False, n_heads=3, n_blocks=8):
@@ -355,8 +402,10 @@ def check_output(call, spec, qkv_fp8=False, n_heads=3, n_blocks=8):
     (first, last and evenly spaced ones) of `n_heads` heads (first, middle, last) and every text row of those heads against a
     dense-masked fp32 reference computed here with plain torch ops on the device from the call's OWN kept lists, R and comp
     (softmax over the kept keys below kv_valid, x R + comp; text rows: exact attention over the valid keys; padded text rows
-    zero).  The selection pass that made the lists is checked bit for bit elsewhere (tests/test_gpu_fullsize.py); this is the
-    check of K5 at the launch's own size.  Returns the record of the bench line's `check` field."""
+    zero).  With fp8 operands the reference that decides `ok` runs on the operands the kernel multiplies
+    (fp8_multiplied_operands); the same reference on the un-quantised inputs is reported beside it (CHECK_TOL).  The selection
+    pass that made the lists is checked bit for bit elsewhere (tests/test_gpu_fullsize.py); this is the check of K5 at the
+    launch's own size.  Returns the record of the bench line's `check` field."""
     import torch
     q, k, v, out = call.q, call.k, call.v, call.out          # [B,H,S,D] x 3, [B,S,H,D]
     B, H, S, D = q.shape
@@ -368,10 +417,23 @@ def check_output(call, spec, qkv_fp8=False, n_heads=3, n_blocks=8):
     cols, counts, Rb, compb = (call.bufs[n] for n in ("cols", "counts", "R", "comp"))
     scale = float(D) ** -0.5
     ar = torch.arange(128, device=dev)
-    tol_max, tol_mean = CHECK_TOL["pv" if qkv_fp8 == "pv" else bool(qkv_fp8)]
-    worst, mean_sum, n_cmp, worst_at, text_rows = 0.0, 0.0, 0, None, 0
-    for h in heads:
-        qf, kf, vf = (x[0, h].float() for x in (q, k, v))
+    mode = "pv" if qkv_fp8 == "pv" else bool(qkv_fp8)
+    tol_max, tol_mean = CHECK_TOL[mode]
+
+    class Dist:
+        def __init__(self):
+            self.worst, self.mean_sum, self.n, self.at = 0.0, 0.0, 0, None
+
+        def add(self, err, where):
+            e = float(err.max())
+            if e > self.worst:
+                self.worst, self.at = e, where
+            self.mean_sum += float(err.mean()); self.n += 1
+
+        def mean(self):
+            return self.mean_sum / max(1, self.n)
+
+    def reference(qf, kf, vf, h, dist):
         for i in blocks:
             n = int(counts[h, i].item())
             sel = cols[h, i, :n].long()
@@ -382,30 +444,43 @@ def check_output(call, spec, qkv_fp8=False, n_heads=3, n_blocks=8):
             sc = (qf[rows] @ kf[key_idx].t()) * scale
             sc = sc.masked_fill(~valid[None, :], float("-inf"))
             ref = torch.softmax(sc, dim=-1) @ vf[key_idx] * Rb[h, i] + compb[h, i][None, :]
-            err = (out[0, rows, h].float() - ref).abs()
-            e = float(err.max())
-            if e > worst:
-                worst, worst_at = e, (h, i)
-            mean_sum += float(err.mean()); n_cmp += 1
+            dist.add((out[0, rows, h].float() - ref).abs(), (h, i))
         if spec.q_text_valid > 0:
             r0 = NBv * 128
             sc = (qf[r0:r0 + spec.q_text_valid] @ kf[:spec.kv_text_valid].t()) * scale
             ref = torch.softmax(sc, dim=-1) @ vf[:spec.kv_text_valid]
-            err = (out[0, r0:r0 + spec.q_text_valid, h].float() - ref).abs()
-            e = float(err.max())
-            if e > worst:
-                worst, worst_at = e, (h, "text")
-            mean_sum += float(err.mean()); n_cmp += 1
+            dist.add((out[0, r0:r0 + spec.q_text_valid, h].float() - ref).abs(), (h, "text"))
+
+    own, plain, text_rows, pad_bad = Dist(), Dist(), 0, None
+    for h in heads:
+        qf, kf, vf = (x[0, h].float() for x in (q, k, v))
+        reference(qf, kf, vf, h, plain)
+        if mode is not False:
+            reference(*fp8_multiplied_operands(call, spec, h, mode == "pv"), h, own)
+        if spec.q_text_valid > 0:
+            r0 = NBv * 128
             text_rows += spec.q_text_valid
             if r0 + spec.q_text_valid < S and float(out[0, r0 + spec.q_text_valid:, h].float().abs().max()) != 0.0:
-                worst, worst_at = float("inf"), (h, "padded text rows not zero")
-    mean_abs = mean_sum / max(1, n_cmp)
-    ok = finite and worst <= tol_max and mean_abs <= tol_mean
-    return dict(ok=bool(ok), finite=finite, heads=heads, blocks=len(blocks) * len(heads), text_rows=text_rows,
-                max_abs=round(worst, 6), mean_abs=round(mean_abs, 6), worst_at=list(worst_at) if worst_at else None,
-                tol=dict(max_abs=tol_max, mean_abs=tol_mean),
-                what="O of the last timed step (all local heads in one launch): finite everywhere; sampled query blocks + all text rows "
-                     "of the listed heads vs a dense-masked fp32 torch reference on the device built from the call's own kept lists, R, comp")
+                pad_bad = (h, "padded text rows not zero")
+    gate = plain if mode is False else own
+    ok = finite and pad_bad is None and gate.worst <= tol_max and gate.mean() <= tol_mean
+    rec = dict(ok=False, finite=finite, heads=heads, blocks=len(blocks) * len(heads), text_rows=text_rows,
+               max_abs=round(gate.worst, 6), mean_abs=round(gate.mean(), 6),
+               worst_at=list(pad_bad or gate.at) if (pad_bad or gate.at) else None,
+               tol=dict(max_abs=tol_max, mean_abs=tol_mean))
+    what = ("O of the last timed step (all local heads in one launch): finite everywhere; sampled query blocks + all text rows "
+            "of the listed heads vs a dense-masked fp32 torch reference on the device built from the call's own kept lists, R, comp")
+    if mode is not False:
+        tol_u = CHECK_TOL_UNQUANTISED_MEAN[mode]
+        ok = ok and plain.mean() <= tol_u
+        rec["vs_unquantised"] = dict(max_abs=round(plain.worst, 6), mean_abs=round(plain.mean(), 6),
+                                     worst_at=list(plain.at) if plain.at else None, tol_mean_abs=tol_u)
+        what += ("; fp8 operands: max_abs / mean_abs are against that reference on the operands the kernel multiplies (dequantised "
+                 "e4m3 images" + ("" if mode is True else " of V, the 2-byte q and k") + "), vs_unquantised against it on the inputs "
+                 "themselves (the number format's distance: reported, only its mean bounded)")
+    rec["ok"] = bool(ok)
+    rec["what"] = what
+    return rec
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -571,9 +646,9 @@ def fp8_records(comm, args, call_bf16, q, k, v, spec, wl, dev):
     w5 = WORKLOADS["wan22_ti2v_720p_121f"]
     s5 = make_spec(w5)
     q5, k5, v5 = gen_inputs(w5, w5["H"], 0, dev, "iid")
-    rec5 = {}
-    for f8 in (False, "pv", True):
-        c5 = _core.StagedCall(q5, k5, v5, s5, w5["top_k"], 0.0, None, qkv_fp8=f8)
+    rec5, calls5 = {}, {}
+    for f8 in (False, "pv", True):     # the three forms timed back to back (the checks, host-bound, come after: they would let the clocks drop)
+        c5 = _core.StagedCall(q5, k5, v5, s5, w5["top_k"], 0.0, None, qkv_fp8=f8, reuse_buffers=False)
 
         def st5(_):
             c5.select()
@@ -581,9 +656,19 @@ def fp8_records(comm, args, call_bf16, q, k, v, spec, wl, dev):
         el5 = timed_steps(comm, st5, 10, 3)
         pr5 = float(c5.bufs["counts"].sum().item())
         fl5 = 4.0 * 128 * 128 * 128 * pr5
-        rec5["pv" if f8 == "pv" else ("e4m3" if f8 else "bf16")] = dict(ms_per_layer=round(el5 / 10 * 1e3, 4), tflops=round(fl5 / (el5 / 10) / 1e12, 1))
-        del c5
-    rec5["what"] = "BASELINE config 5: Wan2.2-TI2V 720p 121f, S = 27 280, 24 heads, top_k 53 (regime r2), whole layer (select + K5)"
+        name5 = "pv" if f8 == "pv" else ("e4m3" if f8 else "bf16")
+        rec5[name5] = dict(ms_per_layer=round(el5 / 10 * 1e3, 4), tflops=round(fl5 / (el5 / 10) / 1e12, 1))
+        calls5[name5] = (c5, f8)
+    for name5, (c5, f8) in calls5.items():
+        try:      # the output of the launch just timed (check_output: the ragged last query block is one of the sampled ones)
+            ck5 = check_output(c5, s5, f8)
+            ck5 = {n: ck5[n] for n in ("ok", "blocks", "max_abs", "mean_abs", "vs_unquantised") if n in ck5}
+        except Exception as e:  # noqa: BLE001
+            ck5 = dict(ok=False, error=repr(e)[:200])
+        rec5[name5]["check"] = ck5
+    del calls5, c5
+    rec5["what"] = ("BASELINE config 5: Wan2.2-TI2V 720p 121f, S = 27 280, 24 heads, top_k 53 (regime r2), whole layer (select + K5); `check` = "
+                    "check_output of that launch (fp8 forms: against the operands the kernel multiplies, vs_unquantised beside it)")
     out["config5_wan22_ti2v"] = rec5
     return out
 

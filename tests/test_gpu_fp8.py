@@ -693,3 +693,61 @@ def test_fp8_pv_form_head_dim_64(dt):
         err = np.abs(od[0, :, h].float().cpu().numpy() - ref)
         assert err.max() <= PV_MAX_VS_ORACLE and err.mean() <= 5 * PV_MEAN_VS_ORACLE, (err.max(), err.mean())
     assert (od.float() - rd.float()).abs().mean() <= PV_MEAN_VS_BF16
+
+
+@pytest.mark.parametrize("mode", [True, "pv"], ids=["e4m3", "pv"])
+def test_fp8_config5_full_size_ragged_last_block_and_the_bench_check(mode):
+    """BASELINE config 5 at its own size (Wan2.2-TI2V 720p 121f: S = 27 280 = 213 x 128 + 16, top_k 53), fp8 operands.  The last query
+    block has 16 rows that hang on a handful of keys; there the e4m3 rounding of Q and K alone moves O by 0.35 (the oracle on the
+    dequantised operands against the oracle on the inputs: tests/diag/diag_fp8_ragged_block.py), which is the number format and not
+    the kernel.  So the kernel is held to the oracle on ITS operands (P formed as the kernel forms it, and P exact), the format's
+    distance is bounded only in the mean, and `bench.check_output` -- the check the fp8 bench lines carry -- must say the same."""
+    import bench
+    from rectified_spaattn_amd import _core
+    wl = bench.WORKLOADS["wan22_ti2v_720p_121f"]
+    spec = bench.make_spec(wl)
+    H = 3
+    tq, tk, tv = bench.gen_inputs(wl, H, 0, torch.device(DEV), "iid")
+    S = tq.shape[2]
+    lay = orc.layout_wan(S, wl["ffb"])
+    call = _core.StagedCall(tq, tk, tv, spec, wl["top_k"], 0.0, None, qkv_fp8=mode, reuse_buffers=False)
+    call.select(); call.attend()
+    torch.cuda.synchronize()
+    chk = bench.check_output(call, spec, mode)
+    assert chk["ok"] and chk["finite"], chk
+    assert chk["worst_at"] is not None and chk["vs_unquantised"]["mean_abs"] <= chk["vs_unquantised"]["tol_mean_abs"]
+    # the oracle on head 0: first, middle, the last full and the ragged last query block
+    h = 0
+    qh, kh, vh = (x[0, h].float().cpu().numpy() for x in (call.q, call.k, call.v))
+    q8, k8, v8, ops = orc.fp8_dequantized_qkv(qh[None, None], kh[None, None], vh[None, None], lay)
+    q8, k8, v8 = q8[0, 0], k8[0, 0], v8[0, 0]
+    SP = spec.NB_total * 128
+    assert np.array_equal(call.fp8["v8t"].view(H, SP // 64, 128, 64)[h].cpu().numpy(), ops["v8t"][0]), "v8t"
+    if mode is True:
+        assert np.array_equal(call.fp8["q8"].view(H, SP, 128)[h].cpu().numpy(), ops["q8"][0]), "q8"
+        assert np.array_equal(call.fp8["k8"].view(H, SP, 128)[h].cpu().numpy(), ops["k8"][0]), "k8"
+    else:
+        q8, k8 = qh, kh          # pv: the scores come from the 2-byte q and k themselves
+    kept = _core.unpack_bitmask(call.bufs["bitmask"][h:h + 1], spec.NB_total)[0].cpu().numpy()
+    R, comp = call.bufs["R"][h].cpu().numpy(), call.bufs["comp"][h].cpu().numpy()
+    blocks = [0, spec.NBv // 2, spec.NBv - 2, spec.NBv - 1]
+    km = kept[blocks].astype(np.uint8)
+    fin = lambda o: o * R[blocks][:, None, None] + comp[blocks][:, None, :]   # noqa: E731
+    ref8 = fin(orc.sparse_attention_head(q8, k8, v8, lay, km, blocks))
+    ref8c = fin(orc.sparse_attention_head_pcode(q8, k8, v8, lay, km, blocks))
+    ref16 = fin(orc.sparse_attention_head(qh, kh, vh, lay, km, blocks))
+    for a, i in enumerate(blocks):
+        nrow = min(128, S - i * 128)
+        got = call.out[0, i * 128:i * 128 + nrow, h].float().cpu().numpy()
+        d8, d8c, d16 = (np.abs(got - r[a][:nrow]) for r in (ref8, ref8c, ref16))
+        fmt = np.abs(ref8[a][:nrow] - ref16[a][:nrow])
+        print(f"{mode} block {i} ({nrow} rows): vs exact-P {d8.max():.4f}/{d8.mean():.5f}, vs code-map {d8c.max():.4f}/{d8c.mean():.5f}, "
+              f"vs un-quantised {d16.max():.4f}/{d16.mean():.5f} (format alone {fmt.max():.4f}/{fmt.mean():.5f})")
+        # (the pv kernel rounds q * sm_scale * log2(e) * 8 to the 2-byte type before its Q.K^T, as the 2-byte kernels round their scaled q:
+        # codes on a rounding boundary move, so its code-map distance gets the exact-P bound)
+        assert d8c.max() <= (FP8_MAX_VS_PCODE if mode is True else FP8_MAX_VS_FP8), (i, d8c.max())
+        assert d8c.mean() <= (FP8_MEAN_VS_PCODE if mode is True else FP8_MEAN_VS_FP8) * (2.0 if nrow < 128 else 1.0), (i, d8c.mean())
+        # P exact: the e4m3 rounding of P; a 16-row block whose rows hang on few keys averages less of it (measured 3.0e-2 / 6.1e-3)
+        assert d8.max() <= FP8_MAX_VS_FP8 and d8.mean() <= FP8_MEAN_VS_FP8 * (2.0 if nrow < 128 else 1.0), (i, d8.max(), d8.mean())
+        # the kernel adds nothing to the format's own distance
+        assert d16.max() <= fmt.max() + FP8_MAX_VS_FP8, (i, d16.max(), fmt.max())
