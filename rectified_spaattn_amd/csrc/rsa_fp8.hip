@@ -22,9 +22,10 @@ struct BlocksArgs {
 };
 
 // the K1 load: thread (c, g) gets rows 16 i + g, elements 8c .. 8c+7 of block blk, rows >= valid as zero (2 D threads)
+// (t: the thread's index inside its group of 2 D threads -- the whole workgroup except in kmean_sample_kernel)
 template <int D, typename Tag>
-__device__ __forceinline__ void load_block(const unsigned short* base, long ss, int blk, int valid, float (&x)[8][8]) {
-    const int t = threadIdx.x, c = t % (D / 8), g = t / (D / 8);
+__device__ __forceinline__ void load_block(const unsigned short* base, long ss, int blk, int valid, float (&x)[8][8], int t) {
+    const int c = t % (D / 8), g = t / (D / 8);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int row = blk * RSA_BLOCK + 16 * i + g;
@@ -47,54 +48,84 @@ __global__ __launch_bounds__(2 * D) void fp8_blocks_kernel(BlocksArgs a) {
     if (blk >= a.blk1[which]) return;
     const int b = bh / a.H, h = bh % a.H;
     float x[8][8];
-    load_block<D, Tag>(a.src[which] + (long)b * a.sb[which] + (long)h * a.sh[which], a.ss[which], blk, a.f8.valid[which], x);
+    load_block<D, Tag>(a.src[which] + (long)b * a.sb[which] + (long)h * a.sh[which], a.ss[which], blk, a.f8.valid[which], x, threadIdx.x);
     __shared__ __attribute__((aligned(16))) unsigned char f8lds[rsa_f8_lds(D)];
     fp8_emit_block<D, Tag>(x, a.f8, which, blk, bh, f8lds);
 }
 
-// mu[bh][d]: grid (BH), 2 D threads.  Block mean = K1's (contract C2): per thread the 8 rows in order, xor-tree over the
-// row groups of a wave, (w0 + w1) + (w2 + w3) over the waves (w0 + w1 at head dim 64), times 1/128.
+// mu[bh][d]: grid (BH), 1 024 threads = G groups of 2 D.  Block mean = K1's (contract C2): per thread the 8 rows in order, xor-tree
+// over the row groups of a wave, (w0 + w1) + (w2 + w3) over the waves of the group (w0 + w1 at head dim 64), times 1/128.  The up to 8
+// sampled blocks are pooled side by side (round 6: one or two blocks per group of threads, every load issued before the first reduction,
+// instead of one block after the other -- eight dependent trips to memory, 16.5 us at any size); their means are then added in block order by one thread per column,
+// starting from zero, and divided by their number: the same bits as the serial form.
 template <int D, typename Tag>
-__global__ __launch_bounds__(2 * D) void kmean_sample_kernel(const unsigned short* k, long sb, long sh, long ss, int H, int valid,
-                                                             float* kmean) {
-    constexpr int CH = D / 8, NW = (2 * D) / 64;
+__global__ __launch_bounds__(1024) void kmean_sample_kernel(const unsigned short* k, long sb, long sh, long ss, int H, int valid,
+                                                            float* kmean) {
+    constexpr int CH = D / 8, TPG = 2 * D, NW = TPG / 64, G = 1024 / TPG;
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
-    const int t = threadIdx.x, c = t % CH;
+    const int g = threadIdx.x / TPG, t = threadIdx.x % TPG, c = t % CH;
     const unsigned short* base = k + (long)b * sb + (long)h * sh;
-    __shared__ float red[NW][D];
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    __shared__ float red[G][NW][D];
+    __shared__ float bmean[8][D];
     const int nb = valid / RSA_BLOCK > 0 ? valid / RSA_BLOCK : 1;
     const int n = valid <= 0 ? 0 : (nb < 8 ? nb : 8);
-    for (int i = 0; i < n; ++i) {
-        const int blk = (int)(((long)i * nb) / n);
-        float x[8][8];
-        load_block<D, Tag>(base, ss, blk, valid, x);
-        float s[8];
+    // group g pools blocks g, g + G, ...: PER = 8 / G of them, all loaded before the first is reduced (one trip to memory)
+    // (kept as loaded -- 8 x 16 bytes per block -- and widened block by block: 1 024 threads leave 128 registers each)
+    constexpr int PER = 8 / G;
+    uint4 raw[PER][8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            s[e] = x[0][e];
+    for (int p = 0; p < PER; ++p) {
+        const int i = g + G * p;
+        const int blk = i < n ? (int)(((long)i * nb) / n) : 0;
 #pragma unroll
-            for (int r = 1; r < 8; ++r) s[e] = s[e] + x[r][e];
-        }
-#pragma unroll
-        for (int m = CH; m < 64; m <<= 1)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s[e] = s[e] + __shfl_xor(s[e], m, 64);
-        __syncthreads();
-        if ((t & 63) < CH)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) red[t >> 6][c * 8 + e] = s[e];
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float tot = red[0][c * 8 + e] + red[1][c * 8 + e];
-            if constexpr (NW == 4) tot = tot + (red[2][c * 8 + e] + red[3][c * 8 + e]);
-            acc[e] = acc[e] + tot * (1.0f / RSA_BLOCK);
+        for (int r = 0; r < 8; ++r) {          // load_block's rows and columns: thread (c, t / CH) reads rows 16 r + t / CH, elements 8 c .. 8 c + 7
+            const int row = blk * RSA_BLOCK + 16 * r + t / CH;
+            raw[p][r] = make_uint4(0, 0, 0, 0);
+            if (i < n && row < valid) raw[p][r] = *reinterpret_cast<const uint4*>(base + (long)row * ss + c * 8);
         }
     }
-    if (t < CH) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) kmean[(long)bh * D + c * 8 + e] = n > 0 ? acc[e] / (float)n : 0.0f;
+    for (int p = 0; p < PER; ++p) {           // (uniform trip count: every group meets the barriers, a group past the last block idles)
+        const int i = g + G * p;
+        const bool on = i < n;
+        if (on) {
+            float s[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const unsigned w[4] = {raw[p][r].x, raw[p][r].y, raw[p][r].z, raw[p][r].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float lo = rsa_to_f32<Tag>((unsigned short)(w[e] & 0xFFFF)), hi = rsa_to_f32<Tag>((unsigned short)(w[e] >> 16));
+                    s[2 * e] = r == 0 ? lo : s[2 * e] + lo;
+                    s[2 * e + 1] = r == 0 ? hi : s[2 * e + 1] + hi;
+                }
+            }
+#pragma unroll
+            for (int m = CH; m < 64; m <<= 1)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[e] = s[e] + __shfl_xor(s[e], m, 64);
+            if ((t & 63) < CH)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) red[g][t >> 6][c * 8 + e] = s[e];
+        }
+        __syncthreads();
+        if (on && t < CH) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float tot = red[g][0][c * 8 + e] + red[g][1][c * 8 + e];
+                if constexpr (NW == 4) tot = tot + (red[g][2][c * 8 + e] + red[g][3][c * 8 + e]);
+                bmean[i][c * 8 + e] = tot * (1.0f / RSA_BLOCK);
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < CH) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float acc = 0.0f;
+            for (int i = 0; i < n; ++i) acc = acc + bmean[i][c * 8 + e];
+            kmean[(long)bh * D + c * 8 + e] = n > 0 ? acc / (float)n : 0.0f;
+        }
     }
 }
 
@@ -141,7 +172,7 @@ int g_fp8_smooth_k = 1;   // tuning key "fp8_smooth_k" (0: mu = 0, for the accur
 void launch_kmean(int D, int dtype, const rsa_tensor4& k, int BH, int H, int valid, float* kmean, hipStream_t s) {
     if (!g_fp8_smooth_k) { (void)hipMemsetAsync(kmean, 0, (size_t)BH * D * 4, s); return; }
     const unsigned short* kp = static_cast<const unsigned short*>(k.ptr);
-#define RSA_KM(DD, TT) kmean_sample_kernel<DD, TT><<<BH, 2 * DD, 0, s>>>(kp, k.stride_b, k.stride_h, k.stride_s, H, valid, kmean)
+#define RSA_KM(DD, TT) kmean_sample_kernel<DD, TT><<<BH, 1024, 0, s>>>(kp, k.stride_b, k.stride_h, k.stride_s, H, valid, kmean)
     if (D == 128) { if (dtype == RSA_BF16) RSA_KM(128, bf16_tag); else RSA_KM(128, fp16_tag); }
     else { if (dtype == RSA_BF16) RSA_KM(64, bf16_tag); else RSA_KM(64, fp16_tag); }
 #undef RSA_KM
