@@ -175,3 +175,47 @@ def test_library_rejects_bad_arguments():
     qc = torch.zeros(1, 1, 256, 128, dtype=torch.bfloat16)
     with pytest.raises(_lib.RsaError):
         _core.dense_attention(qc, qc, qc)
+
+
+@pytest.mark.parametrize("Sq,Sk,causal", [(1, 1, False), (1, 129, False), (127, 1, False), (129, 257, False), (1, 1, True), (5, 300, True)])
+def test_dense_degenerate_shapes(Sq, Sk, causal):
+    """One query row, one key, a ragged block on either side: the right numbers (fullattn, attn.py:101-120)."""
+    from rectified_spaattn_amd import _core
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(Sq * 1000 + Sk)
+    q = torch.randn(1, 2, Sq, 128, generator=g).to(dev, torch.bfloat16)
+    k = torch.randn(1, 2, Sk, 128, generator=g).to(dev, torch.bfloat16)
+    v = torch.randn(1, 2, Sk, 128, generator=g).to(dev, torch.bfloat16)
+    out = _core.dense_attention(q, k, v, causal=causal).float().cpu().numpy()      # [B, Sq, H, D]
+    for h in range(2):
+        ref = orc.dense_attention(*(x[0, h].float().cpu().numpy() for x in (q, k, v)), causal=causal)
+        assert np.abs(out[0, :, h] - ref).max() <= 2e-2, (h, np.abs(out[0, :, h] - ref).max())
+
+
+def test_dense_empty_operands_raise():
+    """No query rows or no keys: an exception from the library's argument check, never a launch."""
+    from rectified_spaattn_amd import _core, _lib
+    dev = torch.device("cuda:0")
+    mk = lambda s: torch.zeros(1, 2, s, 128, dtype=torch.bfloat16, device=dev)   # noqa: E731
+    for Sq, Sk in ((0, 128), (128, 0), (0, 0)):
+        with pytest.raises(_lib.RsaError):
+            _core.dense_attention(mk(Sq), mk(Sk), mk(Sk))
+
+
+@pytest.mark.parametrize("S,top_k,p", [(1, 1, 0.5), (100, 0, 0.0), (128, 1, 0.0), (129, 1, 0.0), (300, 0, 0.0), (300, 99, 1.0),
+                                       (300, 1, -1.0), (300, 1, 2.0)])
+def test_operator_degenerate_shapes_and_parameters(S, top_k, p):
+    """A one-token sequence, a single ragged block, top_k = 0 / larger than the row, p outside [0, 1]: the oracle's answer
+    (n = max(#{cumsum <= p} + 1, top_k) clamped to the row: rectified_wan21_attn.py:230-235)."""
+    from rectified_spaattn_amd import synth
+    lay = orc.layout_wan(S, 0)
+    q, k, v = synth.structured_qkv(77 + S, 1, 2, S, 128, smooth=0.0)
+    out, bufs, (q, k, v) = _run(q, k, v, lay, top_k, p, None, torch.bfloat16)
+    ref, parts = orc.rectified_attention(q, k, v, lay, top_k, p, None, want_parts=True)
+    assert np.isfinite(out).all()
+    err = np.abs(out - ref)
+    assert err.max() <= 2e-2 and err.mean() <= 2e-3, (err.max(), err.mean())
+    kept = np.stack([sel["kept"] for sel in parts])
+    from rectified_spaattn_amd import _core
+    got = _core.unpack_bitmask(torch.from_numpy(bufs["bitmask"]), lay.NB_total).numpy()
+    assert np.array_equal(got.reshape(kept.shape), kept), "block mask"
