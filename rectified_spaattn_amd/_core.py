@@ -62,6 +62,12 @@ class LayoutSpec:
         NB = (S + BLOCK - 1) // BLOCK
         pad = NB * BLOCK - S
         NBv = NB - (text_length + pad) // BLOCK
+        if NBv < 0 or text_length > S - NBv * BLOCK:
+            # the reference cuts the text rows at normal_blocks * 128 and hands flash-attn cu_seqlens_q = [0, text_length]
+            # (rectified_cogvideo_attn.py:318-320,:359-366): with fewer rows than text_length behind the cut that reads past the
+            # tensor -- the layout only exists when the visual tokens fill whole blocks
+            raise ValueError(f"CogVideoX layout: the {S - text_length} visual tokens of S = {S}, text_length = {text_length} must be a "
+                             f"multiple of {BLOCK}")
         s_k = S if s_k is None else int(s_k)
         return LayoutSpec(S, NB, NBv, text_length, S, S, NB, 0, text_length, s_k)
 

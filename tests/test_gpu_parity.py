@@ -219,3 +219,39 @@ def test_operator_degenerate_shapes_and_parameters(S, top_k, p):
     from rectified_spaattn_amd import _core
     got = _core.unpack_bitmask(torch.from_numpy(bufs["bitmask"]), lay.NB_total).numpy()
     assert np.array_equal(got.reshape(kept.shape), kept), "block mask"
+
+
+_S_H = 6 * 128 + 256
+EXTREME_LAYOUTS = [
+    ("hunyuan_1_text_token", lambda: orc.layout_hunyuan(_S_H, 6 * 128 + 1), 2, 0.3, None),
+    ("hunyuan_256_text_tokens", lambda: orc.layout_hunyuan(_S_H, _S_H), 2, 0.3, None),
+    ("hunyuan_128_text_tokens", lambda: orc.layout_hunyuan(_S_H, 6 * 128 + 128), 2, 0.3, None),
+    ("hunyuan_129_text_tokens", lambda: orc.layout_hunyuan(_S_H, 6 * 128 + 129), 2, 0.3, None),
+    ("hunyuan_one_visual_block", lambda: orc.layout_hunyuan(128 + 256, 128 + 77), 1, 0.3, None),
+    ("flux_one_visual_block", lambda: orc.layout_flux(128 + 512, 512), 1, 0.2, None),
+    ("flux_text_128", lambda: orc.layout_flux(5 * 128 + 128, 128), 2, 0.2, None),
+    ("cogvideo_one_visual_block", lambda: orc.layout_cogvideo(128 + 226, 226), 1, 0.3, None),
+    ("wan_ffb_beyond_the_row", lambda: orc.layout_wan(5 * 128 + 3, 99), 1, 0.1, None),
+    ("wan_ffb_equals_nb", lambda: orc.layout_wan(5 * 128, 5), 1, 0.1, None),
+    ("wan_neighbours_all_true", lambda: orc.layout_wan(5 * 128, 0), 1, 0.0, True),
+    ("wan_neighbours_all_false", lambda: orc.layout_wan(5 * 128, 0), 1, 0.0, False),
+]
+
+
+@pytest.mark.parametrize("case", EXTREME_LAYOUTS, ids=lambda c: c[0])
+def test_operator_extreme_layouts(case):
+    """The corners of each layout's geometry (hunyuan :313-332, flux :307-320, cogvideo :306-322, wan21 :297-313, :265-274): one
+    and 256 valid text tokens, a text tail that ends on / one past a block edge, a single visual block, first_frame_blocks at and
+    beyond the row, neighbour matrices that keep everything / nothing: mask bit-exact, O within the bf16 bound."""
+    from rectified_spaattn_amd import _core, synth
+    name, mk, top_k, p, nb = case
+    lay = mk()
+    nbr = None if nb is None else np.full((lay.NBv, lay.NBv), nb, np.bool_)
+    q, k, v = synth.structured_qkv(1234 + lay.S, 1, 2, lay.S, 128, smooth=0.0)
+    out, bufs, (q, k, v) = _run(q, k, v, lay, top_k, p, nbr, torch.bfloat16)
+    ref, parts = orc.rectified_attention(q, k, v, lay, top_k, p, nbr, want_parts=True)
+    kept = np.stack([sel["kept"] for sel in parts])
+    got = _core.unpack_bitmask(torch.from_numpy(bufs["bitmask"]), lay.NB_total).numpy().reshape(kept.shape)
+    assert np.array_equal(got, kept), "block mask"
+    err = np.abs(out - ref)
+    assert np.isfinite(out).all() and err.max() <= 2e-2 and err.mean() <= 2e-3, (err.max(), err.mean())

@@ -262,3 +262,22 @@ def test_cogvideo_batch_of_two_dense():
     o, e = p(helpers.fake_attn(106, 4, 64, added=False), helpers.hidden(106, 30, 2, 768, 256),
              helpers.hidden(106, 31, 2, 226, 256), None, helpers.rope_tables(768, 64))
     close2(o, "cog_b2_out"); close2(e, "cog_b2_enc")
+
+
+def test_layout_specs_refuse_geometries_the_reference_cannot_run():
+    """Host logic only: the layouts the reference's own slicing cannot serve raise ValueError here instead of reaching the library
+    (rectified_hunyuan_attn.py:313-332 with no valid text token; rectified_cogvideo_attn.py:318-320,:359-366 with visual tokens that
+    do not fill whole blocks; the un-padded reshapes of the HunyuanVideo / Flux paths)."""
+    from rectified_spaattn_amd import _core
+    with pytest.raises(ValueError):
+        _core.LayoutSpec.hunyuan(6 * 128 + 256, 6 * 128)          # 0 valid text tokens
+    with pytest.raises(ValueError):
+        _core.LayoutSpec.hunyuan(6 * 128 + 200, 6 * 128 + 100)    # S % 128 != 0
+    with pytest.raises(ValueError):
+        _core.LayoutSpec.flux(5 * 128 + 100, 128)
+    with pytest.raises(ValueError):
+        _core.LayoutSpec.cogvideo(7 * 128, 226)                   # 670 visual tokens: the text rows would start inside a visual block
+    ok = _core.LayoutSpec.cogvideo(6 * 128 + 226, 226)            # the shipped shape: visual tokens a multiple of 128, 30 pad rows
+    assert (ok.NB_total, ok.NBv, ok.q_text_valid) == (8, 6, 226)
+    one = _core.LayoutSpec.cogvideo(128 + 226, 226)
+    assert (one.NB_total, one.NBv) == (3, 1)
